@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched Space Fortress env.step() on MI355X.
+
+    python bench.py --gpus 1 --steps 2000 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one sf_step launch: one 34 ms game tick for every env of the batch, fused
+with action decoding, reward shaping, the 19-float observation and auto-reset.  Workload:
+BASELINE.json's metric config -- youturn, 65 536 envs per GPU, features obs (f32), uniform
+random discrete actions pre-generated in HBM (a ring of 64 action batches).  N > 1: one
+process per GPU, each with its own 65 536-lane shard (weak scaling, no data-path
+collective); RCCL all-reduces the 8-element episode-statistics vector once at the end of
+the timed region.
+
+The JSON line also carries
+  roofline     the step kernel against the HBM roofline: algorithmic bytes per launch
+               (464 B/env-step youturn, 408 autoturn) / mean launch duration,
+               measured here with HIP events on the launch stream;
+  cpu_baseline the REAL reference engine (oracle/_ref, bare C++ tick loop) -- or the C
+               restatement if that build is absent -- timed on the host cores, one process
+               per core as the reference itself parallelises, ~10 s sample.  Runs before
+               the GPU is touched.  Reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = {"youturn": 464, "autoturn": 408, "test-youturn": 464, "test-autoturn": 408}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def cpu_baseline(gametype, seconds, cores):
+    """One OS process per core, each stepping one env with random actions (oracle/cpu_bench.py)."""
+    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsfref.so")) else "port"
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--kind", kind, "--gametype", gametype,
+           "--seconds", str(seconds)]
+    procs = [subprocess.Popen(cmd + ["--seed", str(100 + i)], stdout=subprocess.PIPE, text=True) for i in range(cores)]
+    total, kinds = 0.0, set()
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            return None
+        r = json.loads(out.strip().splitlines()[-1])
+        total += r["steps"] / r["seconds"]
+        kinds.add(r["kind"])
+    kind = kinds.pop() if len(kinds) == 1 else "port"
+    what = ("reference C++ engine (oracle/_ref: Game::pressKey/releaseKey + stepOneTick(34) loop, new Game at game over)"
+            if kind == "reference" else "C restatement of the engine (oracle/sf_oracle.c), same loop")
+    return {"value": total, "unit": "env-steps/s", "cores": cores, "kind": kind,
+            "sample": "%s, %s, uniform random actions, one process per core x %d, %.0f s each; "
+                      "bare engine only (no Python wrapper, no IPC)" % (what, gametype, cores, seconds)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--gametype", default="youturn")
+    ap.add_argument("--obs-type", default="features")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-timing-launches", type=int, default=200)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # before anything initialises the GPU in this process (children are plain CPU processes)
+        base = cpu_baseline(args.gametype, args.cpu_seconds, os.cpu_count() or 1)
+
+    import numpy as np
+    import torch
+
+    from spacefortress_amd import SFVecEnv
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.envs
+    # lanes of different ranks take different stretches of the spawn stream
+    env = SFVecEnv(n, gametype=args.gametype, obs_type=args.obs_type, device=dev, spawn_stride=1,
+                   spawn_skip=rank * 7919, reuse_buffers=True)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    ring = 64
+    actions = torch.randint(0, env.n_actions, (ring, n), device=dev, dtype=torch.uint8, generator=g)
+    env.reset()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        env.step_tensors(actions[t % ring])
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        env.step_tensors(actions[t % ring])
+    stats = torch.from_numpy(env.episode_stats()[:6].copy()).to(dev)  # syncs this rank's stream
+    if dist is not None:
+        dist.all_reduce(stats)  # RCCL: the only collective of the path (episode statistics)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- kernel launch duration with HIP events on the launch stream (outside the timed region)
+    k = min(args.kernel_timing_launches, max(1, args.steps))
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(k)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(k)]
+    for t in range(k):
+        starts[t].record()
+        env.step_tensors(actions[t % ring])
+        stops[t].record()
+    torch.cuda.synchronize()
+    per = sorted(starts[t].elapsed_time(stops[t]) for t in range(k))
+    kern_ms = float(np.mean(per))
+    kern_ms_med = per[len(per) // 2]
+    env.check_actions()
+
+    if rank == 0:
+        total_steps = float(n) * args.steps * world
+        value = total_steps / elapsed
+        algo = ALGO_BYTES[args.gametype] * n
+        achieved = algo / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), youturn random-action rollout @65536 envs/GPU",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s, %d envs/GPU, %s obs (f32), uniform random discrete actions resident in HBM, "
+                                   "per-lane auto-reset" % (args.gametype, n, args.obs_type),
+                       "envs_per_gpu": n, "gametype": args.gametype, "obs_type": args.obs_type,
+                       "parallelism": "%d independent shard(s), one process per GPU" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sf_step_kernel", "kernel_ms_mean": kern_ms, "kernel_ms_median": kern_ms_med,
+                         "algorithmic_bytes_per_launch": algo, "launches_timed": k},
+            "cpu_baseline": base,
+            "episode_stats": {"episodes": int(stats[0]), "sum_return": int(stats[1]), "fort_kills": int(stats[3]),
+                              "ship_deaths": int(stats[4]), "shots": int(stats[5])},
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

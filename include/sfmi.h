@@ -1,0 +1,183 @@
+/*
+ * sfmi.h -- C ABI of libsfmi.so, the MI355X-native batched Space Fortress engine.
+ *
+ * This is the drop-in boundary for the env.step() hot path.  The reference binds
+ * its engine to Python one environment at a time through the CPython type
+ * `_spacefortress.Game` (SRC/pymodule.cpp:361-411, SRC = python/spacefortress/src
+ * of the reference) and drives N of them from N processes
+ * (gym_vecenv.SubprocVecEnv, rl/train.py:30-32).  libsfmi.so replaces that whole
+ * stack -- Game + SSF_Env.step + the vec-env worker loop -- with one batch handle
+ * whose state lives in HBM; each entry point below names the reference interface
+ * it stands in for.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no torch / HIP types in signatures;
+ *     `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - every *_dev pointer is DEVICE memory owned by the caller (PyTorch); the
+ *     library borrows it for the duration of the stream work it enqueues and
+ *     makes no allocation after sf_create.
+ *   - calls are asynchronous and stream-ordered; nothing synchronises unless
+ *     documented (sf_get_field / sf_episode_stats do).
+ *   - every function returns an sf_status (0 = ok, < 0 = error);
+ *     sf_last_error() gives the text for the calling thread.
+ *   - there is NO CPU fallback: without a usable HIP device sf_create fails with
+ *     SF_ERR_NO_DEVICE / SF_ERR_HIP.
+ */
+#ifndef SFMI_H
+#define SFMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFMI_VERSION 1
+
+/* SRC/game.hh:3-4, exported by the reference module at SRC/pymodule.cpp:472-473 */
+#define SF_MAX_MISSILES 20
+#define SF_MAX_SHELLS 20
+/* SRC/game.hh:15-17, exported at SRC/pymodule.cpp:467-470; bit (key-1) of a key mask */
+#define SF_FIRE_KEY 1
+#define SF_THRUST_KEY 2
+#define SF_LEFT_KEY 3
+#define SF_RIGHT_KEY 4
+
+typedef enum {
+  SF_OK = 0,
+  SF_ERR_PRESET = -1,    /* unknown gametype: reference raises RuntimeError (SRC/pymodule.cpp:341) */
+  SF_ERR_ARG = -2,       /* bad argument: reference raises from PyArg_ParseTuple / assert (ENV:51) */
+  SF_ERR_HIP = -3,       /* a HIP call failed */
+  SF_ERR_NO_DEVICE = -4, /* no GPU visible: the product path never falls back to the CPU */
+  SF_ERR_ACTION = -5,    /* an action index was out of range (reference: IndexError/KeyError, ENV:211-212) */
+  SF_ERR_FIELD = -6      /* unknown field id / size mismatch in sf_get_field / sf_set_field */
+} sf_status;
+
+/* obs_type of SSF_Env (ENV:50-52); image observations are not built yet */
+#define SF_OBS_FEATURES 0   /* ENV:134-157: 19 (youturn) / 17 (autoturn) values */
+#define SF_OBS_NORMALIZED 1 /* ENV:109-133 */
+#define SF_OBS_MONITORS 2   /* ENV:96-108: 10 values */
+#define SF_OBS_NONE 3       /* skip the observation epilogue */
+
+/* flags */
+#define SF_FLAG_OBS_F64 1u          /* write observations as float64 (the reference's dtype) instead of float32 */
+#define SF_FLAG_REAL_SHELL_COUNT 2u /* feature 14 = live shells; default reproduces the reference, whose
+                                       `shells` getter walks the missiles (SRC/pymodule.cpp:131-134) */
+#define SF_FLAG_NO_AUTO_RESET 4u    /* bare SSF_Env semantics: a finished lane keeps ticking until sf_reset
+                                       (the default is the vec-env worker's reset-on-done, rl/train.py:80) */
+
+/* element type of the action array handed to sf_step */
+#define SF_ACT_U8 1
+#define SF_ACT_I32 4
+#define SF_ACT_I64 8
+
+typedef struct {
+  const char* gametype;    /* "youturn" | "autoturn" | "test-youturn" | "test-autoturn" (SRC/pymodule.cpp:332-339) */
+  int32_t n_envs;          /* environments in this batch (lanes) */
+  int32_t device_id;       /* HIP device ordinal */
+  int32_t action_set;      /* ENV:50,67-89: 1 = reduced (5 / 3 actions), 0 or -1 = every key combination */
+  int32_t obs_type;        /* SF_OBS_* */
+  uint32_t flags;          /* SF_FLAG_* */
+  uint32_t seed;           /* libc rand() seed of every env process; the reference never seeds => 1 */
+  int32_t spawn_skip;      /* spawns already drawn from the stream before lane 0's first Game
+                              (rl/train.py:17 draws one in the parent before forking) */
+  int32_t spawn_stride;    /* extra skip per lane; 0 = every lane sees the same stream, as in the reference */
+  int32_t spawn_table_len; /* entries of the precomputed spawn sequence (power of two; 0 = 65536);
+                              a lane wraps around after this many respawns */
+} sf_create_params;
+
+typedef struct sf_batch sf_batch; /* opaque: device state + constant tables */
+
+/* ---- lifecycle: `sf.Game(...)` x N + SSF_Env.__init__ (SRC/pymodule.cpp:319-354, ENV:50-93) ---- */
+int sf_create(const sf_create_params* params, sf_batch** out);
+int sf_destroy(sf_batch* b); /* tp_dealloc, SRC/pymodule.cpp:295-302 */
+
+int sf_n_envs(const sf_batch* b);
+int sf_obs_dim(const sf_batch* b);   /* shape[-1] of the observation (ENV:175) */
+int sf_n_actions(const sf_batch* b); /* action_space.n (ENV:90) */
+int sf_tick_ms(const sf_batch* b);   /* ENV:61 -> 34 */
+int sf_max_ticks(const sf_batch* b); /* ENV:165 -> 5294 */
+
+/* ---- VecEnv.reset(): env.reset() in every worker (ENV:163-178; a brand-new Game per lane,
+ *      prev_vlner kept).  obs_dev: [n_envs, obs_dim] f32 (f64 with SF_FLAG_OBS_F64), may be NULL. ---- */
+int sf_reset(sf_batch* b, void* obs_dev, void* stream);
+
+/* ---- VecEnv.step(actions): SSF_Env.step in every worker (ENV:208-253 -> press_key/release_key x4|x2
+ *      + step_one_tick(34) + is_game_over, SRC/pymodule.cpp:199-240 -> Game::stepOneTick
+ *      SRC/game.cpp:473-485), reward shaping (ENV:233-244), feature vector (ENV:95-157) and the
+ *      worker's auto-reset (rl/train.py:80).  One fused kernel launch.
+ *      actions_dev [n_envs] of act_type; obs_dev [n_envs, obs_dim]; reward_dev int32[n_envs];
+ *      done_dev, info_dev uint8[n_envs] (info is the bare fort_kill bool, ENV:253).
+ *      Any output pointer may be NULL. ---- */
+int sf_step(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
+            uint8_t* done_dev, uint8_t* info_dev, void* stream);
+
+/* Out-of-range actions are executed as NOOP and counted on the device; this reads and clears the
+ * count (synchronises `stream`).  Returns SF_ERR_ACTION if any were seen since the last call. */
+int sf_check_actions(sf_batch* b, void* stream);
+
+/* ---- state access: the 37 read-only attributes of `Game` (SRC/pymodule.cpp:372-411) in batched
+ *      form, plus writes for checkpoint/restore and constructed test states.  `host` is HOST memory,
+ *      n_envs * sf_field_info().bytes_per_env bytes, slot-major for per-projectile fields
+ *      ([slot][env]).  Synchronous. ---- */
+typedef struct {
+  const char* name;
+  int32_t elem_size;     /* 1, 2, 4 or 8 */
+  int32_t count;         /* elements per env (20 for per-slot fields, 13 for stats) */
+  int32_t is_float;      /* 1 = IEEE float of elem_size, 0 = integer */
+} sf_field_desc;
+
+int sf_n_fields(void);
+int sf_field_info(int field_id, sf_field_desc* out);
+int sf_field_id(const char* name); /* < 0 if unknown */
+int sf_get_field(sf_batch* b, int field_id, void* host, size_t bytes);
+int sf_set_field(sf_batch* b, int field_id, const void* host, size_t bytes);
+
+/* ---- episode statistics (host side of rl/train.py:81,84-88,161-164): accumulated on the device
+ *      at every episode end; this copies them out (synchronises `stream`) and optionally clears.
+ *      out[0]=episodes, [1]=sum of returns, [2]=sum of squared returns, [3]=fortress kills seen by
+ *      the wrapper (sum of info), [4]=ship deaths, [5]=shots, [6]=min return, [7]=max return
+ *      ([6],[7] are INT64_MAX / INT64_MIN while no episode has ended). ---- */
+#define SF_EPISODE_STATS_LEN 8
+int sf_episode_stats(sf_batch* b, int64_t* out, int clear, void* stream);
+
+/* ---- host-only helpers (usable without a GPU) ---- */
+typedef struct {
+  int32_t width, height, game_time;
+  int32_t destroy_fortress, ship_death_penalty;
+  double missile_penalty;
+  int32_t miss_penalty;
+  int32_t shell_speed, shell_radius, missile_speed, missile_radius;
+  int32_t auto_turn;
+  int32_t sector_size, lock_time, vuln_time, vuln_threshold, fortress_radius;
+  int32_t big_hex, small_hex;
+  int32_t explode_duration;
+  double start_vx, start_vy;
+  int32_t ship_radius;
+  double ship_accel;
+  int32_t turn_speed;
+  int32_t shaped;   /* ENV:235: reward shaping applies to "autoturn"/"youturn" only */
+  int32_t n_keys;   /* 4 for youturn games, 2 for autoturn games (ENV:213-229) */
+} sf_preset;
+
+/* `Game.config(key)` for the keys the path reads (SRC/pymodule.cpp:266-288, SRC/configs.cpp:3-89) */
+int sf_preset_get(const char* gametype, sf_preset* out);
+/* ENV:64-89: key mask per action index; out_keys has room for 16; returns the count or < 0 */
+int sf_action_table(const char* gametype, int action_set, uint8_t* out_keys);
+/* accepted spawns (x, y, angle) of resetShip() (SRC/game.cpp:133-149) for libc seed `seed`:
+ * out is int16[n][4] (x, y, angle, 0) */
+int sf_spawn_table(uint32_t seed, int n, int16_t* out);
+/* cos/sin(deg2rad(k)), k = 0..359, as the reference evaluates them (SRC/vector.cpp:34-36 + libm):
+ * out is double[360][2] */
+int sf_trig_table(double* out);
+/* hexagon vertices (SRC/hexagon.cpp:13-34): out is double[6][2] */
+int sf_hex_points(int radius, double* out);
+
+const char* sf_last_error(void);
+int sf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFMI_H */

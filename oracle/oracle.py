@@ -66,8 +66,7 @@ def build(force=False):
 def oracle_lib():
     global _oracle
     if _oracle is None:
-        if not os.path.exists(ORACLE_SO):
-            build()
+        build()  # mtime check; compiles only when sf_oracle.c is newer
         L = C.CDLL(ORACLE_SO)
         assert L.sfo_snapshot_size() == SNAPSHOT_DTYPE.itemsize, (L.sfo_snapshot_size(), SNAPSHOT_DTYPE.itemsize)
         L.sfo_env_new.restype = C.c_void_p
@@ -98,6 +97,8 @@ def oracle_lib():
         L.sfo_vec_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.sfo_vec_prev_vlner.argtypes = [C.c_void_p, C.c_int]
         L.sfo_env_hex_points.argtypes = [C.c_void_p, C.c_void_p]
+        L.sfo_env_load_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.sfo_vec_load_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.sfo_env_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int]
         L.sfo_srand.argtypes = [C.c_void_p, C.c_uint]
         L.sfo_rand.argtypes = [C.c_void_p]
@@ -294,6 +295,13 @@ class OracleVecEnv:
 
     def prev_vlner(self):
         return np.array([self.L.sfo_vec_prev_vlner(self.h, i) for i in range(self.n)], np.int32)
+
+    def load_snapshots(self, snaps, prev_vlner=None):
+        """Put every env into a constructed state (snaps: SNAPSHOT_DTYPE[n])."""
+        snaps = np.ascontiguousarray(snaps, SNAPSHOT_DTYPE)
+        for i in range(self.n):
+            pv = 0 if prev_vlner is None else int(prev_vlner[i])
+            self.L.sfo_vec_load_snapshot(self.h, i, C.c_void_p(snaps.ctypes.data + i * SNAPSHOT_DTYPE.itemsize), pv)
 
 
 class RefGame(_GameApi):

@@ -909,3 +909,63 @@ int sfo_env_replay(sfo_env* e, const uint8_t* actions, int T, sfo_snapshot* snap
   }
   return n_resets;
 }
+
+/* Inverse of sfo_game_snapshot: put an env into a constructed state (edge-case tests that play
+ * cannot reach, e.g. all 20 missile slots live).  Key flags/timers/score/stats/projectiles are
+ * taken from the snapshot; prev_vlner is set separately. */
+void sfo_env_load_snapshot(sfo_env* e, const sfo_snapshot* s, int prev_vlner) {
+  sfo_game* g = &e->g;
+  int i;
+  g->time = s->time;
+  g->tick = s->tick;
+  g->ship.alive = s->ship_alive;
+  g->ship.pos.x = s->ship_x;
+  g->ship.pos.y = s->ship_y;
+  g->ship.vel.x = s->ship_vx;
+  g->ship.vel.y = s->ship_vy;
+  g->ship.angle = s->ship_angle;
+  g->ship_death_timer = s->ship_death_timer;
+  g->fire_timer = s->fire_timer;
+  g->thrust_timer = s->thrust_timer;
+  g->left_timer = s->left_timer;
+  g->right_timer = s->right_timer;
+  g->thrust_flag = s->thrust_flag;
+  g->fire_flag = s->fire_flag;
+  g->left_flag = s->left_flag;
+  g->right_flag = s->right_flag;
+  g->turn_flag = s->turn_flag;
+  g->fortress.alive = s->fort_alive;
+  g->fortress.angle = s->fort_angle;
+  g->fort_last_angle = s->fort_last_angle;
+  g->fort_timer = s->fort_timer;
+  g->fort_death_timer = s->fort_death_timer;
+  g->fort_vuln_timer = s->fort_vuln_timer;
+  g->points = s->points;
+  g->raw_points = s->raw_points;
+  g->vlner = s->vlner;
+  memcpy(&g->stats, s->stats, sizeof(s->stats));
+  for (i = 0; i < SFO_MAX_MISSILES; i++) {
+    g->missiles[i].alive = s->missile_alive[i];
+    g->missiles[i].pos.x = s->missile_x[i];
+    g->missiles[i].pos.y = s->missile_y[i];
+    g->missiles[i].vel.x = s->missile_vx[i];
+    g->missiles[i].vel.y = s->missile_vy[i];
+    g->missiles[i].angle = s->missile_angle[i];
+    g->missiles[i].radius = g->cfg.missile_radius;
+  }
+  for (i = 0; i < SFO_MAX_SHELLS; i++) {
+    g->shells[i].alive = s->shell_alive[i];
+    g->shells[i].pos.x = s->shell_x[i];
+    g->shells[i].pos.y = s->shell_y[i];
+    g->shells[i].vel.x = s->shell_vx[i];
+    g->shells[i].vel.y = s->shell_vy[i];
+    g->shells[i].angle = s->shell_angle[i];
+    g->shells[i].radius = g->cfg.shell_radius;
+  }
+  compute_extra(g);
+  e->prev_vlner = prev_vlner;
+}
+
+void sfo_vec_load_snapshot(sfo_vec_env* v, int i, const sfo_snapshot* s, int prev_vlner) {
+  sfo_env_load_snapshot(&v->envs[i], s, prev_vlner);
+}

@@ -205,6 +205,8 @@ void sfo_env_snapshot(const sfo_env* e, sfo_snapshot* s);
 void sfo_vec_snapshot(sfo_vec_env* v, int i, sfo_snapshot* s);
 int sfo_vec_prev_vlner(sfo_vec_env* v, int i);
 void sfo_env_hex_points(const sfo_env* e, double* out24);
+void sfo_env_load_snapshot(sfo_env* e, const sfo_snapshot* s, int prev_vlner);
+void sfo_vec_load_snapshot(sfo_vec_env* v, int i, const sfo_snapshot* s, int prev_vlner);
 int sfo_env_replay(sfo_env* e, const uint8_t* actions, int T, sfo_snapshot* snaps, double* obs,
                    int32_t* reward, uint8_t* done, uint8_t* info, sfo_snapshot* reset_snaps,
                    int max_resets);

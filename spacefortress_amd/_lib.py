@@ -1,0 +1,117 @@
+"""ctypes binding of libsfmi.so (include/sfmi.h).
+
+Fails loudly: if the HIP extension is missing or no GPU is usable there is NO
+fallback -- importing works (so host-only helpers and symbol checks run on a
+CPU box), but creating a batch raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsfmi.so")
+
+SF_OK = 0
+SF_ERR_PRESET, SF_ERR_ARG, SF_ERR_HIP, SF_ERR_NO_DEVICE, SF_ERR_ACTION, SF_ERR_FIELD = -1, -2, -3, -4, -5, -6
+OBS_TYPES = {"features": 0, "normalized-features": 1, "monitors": 2, "none": 3}
+FLAG_OBS_F64 = 1
+FLAG_REAL_SHELL_COUNT = 2
+FLAG_NO_AUTO_RESET = 4
+EPISODE_STATS_LEN = 8
+
+
+class SfmiError(RuntimeError):
+    pass
+
+
+class CreateParams(C.Structure):
+    _fields_ = [
+        ("gametype", C.c_char_p), ("n_envs", C.c_int32), ("device_id", C.c_int32), ("action_set", C.c_int32),
+        ("obs_type", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint32), ("spawn_skip", C.c_int32),
+        ("spawn_stride", C.c_int32), ("spawn_table_len", C.c_int32),
+    ]
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("elem_size", C.c_int32), ("count", C.c_int32), ("is_float", C.c_int32)]
+
+
+class Preset(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("game_time", C.c_int32),
+        ("destroy_fortress", C.c_int32), ("ship_death_penalty", C.c_int32),
+        ("missile_penalty", C.c_double), ("miss_penalty", C.c_int32),
+        ("shell_speed", C.c_int32), ("shell_radius", C.c_int32), ("missile_speed", C.c_int32),
+        ("missile_radius", C.c_int32), ("auto_turn", C.c_int32),
+        ("sector_size", C.c_int32), ("lock_time", C.c_int32), ("vuln_time", C.c_int32),
+        ("vuln_threshold", C.c_int32), ("fortress_radius", C.c_int32),
+        ("big_hex", C.c_int32), ("small_hex", C.c_int32), ("explode_duration", C.c_int32),
+        ("start_vx", C.c_double), ("start_vy", C.c_double), ("ship_radius", C.c_int32),
+        ("ship_accel", C.c_double), ("turn_speed", C.c_int32), ("shaped", C.c_int32), ("n_keys", C.c_int32),
+    ]
+
+
+# every symbol include/sfmi.h declares: (restype, argtypes)
+SYMBOLS = {
+    "sf_create": (C.c_int, [C.POINTER(CreateParams), C.POINTER(C.c_void_p)]),
+    "sf_destroy": (C.c_int, [C.c_void_p]),
+    "sf_n_envs": (C.c_int, [C.c_void_p]),
+    "sf_obs_dim": (C.c_int, [C.c_void_p]),
+    "sf_n_actions": (C.c_int, [C.c_void_p]),
+    "sf_tick_ms": (C.c_int, [C.c_void_p]),
+    "sf_max_ticks": (C.c_int, [C.c_void_p]),
+    "sf_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_check_actions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sf_n_fields": (C.c_int, []),
+    "sf_field_info": (C.c_int, [C.c_int, C.POINTER(FieldDesc)]),
+    "sf_field_id": (C.c_int, [C.c_char_p]),
+    "sf_get_field": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "sf_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "sf_episode_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sf_preset_get": (C.c_int, [C.c_char_p, C.POINTER(Preset)]),
+    "sf_action_table": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p]),
+    "sf_spawn_table": (C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
+    "sf_trig_table": (C.c_int, [C.c_void_p]),
+    "sf_hex_points": (C.c_int, [C.c_int, C.c_void_p]),
+    "sf_last_error": (C.c_char_p, []),
+    "sf_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libsfmi.so; raises SfmiError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SfmiError(
+                "libsfmi.so is missing (%s): build it with `python -m spacefortress_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().sf_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Map sf_status to the exception class the reference raises for the same misuse."""
+    if rc >= 0:
+        return rc
+    msg = last_error()
+    if rc == SF_ERR_PRESET:
+        raise RuntimeError(msg)  # SRC/pymodule.cpp:341
+    if rc == SF_ERR_ARG:
+        raise ValueError(msg)
+    if rc == SF_ERR_ACTION:
+        raise IndexError(msg)  # ENV:211-212
+    if rc == SF_ERR_FIELD:
+        raise KeyError(msg)
+    raise SfmiError("libsfmi: %s (status %d)" % (msg, rc))

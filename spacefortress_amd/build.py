@@ -1,0 +1,47 @@
+"""Build recipe for libsfmi.so (HIP kernels + C ABI), in-tree, for gfx950 only.
+
+    python -m spacefortress_amd.build
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the contract:
+the reference engine rounds a*b+c twice (baseline x86-64 build, no FMA) and the
+kernels must do the same to stay bit-exact.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsfmi.so")
+SOURCES = ["sf_kernels.hip", "sf_capi.cpp", "sf_host.cpp"]
+HEADERS = ["sf_layout.h", "sf_internal.h", os.path.join(ROOT, "include", "sfmi.h")]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps.append(os.path.abspath(__file__))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [
+        hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "-ffp-contract=off", "-fno-fast-math",
+        "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+    ] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

@@ -1,0 +1,328 @@
+// sf_capi.cpp -- the C ABI of include/sfmi.h: batch lifecycle, step/reset launches, state access.
+// Host code only; the kernels are in sf_kernels.hip.  There is no CPU implementation of the
+// path in this library: every entry point that computes needs a HIP device.
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sf_internal.h"
+
+struct sf_batch {
+  SfKernelArgs args;
+  sf_preset preset;
+  bool autoturn;
+  int device;
+  int n_envs;
+  int act_count;
+  int spawn_skip, spawn_stride;
+  unsigned char* d_state;
+  size_t state_bytes;
+  double* d_consts;
+  int16_t* d_spawn;
+  unsigned long long* d_acc;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      sf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return SF_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+// keep the caller's (PyTorch's) current device untouched
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
+const unsigned long long kAccInit[SF_EPISODE_STATS_LEN + 1] = {
+    0, 0, 0, 0, 0, 0, (unsigned long long)LLONG_MAX, (unsigned long long)LLONG_MIN, 0};
+
+bool is_pow2(long v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
+  if (!p || !out || !p->gametype) {
+    sf_set_error("sf_create: null argument");
+    return SF_ERR_ARG;
+  }
+  *out = nullptr;
+  sf_preset preset;
+  int rc = sf_preset_get(p->gametype, &preset);
+  if (rc != SF_OK) return rc;
+  if (p->n_envs <= 0) {
+    sf_set_error("sf_create: n_envs must be positive (got %d)", p->n_envs);
+    return SF_ERR_ARG;
+  }
+  if (p->obs_type < SF_OBS_FEATURES || p->obs_type > SF_OBS_NONE) {
+    // ENV:51 assert obs_type in (...); 'image' is not built yet
+    sf_set_error("sf_create: unsupported obs_type %d", p->obs_type);
+    return SF_ERR_ARG;
+  }
+  uint8_t keys[16];
+  int n_actions = sf_action_table(p->gametype, p->action_set, keys);
+  if (n_actions < 0) return n_actions;
+  long spawn_len = p->spawn_table_len ? p->spawn_table_len : 65536;
+  if (!is_pow2(spawn_len) || spawn_len > (1l << 24)) {
+    sf_set_error("sf_create: spawn_table_len must be a power of two <= 2^24 (got %ld)", spawn_len);
+    return SF_ERR_ARG;
+  }
+  if (p->spawn_skip < 0 || p->spawn_stride < 0) {
+    sf_set_error("sf_create: spawn_skip / spawn_stride must be >= 0");
+    return SF_ERR_ARG;
+  }
+
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0) {
+    sf_set_error("sf_create: no HIP device available (%s); libsfmi has no CPU path",
+                 e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return SF_ERR_NO_DEVICE;
+  }
+  if (p->device_id < 0 || p->device_id >= n_dev) {
+    sf_set_error("sf_create: device_id %d out of range (%d devices)", p->device_id, n_dev);
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(p->device_id);
+
+  sf_batch* b = new sf_batch();
+  memset(b, 0, sizeof(*b));
+  b->preset = preset;
+  b->autoturn = preset.auto_turn != 0;
+  b->device = p->device_id;
+  b->n_envs = p->n_envs;
+  b->act_count = n_actions;
+  b->spawn_skip = p->spawn_skip;
+  b->spawn_stride = p->spawn_stride;
+
+  const long lanes = ((long)p->n_envs + 255) / 256 * 256;
+  b->state_bytes = (size_t)sfl::kBytesPerLane * lanes;
+
+  // host tables
+  std::vector<double> consts(SF_LDS_DOUBLES);
+  sf_host_fill_consts(preset, consts.data());
+  std::vector<int16_t> spawn(4 * (size_t)spawn_len);
+  rc = sf_spawn_table(p->seed, (int)spawn_len, spawn.data());
+  if (rc != SF_OK) {
+    delete b;
+    return rc;
+  }
+
+#define HIP_TRY_FREE(expr)                                                             \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      sf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      sf_destroy(b);                                                                   \
+      return SF_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+  HIP_TRY_FREE(hipMalloc((void**)&b->d_state, b->state_bytes));
+  HIP_TRY_FREE(hipMalloc((void**)&b->d_consts, consts.size() * sizeof(double)));
+  HIP_TRY_FREE(hipMalloc((void**)&b->d_spawn, spawn.size() * sizeof(int16_t)));
+  HIP_TRY_FREE(hipMalloc((void**)&b->d_acc, sizeof(kAccInit)));
+  HIP_TRY_FREE(hipMemcpy(b->d_consts, consts.data(), consts.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY_FREE(hipMemcpy(b->d_spawn, spawn.data(), spawn.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  HIP_TRY_FREE(hipMemcpy(b->d_acc, kAccInit, sizeof(kAccInit), hipMemcpyHostToDevice));
+
+  SfKernelArgs& a = b->args;
+  a.state = b->d_state;
+  a.lanes = lanes;
+  a.n_envs = p->n_envs;
+  a.consts = b->d_consts;
+  a.spawn = b->d_spawn;
+  a.spawn_mask = (unsigned)(spawn_len - 1);
+  a.action_keys = 0;
+  for (int i = 0; i < n_actions; i++) a.action_keys |= (unsigned long long)(keys[i] & 0xF) << (4 * i);
+  a.n_actions = n_actions;
+  a.width = preset.width;
+  a.height = preset.height;
+  a.game_time = preset.game_time;
+  a.tick_ms = 34;  // ENV:61: int(ceil(1/30 * 1000))
+  a.sector_size = preset.sector_size;
+  a.lock_time = preset.lock_time;
+  a.vuln_time = preset.vuln_time;
+  a.vuln_threshold = preset.vuln_threshold;
+  a.explode_duration = preset.explode_duration;
+  a.turn_speed = preset.turn_speed;
+  a.shaped = preset.shaped;
+  a.missile_speed = preset.missile_speed;
+  a.shell_speed = preset.shell_speed;
+  a.missile_penalty = (float)preset.missile_penalty;        // penalize(float): SRC/game.cpp:104,187
+  a.death_penalty = (float)preset.ship_death_penalty;       // :339,345,415
+  a.destroy_reward = (float)(preset.destroy_fortress + 0);  // + mDestroyFortressExtraPoints (:47,380)
+  a.miss_penalty = (float)preset.miss_penalty;              // :397
+  a.ship_accel = preset.ship_accel;
+  a.start_vx = preset.start_vx;
+  a.start_vy = preset.start_vy;
+  {
+    const double rm = (double)(preset.missile_radius + preset.fortress_radius);
+    const double rs = (double)(preset.shell_radius + preset.ship_radius);
+    a.missile_hit_r2 = rm * rm;
+    a.shell_hit_r2 = rs * rs;
+  }
+  a.fort_x = 355;  // SRC/game.cpp:38-39
+  a.fort_y = 315;
+  a.ndist_a = (double)preset.small_hex;
+  a.ndist_b = ((double)preset.big_hex - (double)preset.small_hex) / 2.0;
+  a.obs_type = p->obs_type;
+  a.obs_f64 = (p->flags & SF_FLAG_OBS_F64) ? 1 : 0;
+  a.real_shell_count = (p->flags & SF_FLAG_REAL_SHELL_COUNT) ? 1 : 0;
+  a.auto_reset = (p->flags & SF_FLAG_NO_AUTO_RESET) ? 0 : 1;
+  a.obs_dim = p->obs_type == SF_OBS_MONITORS ? 10 : (p->obs_type == SF_OBS_NONE ? 0 : 15 + preset.n_keys);
+  a.pb_width = (double)(int)(450 * .2);   // ENV:57 with the default viewport/scale
+  a.pb_height = (double)(int)(460 * .2);  // ENV:58
+  a.max_ticks = floor((double)preset.game_time / a.tick_ms);  // ENV:165
+  a.acc = b->d_acc;
+
+  HIP_TRY_FREE(sf_launch_reset(a, 1, (unsigned)p->spawn_skip, (unsigned)p->spawn_stride, nullptr, nullptr));
+  HIP_TRY_FREE(hipStreamSynchronize(nullptr));
+#undef HIP_TRY_FREE
+  *out = b;
+  return SF_OK;
+}
+
+extern "C" int sf_destroy(sf_batch* b) {
+  if (!b) return SF_OK;
+  DeviceGuard guard(b->device);
+  if (b->d_state) (void)hipFree(b->d_state);
+  if (b->d_consts) (void)hipFree(b->d_consts);
+  if (b->d_spawn) (void)hipFree(b->d_spawn);
+  if (b->d_acc) (void)hipFree(b->d_acc);
+  delete b;
+  return SF_OK;
+}
+
+extern "C" int sf_n_envs(const sf_batch* b) { return b ? b->n_envs : SF_ERR_ARG; }
+extern "C" int sf_obs_dim(const sf_batch* b) { return b ? b->args.obs_dim : SF_ERR_ARG; }
+extern "C" int sf_n_actions(const sf_batch* b) { return b ? b->act_count : SF_ERR_ARG; }
+extern "C" int sf_tick_ms(const sf_batch* b) { return b ? b->args.tick_ms : SF_ERR_ARG; }
+extern "C" int sf_max_ticks(const sf_batch* b) { return b ? (int)b->args.max_ticks : SF_ERR_ARG; }
+
+extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
+  if (!b) {
+    sf_set_error("sf_reset: null batch");
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  HIP_TRY(sf_launch_reset(b->args, 0, 0, 0, obs_dev, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_step(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
+                       uint8_t* done_dev, uint8_t* info_dev, void* stream) {
+  if (!b || !actions_dev) {
+    sf_set_error("sf_step: null batch or actions");
+    return SF_ERR_ARG;
+  }
+  if (act_type != SF_ACT_U8 && act_type != SF_ACT_I32 && act_type != SF_ACT_I64) {
+    sf_set_error("sf_step: act_type must be 1, 4 or 8 (got %d)", act_type);
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  HIP_TRY(sf_launch_step(b->args, b->autoturn, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev,
+                         (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_check_actions(sf_batch* b, void* stream) {
+  if (!b) return SF_ERR_ARG;
+  DeviceGuard guard(b->device);
+  unsigned long long bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, b->d_acc + SF_EPISODE_STATS_LEN, sizeof(bad), hipMemcpyDeviceToHost,
+                         (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if (bad) {
+    HIP_TRY(hipMemsetAsync(b->d_acc + SF_EPISODE_STATS_LEN, 0, sizeof(bad), (hipStream_t)stream));
+    sf_set_error("%llu action indices were outside [0, %d) and ran as NOOP", bad, b->act_count);
+    return SF_ERR_ACTION;
+  }
+  return SF_OK;
+}
+
+extern "C" int sf_episode_stats(sf_batch* b, int64_t* out, int clear, void* stream) {
+  if (!b || !out) return SF_ERR_ARG;
+  DeviceGuard guard(b->device);
+  HIP_TRY(hipMemcpyAsync(out, b->d_acc, SF_EPISODE_STATS_LEN * sizeof(int64_t), hipMemcpyDeviceToHost,
+                         (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if (clear)
+    HIP_TRY(hipMemcpyAsync(b->d_acc, kAccInit, SF_EPISODE_STATS_LEN * sizeof(int64_t), hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+  return SF_OK;
+}
+
+// ---- field access -------------------------------------------------------------------------
+
+extern "C" int sf_n_fields(void) { return SF_F_COUNT; }
+
+extern "C" int sf_field_info(int f, sf_field_desc* out) {
+  if (f < 0 || f >= SF_F_COUNT || !out) {
+    sf_set_error("sf_field_info: bad field id %d", f);
+    return SF_ERR_FIELD;
+  }
+  out->name = sfl::kFields[f].name;
+  out->elem_size = sfl::kFields[f].elem_size;
+  out->count = sfl::kFields[f].count;
+  out->is_float = sfl::kFields[f].is_float;
+  return SF_OK;
+}
+
+extern "C" int sf_field_id(const char* name) {
+  if (!name) return SF_ERR_FIELD;
+  for (int f = 0; f < SF_F_COUNT; f++)
+    if (!strcmp(name, sfl::kFields[f].name)) return f;
+  sf_set_error("unknown field `%s'", name);
+  return SF_ERR_FIELD;
+}
+
+static long field_offset(int f) {
+  long o = 0;
+  for (int i = 0; i < f; i++) o += (long)sfl::kFields[i].elem_size * sfl::kFields[i].count;
+  return o;
+}
+
+static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host) {
+  if (!b || !host) return SF_ERR_ARG;
+  if (f < 0 || f >= SF_F_COUNT) {
+    sf_set_error("bad field id %d", f);
+    return SF_ERR_FIELD;
+  }
+  const sfl::FieldMeta& m = sfl::kFields[f];
+  const size_t row = (size_t)b->n_envs * m.elem_size;
+  if (bytes != row * m.count) {
+    sf_set_error("field %s: expected %zu bytes, got %zu", m.name, row * m.count, bytes);
+    return SF_ERR_FIELD;
+  }
+  DeviceGuard guard(b->device);
+  unsigned char* dev = b->d_state + field_offset(f) * b->args.lanes;
+  const size_t dpitch = (size_t)b->args.lanes * m.elem_size;
+  HIP_TRY(hipDeviceSynchronize());
+  if (to_host)
+    HIP_TRY(hipMemcpy2D(host, row, dev, dpitch, row, m.count, hipMemcpyDeviceToHost));
+  else
+    HIP_TRY(hipMemcpy2D(dev, dpitch, host, row, row, m.count, hipMemcpyHostToDevice));
+  return SF_OK;
+}
+
+extern "C" int sf_get_field(sf_batch* b, int f, void* host, size_t bytes) {
+  return field_copy(b, f, host, bytes, true);
+}
+extern "C" int sf_set_field(sf_batch* b, int f, const void* host, size_t bytes) {
+  return field_copy(b, f, const_cast<void*>(host), bytes, false);
+}

@@ -1,0 +1,17 @@
+// sf_internal.h -- declarations shared between the kernels, the host tables and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sf_layout.h"
+#include "sfmi.h"
+
+// sf_kernels.hip
+hipError_t sf_launch_reset(const SfKernelArgs& a, int first, unsigned cursor0, unsigned stride, void* obs,
+                           hipStream_t stream);
+hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, const void* actions, int act_type, void* obs,
+                          int32_t* reward, uint8_t* done, uint8_t* info, hipStream_t stream);
+
+// sf_host.cpp (no HIP calls: usable and tested without a GPU)
+void sf_host_fill_consts(const sf_preset& p, double* consts /* SF_LDS_DOUBLES */);
+void sf_set_error(const char* fmt, ...);

@@ -1,0 +1,205 @@
+"""SFVecEnv -- the on-device batch that stands in for gym_vecenv.SubprocVecEnv.
+
+The reference runs N `SSF_Env`s in N processes and the trainer talks to them as
+one VecEnv (rl/train.py:30-41,60,80-85,179):
+
+    envs.observation_space.shape, envs.action_space
+    obs = envs.reset()                        -> [N, ...]
+    obs, reward, done, info = envs.step(a)    -> [N, ...], [N], [N], N bools
+    envs.close()
+
+SFVecEnv keeps that surface.  The N environments are lanes of one HIP kernel
+(libsfmi.so, include/sfmi.h); PyTorch only owns the I/O buffers and the stream.
+`step` accepts a CUDA/HIP tensor (returns tensors, nothing leaves the device,
+nothing synchronises) or a numpy array / list (returns numpy arrays, like the
+reference).  Auto-reset on `done` is the worker loop's: the observation of a
+finished lane is the first one of its next episode, reward/done/info belong to
+the finished step.
+
+There is no CPU fallback: without a GPU (or without libsfmi.so) construction raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spaces import Box, Discrete
+
+_ACT_TYPES = {torch.uint8: 1, torch.int32: 4, torch.int64: 8}
+_NP_FIELD_DTYPES = {(1, 0): np.uint8, (2, 0): np.int16, (4, 0): np.int32, (8, 0): np.int64,
+                    (4, 1): np.float32, (8, 1): np.float64}
+_UNSIGNED_FIELDS = {"spawn_cursor", "missile_mask", "shell_mask", "flags"}
+
+
+class SFVecEnv:
+    def __init__(self, num_envs, gametype="youturn", obs_type="features", action_set=1, device=None,
+                 seed=1, spawn_skip=0, spawn_stride=0, obs_dtype=torch.float32, faithful_bugs=True,
+                 auto_reset=True, spawn_table_len=0, reuse_buffers=False):
+        if obs_type == "image":
+            raise NotImplementedError("image observations (SURVEY 8f rank 1) are not built yet")
+        if obs_type not in _lib.OBS_TYPES:
+            raise AssertionError("obs_type %r" % (obs_type,))  # ENV:51
+        self._L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise _lib.SfmiError("SFVecEnv needs a HIP device (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise _lib.SfmiError("SFVecEnv runs on the GPU only (got device %s)" % (self.device,))
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        if obs_dtype not in (torch.float32, torch.float64):
+            raise ValueError("obs_dtype must be torch.float32 or torch.float64")
+        flags = 0
+        if obs_dtype == torch.float64:
+            flags |= _lib.FLAG_OBS_F64
+        if not faithful_bugs:
+            flags |= _lib.FLAG_REAL_SHELL_COUNT
+        if not auto_reset:
+            flags |= _lib.FLAG_NO_AUTO_RESET
+        p = _lib.CreateParams(gametype.encode(), int(num_envs), dev_index, int(action_set),
+                              _lib.OBS_TYPES[obs_type], flags, int(seed) & 0xFFFFFFFF, int(spawn_skip),
+                              int(spawn_stride), int(spawn_table_len))
+        h = C.c_void_p()
+        _lib.check(self._L.sf_create(C.byref(p), C.byref(h)))
+        self._h = h
+        self.num_envs = int(num_envs)
+        self.gametype = gametype
+        self.obs_type = obs_type
+        self.obs_dtype = obs_dtype
+        self.obs_dim = self._L.sf_obs_dim(h)
+        self.n_actions = self._L.sf_n_actions(h)
+        self.tickdur = self._L.sf_tick_ms(h)      # ENV:61
+        self.max_ticks = self._L.sf_max_ticks(h)  # ENV:165
+        self.action_space = Discrete(self.n_actions)  # ENV:90
+        # ENV:175 declares dtype uint8 for the feature Box; the values are floats
+        self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32 if obs_dtype == torch.float32 else np.float64)
+        self.reuse_buffers = reuse_buffers
+        self._bufs = None
+        self._pending = None
+        self._fields = None
+
+    # ------------------------------------------------------------------ buffers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _alloc(self):
+        if self.reuse_buffers and self._bufs is not None:
+            return self._bufs
+        n = self.num_envs
+        bufs = (torch.empty((n, self.obs_dim), dtype=self.obs_dtype, device=self.device),
+                torch.empty(n, dtype=torch.int32, device=self.device),
+                torch.empty(n, dtype=torch.uint8, device=self.device),
+                torch.empty(n, dtype=torch.uint8, device=self.device))
+        if self.reuse_buffers:
+            self._bufs = bufs
+        return bufs
+
+    # ------------------------------------------------------------------ VecEnv API
+    def reset(self, numpy=False):
+        """env.reset() in every lane (ENV:163-178): new games; returns obs [N, obs_dim]."""
+        obs = self._alloc()[0]
+        _lib.check(self._L.sf_reset(self._h, C.c_void_p(obs.data_ptr()), self._stream()))
+        return obs.cpu().numpy() if numpy else obs
+
+    def step_tensors(self, actions, out=None):
+        """Device fast path: `actions` is a contiguous uint8/int32/int64 tensor on this device.
+        Returns (obs, reward int32, done uint8, info uint8) tensors; nothing synchronises."""
+        if actions.device != self.device or not actions.is_contiguous() or actions.numel() != self.num_envs:
+            raise ValueError("actions must be a contiguous tensor of %d elements on %s" % (self.num_envs, self.device))
+        at = _ACT_TYPES.get(actions.dtype)
+        if at is None:
+            raise TypeError("actions dtype must be uint8, int32 or int64 (got %s)" % (actions.dtype,))
+        obs, rew, done, info = out if out is not None else self._alloc()
+        _lib.check(self._L.sf_step(self._h, C.c_void_p(actions.data_ptr()), at, C.c_void_p(obs.data_ptr()),
+                                   C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
+                                   C.c_void_p(info.data_ptr()), self._stream()))
+        return obs, rew, done, info
+
+    def step_async(self, actions):
+        if torch.is_tensor(actions):
+            self._pending = (self.step_tensors(actions), False)
+            return
+        a = np.asarray(actions)
+        if a.shape != (self.num_envs,):
+            a = a.reshape(self.num_envs)
+        if a.size and (a.min() < 0 or a.max() >= self.n_actions):
+            # ENV:211-212: actions_taken[action] / action_combinations[action]
+            raise IndexError("action out of range for Discrete(%d)" % self.n_actions)
+        t = torch.from_numpy(np.ascontiguousarray(a, np.int64)).to(self.device)
+        self._pending = (self.step_tensors(t), True)
+
+    def step_wait(self):
+        (obs, rew, done, info), as_numpy = self._pending
+        self._pending = None
+        if not as_numpy:
+            return obs, rew, done.bool(), info.bool()
+        # np.stack of per-env python ints / bools, as the subprocess vec-env returns them
+        return (obs.cpu().numpy(), rew.cpu().numpy().astype(np.int64), done.cpu().numpy().astype(bool),
+                info.cpu().numpy().astype(bool))
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.sf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ extras
+    def check_actions(self):
+        """Raise IndexError if any action since the last call was out of range (device path)."""
+        _lib.check(self._L.sf_check_actions(self._h, self._stream()))
+
+    def episode_stats(self, clear=False):
+        """Device-accumulated episode statistics as an int64 tensor of 8 (see sfmi.h)."""
+        out = np.zeros(_lib.EPISODE_STATS_LEN, np.int64)
+        _lib.check(self._L.sf_episode_stats(self._h, out.ctypes.data_as(C.c_void_p), int(clear), self._stream()))
+        return out
+
+    def field_names(self):
+        if self._fields is None:
+            self._fields = {}
+            d = _lib.FieldDesc()
+            for f in range(self._L.sf_n_fields()):
+                self._L.sf_field_info(f, C.byref(d))
+                name = d.name.decode()
+                dt = _NP_FIELD_DTYPES[(d.elem_size, d.is_float)]
+                if name in _UNSIGNED_FIELDS:
+                    dt = {1: np.uint8, 4: np.uint32}[d.elem_size]
+                self._fields[name] = (f, dt, d.count)
+        return list(self._fields)
+
+    def get_field(self, name):
+        """One state field as numpy: [N] or [count, N] (slot-major)."""
+        self.field_names()
+        if name not in self._fields:
+            raise KeyError(name)
+        f, dt, count = self._fields[name]
+        arr = np.empty((count, self.num_envs), dt)
+        _lib.check(self._L.sf_get_field(self._h, f, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return arr[0] if count == 1 else arr
+
+    def set_field(self, name, value):
+        self.field_names()
+        if name not in self._fields:
+            raise KeyError(name)
+        f, dt, count = self._fields[name]
+        arr = np.ascontiguousarray(np.asarray(value, dt).reshape(count, self.num_envs))
+        _lib.check(self._L.sf_set_field(self._h, f, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def state_dict(self):
+        """Every state field (checkpoint / golden replay)."""
+        return {n: self.get_field(n) for n in self.field_names()}
+
+    def load_state_dict(self, sd):
+        for n in self.field_names():
+            self.set_field(n, sd[n])

@@ -1,0 +1,355 @@
+"""Parity of the HIP path (libsfmi.so through SFVecEnv / the C ABI) against
+  * the golden vectors recorded from the real reference engine, and
+  * the CPU oracle on seeded random batches,
+plus size-independent properties at BASELINE.json's full batch sizes.
+
+Bar: integers, flags, float32 scores, ship and missile positions BIT-EXACT; shell
+positions (their velocity comes from a device sin/cos of a non-integer heading)
+within 1e-9; observations within 1e-5 relative to the float32 the wrapper emits
+(float64 observations: 1e-9)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_names
+from sfcompare import compare_state, snapshots_to_fields
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+@pytest.fixture(scope="module")
+def sfa():
+    import spacefortress_amd as m
+    from spacefortress_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "libsfmi.so not built: the GPU tests never fall back"
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return m
+
+
+def run_device(env, acts_tn, state_every=None, state_cb=None):
+    """Step `env` through acts_tn [T, N] (uint8) on the device; returns numpy obs/reward/done/info."""
+    T, N = acts_tn.shape
+    dev = env.device
+    a = torch.from_numpy(np.ascontiguousarray(acts_tn)).to(dev)
+    obs = torch.empty((T, N, env.obs_dim), dtype=env.obs_dtype, device=dev)
+    rew = torch.empty((T, N), dtype=torch.int32, device=dev)
+    done = torch.empty((T, N), dtype=torch.uint8, device=dev)
+    info = torch.empty((T, N), dtype=torch.uint8, device=dev)
+    for t in range(T):
+        env.step_tensors(a[t], out=(obs[t], rew[t], done[t], info[t]))
+        if state_every and (t + 1) % state_every == 0:
+            state_cb(t, env.state_dict())
+    torch.cuda.synchronize()
+    env.check_actions()
+    return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool), info.cpu().numpy().astype(bool)
+
+
+def obs_close(a, b, f64):
+    tol = 1e-9 if f64 else 1e-5
+    scale = np.maximum(1.0, np.abs(b))
+    return np.abs(a.astype(np.float64) - b) <= tol * scale + (0 if f64 else 4e-5)
+
+
+# ------------------------------------------------------------------ golden vectors
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_replays_golden(sfa, name):
+    """The recorded reference run, replayed on the GPU: rewards/done/info every step,
+    full state at every recorded snapshot."""
+    z, meta = load(name)
+    N = 3  # identical lanes: also checks lanes do not interfere
+    env = sfa.SFVecEnv(N, gametype=meta["gametype"], action_set=meta["action_set"], seed=meta["seed"],
+                       spawn_skip=meta["spawn_skip"], obs_dtype=torch.float64)
+    acts = np.repeat(z["actions"][:, None], N, 1)
+    every = meta["snap_every"]
+    done_steps = set(np.flatnonzero(z["done"]).tolist())
+    problems = []
+
+    def cb(t, sd):
+        if t in done_steps:
+            return  # the lane was auto-reset; the golden snapshot is the pre-reset state
+        snaps = np.repeat(z["snaps"][(t + 1) // every - 1][None], N)
+        bad = compare_state(sd, snaps)
+        if bad and len(problems) < 5:
+            problems.append((t, bad))
+
+    # comparing the state each `every` steps costs a sync; thin it out on the long runs
+    stride = every if len(acts) <= 700 else every * max(1, 40 // every)
+    obs, rew, done, info = run_device(env, acts, state_every=stride, state_cb=cb)
+    assert not problems, problems
+    for lane in range(N):
+        assert np.array_equal(rew[:, lane], z["reward"]), np.flatnonzero(rew[:, lane] != z["reward"])[:5]
+        assert np.array_equal(done[:, lane], z["done"].astype(bool))
+        assert np.array_equal(info[:, lane], z["info"].astype(bool))
+    # observation columns that the golden scalars pin (features obs): x, y, vlner
+    nd = ~z["done"].astype(bool)
+    assert np.array_equal(obs[nd, 0, 1], z["scal_ship_x"][nd]) and np.array_equal(obs[nd, 0, 2], z["scal_ship_y"][nd])
+    assert np.array_equal(obs[nd, 0, 11], z["scal_vlner"][nd])
+    assert np.array_equal(obs[nd, 0, 13], z["scal_n_missiles"][nd])
+    env.close()
+
+
+# ------------------------------------------------------------------ oracle, random batches
+
+@pytest.mark.parametrize("gametype,action_set,obs_type,f64", [
+    ("youturn", 1, "features", True),
+    ("autoturn", 1, "features", True),
+    ("youturn", 0, "features", False),
+    ("autoturn", 0, "normalized-features", True),
+    ("test-youturn", 1, "monitors", False),
+    ("test-autoturn", 1, "normalized-features", False),
+    ("youturn", 1, "normalized-features", True),
+    ("autoturn", 1, "monitors", True),
+])
+def test_hip_vs_oracle_random(sfa, oracle_mod, gametype, action_set, obs_type, f64):
+    """2048 lanes, different random actions and spawn offsets per lane, 1500 steps in lock-step
+    with the CPU oracle: every output of every step, and the full state at checkpoints."""
+    O = oracle_mod
+    N, T = 2048, 1500
+    rng = np.random.default_rng(sum(map(ord, gametype)) + action_set)
+    env = sfa.SFVecEnv(N, gametype=gametype, action_set=action_set, obs_type=obs_type, spawn_stride=3,
+                       spawn_skip=1, obs_dtype=torch.float64 if f64 else torch.float32)
+    orc = O.OracleVecEnv(gametype, N, action_set=action_set, obs_type=obs_type, spawn_stride=3, spawn_skip=1)
+    acts = rng.integers(0, env.n_actions, (T, N)).astype(np.uint8)
+    o0 = env.reset().cpu().numpy()
+    oo0 = orc.reset()
+    assert obs_close(o0, oo0, f64).all()
+    checkpoints = {}
+
+    def cb(t, sd):
+        checkpoints[t] = sd
+
+    obs, rew, done, info = run_device(env, acts, state_every=250, state_cb=cb)
+    for t in range(T):
+        oo, orw, od, oi = orc.step(acts[t].astype(np.int32))
+        assert np.array_equal(rew[t], orw), (t, np.flatnonzero(rew[t] != orw)[:5])
+        assert np.array_equal(done[t], od) and np.array_equal(info[t], oi), t
+        ok = obs_close(obs[t], oo, f64)
+        assert ok.all(), (t, np.argwhere(~ok)[:5], obs[t][~ok][:5], oo[~ok][:5])
+        if t in checkpoints:
+            bad = compare_state(checkpoints[t], orc.snapshots())
+            assert not bad, (t, bad)
+            assert np.array_equal(checkpoints[t]["prev_vlner"], orc.prev_vlner())
+    env.close()
+
+
+def test_episode_rollover_and_stats(sfa, oracle_mod):
+    """Every lane finishes its episode at step 5295 and is auto-reset in the kernel; the
+    device-side episode accumulators equal what the trainer would compute (rl/train.py:81-88)."""
+    O = oracle_mod
+    N, T = 64, 5295 + 40
+    rng = np.random.default_rng(7)
+    env = sfa.SFVecEnv(N, gametype="youturn", spawn_stride=1)
+    orc = O.OracleVecEnv("youturn", N, spawn_stride=1)
+    acts = rng.integers(0, 5, (T, N)).astype(np.uint8)
+    obs, rew, done, info = run_device(env, acts)
+    ret = np.zeros(N, np.int64)
+    fin = []
+    for t in range(T):
+        oo, orw, od, oi = orc.step(acts[t].astype(np.int32))
+        assert np.array_equal(rew[t], orw) and np.array_equal(done[t], od) and np.array_equal(info[t], oi), t
+        assert obs_close(obs[t], oo, False).all(), t
+        ret += orw
+        for i in np.flatnonzero(od):
+            fin.append(int(ret[i]))
+            ret[i] = 0
+    assert done[5294].all() and done.sum() == N
+    st = env.episode_stats()
+    fin = np.array(fin)
+    assert st[0] == N and st[1] == fin.sum() and st[2] == (fin ** 2).sum()
+    assert st[3] == info[:5295].sum() and st[6] == fin.min() and st[7] == fin.max()
+    assert not compare_state(env.state_dict(), orc.snapshots())
+    env.close()
+
+
+# ------------------------------------------------------------------ constructed edge cases
+
+def _load_both(sfa, O, gametype, snaps, prev_vlner=None, **kw):
+    n = len(snaps)
+    env = sfa.SFVecEnv(n, gametype=gametype, obs_dtype=torch.float64, **kw)
+    orc = O.OracleVecEnv(gametype, n, **{k: v for k, v in kw.items() if k in ("action_set", "obs_type")})
+    orc.load_snapshots(snaps, prev_vlner)
+    for k, v in snapshots_to_fields(snaps).items():
+        env.set_field(k, v)
+    if prev_vlner is not None:
+        env.set_field("prev_vlner", np.asarray(prev_vlner, np.int32))
+    return env, orc
+
+
+def test_missile_slots_exhausted(sfa, oracle_mod):
+    """All 20 missile slots live (unreachable in play): FIRE counts a shot, creates nothing, costs nothing
+    (SRC/game.cpp:176-191,239-245).  Also 19 live -> the free slot in the middle is taken."""
+    O = oracle_mod
+    base = O.OracleVecEnv("youturn", 4).snapshots()
+    for i in range(4):
+        n_live = (20, 19, 20, 7)[i]
+        for s in range(20):
+            live = s < n_live if i != 1 else s != 11
+            base["missile_alive"][i, s] = int(live)
+            base["missile_x"][i, s] = 300 + 3 * s
+            base["missile_y"][i, s] = 200 + 2 * s
+            base["missile_angle"][i, s] = (17 * s + 5) % 360
+    # the oracle moves missiles by their stored velocity: take it from the reference's own table
+    tab = np.load(os.path.join(GOLDEN, "tables.npz"))["missile_vel_by_angle"]
+    ang = base["missile_angle"].astype(int)
+    base["missile_vx"] = tab[ang, 0]
+    base["missile_vy"] = tab[ang, 1]
+    env, orc = _load_both(sfa, O, "youturn", base)
+    acts = np.array([[1, 1, 0, 1], [0, 0, 1, 0], [1, 1, 1, 1], [0, 0, 0, 0], [1, 0, 1, 1]], np.uint8)
+    obs, rew, done, info = run_device(env, acts)
+    for t in range(len(acts)):
+        oo, orw, od, oi = orc.step(acts[t].astype(np.int32))
+        assert np.array_equal(rew[t], orw), t
+        assert obs_close(obs[t], oo, True).all(), t
+    assert not compare_state(env.state_dict(), orc.snapshots())
+    env.close()
+
+
+def test_autoturn_heading_on_the_spawn_lattice(sfa, oracle_mod):
+    """autoturn rounds atan2 up to an integer degree (SRC/game.cpp:317-319).  A spawned ship sits on
+    integer coordinates, where the exact heading can BE an integer (axes, diagonals): the device
+    atan2 must land on the same side as glibc's for every lattice point of the spawn box
+    (SRC/game.cpp:137-138), and the fortress sector (ceil to 10 degrees, :206) too."""
+    O = oracle_mod
+    xs, ys = np.meshgrid(np.arange(170, 550), np.arange(150, 480), indexing="ij")
+    pts = np.stack([xs.ravel(), ys.ravel()], 1)
+    keep = ~((pts[:, 0] == 355) & (pts[:, 1] == 315))
+    pts = pts[keep]
+    # a stride keeps the CPU side quick while covering every diagonal/axis point explicitly
+    diag = (np.abs(pts[:, 0] - 355) == np.abs(pts[:, 1] - 315)) | (pts[:, 0] == 355) | (pts[:, 1] == 315)
+    sel = np.flatnonzero(diag | (np.arange(len(pts)) % 7 == 0))
+    pts = pts[sel]
+    n = len(pts)
+    base = O.OracleVecEnv("autoturn", n).snapshots()
+    base["ship_x"] = pts[:, 0]
+    base["ship_y"] = pts[:, 1]
+    base["ship_vx"] = 0.0  # stay on the lattice so the fortress sees integer coordinates too
+    base["ship_vy"] = 0.0
+    env, orc = _load_both(sfa, O, "autoturn", base)
+    acts = np.zeros((1, n), np.uint8)
+    obs, rew, done, info = run_device(env, acts)
+    oo, orw, od, oi = orc.step(acts[0].astype(np.int32))
+    sd, sn = env.state_dict(), orc.snapshots()
+    assert np.array_equal(sd["ship_angle"].astype(np.float64), sn["ship_angle"]), \
+        pts[sd["ship_angle"] != sn["ship_angle"]][:10]
+    assert np.array_equal(sd["fort_angle"].astype(np.float64), sn["fort_angle"])
+    assert not compare_state(sd, sn)
+    assert obs_close(obs[0], oo, True).all()
+    env.close()
+
+
+def test_no_auto_reset_and_reset_keeps_prev_vlner(sfa, oracle_mod):
+    """auto_reset=False is the bare SSF_Env: a finished game keeps ticking (ENV:246 only reports);
+    sf_reset starts new games and keeps prev_vlner (ENV:92,163-178)."""
+    O = oracle_mod
+    z, meta = load("autoturn_destroy")
+    acts = z["actions"][:110]  # ends with vulnerability > 0
+    env = sfa.SFVecEnv(2, gametype="autoturn", auto_reset=False, obs_dtype=torch.float64)
+    o = O.OracleEnv("autoturn")
+    run_device(env, np.repeat(acts[:, None], 2, 1))
+    out = o.replay(acts)
+    pv = int(out["snaps"]["vlner"][-1])
+    assert pv > 0 and (env.get_field("prev_vlner") == pv).all()
+    obs = env.reset().cpu().numpy()
+    o_obs = o.reset()
+    assert (env.get_field("prev_vlner") == pv).all() and o.prev_vlner == pv
+    assert obs_close(obs[0], o_obs, True).all()
+    # first step of the new episode sees vlner_change = 0 - prev_vlner
+    obs, rew, done, info = run_device(env, np.zeros((1, 2), np.uint8))
+    oo, orw, od, oi = o.step(0)
+    assert rew[0, 0] == orw == -1
+    env.close()
+
+
+def test_bad_arguments(sfa):
+    with pytest.raises(RuntimeError):  # SRC/pymodule.cpp:341
+        sfa.SFVecEnv(4, gametype="nope")
+    with pytest.raises(ValueError):
+        sfa.SFVecEnv(4, action_set=5)
+    env = sfa.SFVecEnv(4)
+    with pytest.raises(IndexError):  # ENV:211-212
+        env.step(np.array([0, 1, 5, 0]))
+    env.step_tensors(torch.tensor([0, 1, 9, 0], device=env.device))
+    with pytest.raises(IndexError):
+        env.check_actions()
+    env.check_actions()  # cleared
+    env.close()
+
+
+def test_numpy_api_and_single_env(sfa, oracle_mod):
+    """The numpy round trip returns the reference's kinds: float obs, int64 rewards, bool arrays."""
+    O = oracle_mod
+    env = sfa.SFVecEnv(8, gametype="youturn")
+    obs = env.reset(numpy=True)
+    assert obs.shape == (8, 19) and env.observation_space.shape == (19,) and env.action_space.n == 5
+    obs, r, d, i = env.step(np.array([1, 2, 3, 4, 0, 1, 2, 3]))
+    assert obs.dtype == np.float32 and r.dtype == np.int64 and d.dtype == bool and i.dtype == bool
+    assert sum(i) == 0
+    env.close()
+    e1 = sfa.SSF_Env(gametype="autoturn", obs_type="features")
+    o = O.OracleEnv("autoturn")
+    assert e1.action_space.n == 3 and e1.tickdur == 34 and e1.max_ticks == 5294.0
+    ob = e1.reset()
+    assert np.allclose(ob, o.features(), rtol=0, atol=1e-9)
+    for a in (1, 0, 2, 2, 1, 0):
+        ob, r, d, i = e1.step(a)
+        oo, orw, od, oi = o.step(a)
+        assert (r, d, i) == (orw, od, oi) and isinstance(r, int)
+        assert np.allclose(ob, oo, rtol=0, atol=1e-9)
+    with pytest.raises(KeyError):
+        e1.step(7)
+    e1.close()
+
+
+# ------------------------------------------------------------------ full-size properties
+
+@pytest.mark.parametrize("gametype,n", [("youturn", 65536), ("autoturn", 65536), ("youturn", 4096)])
+def test_full_size_properties(sfa, oracle_mod, gametype, n):
+    """BASELINE.json batch sizes.  (1) a random sample of lanes equals the oracle run on just
+    those lanes (lanes are independent); (2) two runs give identical bits; (3) invariants:
+    deaths add up, points >= 0, time = 34 * steps, masks within 20 bits, shots counted."""
+    O = oracle_mod
+    T = 300 if n >= 65536 else 600
+    rng = np.random.default_rng(n + len(gametype))
+    n_act = 5 if gametype == "youturn" else 3
+    acts = rng.integers(0, n_act, (T, n)).astype(np.uint8)
+    outs = []
+    for rep in range(2):
+        env = sfa.SFVecEnv(n, gametype=gametype, spawn_stride=1)
+        obs, rew, done, info = run_device(env, acts)
+        sd = env.state_dict()
+        outs.append((obs, rew, sd))
+        env.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert np.array_equal(outs[0][2][k], outs[1][2][k]), k
+    obs, rew, sd = outs[0]
+    st = sd["stats"]
+    assert np.array_equal(st[3], st[0] + st[1] + st[2])          # shipDeaths = bigHex + smallHex + shell
+    assert (sd["points"] >= 0).all() and (sd["time"] == 34 * T).all()
+    assert (sd["missile_mask"] < (1 << 20)).all() and (sd["shell_mask"] < (1 << 20)).all()
+    press = (acts == 1)
+    edges = press[0].astype(np.int64) + (press[1:] & ~press[:-1]).sum(0)
+    assert np.array_equal(st[7], edges)                           # totalShots = FIRE press edges
+    assert np.isfinite(obs).all()
+    lanes = np.sort(rng.choice(n, 192, replace=False))
+    # the oracle on the sampled lanes only (spawn_skip = lane because spawn_stride = 1)
+    snaps = []
+    for lane in lanes:
+        o = O.OracleEnv(gametype, spawn_skip=int(lane))
+        out = o.replay(acts[:, lane], want_obs=True)
+        assert np.array_equal(out["reward"], rew[:, lane]), lane
+        assert obs_close(obs[:, lane], out["obs"], False).all(), lane
+        snaps.append(out["snaps"][-1])
+    bad = compare_state(sd, np.array(snaps), lanes=lanes)
+    assert not bad, bad
