@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--gametype", default="youturn")
     ap.add_argument("--obs-type", default="features")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="baseline processes (0 = this box's share, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timing-launches", type=int, default=200)
     args = ap.parse_args()
@@ -77,7 +78,13 @@ def main():
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # before anything initialises the GPU in this process (children are plain CPU processes)
-        base = cpu_baseline(args.gametype, args.cpu_seconds, os.cpu_count() or 1)
+        try:
+            share = len(os.sched_getaffinity(0))
+        except AttributeError:
+            share = os.cpu_count() or 1
+        # a one-GPU box owns 16 host cores of the node whatever os.cpu_count() says
+        cores = args.cpu_cores or max(1, min(share, 16))
+        base = cpu_baseline(args.gametype, args.cpu_seconds, cores)
 
     import numpy as np
     import torch

@@ -39,19 +39,15 @@ class SSF_Env(_Base):
         self.action_space = self._vec.action_space
         self.observation_space = self._vec.observation_space
         self.actions_taken = {i: 0 for i in range(self.action_space.n)}  # ENV:91
-        self._first = self._vec.reset(numpy=True)[0]  # ENV:93: __init__ ends with reset()
+        # ENV:93: __init__ ends with reset(), i.e. the first Game -- sf_create already made it
 
     def seed(self, seed=None):  # ENV:159-161: seeds an RNG the game never reads
         return [seed]
 
     def reset(self):
-        if self._first is not None:
-            obs, self._first = self._first, None
-            return obs
         return self._vec.reset(numpy=True)[0]
 
     def step(self, action):
-        self._first = None
         self.actions_taken[action] += 1  # KeyError for an unknown action, like ENV:211
         obs, r, d, i = self._vec.step(np.array([action]))
         self.last_action = action

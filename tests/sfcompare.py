@@ -21,10 +21,12 @@ def compare_state(sd, snaps, shell_tol=1e-9, lanes=None):
     """sd: SFVecEnv.state_dict(); snaps: oracle SNAPSHOT_DTYPE[n].  Returns a list of mismatches.
     Bit-exact for everything except shell positions/velocities (real device sin/cos feeds them)."""
     bad = []
-    sel = slice(None) if lanes is None else lanes
+    if lanes is not None:
+        sd = {k: np.asarray(v)[..., lanes] for k, v in sd.items()}
+    sel = slice(None)
 
     def chk(name, a, b, exact=True, tol=0.0):
-        a = np.asarray(a)[..., sel] if a.ndim > 1 else np.asarray(a)[sel]
+        a = np.asarray(a)
         if exact:
             ok = a.tobytes() == np.ascontiguousarray(b, a.dtype).tobytes() if a.dtype.kind == "f" else np.array_equal(a, b)
             if not ok:

@@ -299,8 +299,8 @@ def test_numpy_api_and_single_env(sfa, oracle_mod):
     e1 = sfa.SSF_Env(gametype="autoturn", obs_type="features")
     o = O.OracleEnv("autoturn")
     assert e1.action_space.n == 3 and e1.tickdur == 34 and e1.max_ticks == 5294.0
-    ob = e1.reset()
-    assert np.allclose(ob, o.features(), rtol=0, atol=1e-9)
+    ob = e1.reset()  # the second Game of this "process": __init__ made the first (ENV:93)
+    assert np.allclose(ob, o.reset(), rtol=0, atol=1e-9)
     for a in (1, 0, 2, 2, 1, 0):
         ob, r, d, i = e1.step(a)
         oo, orw, od, oi = o.step(a)
