@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsfmi.so")
+# SFMI_LIB_PATH: load a differently-built libsfmi (profiling / ablation builds); still HIP-only
+LIB_PATH = os.environ.get("SFMI_LIB_PATH") or os.path.join(HERE, "libsfmi.so")
 
 SF_OK = 0
 SF_ERR_PRESET, SF_ERR_ARG, SF_ERR_HIP, SF_ERR_NO_DEVICE, SF_ERR_ACTION, SF_ERR_FIELD = -1, -2, -3, -4, -5, -6

@@ -189,6 +189,11 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   a.pb_height = (double)(int)(460 * .2);  // ENV:58
   a.max_ticks = floor((double)preset.game_time / a.tick_ms);  // ENV:165
   a.acc = b->d_acc;
+  a.dbg = nullptr;
+#ifdef SF_STAMPS  // diagnostic build (tools/stamps.py): per-wave clock stamps, never in the product
+  HIP_TRY_FREE(hipMalloc((void**)&a.dbg, (size_t)(lanes / 64) * 16 * sizeof(unsigned long long)));
+  HIP_TRY_FREE(hipMemset(a.dbg, 0, (size_t)(lanes / 64) * 16 * sizeof(unsigned long long)));
+#endif
 
   HIP_TRY_FREE(sf_launch_reset(a, 1, (unsigned)p->spawn_skip, (unsigned)p->spawn_stride, nullptr, nullptr));
   HIP_TRY_FREE(hipStreamSynchronize(nullptr));
@@ -207,6 +212,16 @@ extern "C" int sf_destroy(sf_batch* b) {
   delete b;
   return SF_OK;
 }
+
+#ifdef SF_STAMPS
+extern "C" int sf_debug_read(sf_batch* b, unsigned long long* host) {
+  DeviceGuard guard(b->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host, b->args.dbg, (size_t)(b->args.lanes / 64) * 16 * sizeof(unsigned long long),
+                    hipMemcpyDeviceToHost));
+  return SF_OK;
+}
+#endif
 
 extern "C" int sf_n_envs(const sf_batch* b) { return b ? b->n_envs : SF_ERR_ARG; }
 extern "C" int sf_obs_dim(const sf_batch* b) { return b ? b->args.obs_dim : SF_ERR_ARG; }

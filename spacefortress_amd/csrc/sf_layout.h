@@ -125,4 +125,5 @@ struct SfKernelArgs {
   double pb_width, pb_height, max_ticks; // ENV:57-58,165
   // episode accumulators / error counter (device)
   unsigned long long* acc;   // SF_EPISODE_STATS_LEN + 1 words; [8] = bad-action count
+  unsigned long long* dbg;   // SF_STAMPS diagnostic builds only: [wave][16] clock stamps; else null
 };

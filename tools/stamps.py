@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Where does a wave of sf_step_kernel spend its cycles?  DIAGNOSTIC ONLY.
+
+Builds libsfmi with -DSF_STAMPS into build/diag/ (shader-clock stamps at phase boundaries, with
+forced waits so each phase owns its memory latency), steps a batch, and prints the median
+per-phase cycles over all waves plus the first-wave-start -> last-wave-end span in real time.
+Read the SHARES, not the length: the forced waits forbid overlaps the real kernel has.
+
+    python tools/stamps.py [--envs 65536] [--gametype youturn]
+"""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DIAG = os.path.join(ROOT, "build", "diag", "libsfmi_stamps.so")
+
+
+def build():
+    os.makedirs(os.path.dirname(DIAG), exist_ok=True)
+    csrc = os.path.join(ROOT, "spacefortress_amd", "csrc")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off", "-fno-fast-math", "-DSF_STAMPS", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+           os.path.join(csrc, "sf_kernels.hip"), os.path.join(csrc, "sf_capi.cpp"), os.path.join(csrc, "sf_host.cpp"),
+           "-o", DIAG]
+    subprocess.check_call(cmd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=65536)
+    ap.add_argument("--gametype", default="youturn")
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--build-only", action="store_true")
+    a = ap.parse_args()
+    if not os.path.exists(DIAG) or a.build_only:
+        build()
+    if a.build_only:
+        return
+    os.environ["SFMI_LIB_PATH"] = DIAG
+    import numpy as np
+    import torch
+    from spacefortress_amd import SFVecEnv, _lib
+
+    env = SFVecEnv(a.envs, gametype=a.gametype, spawn_stride=1, reuse_buffers=True)
+    acts = torch.randint(0, env.n_actions, (64, a.envs), device=env.device, dtype=torch.uint8)
+    for t in range(a.steps):
+        env.step_tensors(acts[t % 64])
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    n_waves = (a.envs + 255) // 256 * 4
+    buf = np.zeros((n_waves, 16), np.uint64)
+    L.sf_debug_read.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.sf_debug_read(env._h, buf.ctypes.data_as(C.c_void_p)) == 0
+    s = buf[:, :10].astype(np.int64)
+    names = ["issue loads (round trip 1)", "wait round trip 1", "prefetch issue + LDS stage + barrier",
+             "keys/ship/atan2 x2/fortress", "wait projectile prefetch", "shells + missiles",
+             "timers/reward/stats atomics/stores issue", "obs: extras + LDS transpose + flush", "drain stores"]
+    d = np.diff(s, axis=1)
+    tot = s[:, 9] - s[:, 0]
+    print("waves %d; per-wave cycles (median / p90):" % n_waves)
+    for k, nm in enumerate(names):
+        print("  %-45s %7.0f %7.0f  (%4.1f%%)" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 90),
+                                                100 * np.median(d[:, k]) / np.median(tot)))
+    print("  %-45s %7.0f %7.0f" % ("wave total", np.median(tot), np.percentile(tot, 90)))
+    rt = buf[:, 12:14].astype(np.int64)  # 100 MHz
+    print("real time: first wave start -> last wave end %.2f us; median wave life %.2f us; start spread %.2f us" % (
+        (rt[:, 1].max() - rt[:, 0].min()) / 100.0, np.median(rt[:, 1] - rt[:, 0]) / 100.0,
+        (rt[:, 0].max() - rt[:, 0].min()) / 100.0))
+    print("shader clock estimate: %.2f GHz" % (np.median(tot) / np.median(rt[:, 1] - rt[:, 0]) / 10.0))
+
+
+if __name__ == "__main__":
+    main()
