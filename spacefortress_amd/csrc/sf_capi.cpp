@@ -23,6 +23,7 @@ struct sf_batch {
   double* d_consts;
   int16_t* d_spawn;
   unsigned long long* d_acc;
+  unsigned char* d_scratch;  // linear staging for sf_get_field / sf_set_field (largest field)
 };
 
 namespace {
@@ -113,7 +114,7 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   b->state_bytes = (size_t)sfl::kBytesPerLane * lanes;
 
   // host tables
-  std::vector<double> consts(SF_LDS_DOUBLES);
+  std::vector<double> consts(SF_CONST_DOUBLES);
   sf_host_fill_consts(preset, consts.data());
   std::vector<int16_t> spawn(4 * (size_t)spawn_len);
   rc = sf_spawn_table(p->seed, (int)spawn_len, spawn.data());
@@ -136,6 +137,7 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   HIP_TRY_FREE(hipMalloc((void**)&b->d_consts, consts.size() * sizeof(double)));
   HIP_TRY_FREE(hipMalloc((void**)&b->d_spawn, spawn.size() * sizeof(int16_t)));
   HIP_TRY_FREE(hipMalloc((void**)&b->d_acc, sizeof(kAccInit)));
+  HIP_TRY_FREE(hipMalloc((void**)&b->d_scratch, (size_t)p->n_envs * SF_NSLOT * sizeof(double)));
   HIP_TRY_FREE(hipMemcpy(b->d_consts, consts.data(), consts.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY_FREE(hipMemcpy(b->d_spawn, spawn.data(), spawn.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   HIP_TRY_FREE(hipMemcpy(b->d_acc, kAccInit, sizeof(kAccInit), hipMemcpyHostToDevice));
@@ -178,6 +180,8 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   }
   a.fort_x = 355;  // SRC/game.cpp:38-39
   a.fort_y = 315;
+  a.width_d = (double)preset.width;
+  a.height_d = (double)preset.height;
   a.ndist_a = (double)preset.small_hex;
   a.ndist_b = ((double)preset.big_hex - (double)preset.small_hex) / 2.0;
   a.obs_type = p->obs_type;
@@ -209,6 +213,8 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_consts) (void)hipFree(b->d_consts);
   if (b->d_spawn) (void)hipFree(b->d_spawn);
   if (b->d_acc) (void)hipFree(b->d_acc);
+  if (b->d_scratch) (void)hipFree(b->d_scratch);
+  if (b->args.dbg) (void)hipFree(b->args.dbg);
   delete b;
   return SF_OK;
 }
@@ -306,12 +312,14 @@ extern "C" int sf_field_id(const char* name) {
   return SF_ERR_FIELD;
 }
 
-static long field_offset(int f) {
+static long field_offset_per_lane(int f) {
   long o = 0;
   for (int i = 0; i < f; i++) o += (long)sfl::kFields[i].elem_size * sfl::kFields[i].count;
   return o;
 }
 
+// The tiled device layout never leaves the library: a small kernel gathers the field into (or
+// scatters it from) a linear [count][n_envs] staging buffer, which is what the host sees.
 static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host) {
   if (!b || !host) return SF_ERR_ARG;
   if (f < 0 || f >= SF_F_COUNT) {
@@ -319,19 +327,18 @@ static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host
     return SF_ERR_FIELD;
   }
   const sfl::FieldMeta& m = sfl::kFields[f];
-  const size_t row = (size_t)b->n_envs * m.elem_size;
-  if (bytes != row * m.count) {
-    sf_set_error("field %s: expected %zu bytes, got %zu", m.name, row * m.count, bytes);
+  const size_t total = (size_t)b->n_envs * m.elem_size * m.count;
+  if (bytes != total) {
+    sf_set_error("field %s: expected %zu bytes, got %zu", m.name, total, bytes);
     return SF_ERR_FIELD;
   }
   DeviceGuard guard(b->device);
-  unsigned char* dev = b->d_state + field_offset(f) * b->args.lanes;
-  const size_t dpitch = (size_t)b->args.lanes * m.elem_size;
   HIP_TRY(hipDeviceSynchronize());
-  if (to_host)
-    HIP_TRY(hipMemcpy2D(host, row, dev, dpitch, row, m.count, hipMemcpyDeviceToHost));
-  else
-    HIP_TRY(hipMemcpy2D(dev, dpitch, host, row, row, m.count, hipMemcpyHostToDevice));
+  if (!to_host) HIP_TRY(hipMemcpy(b->d_scratch, host, total, hipMemcpyHostToDevice));
+  HIP_TRY(sf_launch_field_copy(b->d_state, b->n_envs, field_offset_per_lane(f), m.elem_size, m.count,
+                               b->d_scratch, to_host ? 1 : 0, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  if (to_host) HIP_TRY(hipMemcpy(host, b->d_scratch, total, hipMemcpyDeviceToHost));
   return SF_OK;
 }
 

@@ -13,16 +13,23 @@
 // build (baseline x86-64, no FMA).
 //
 // Hardware mapping:
-//  * state is struct-of-arrays in HBM (sf_layout.h): a wave's 64 lanes read 64
-//    consecutive elements of each field -- every access is a full coalesced row;
+//  * state is struct-of-arrays per 64-env wave tile in HBM (sf_layout.h): a wave's 64
+//    lanes read 64 consecutive elements of each field -- every access is a full
+//    coalesced row -- and the whole state of the wave hangs off ONE scalar base with
+//    compile-time field offsets (the batch-wide SoA first tried spent a quarter of its
+//    instructions on per-field 64-bit address arithmetic and SGPR spills);
 //  * at 65 536 envs a launch is 1024 waves = ONE wave per SIMD of the chip, so the
 //    kernel is a latency chain, not a throughput problem.  It is organised so that a
 //    wave makes two memory round trips, not twenty: (1) every unconditional load is
 //    issued up front; (2) as soon as the two alive-bitmasks arrive, the live
-//    projectile slots are prefetched -- a wave ballot per slot skips slots no lane
-//    uses -- and their latency hides under the key / ship / fortress arithmetic;
-//  * the per-lane-indexed constants (360-entry cos/sin table, hexagon edges) are
-//    staged into LDS once per workgroup; scalar constants are kernel arguments (SGPRs);
+//    projectile slots are prefetched -- a wave ballot skips slot groups no lane uses --
+//    and their latency hides under the key / ship / fortress arithmetic;
+//  * projectile ballistics run as straight-line code over the prefetched slots (the
+//    slots are independent until a hit), so their f64 chains interleave; only the
+//    rare hit / miss events walk the fortress state machine, in slot order;
+//  * the fixed game constants that are tables -- the 360-entry cos/sin table (indexed per
+//    lane) and the 12 hexagon edges -- are staged into LDS once per workgroup (6 KB);
+//    scalar presets are kernel arguments (SGPRs);
 //  * the 13 statistics counters are never loaded: events add to them with no-return
 //    atomics (executed at the memory side), so a step reads and dirties less;
 //  * observations are transposed through LDS and leave as 16-byte coalesced stores;
@@ -57,8 +64,14 @@
 #define SF_STAMP(k, drain)
 #endif
 
-#define SF_PTR(a, name, ctype) \
-  (reinterpret_cast<ctype*>((a).state + sfl::offset_per_lane(SF_F_##name) * (a).lanes))
+// Field access inside the wave's tile (sf_layout.h): `tb` is the tile base -- wave-uniform, one
+// SGPR pair for the whole state -- the field/slot offset is a compile-time constant and the lane
+// contributes a 32-bit byte offset (one VGPR per element size).
+#define SF_BASE(a, name) (tb + sfl::tile_offset(SF_F_##name))
+#define SF_SLOT(a, name, T, s) \
+  (tb + sfl::offset_per_lane(SF_F_##name) * sfl::kTileLanes + (size_t)(s) * (sfl::kTileLanes * sizeof(T)))
+#define SF_LD(T, base, off) (*reinterpret_cast<const T*>((base) + (off)))
+#define SF_ST(T, base, off, v) (*reinterpret_cast<T*>((base) + (off)) = (v))
 
 namespace {
 
@@ -75,13 +88,17 @@ struct Lane {
   unsigned cursor, mmask, smask;
 };
 
-// what one tick adds to the statistics (SRC/game.hh:29-43); flushed with atomics
-// (named scalars, not an array: the compiler merges `if (c) d[5]++; else d[4]++;` into a
-// dynamically indexed update, which would push an array into scratch memory)
+// What one tick adds to the statistics (SRC/game.hh:29-43); flushed with atomics.
+// (Named scalars, not an array: the compiler merges `if (c) d[5]++; else d[4]++;` into a
+// dynamically indexed update, which would push an array into scratch memory.)
 struct StatDelta {
   int big_hex_deaths = 0, small_hex_deaths = 0, shell_deaths = 0, ship_deaths = 0, resets = 0, destroyed = 0,
       missed = 0, shots = 0, thrusts = 0, lefts = 0, rights = 0, vlner_incs = 0;
   int max_vlner = 0;  // candidate for counter 12 (a running maximum)
+};
+
+struct Off {  // 32-bit byte offsets of this lane for 8-, 4-, 2- and 1-byte fields
+  unsigned o8, o4, o2, o1;
 };
 
 __device__ __forceinline__ double rad2deg(double a) { return a / M_PI * 180; }  // SRC/vector.cpp:38-40
@@ -95,21 +112,20 @@ __device__ __forceinline__ void score(float amount, float& rew, Lane& L) {
   if (L.points < 0) L.points = 0;
 }
 
-// Hexagon::isInside (SRC/hexagon.cpp:36-48); hex -> 6 x (nx, ny, px, py) in LDS.
-__device__ __forceinline__ bool hex_inside(const double* hex, double x, double y) {
+// Hexagon::isInside (SRC/hexagon.cpp:36-48); e -> 6 x (nx, ny, px, py) in LDS (uniform address: broadcast)
+__device__ __forceinline__ bool hex_inside(const double* e, double x, double y) {
   bool in = true;
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    double nx = hex[4 * i + 0], ny = hex[4 * i + 1];
-    double dx = x - hex[4 * i + 2], dy = y - hex[4 * i + 3];
-    in = in && !(nx * dx + ny * dy < 0);
+    const double dx = x - e[4 * i + 2], dy = y - e[4 * i + 3];
+    in = in & !(e[4 * i + 0] * dx + e[4 * i + 1] * dy < 0);
   }
   return in;
 }
 
 // Game::isOutsideGameArea (SRC/game.cpp:129-131)
 __device__ __forceinline__ bool outside_area(const SfKernelArgs& a, double x, double y) {
-  return x < 0 || x > a.width || y > a.height || y < 0;
+  return (x < 0) | (x > a.width_d) | (y > a.height_d) | (y < 0);
 }
 
 // Game::resetShip (SRC/game.cpp:133-149).  The accepted (x, y, angle) of the rejection loop over
@@ -151,64 +167,64 @@ __device__ __forceinline__ void kill_ship(Lane& L, StatDelta& S) {  // SRC/game.
   }
 }
 
-__device__ __forceinline__ void load_lane(const SfKernelArgs& a, long i, Lane& L) {
-  L.mmask = SF_PTR(a, missile_mask, uint32_t)[i];  // first: the projectile prefetch waits on these
-  L.smask = SF_PTR(a, shell_mask, uint32_t)[i];
-  L.sx = SF_PTR(a, ship_x, double)[i];
-  L.sy = SF_PTR(a, ship_y, double)[i];
-  L.vx = SF_PTR(a, ship_vx, double)[i];
-  L.vy = SF_PTR(a, ship_vy, double)[i];
-  L.angle = SF_PTR(a, ship_angle, int16_t)[i];
-  L.fl = SF_PTR(a, flags, uint8_t)[i];
-  L.death_t = SF_PTR(a, ship_death_timer, int32_t)[i];
-  L.fire_t = SF_PTR(a, fire_timer, int32_t)[i];
-  L.thrust_t = SF_PTR(a, thrust_timer, int32_t)[i];
-  L.left_t = SF_PTR(a, left_timer, int32_t)[i];
-  L.right_t = SF_PTR(a, right_timer, int32_t)[i];
-  L.fort_t = SF_PTR(a, fort_timer, int32_t)[i];
-  L.fort_death_t = SF_PTR(a, fort_death_timer, int32_t)[i];
-  L.fort_vuln_t = SF_PTR(a, fort_vuln_timer, int32_t)[i];
-  L.fort_angle = SF_PTR(a, fort_angle, int16_t)[i];
-  L.fort_last = SF_PTR(a, fort_last_angle, int16_t)[i];
-  L.points = SF_PTR(a, points, float)[i];
-  L.raw = SF_PTR(a, raw_points, float)[i];
-  L.vlner = SF_PTR(a, vlner, int32_t)[i];
-  L.time = SF_PTR(a, time, int32_t)[i];
-  L.prev_vlner = SF_PTR(a, prev_vlner, int32_t)[i];
-  L.cursor = SF_PTR(a, spawn_cursor, uint32_t)[i];
+__device__ __forceinline__ void load_lane(const unsigned char* tb, const Off& o, Lane& L) {
+  L.mmask = SF_LD(uint32_t, SF_BASE(a, missile_mask), o.o4);  // first: the prefetch waits on these
+  L.smask = SF_LD(uint32_t, SF_BASE(a, shell_mask), o.o4);
+  L.sx = SF_LD(double, SF_BASE(a, ship_x), o.o8);
+  L.sy = SF_LD(double, SF_BASE(a, ship_y), o.o8);
+  L.vx = SF_LD(double, SF_BASE(a, ship_vx), o.o8);
+  L.vy = SF_LD(double, SF_BASE(a, ship_vy), o.o8);
+  L.angle = SF_LD(int16_t, SF_BASE(a, ship_angle), o.o2);
+  L.fl = SF_LD(uint8_t, SF_BASE(a, flags), o.o1);
+  L.death_t = SF_LD(int32_t, SF_BASE(a, ship_death_timer), o.o4);
+  L.fire_t = SF_LD(int32_t, SF_BASE(a, fire_timer), o.o4);
+  L.thrust_t = SF_LD(int32_t, SF_BASE(a, thrust_timer), o.o4);
+  L.left_t = SF_LD(int32_t, SF_BASE(a, left_timer), o.o4);
+  L.right_t = SF_LD(int32_t, SF_BASE(a, right_timer), o.o4);
+  L.fort_t = SF_LD(int32_t, SF_BASE(a, fort_timer), o.o4);
+  L.fort_death_t = SF_LD(int32_t, SF_BASE(a, fort_death_timer), o.o4);
+  L.fort_vuln_t = SF_LD(int32_t, SF_BASE(a, fort_vuln_timer), o.o4);
+  L.fort_angle = SF_LD(int16_t, SF_BASE(a, fort_angle), o.o2);
+  L.fort_last = SF_LD(int16_t, SF_BASE(a, fort_last_angle), o.o2);
+  L.points = SF_LD(float, SF_BASE(a, points), o.o4);
+  L.raw = SF_LD(float, SF_BASE(a, raw_points), o.o4);
+  L.vlner = SF_LD(int32_t, SF_BASE(a, vlner), o.o4);
+  L.time = SF_LD(int32_t, SF_BASE(a, time), o.o4);
+  L.prev_vlner = SF_LD(int32_t, SF_BASE(a, prev_vlner), o.o4);
+  L.cursor = SF_LD(uint32_t, SF_BASE(a, spawn_cursor), o.o4);
 }
 
-__device__ __forceinline__ void store_lane(const SfKernelArgs& a, long i, const Lane& L) {
-  SF_PTR(a, ship_x, double)[i] = L.sx;
-  SF_PTR(a, ship_y, double)[i] = L.sy;
-  SF_PTR(a, ship_vx, double)[i] = L.vx;
-  SF_PTR(a, ship_vy, double)[i] = L.vy;
-  SF_PTR(a, ship_angle, int16_t)[i] = (int16_t)L.angle;
-  SF_PTR(a, flags, uint8_t)[i] = (uint8_t)L.fl;
-  SF_PTR(a, ship_death_timer, int32_t)[i] = L.death_t;
-  SF_PTR(a, fire_timer, int32_t)[i] = L.fire_t;
-  SF_PTR(a, thrust_timer, int32_t)[i] = L.thrust_t;
-  SF_PTR(a, left_timer, int32_t)[i] = L.left_t;
-  SF_PTR(a, right_timer, int32_t)[i] = L.right_t;
-  SF_PTR(a, fort_timer, int32_t)[i] = L.fort_t;
-  SF_PTR(a, fort_death_timer, int32_t)[i] = L.fort_death_t;
-  SF_PTR(a, fort_vuln_timer, int32_t)[i] = L.fort_vuln_t;
-  SF_PTR(a, fort_angle, int16_t)[i] = (int16_t)L.fort_angle;
-  SF_PTR(a, fort_last_angle, int16_t)[i] = (int16_t)L.fort_last;
-  SF_PTR(a, points, float)[i] = L.points;
-  SF_PTR(a, raw_points, float)[i] = L.raw;
-  SF_PTR(a, vlner, int32_t)[i] = L.vlner;
-  SF_PTR(a, time, int32_t)[i] = L.time;
-  SF_PTR(a, prev_vlner, int32_t)[i] = L.prev_vlner;
-  SF_PTR(a, missile_mask, uint32_t)[i] = L.mmask;
-  SF_PTR(a, shell_mask, uint32_t)[i] = L.smask;
+__device__ __forceinline__ void store_lane(unsigned char* tb, const Off& o, const Lane& L) {
+  SF_ST(double, SF_BASE(a, ship_x), o.o8, L.sx);
+  SF_ST(double, SF_BASE(a, ship_y), o.o8, L.sy);
+  SF_ST(double, SF_BASE(a, ship_vx), o.o8, L.vx);
+  SF_ST(double, SF_BASE(a, ship_vy), o.o8, L.vy);
+  SF_ST(int16_t, SF_BASE(a, ship_angle), o.o2, (int16_t)L.angle);
+  SF_ST(uint8_t, SF_BASE(a, flags), o.o1, (uint8_t)L.fl);
+  SF_ST(int32_t, SF_BASE(a, ship_death_timer), o.o4, L.death_t);
+  SF_ST(int32_t, SF_BASE(a, fire_timer), o.o4, L.fire_t);
+  SF_ST(int32_t, SF_BASE(a, thrust_timer), o.o4, L.thrust_t);
+  SF_ST(int32_t, SF_BASE(a, left_timer), o.o4, L.left_t);
+  SF_ST(int32_t, SF_BASE(a, right_timer), o.o4, L.right_t);
+  SF_ST(int32_t, SF_BASE(a, fort_timer), o.o4, L.fort_t);
+  SF_ST(int32_t, SF_BASE(a, fort_death_timer), o.o4, L.fort_death_t);
+  SF_ST(int32_t, SF_BASE(a, fort_vuln_timer), o.o4, L.fort_vuln_t);
+  SF_ST(int16_t, SF_BASE(a, fort_angle), o.o2, (int16_t)L.fort_angle);
+  SF_ST(int16_t, SF_BASE(a, fort_last_angle), o.o2, (int16_t)L.fort_last);
+  SF_ST(float, SF_BASE(a, points), o.o4, L.points);
+  SF_ST(float, SF_BASE(a, raw_points), o.o4, L.raw);
+  SF_ST(int32_t, SF_BASE(a, vlner), o.o4, L.vlner);
+  SF_ST(int32_t, SF_BASE(a, time), o.o4, L.time);
+  SF_ST(int32_t, SF_BASE(a, prev_vlner), o.o4, L.prev_vlner);
+  SF_ST(uint32_t, SF_BASE(a, missile_mask), o.o4, L.mmask);
+  SF_ST(uint32_t, SF_BASE(a, shell_mask), o.o4, L.smask);
 }
 
-__device__ __forceinline__ void zero_counters(const SfKernelArgs& a, long i) {
+__device__ __forceinline__ void zero_counters(unsigned char* tb, const Off& o) {
 #pragma unroll
-  for (int k = 0; k < SF_NSTAT; k++) SF_PTR(a, stats, int32_t)[k * a.lanes + i] = 0;
-  SF_PTR(a, ep_return, int32_t)[i] = 0;
-  SF_PTR(a, ep_kills, int32_t)[i] = 0;
+  for (int k = 0; k < SF_NSTAT; k++) SF_ST(int32_t, SF_SLOT(a, stats, int32_t, k), o.o4, 0);
+  SF_ST(int32_t, SF_BASE(a, ep_return), o.o4, 0);
+  SF_ST(int32_t, SF_BASE(a, ep_kills), o.o4, 0);
 }
 
 // ExtraGameValues of Game::computeExtra (SRC/game.cpp:282-312).  They are a pure function of the
@@ -229,7 +245,7 @@ __device__ __forceinline__ Extras compute_extras(const SfKernelArgs& a, const La
   // atan2(-(fy-sy), fx-sx) = atan2(dy, -dx) = +-pi - a_pos: derived from a_pos (observation-only
   // value, differs from a second libm call by <= 1 ulp of pi).
   {
-    double dy = L.sy - a.fort_y;
+    const double dy = L.sy - a.fort_y;
     double ov;
     if (dy == 0)  // on the fortress row the two calls sit on different branch cuts: call it
       ov = atan2(-(a.fort_y - L.sy), a.fort_x - L.sx);
@@ -242,7 +258,7 @@ __device__ __forceinline__ Extras compute_extras(const SfKernelArgs& a, const La
   }
   // fdist, ndist (SRC/game.cpp:310-311): the y term of the reference subtracts the ship from
   // itself, so fdist = sqrt(dx^2 + 0) = |dx|.
-  double fdist = fabs(L.sx - a.fort_x);
+  const double fdist = fabs(L.sx - a.fort_x);
   e.ndist = -1 + (fdist - a.ndist_a) / a.ndist_b;
   return e;
 }
@@ -356,20 +372,23 @@ __device__ __forceinline__ void flush_obs_block(const SfKernelArgs& a, const T* 
 // initialises what SSF_Env.__init__ sets once (prev_vlner, ENV:92) and the spawn cursors.
 __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int first, unsigned cursor0,
                                                            unsigned cursor_stride, void* obs) {
-  const long i = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
+  const unsigned i = blockIdx.x * SF_BLOCK + threadIdx.x;
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned char* const tb = a.state + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * sfl::kTileBytes;
+  const Off o = {lane * 8u, lane * 4u, lane * 2u, lane};
   Lane L;
   if (first) {
     L.prev_vlner = 0;
-    L.cursor = cursor0 + cursor_stride * (unsigned)i;
+    L.cursor = cursor0 + cursor_stride * i;
   } else {
-    L.prev_vlner = SF_PTR(a, prev_vlner, int32_t)[i];
-    L.cursor = SF_PTR(a, spawn_cursor, uint32_t)[i];
+    L.prev_vlner = SF_LD(int32_t, SF_BASE(a, prev_vlner), o.o4);
+    L.cursor = SF_LD(uint32_t, SF_BASE(a, spawn_cursor), o.o4);
   }
   new_game(a, L);
-  store_lane(a, i, L);
-  SF_PTR(a, spawn_cursor, uint32_t)[i] = L.cursor;
-  zero_counters(a, i);
-  if (obs != nullptr && i < a.n_envs && a.obs_type != 3) {
+  store_lane(tb, o, L);
+  SF_ST(uint32_t, SF_BASE(a, spawn_cursor), o.o4, L.cursor);
+  zero_counters(tb, o);
+  if (obs != nullptr && i < (unsigned)a.n_envs && a.obs_type != 3) {
     // the reference's extras are stale heap until the first tick; defined as computeExtra(spawn)
     Extras e = compute_extras(a, L, atan2(L.sy - a.fort_y, L.sx - a.fort_x), atan2(L.vy, L.vx));
     if (a.obs_f64)
@@ -384,10 +403,15 @@ template <bool AUTOTURN>
 __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const void* actions, int act_type,
                                                           void* obs, int obs_vec_ok, int32_t* reward_out,
                                                           uint8_t* done_out, uint8_t* info_out) {
-  extern __shared__ double lds[];  // [SF_LDS_DOUBLES] constants, then the obs staging rows
-  const int tid = threadIdx.x;
-  const long i = (long)blockIdx.x * SF_BLOCK + tid;
-  const bool real = i < a.n_envs;  // lanes in [n_envs, lanes) are padding: they run NOOPs
+  extern __shared__ double lds[];  // [SF_LDS_DOUBLES] cos/sin table, then the obs staging rows
+  const unsigned tid = threadIdx.x;
+  const unsigned i = blockIdx.x * SF_BLOCK + tid;  // env index: actions and outputs
+  const unsigned lane = tid & 63u;
+  // this wave's tile: wave-uniform by construction, made scalar for the compiler
+  unsigned char* const tb = a.state + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * sfl::kTileBytes;
+  const Off o = {lane * 8u, lane * 4u, lane * 2u, lane};  // lane offsets inside the tile's rows
+  const Off g = {i * 8u, i * 4u, i * 2u, i};              // env offsets into the caller's arrays
+  const bool real = i < (unsigned)a.n_envs;  // lanes in [n_envs, lanes) are padding: they run NOOPs
 #ifdef SF_STAMPS
   unsigned long long stamp_[16];
   stamp_[12] = __builtin_amdgcn_s_memrealtime();
@@ -397,69 +421,77 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   // ================= round trip 1: every unconditional load =================
   int act = 0;
   if (real) {  // ENV:211-212
+    const unsigned char* ab = (const unsigned char*)actions;
     if (act_type == 8)
-      act = (int)((const long long*)actions)[i];
+      act = (int)SF_LD(long long, ab, g.o8);
     else if (act_type == 4)
-      act = ((const int*)actions)[i];
+      act = SF_LD(int, ab, g.o4);
     else
-      act = ((const unsigned char*)actions)[i];
+      act = SF_LD(unsigned char, ab, g.o1);
   }
   Lane L;
-  load_lane(a, i, L);
-  // the constant block: SF_LDS_DOUBLES == 3 * SF_BLOCK
-  const double c0 = a.consts[tid], c1 = a.consts[tid + SF_BLOCK], c2 = a.consts[tid + 2 * SF_BLOCK];
+  load_lane(tb, o, L);
+  // constant block (cos/sin table + hexagon edges): SF_LDS_DOUBLES = 3 doubles per thread
+  const unsigned char* cb = (const unsigned char*)a.consts;
+  const double c0 = SF_LD(double, cb, tid * 8u), c1 = SF_LD(double, cb, (tid + SF_BLOCK) * 8u);
+  const double c2 = SF_LD(double, cb, (tid + 2 * SF_BLOCK) * 8u);
   SF_STAMP(1, false);
   SF_STAMP(2, true);
 
   // ================= round trip 2: live projectile slots, predicated by the alive masks ======
+  // Slot groups {0,1} {2,3} {4..7}: a wave ballot skips a group no lane uses.
   double mx[SF_MPF], my[SF_MPF];
   int mang[SF_MPF];
   double shx[SF_SPF], shy[SF_SPF], shvx[SF_SPF], shvy[SF_SPF];
+#pragma unroll
+  for (int s = 0; s < SF_MPF; s++) {
+    mx[s] = 0;
+    my[s] = 0;
+    mang[s] = 0;
+  }
+#pragma unroll
+  for (int s = 0; s < SF_SPF; s++) shx[s] = shy[s] = shvx[s] = shvy[s] = 0;
   {
-    const double* gx = SF_PTR(a, missile_x, double);
-    const double* gy = SF_PTR(a, missile_y, double);
-    const int16_t* ga = SF_PTR(a, missile_angle, int16_t);
-#pragma unroll
-    for (int s = 0; s < SF_MPF; s++) {
-      const bool live = (L.mmask >> s) & 1u;
-      mx[s] = 0;
-      my[s] = 0;
-      mang[s] = 0;
-      if (__ballot(live) != 0ull) {  // some lane of this wave uses slot s
-        if (live) {
-          const long idx = (long)s * a.lanes + i;
-          mx[s] = gx[idx];
-          my[s] = gy[idx];
-          mang[s] = ga[idx];
-        }
+    auto m_load = [&](int s) __attribute__((always_inline)) {
+      if ((L.mmask >> s) & 1u) {
+        mx[s] = SF_LD(double, SF_SLOT(a, missile_x, double, s), o.o8);
+        my[s] = SF_LD(double, SF_SLOT(a, missile_y, double, s), o.o8);
+        mang[s] = SF_LD(int16_t, SF_SLOT(a, missile_angle, int16_t, s), o.o2);
       }
+    };
+    if (__ballot((L.mmask & 0x03u) != 0u) != 0ull) {
+      m_load(0);
+      m_load(1);
     }
-    const double* hx = SF_PTR(a, shell_x, double);
-    const double* hy = SF_PTR(a, shell_y, double);
-    const double* hvx = SF_PTR(a, shell_vx, double);
-    const double* hvy = SF_PTR(a, shell_vy, double);
+    if (__ballot((L.mmask & 0x0Cu) != 0u) != 0ull) {
+      m_load(2);
+      m_load(3);
+    }
+    if (__ballot((L.mmask & 0xF0u) != 0u) != 0ull) {
+      m_load(4);
+      m_load(5);
+      m_load(6);
+      m_load(7);
+    }
+    if (__ballot((L.smask & 0x07u) != 0u) != 0ull) {
 #pragma unroll
-    for (int s = 0; s < SF_SPF; s++) {
-      const bool live = (L.smask >> s) & 1u;
-      shx[s] = shy[s] = shvx[s] = shvy[s] = 0;
-      if (__ballot(live) != 0ull) {
-        if (live) {
-          const long idx = (long)s * a.lanes + i;
-          shx[s] = hx[idx];
-          shy[s] = hy[idx];
-          shvx[s] = hvx[idx];
-          shvy[s] = hvy[idx];
+      for (int s = 0; s < SF_SPF; s++) {
+        if ((L.smask >> s) & 1u) {
+          shx[s] = SF_LD(double, SF_SLOT(a, shell_x, double, s), o.o8);
+          shy[s] = SF_LD(double, SF_SLOT(a, shell_y, double, s), o.o8);
+          shvx[s] = SF_LD(double, SF_SLOT(a, shell_vx, double, s), o.o8);
+          shvy[s] = SF_LD(double, SF_SLOT(a, shell_vy, double, s), o.o8);
         }
       }
     }
   }
 
-  // constants -> LDS (the loads were issued in round trip 1)
+  // cos/sin table -> LDS (the loads were issued in round trip 1)
   lds[tid] = c0;
   lds[tid + SF_BLOCK] = c1;
   lds[tid + 2 * SF_BLOCK] = c2;
   __syncthreads();
-  const double* trig = lds + SF_LDS_TRIG;
+  const double* trig = lds;
   SF_STAMP(3, false);
 
   if (act < 0 || act >= a.n_actions) {
@@ -609,141 +641,185 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       }
     }
   }
-
   SF_STAMP(4, false);
   SF_STAMP(5, true);
-  // ---- updateShells (SRC/game.cpp:404-423), slot order
+
+  // ---- updateShells (SRC/game.cpp:404-423).  Ballistics of the prefetched slots first, as
+  //      straight-line code; then the (ship-alive dependent) outcome in slot order.
   {
-    double* px = SF_PTR(a, shell_x, double);
-    double* py = SF_PTR(a, shell_y, double);
-    double* pvx = SF_PTR(a, shell_vx, double);
-    double* pvy = SF_PTR(a, shell_vy, double);
-    auto shell_step = [&](int s, double x, double y, double vx, double vy, bool isnew) __attribute__((always_inline)) {
-      const long idx = (long)s * a.lanes + i;
-      if (isnew) {
-        pvx[idx] = vx;
-        pvy[idx] = vy;
-      }
-      x += vx;
-      y += vy;
-      bool dead = false;
-      if (L.fl & SF_FL_SHIP_ALIVE) {
+    if (__ballot((L.smask & 0x07u) != 0u) != 0ull) {
+      unsigned col = 0, out = 0;
+      double nx[SF_SPF], ny[SF_SPF];
+#pragma unroll
+      for (int s = 0; s < SF_SPF; s++) {
+        const bool isnew = (s == new_s_slot);
+        const double vx = isnew ? new_s_vx : shvx[s], vy = isnew ? new_s_vy : shvy[s];
+        nx[s] = (isnew ? a.fort_x : shx[s]) + vx;
+        ny[s] = (isnew ? a.fort_y : shy[s]) + vy;
         // Object::collided (SRC/object.cpp:12-15): sqrt(dx^2+dy^2) <= r.  With a correctly
         // rounded sqrt and r an integer, RN(sqrt(s)) <= r  <=>  s <= r^2 (r^2 is exactly
         // representable and the next double above r^2 has a root that rounds above r).
-        double dx = x - L.sx, dy = y - L.sy;
-        if (dx * dx + dy * dy <= a.shell_hit_r2) {
-          dead = true;
-          kill_ship(L, S);
-          score(-a.death_penalty, rew, L);
-          S.shell_deaths += 1;
+        const double dx = nx[s] - L.sx, dy = ny[s] - L.sy;
+        col |= (unsigned)(dx * dx + dy * dy <= a.shell_hit_r2) << s;
+        out |= (unsigned)outside_area(a, nx[s], ny[s]) << s;
+        if (isnew) {
+          SF_ST(double, SF_SLOT(a, shell_vx, double, s), o.o8, vx);
+          SF_ST(double, SF_SLOT(a, shell_vy, double, s), o.o8, vy);
         }
       }
-      if (!dead && outside_area(a, x, y)) dead = true;
-      if (dead) {
-        L.smask &= ~(1u << s);
-      } else {
-        px[idx] = x;
-        py[idx] = y;
+      const unsigned live = L.smask & 0x07u;
+      col &= live;
+      // slot order: the first colliding shell kills a live ship; every other shell only
+      // leaves by flying out (`if (alive && collided) ... else if (outside)`, :410-420)
+      unsigned dead = out & live;
+      if ((L.fl & SF_FL_SHIP_ALIVE) && col) {
+        const unsigned k = col & (0u - col);  // lowest colliding slot
+        dead |= k;
+        kill_ship(L, S);
+        score(-a.death_penalty, rew, L);
+        S.shell_deaths += 1;
       }
-    };
+      L.smask &= ~dead;
 #pragma unroll
-    for (int s = 0; s < SF_SPF; s++) {
-      const bool live = (L.smask >> s) & 1u;
-      if (__ballot(live) == 0ull) continue;
-      if (live) {
-        const bool isnew = (s == new_s_slot);
-        shell_step(s, isnew ? a.fort_x : shx[s], isnew ? a.fort_y : shy[s], isnew ? new_s_vx : shvx[s],
-                   isnew ? new_s_vy : shvy[s], isnew);
+      for (int s = 0; s < SF_SPF; s++) {
+        if ((L.smask >> s) & 1u) {
+          SF_ST(double, SF_SLOT(a, shell_x, double, s), o.o8, nx[s]);
+          SF_ST(double, SF_SLOT(a, shell_y, double, s), o.o8, ny[s]);
+        }
       }
     }
     if (__ballot((L.smask >> SF_SPF) != 0u) != 0ull) {  // rare: more than SF_SPF shells in some lane
+#pragma unroll 1
       for (int s = SF_SPF; s < SF_NSLOT; s++) {
         const bool live = (L.smask >> s) & 1u;
         if (__ballot(live) == 0ull) continue;
         if (live) {
-          const long idx = (long)s * a.lanes + i;
-          if (s == new_s_slot)
-            shell_step(s, a.fort_x, a.fort_y, new_s_vx, new_s_vy, true);
-          else
-            shell_step(s, px[idx], py[idx], pvx[idx], pvy[idx], false);
+          double x, y, vx, vy;
+          if (s == new_s_slot) {
+            x = a.fort_x;
+            y = a.fort_y;
+            vx = new_s_vx;
+            vy = new_s_vy;
+            SF_ST(double, SF_SLOT(a, shell_vx, double, s), o.o8, vx);
+            SF_ST(double, SF_SLOT(a, shell_vy, double, s), o.o8, vy);
+          } else {
+            x = SF_LD(double, SF_SLOT(a, shell_x, double, s), o.o8);
+            y = SF_LD(double, SF_SLOT(a, shell_y, double, s), o.o8);
+            vx = SF_LD(double, SF_SLOT(a, shell_vx, double, s), o.o8);
+            vy = SF_LD(double, SF_SLOT(a, shell_vy, double, s), o.o8);
+          }
+          x += vx;
+          y += vy;
+          bool dead = false;
+          if (L.fl & SF_FL_SHIP_ALIVE) {
+            const double dx = x - L.sx, dy = y - L.sy;
+            if (dx * dx + dy * dy <= a.shell_hit_r2) {
+              dead = true;
+              kill_ship(L, S);
+              score(-a.death_penalty, rew, L);
+              S.shell_deaths += 1;
+            }
+          }
+          if (!dead && outside_area(a, x, y)) dead = true;
+          if (dead) {
+            L.smask &= ~(1u << s);
+          } else {
+            SF_ST(double, SF_SLOT(a, shell_x, double, s), o.o8, x);
+            SF_ST(double, SF_SLOT(a, shell_y, double, s), o.o8, y);
+          }
         }
       }
     }
   }
 
-  // ---- updateMissiles (SRC/game.cpp:353-402), slot order
+  // ---- updateMissiles (SRC/game.cpp:353-402).  Ballistics per slot are independent; what a hit
+  //      or a miss does to the fortress / score is order dependent, so the events are collected
+  //      as bitmasks and replayed in slot order afterwards.
   {
-    double* px = SF_PTR(a, missile_x, double);
-    double* py = SF_PTR(a, missile_y, double);
-    int16_t* pa = SF_PTR(a, missile_angle, int16_t);
-    auto missile_step = [&](int s, double x, double y, int ang, bool isnew) __attribute__((always_inline)) {
-      const long idx = (long)s * a.lanes + i;
-      if (isnew) pa[idx] = (int16_t)ang;
+    unsigned ev_hit = 0, ev_out = 0;
+    auto m_move = [&](int s, double x, double y, int ang, bool isnew) __attribute__((always_inline)) {
       // velocity = missileSpeed * (cos, sin)(deg2rad(angle)) with an integer angle: table
-      x += a.missile_speed * trig[2 * ang];
-      y += a.missile_speed * trig[2 * ang + 1];
-      double dx = x - a.fort_x, dy = y - a.fort_y;
-      bool dead = false;
-      if (dx * dx + dy * dy <= a.missile_hit_r2) {  // collided(mFortress), see the shell note
-        dead = true;
-        if (L.fl & SF_FL_FORT_ALIVE) {
-          if (L.fort_vuln_t >= a.vuln_time) {
-            L.vlner += 1;
-            S.vlner_incs += 1;
-            if (L.vlner > S.max_vlner) S.max_vlner = L.vlner;
-          } else {
-            const int destroy = L.vlner >= a.vuln_threshold + 1;
-            if (destroy) {
-              L.fl &= ~SF_FL_FORT_ALIVE;
-              L.fort_death_t = 0;
-              score(a.destroy_reward, rew, L);
-            }
-            // branch-free on purpose: `if (c) destroyed++; else resets++;` gets merged into a
-            // store through a selected address, which forces the counters into scratch memory
-            S.destroyed += destroy;
-            S.resets += 1 - destroy;
-            L.vlner = 0;
-          }
-          L.fort_vuln_t = 0;
-        }
-      } else if (outside_area(a, x, y)) {
-        dead = true;
-        score(-a.miss_penalty, rew, L);
-        S.missed += 1;
-      }
-      if (dead) {
-        L.mmask &= ~(1u << s);
-      } else {
-        px[idx] = x;
-        py[idx] = y;
-      }
-    };
-#pragma unroll
-    for (int s = 0; s < SF_MPF; s++) {
+      const double nx = x + a.missile_speed * trig[2 * ang];
+      const double ny = y + a.missile_speed * trig[2 * ang + 1];
+      const double dx = nx - a.fort_x, dy = ny - a.fort_y;
       const bool live = (L.mmask >> s) & 1u;
-      if (__ballot(live) == 0ull) continue;
-      if (live) {
-        const bool isnew = (s == new_m_slot);
-        missile_step(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], isnew ? new_m_angle : mang[s], isnew);
+      const bool hit = live & (dx * dx + dy * dy <= a.missile_hit_r2);  // collided(mFortress), see shells
+      const bool out = live & !hit & outside_area(a, nx, ny);
+      ev_hit |= (unsigned)hit << s;
+      ev_out |= (unsigned)out << s;
+      if (live & !hit & !out) {
+        SF_ST(double, SF_SLOT(a, missile_x, double, s), o.o8, nx);
+        SF_ST(double, SF_SLOT(a, missile_y, double, s), o.o8, ny);
       }
+      if (isnew) SF_ST(int16_t, SF_SLOT(a, missile_angle, int16_t, s), o.o2, (int16_t)ang);
+    };
+    auto m_pref = [&](int s) __attribute__((always_inline)) {
+      const bool isnew = (s == new_m_slot);
+      m_move(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], isnew ? new_m_angle : mang[s], isnew);
+    };
+    if (__ballot((L.mmask & 0x03u) != 0u) != 0ull) {
+      m_pref(0);
+      m_pref(1);
+    }
+    if (__ballot((L.mmask & 0x0Cu) != 0u) != 0ull) {
+      m_pref(2);
+      m_pref(3);
+    }
+    if (__ballot((L.mmask & 0xF0u) != 0u) != 0ull) {
+      m_pref(4);
+      m_pref(5);
+      m_pref(6);
+      m_pref(7);
     }
     if (__ballot((L.mmask >> SF_MPF) != 0u) != 0ull) {  // rare: a lane with more than SF_MPF missiles
+#pragma unroll 1
       for (int s = SF_MPF; s < SF_NSLOT; s++) {
         const bool live = (L.mmask >> s) & 1u;
         if (__ballot(live) == 0ull) continue;
         if (live) {
-          const long idx = (long)s * a.lanes + i;
           if (s == new_m_slot)
-            missile_step(s, new_m_x, new_m_y, new_m_angle, true);
+            m_move(s, new_m_x, new_m_y, new_m_angle, true);
           else
-            missile_step(s, px[idx], py[idx], pa[idx], false);
+            m_move(s, SF_LD(double, SF_SLOT(a, missile_x, double, s), o.o8),
+                   SF_LD(double, SF_SLOT(a, missile_y, double, s), o.o8),
+                   SF_LD(int16_t, SF_SLOT(a, missile_angle, int16_t, s), o.o2), false);
+        }
+      }
+    }
+    unsigned ev = ev_hit | ev_out;
+    L.mmask &= ~ev;
+    if (__ballot(ev != 0u) != 0ull) {
+      while (ev) {  // slot order (SRC/game.cpp:355)
+        const unsigned bit = ev & (0u - ev);
+        ev &= ~bit;
+        if (ev_hit & bit) {
+          if (L.fl & SF_FL_FORT_ALIVE) {
+            if (L.fort_vuln_t >= a.vuln_time) {
+              L.vlner += 1;
+              S.vlner_incs += 1;
+              if (L.vlner > S.max_vlner) S.max_vlner = L.vlner;
+            } else {
+              const int destroy = L.vlner >= a.vuln_threshold + 1;
+              if (destroy) {
+                L.fl &= ~SF_FL_FORT_ALIVE;
+                L.fort_death_t = 0;
+                score(a.destroy_reward, rew, L);
+              }
+              S.destroyed += destroy;
+              S.resets += 1 - destroy;
+              L.vlner = 0;
+            }
+            L.fort_vuln_t = 0;
+          }
+        } else {
+          score(-a.miss_penalty, rew, L);
+          S.missed += 1;
         }
       }
     }
   }
-
   SF_STAMP(6, false);
+
   // ---- stepTimers (SRC/game.cpp:425-451)
   L.fort_t += a.tick_ms;
   L.fort_death_t += a.tick_ms;
@@ -768,13 +844,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   const int done = L.time >= a.game_time;  // Game::isGameOver (SRC/game.cpp:487-489)
 
   // ================= statistics and the vec-env worker's auto-reset (rl/train.py:80-88) ======
-  int32_t* gstats = SF_PTR(a, stats, int32_t);
   if (done && a.auto_reset) {
     // episode totals = what previous launches accumulated + this tick's share
-    const int ep_ret = SF_PTR(a, ep_return, int32_t)[i] + r;
-    const int ep_kil = SF_PTR(a, ep_kills, int32_t)[i] + fort_kill;
-    const int deaths = gstats[SF_ST_SHIP_DEATHS * a.lanes + i] + S.ship_deaths;
-    const int shots = gstats[SF_ST_SHOTS * a.lanes + i] + S.shots;
+    const int ep_ret = SF_LD(int32_t, SF_BASE(a, ep_return), o.o4) + r;
+    const int ep_kil = SF_LD(int32_t, SF_BASE(a, ep_kills), o.o4) + fort_kill;
+    const int deaths = SF_LD(int32_t, SF_SLOT(a, stats, int32_t, SF_ST_SHIP_DEATHS), o.o4) + S.ship_deaths;
+    const int shots = SF_LD(int32_t, SF_SLOT(a, stats, int32_t, SF_ST_SHOTS), o.o4) + S.shots;
     if (real) {
       atomicAdd(&a.acc[0], 1ull);
       atomicAdd(&a.acc[1], (unsigned long long)(long long)ep_ret);
@@ -786,14 +861,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       atomicMax((long long*)&a.acc[7], (long long)ep_ret);
     }
     new_game(a, L);
-    zero_counters(a, i);
+    zero_counters(tb, o);
     a_pos = atan2(L.sy - a.fort_y, L.sx - a.fort_x);
     a_vel = atan2(L.vy, L.vx);
   } else {
     // no-return atomics, executed at the memory side: the counters are never loaded
-#define SF_FLUSH(idx, v)                                        \
-  if (__ballot((v) != 0) != 0ull) {                             \
-    if ((v) != 0) atomicAdd(&gstats[(idx)*a.lanes + i], (v));   \
+#define SF_FLUSH(idx, v)                                                                      \
+  if (__ballot((v) != 0) != 0ull) {                                                           \
+    if ((v) != 0) atomicAdd(reinterpret_cast<int*>(SF_SLOT(a, stats, int32_t, idx) + o.o4), (v)); \
   }
     SF_FLUSH(SF_ST_BIG_HEX_DEATHS, S.big_hex_deaths)
     SF_FLUSH(SF_ST_SMALL_HEX_DEATHS, S.small_hex_deaths)
@@ -809,23 +884,24 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     SF_FLUSH(SF_ST_VLNER_INCS, S.vlner_incs)
 #undef SF_FLUSH
     if (__ballot(S.max_vlner != 0) != 0ull) {
-      if (S.max_vlner != 0) atomicMax(&gstats[SF_ST_MAX_VLNER * a.lanes + i], S.max_vlner);
+      if (S.max_vlner != 0)
+        atomicMax(reinterpret_cast<int*>(SF_SLOT(a, stats, int32_t, SF_ST_MAX_VLNER) + o.o4), S.max_vlner);
     }
     if (__ballot(r != 0) != 0ull) {
-      if (r != 0) atomicAdd(&SF_PTR(a, ep_return, int32_t)[i], r);
+      if (r != 0) atomicAdd(reinterpret_cast<int*>(SF_BASE(a, ep_return) + o.o4), r);
     }
     if (__ballot(fort_kill != 0) != 0ull) {
-      if (fort_kill) atomicAdd(&SF_PTR(a, ep_kills, int32_t)[i], 1);
+      if (fort_kill) atomicAdd(reinterpret_cast<int*>(SF_BASE(a, ep_kills) + o.o4), 1);
     }
   }
 
-  store_lane(a, i, L);
-  if (__ballot(L.cursor != cursor0) != 0ull) SF_PTR(a, spawn_cursor, uint32_t)[i] = L.cursor;
+  store_lane(tb, o, L);
+  if (__ballot(L.cursor != cursor0) != 0ull) SF_ST(uint32_t, SF_BASE(a, spawn_cursor), o.o4, L.cursor);
 
   if (real) {
-    if (reward_out) reward_out[i] = r;
-    if (done_out) done_out[i] = (uint8_t)done;
-    if (info_out) info_out[i] = (uint8_t)fort_kill;
+    if (reward_out) SF_ST(int32_t, (unsigned char*)reward_out, g.o4, r);
+    if (done_out) SF_ST(uint8_t, (unsigned char*)done_out, g.o1, (uint8_t)done);
+    if (info_out) SF_ST(uint8_t, (unsigned char*)info_out, g.o1, (uint8_t)fort_kill);
   }
   SF_STAMP(7, false);
   if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid
@@ -853,6 +929,47 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     for (int k = 0; k < 14; k++) d[k] = (k < 10 || k >= 12) ? stamp_[k] : 0ull;
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// sf_get_field / sf_set_field: one field between the tiled state and a linear [count][n_envs]
+// buffer (not on the hot path).
+template <typename T>
+__global__ __launch_bounds__(SF_BLOCK) void sf_field_copy_kernel(unsigned char* state, int n_envs, long off_per_lane,
+                                                                int count, T* linear, int to_linear) {
+  const long e = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
+  if (e >= n_envs) return;
+  T* tile = reinterpret_cast<T*>(state + (e >> 6) * sfl::kTileBytes + off_per_lane * sfl::kTileLanes) + (e & 63);
+  for (int c = 0; c < count; c++) {
+    if (to_linear)
+      linear[(long)c * n_envs + e] = tile[(long)c * sfl::kTileLanes];
+    else
+      tile[(long)c * sfl::kTileLanes] = linear[(long)c * n_envs + e];
+  }
+}
+
+hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, long off, int elem_size, int count,
+                                unsigned char* linear, int to_linear, hipStream_t stream) {
+  const unsigned grid = (unsigned)((n_envs + SF_BLOCK - 1) / SF_BLOCK);
+  switch (elem_size) {
+    case 1:
+      hipLaunchKernelGGL(sf_field_copy_kernel<uint8_t>, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, off,
+                         count, (uint8_t*)linear, to_linear);
+      break;
+    case 2:
+      hipLaunchKernelGGL(sf_field_copy_kernel<uint16_t>, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, off,
+                         count, (uint16_t*)linear, to_linear);
+      break;
+    case 4:
+      hipLaunchKernelGGL(sf_field_copy_kernel<uint32_t>, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, off,
+                         count, (uint32_t*)linear, to_linear);
+      break;
+    default:
+      hipLaunchKernelGGL(sf_field_copy_kernel<uint64_t>, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, off,
+                         count, (uint64_t*)linear, to_linear);
+      break;
+  }
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

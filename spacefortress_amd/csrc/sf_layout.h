@@ -1,11 +1,17 @@
 // sf_layout.h -- world state of a batch in HBM, shared by the kernels and the C-ABI host code.
 //
-// Struct-of-arrays: every field is one array [count][lanes] (slot-major for the
-// per-projectile fields), all carved from ONE allocation.  Field k starts at byte
-// offset kOffsetPerLane[k] * lanes, where lanes is the batch size padded to a
-// multiple of 256, so every array starts 256-B aligned and lane i of a wave
-// reads base + i*elem: fully coalesced.  The reference keeps the same data as one
-// 2568-byte `Game` object per env (SRC/game.hh:84-143).
+// Struct-of-arrays per WAVE TILE: the batch is cut into tiles of 64 envs (one wavefront);
+// a tile is one contiguous block of kTileBytes holding, field after field, the 64 lanes'
+// values: [field][slot][64 lanes].  So
+//   * lane l of a wave reads  tile_base + C(field, slot) + l*elem : 64 consecutive elements,
+//     a fully coalesced row of 64*elem bytes, aligned to its own size;
+//   * C(field, slot) is a COMPILE-TIME constant: the whole state of a wave is addressed from
+//     one scalar base (an SGPR pair) plus one per-lane byte offset per element size -- no
+//     per-field base arithmetic (the first, batch-wide SoA version of this kernel spent a
+//     quarter of its instructions on 64-bit address math and SGPR spills);
+//   * a wave's working set is one 74 KB block: page- and channel-local.
+// The batch is padded to a multiple of 256 envs (4 tiles = one workgroup).  The reference keeps
+// the same data as one 2568-byte `Game` object per env (SRC/game.hh:84-143).
 #pragma once
 #include <stdint.h>
 
@@ -89,16 +95,24 @@ constexpr long offset_per_lane(int f) {
   return o;
 }
 constexpr long kBytesPerLane = offset_per_lane(SF_F_COUNT);
+constexpr int kTileLanes = 64;                          // one wavefront
+constexpr long kTileBytes = kBytesPerLane * kTileLanes;  // 74 432 B
+// byte offset, inside a tile, of lane 0 of (field f, slot s)
+constexpr long tile_offset(int f, int s = 0) {
+  return offset_per_lane(f) * kTileLanes + (long)s * kTileLanes * kFields[f].elem_size;
+}
 }  // namespace sfl
 
-// Constant block staged into LDS by every workgroup (doubles):
-//   [0, 720)    cos/sin(deg2rad(k)) interleaved, k = 0..359
+// Host-built constant block (doubles):
+//   [0, 720)    cos/sin(deg2rad(k)) interleaved, k = 0..359 -- indexed per lane, so every
+//               workgroup stages it into LDS (SF_LDS_DOUBLES)
 //   [720, 744)  big hexagon: per edge (nx, ny, px, py)   SRC/hexagon.cpp:36-48
-//   [744, 768)  small hexagon, same
+//   [744, 768)  small hexagon, same -- uniform, so they travel as kernel arguments (SGPRs)
 #define SF_LDS_TRIG 0
 #define SF_LDS_BIGHEX 720
 #define SF_LDS_SMALLHEX 744
-#define SF_LDS_DOUBLES 768
+#define SF_CONST_DOUBLES 768
+#define SF_LDS_DOUBLES 768 /* the whole block is staged: exactly 3 doubles per thread of a 256-block */
 
 // Everything the kernels need that is uniform across lanes; passed by value (kernarg -> SGPRs).
 struct SfKernelArgs {
@@ -119,6 +133,7 @@ struct SfKernelArgs {
   double ship_accel, start_vx, start_vy;
   double missile_hit_r2, shell_hit_r2; // (r1+r2)^2: see sf_kernels.hip on the sqrt-free test
   double fort_x, fort_y;
+  double width_d, height_d;  // width/height as the doubles the comparisons promote them to
   double ndist_a, ndist_b;   // small_hex and (big_hex-small_hex)/2.0 of normDist (SRC/game.cpp:282-284)
   // observation
   int obs_type, obs_f64, real_shell_count, obs_dim, auto_reset;
