@@ -90,6 +90,7 @@ def main():
     import torch
 
     from spacefortress_amd import SFVecEnv
+    from spacefortress_amd.stats import reduce_episode_stats, summarize
 
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
     torch.cuda.set_device(local_rank)
@@ -125,9 +126,8 @@ def main():
     for t in range(args.steps):
         env.step_tensors(actions[t % ring])
     ev1.record()
-    stats = torch.from_numpy(env.episode_stats()[:6].copy()).to(dev)  # syncs this rank's stream
-    if dist is not None:
-        dist.all_reduce(stats)  # RCCL: the only collective of the path (episode statistics)
+    stats = torch.from_numpy(env.episode_stats()).to(dev)  # syncs this rank's stream
+    stats = reduce_episode_stats(stats)  # RCCL over xGMI: the only collective of the path (64 bytes)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -181,8 +181,7 @@ def main():
                          "kernel_ms_event_pair_mean": kern_ms, "kernel_ms_event_pair_median": kern_ms_med,
                          "algorithmic_bytes_per_launch": algo, "launches_timed": k},
             "cpu_baseline": base,
-            "episode_stats": {"episodes": int(stats[0]), "sum_return": int(stats[1]), "fort_kills": int(stats[3]),
-                              "ship_deaths": int(stats[4]), "shots": int(stats[5])},
+            "episode_stats": summarize(stats.cpu()),
         }
         print(json.dumps(out))
     if dist is not None:

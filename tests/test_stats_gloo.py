@@ -1,0 +1,103 @@
+"""The N > 1 path on CPU: two `gloo` processes, each owning a contiguous lane shard (the oracle
+plays the shard here -- on GPUs it is an SFVecEnv per rank), accumulate the episode-statistics
+vector the kernel keeps on the device, and all-reduce it exactly as bench.py / a trainer does
+with RCCL.  The reduced vector must equal the single-process statistics of the whole batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+TOTAL, T = 10, 5295 + 5
+
+
+def episode_vector(gametype, lanes, actions):
+    """What libsfmi accumulates (sfmi.h: sf_episode_stats) for the lanes [lo, hi) of the batch."""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+
+    lo, hi = lanes
+    v = np.array([0, 0, 0, 0, 0, 0, (1 << 63) - 1, -(1 << 63)], np.int64)
+    for lane in range(lo, hi):
+        env = O.OracleEnv(gametype, spawn_skip=lane)  # spawn_stride = 1
+        out = env.replay(actions[:, lane], want_obs=False)
+        ends = np.flatnonzero(out["done"])
+        start = 0
+        for e in ends:
+            ret = int(out["reward"][start:e + 1].sum())
+            v[0] += 1
+            v[1] += ret
+            v[2] += ret * ret
+            v[3] += int(out["info"][start:e + 1].sum())
+            v[4] += int(out["snaps"]["stats"][e][3])
+            v[5] += int(out["snaps"]["stats"][e][7])
+            v[6] = min(v[6], ret)
+            v[7] = max(v[7], ret)
+            start = e + 1
+    return v
+
+
+def worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from spacefortress_amd.stats import reduce_episode_stats, shard_lanes
+
+    rng = np.random.default_rng(5)
+    actions = rng.integers(0, 5, (T, TOTAL)).astype(np.uint8)  # same on every rank
+    local = episode_vector("youturn", shard_lanes(TOTAL, world, rank), actions)
+    red = reduce_episode_stats(torch.from_numpy(local))
+    dist.barrier()
+    q.put((rank, local.tolist(), red.tolist()))
+    dist.destroy_process_group()
+
+
+def test_shard_lanes():
+    from spacefortress_amd.stats import shard_lanes
+
+    for total, world in ((262144, 8), (10, 3), (7, 8), (65536, 1)):
+        cuts = [shard_lanes(total, world, r) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == total
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_lanes(262144, 8, 3) == (3 * 32768, 4 * 32768)
+    with pytest.raises(ValueError):
+        shard_lanes(8, 2, 2)
+
+
+def test_two_rank_gloo_reduction_equals_single_process():
+    from spacefortress_amd.stats import summarize
+
+    world, port = 2, 29500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(5)
+    actions = rng.integers(0, 5, (T, TOTAL)).astype(np.uint8)
+    whole = episode_vector("youturn", (0, TOTAL), actions)
+    assert res[0][2] == res[1][2] == whole.tolist()
+    assert res[0][1] != res[1][1]  # the shards really differ
+    s = summarize(whole)
+    assert s["episodes"] == TOTAL and s["min_return"] <= s["mean_return"] <= s["max_return"]
+
+
+def test_single_process_reduce_is_identity():
+    from spacefortress_amd.stats import reduce_episode_stats, summarize
+
+    v = torch.tensor([3, -30, 400, 1, 20, 50, -20, -5])
+    assert torch.equal(reduce_episode_stats(v), v)
+    s = summarize(v)
+    assert s["mean_return"] == -10 and abs(s["std_return"] ** 2 - (400 / 3 - 100)) < 1e-9
+    assert summarize(torch.tensor([0, 0, 0, 0, 0, 0, (1 << 63) - 1, -(1 << 63)]))["episodes"] == 0
