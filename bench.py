@@ -57,6 +57,20 @@ def cpu_baseline(gametype, seconds, cores):
                       "bare engine only (no Python wrapper, no IPC)" % (what, gametype, cores, seconds)}
 
 
+def pmc_traffic(gametype, envs, obs_type):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic_latest.json,
+    written by tools/pmc_report.py): a profiler measurement of this same command, not something
+    bench.py can observe itself.  None when no profile matches the workload."""
+    try:
+        rep = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+    except Exception:
+        return None
+    w = rep.get("workload", {})
+    if (w.get("gametype"), w.get("envs_per_gpu"), w.get("obs_type")) != (gametype, envs, obs_type):
+        return None
+    return rep["traffic_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +166,12 @@ def main():
     kern_ms = float(np.mean(per))
     kern_ms_med = per[len(per) // 2]
     env.check_actions()
+    if os.environ.get("SF_PMC_CALIB"):
+        # known-byte calibration dispatches for the rocprofv3 --pmc passes (tools/pmc_report.py):
+        # the field gather kernel reads n*count*elem bytes in the step kernel's own access pattern
+        # (8 / 4 / 2 bytes per lane, 64-lane rows) and writes the same number linearly
+        for name in ("missile_x", "shell_vx", "stats", "missile_angle", "ship_x", "time"):
+            env.get_field(name)
 
     if rank == 0:
         total_steps = float(n) * args.steps * world
@@ -176,7 +196,8 @@ def main():
                        "envs_per_gpu": n, "gametype": args.gametype, "obs_type": args.obs_type,
                        "parallelism": "%d independent shard(s), one process per GPU" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.gametype, n, args.obs_type),
                          "kernel": "sf_step_kernel", "kernel_ms_mean": region_ms,
                          "kernel_ms_event_pair_mean": kern_ms, "kernel_ms_event_pair_median": kern_ms_med,
                          "algorithmic_bytes_per_launch": algo, "launches_timed": k},

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass, as
+MI355X_MICROARCH.md prescribes) of bench.py into HBM bytes per sf_step_kernel launch.
+
+    SF_PMC_CALIB=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DIR_F -- python bench.py ...
+    SF_PMC_CALIB=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d DIR_W -- python bench.py ...
+    python tools/pmc_report.py DIR_F DIR_W --envs 65536 --out profiles/rNN_pmc_traffic.json
+
+gfx950 correction (guide, HBM section): FETCH_SIZE counts 64 B per 128-B request, i.e. half the
+bytes of a coalesced stream.  It is calibrated here, not assumed: with SF_PMC_CALIB=1 bench.py
+also dispatches the field-gather kernel on fields of known size, in the step kernel's own access
+pattern (8/4/2 bytes per lane in 64-lane rows); the read factor is fitted on those, the write
+counter is checked to be exact on them.  Counter unit: KiB.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+
+CALIB = [  # (kernel template arg, bytes per env) in the order bench.py dispatches them
+    ("unsigned long", 20 * 8), ("unsigned long", 20 * 8), ("unsigned int", 13 * 4),
+    ("unsigned short", 20 * 2), ("unsigned long", 8), ("unsigned int", 4),
+]
+
+
+def load(d):
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    by = collections.defaultdict(list)
+    for r in rows:
+        by[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return by
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir")
+    ap.add_argument("write_dir")
+    ap.add_argument("--envs", type=int, default=65536)
+    ap.add_argument("--gametype", default="youturn")
+    ap.add_argument("--obs-type", default="features")
+    ap.add_argument("--out")
+    a = ap.parse_args()
+    fe, wr = load(a.fetch_dir), load(a.write_dir)
+
+    def calib(by):
+        seq = []
+        for k, v in by.items():
+            if "sf_field_copy_kernel" in k:
+                seq.append((k, v))
+        out = []
+        order = collections.defaultdict(list)
+        for k, v in seq:
+            for t, _ in CALIB:
+                if "<" + t + ">" in k:
+                    order[t] = v
+        idx = collections.defaultdict(int)
+        for t, bpe in CALIB:
+            v = order[t][idx[t]]
+            idx[t] += 1
+            out.append((t, bpe * a.envs, v * 1024))
+        return out
+
+    cf, cw = calib(fe), calib(wr)
+    big = [(b, m) for _, b, m in cf if b >= (1 << 20)]
+    read_factor = sum(b for b, m in big) / sum(m for b, m in big)
+    write_factor = sum(b for _, b, m in cw if b >= (1 << 20)) / sum(m for _, b, m in cw if b >= (1 << 20))
+    step_f = [v for k, v in fe.items() if "sf_step_kernel" in k][0]
+    step_w = [v for k, v in wr.items() if "sf_step_kernel" in k][0]
+    fetch_kib = sum(step_f) / len(step_f)
+    write_kib = sum(step_w) / len(step_w)
+    read_b = fetch_kib * 1024 * read_factor
+    write_b = write_kib * 1024 * write_factor
+    rep = {
+        "workload": {"gametype": a.gametype, "envs_per_gpu": a.envs, "obs_type": a.obs_type},
+        "kernel": "sf_step_kernel", "launches": len(step_f),
+        "FETCH_SIZE_KiB_mean": fetch_kib, "WRITE_SIZE_KiB_mean": write_kib,
+        "calibration": {"read_factor": read_factor, "write_factor": write_factor,
+                        "read_samples": [dict(elem=t, true_bytes=b, counter_bytes=m) for t, b, m in cf],
+                        "write_samples": [dict(elem=t, true_bytes=b, counter_bytes=m) for t, b, m in cw]},
+        "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
+        "traffic_bytes_per_launch": read_b + write_b,
+        "per_env_step": {"read": read_b / a.envs, "write": write_b / a.envs},
+    }
+    print(json.dumps(rep, indent=1))
+    if a.out:
+        json.dump(rep, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
