@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="baseline processes (0 = this box's share, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timing-launches", type=int, default=200)
+    ap.add_argument("--numpy-api", type=int, default=0, metavar="K",
+                    help="also time K steps through the host-buffer (numpy) API: actions H2D, results D2H every "
+                         "step -- the PCIe-inclusive rate, reported as host_api, never as value")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,6 +169,16 @@ def main():
     kern_ms = float(np.mean(per))
     kern_ms_med = per[len(per) // 2]
     env.check_actions()
+    host_api = None
+    if args.numpy_api > 0 and rank == 0:
+        np_actions = actions.cpu().numpy().astype(np.int64)  # what rl/train.py:79 hands over
+        env.step(np_actions[0])
+        th = time.perf_counter()
+        for t in range(args.numpy_api):
+            env.step(np_actions[t % ring])
+        dt = time.perf_counter() - th
+        host_api = {"value": n * args.numpy_api / dt, "unit": "env-steps/s", "ms_per_step": dt / args.numpy_api * 1e3,
+                    "note": "numpy int64 actions in, numpy obs/reward/done/info out every step (PCIe both ways)"}
     if os.environ.get("SF_PMC_CALIB"):
         # known-byte calibration dispatches for the rocprofv3 --pmc passes (tools/pmc_report.py):
         # the field gather kernel reads n*count*elem bytes in the step kernel's own access pattern
@@ -202,6 +215,7 @@ def main():
                          "kernel_ms_event_pair_mean": kern_ms, "kernel_ms_event_pair_median": kern_ms_med,
                          "algorithmic_bytes_per_launch": algo, "launches_timed": k},
             "cpu_baseline": base,
+            "host_api": host_api,
             "episode_stats": summarize(stats.cpu()),
         }
         print(json.dumps(out))
