@@ -152,46 +152,45 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   a.action_keys = 0;
   for (int i = 0; i < n_actions; i++) a.action_keys |= (unsigned long long)(keys[i] & 0xF) << (4 * i);
   a.n_actions = n_actions;
-  a.width = preset.width;
-  a.height = preset.height;
-  a.game_time = preset.game_time;
-  a.tick_ms = 34;  // ENV:61: int(ceil(1/30 * 1000))
-  a.sector_size = preset.sector_size;
-  a.lock_time = preset.lock_time;
-  a.vuln_time = preset.vuln_time;
-  a.vuln_threshold = preset.vuln_threshold;
-  a.explode_duration = preset.explode_duration;
-  a.turn_speed = preset.turn_speed;
-  a.shaped = preset.shaped;
-  a.missile_speed = preset.missile_speed;
-  a.shell_speed = preset.shell_speed;
-  a.missile_penalty = (float)preset.missile_penalty;        // penalize(float): SRC/game.cpp:104,187
-  a.death_penalty = (float)preset.ship_death_penalty;       // :339,345,415
-  a.destroy_reward = (float)(preset.destroy_fortress + 0);  // + mDestroyFortressExtraPoints (:47,380)
-  a.miss_penalty = (float)preset.miss_penalty;              // :397
-  a.ship_accel = preset.ship_accel;
-  a.start_vx = preset.start_vx;
+  a.start_vx = preset.start_vx;  // libm values of the host, SRC/configs.cpp:43-44
   a.start_vy = preset.start_vy;
   {
+    // Everything else of baseConfig (SRC/configs.cpp:3-49) is identical in the four presets and is
+    // compiled into the kernels (namespace sfc); the scoring triple is the SHAPED template
+    // argument.  Refuse to run if a preset ever disagrees with what was compiled in.
     const double rm = (double)(preset.missile_radius + preset.fortress_radius);
     const double rs = (double)(preset.shell_radius + preset.ship_radius);
-    a.missile_hit_r2 = rm * rm;
-    a.shell_hit_r2 = rs * rs;
+    const bool same =
+        preset.width == (int)sfc::width_d && preset.height == (int)sfc::height_d &&
+        preset.game_time == sfc::game_time && preset.sector_size == sfc::sector_size &&
+        preset.lock_time == sfc::lock_time && preset.vuln_time == sfc::vuln_time &&
+        preset.vuln_threshold == sfc::vuln_threshold && preset.explode_duration == sfc::explode_duration &&
+        preset.turn_speed == sfc::turn_speed && preset.missile_speed == sfc::missile_speed &&
+        preset.shell_speed == sfc::shell_speed && preset.ship_accel == sfc::ship_accel &&
+        rm * rm == sfc::missile_hit_r2 && rs * rs == sfc::shell_hit_r2 &&
+        (double)preset.small_hex == sfc::ndist_a &&
+        ((double)preset.big_hex - (double)preset.small_hex) / 2.0 == sfc::ndist_b && preset.miss_penalty == 0 &&
+        (preset.shaped ? (preset.missile_penalty == 0.05 && preset.ship_death_penalty == 1 && preset.destroy_fortress == 1)
+                       : (preset.missile_penalty == 2.0 && preset.ship_death_penalty == 100 &&
+                          preset.destroy_fortress == 100));
+#define SF_E(nx, ny, px, py) nx, ny, px, py,
+    const double compiled_hex[48] = {SF_BIG_HEX_EDGES(SF_E) SF_SMALL_HEX_EDGES(SF_E)};
+#undef SF_E
+    const bool same_hex = preset.big_hex == 200 && preset.small_hex == 40 &&
+                          memcmp(compiled_hex, consts.data() + SF_LDS_BIGHEX, sizeof(compiled_hex)) == 0;
+    if (!same || !same_hex) {
+      sf_set_error("sf_create: preset `%s' differs from the constants compiled into the kernels", p->gametype);
+      sf_destroy(b);
+      return SF_ERR_ARG;
+    }
   }
-  a.fort_x = 355;  // SRC/game.cpp:38-39
-  a.fort_y = 315;
-  a.width_d = (double)preset.width;
-  a.height_d = (double)preset.height;
-  a.ndist_a = (double)preset.small_hex;
-  a.ndist_b = ((double)preset.big_hex - (double)preset.small_hex) / 2.0;
   a.obs_type = p->obs_type;
   a.obs_f64 = (p->flags & SF_FLAG_OBS_F64) ? 1 : 0;
   a.real_shell_count = (p->flags & SF_FLAG_REAL_SHELL_COUNT) ? 1 : 0;
   a.auto_reset = (p->flags & SF_FLAG_NO_AUTO_RESET) ? 0 : 1;
   a.obs_dim = p->obs_type == SF_OBS_MONITORS ? 10 : (p->obs_type == SF_OBS_NONE ? 0 : 15 + preset.n_keys);
-  a.pb_width = (double)(int)(450 * .2);   // ENV:57 with the default viewport/scale
-  a.pb_height = (double)(int)(460 * .2);  // ENV:58
-  a.max_ticks = floor((double)preset.game_time / a.tick_ms);  // ENV:165
+  static_assert(sfc::pb_width == (double)(int)(450 * .2) && sfc::pb_height == (double)(int)(460 * .2), "ENV:57-58");
+  static_assert(sfc::max_ticks == (double)(sfc::game_time / sfc::tick_ms), "ENV:165");
   a.acc = b->d_acc;
   a.dbg = nullptr;
 #ifdef SF_STAMPS  // diagnostic build (tools/stamps.py): per-wave clock stamps, never in the product
@@ -232,8 +231,8 @@ extern "C" int sf_debug_read(sf_batch* b, unsigned long long* host) {
 extern "C" int sf_n_envs(const sf_batch* b) { return b ? b->n_envs : SF_ERR_ARG; }
 extern "C" int sf_obs_dim(const sf_batch* b) { return b ? b->args.obs_dim : SF_ERR_ARG; }
 extern "C" int sf_n_actions(const sf_batch* b) { return b ? b->act_count : SF_ERR_ARG; }
-extern "C" int sf_tick_ms(const sf_batch* b) { return b ? b->args.tick_ms : SF_ERR_ARG; }
-extern "C" int sf_max_ticks(const sf_batch* b) { return b ? (int)b->args.max_ticks : SF_ERR_ARG; }
+extern "C" int sf_tick_ms(const sf_batch* b) { return b ? sfc::tick_ms : SF_ERR_ARG; }
+extern "C" int sf_max_ticks(const sf_batch* b) { return b ? (int)sfc::max_ticks : SF_ERR_ARG; }
 
 extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
   if (!b) {
@@ -256,7 +255,7 @@ extern "C" int sf_step(sf_batch* b, const void* actions_dev, int act_type, void*
     return SF_ERR_ARG;
   }
   DeviceGuard guard(b->device);
-  HIP_TRY(sf_launch_step(b->args, b->autoturn, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev,
+  HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev,
                          (hipStream_t)stream));
   return SF_OK;
 }

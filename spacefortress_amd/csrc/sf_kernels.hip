@@ -40,7 +40,11 @@
 #include "sf_internal.h"
 #include "sf_layout.h"
 
+// Four waves per workgroup share one LDS copy of the cos/sin table (one barrier, early, while the
+// waves are still in step; a copy per wave was tried: 1024 waves pulling the same 45 cache lines
+// out of L2 at once made the load phase 3x longer).  Everything after that is wave-private.
 #define SF_BLOCK 256
+#define SF_TRIG_PIECES ((SF_LDS_DOUBLES / 2 + SF_BLOCK - 1) / SF_BLOCK)
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #define SF_MPF 8 /* missile slots prefetched into registers; higher slots take the slow loop */
 #define SF_SPF 3 /* shell slots prefetched */
@@ -71,7 +75,36 @@
 #define SF_SLOT(a, name, T, s) \
   (tb + sfl::offset_per_lane(SF_F_##name) * sfl::kTileLanes + (size_t)(s) * (sfl::kTileLanes * sizeof(T)))
 #define SF_LD(T, base, off) (*reinterpret_cast<const T*>((base) + (off)))
-#define SF_ST(T, base, off, v) (*reinterpret_cast<T*>((base) + (off)) = (v))
+// SF_STORE_MODE (A/B switch, default set below): 0 plain stores (stay dirty in L2 until the
+// end-of-kernel write-back), 1 non-temporal (`nt`), 2 agent-scope relaxed atomic stores (`sc1`
+// write-through: the bytes leave L2 while the kernel still runs, so the kernel boundary has
+// nothing left to flush).
+#ifndef SF_STORE_MODE
+#define SF_STORE_MODE 0
+#endif
+template <typename T>
+__device__ __forceinline__ void sf_store(T* p, T v) {
+#if SF_STORE_MODE == 1
+  __builtin_nontemporal_store(v, p);
+#elif SF_STORE_MODE == 2
+  if constexpr (sizeof(T) == 8) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if constexpr (sizeof(T) == 4) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  } else if constexpr (sizeof(T) == 2) {
+    __hip_atomic_store(reinterpret_cast<unsigned short*>(p), __builtin_bit_cast(unsigned short, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __hip_atomic_store(reinterpret_cast<unsigned char*>(p), __builtin_bit_cast(unsigned char, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+#else
+  *p = v;
+#endif
+}
+#define SF_ST(T, base, off, v) sf_store<T>(reinterpret_cast<T*>((base) + (off)), (T)(v))
 
 namespace {
 
@@ -112,20 +145,24 @@ __device__ __forceinline__ void score(float amount, float& rew, Lane& L) {
   if (L.points < 0) L.points = 0;
 }
 
-// Hexagon::isInside (SRC/hexagon.cpp:36-48); e -> 6 x (nx, ny, px, py) in LDS (uniform address: broadcast)
-__device__ __forceinline__ bool hex_inside(const double* e, double x, double y) {
+// Hexagon::isInside (SRC/hexagon.cpp:36-48).  The edges (nx, ny, px, py) are compile-time
+// constants (sf_layout.h: both radii are the same in every preset), so they are immediates.
+#define SF_EDGE_TEST(nx, ny, px, py) in = in & !((nx) * (x - (px)) + (ny) * (y - (py)) < 0);
+__device__ __forceinline__ bool inside_big_hex(double x, double y) {
   bool in = true;
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    const double dx = x - e[4 * i + 2], dy = y - e[4 * i + 3];
-    in = in & !(e[4 * i + 0] * dx + e[4 * i + 1] * dy < 0);
-  }
+  SF_BIG_HEX_EDGES(SF_EDGE_TEST)
   return in;
 }
+__device__ __forceinline__ bool inside_small_hex(double x, double y) {
+  bool in = true;
+  SF_SMALL_HEX_EDGES(SF_EDGE_TEST)
+  return in;
+}
+#undef SF_EDGE_TEST
 
 // Game::isOutsideGameArea (SRC/game.cpp:129-131)
 __device__ __forceinline__ bool outside_area(const SfKernelArgs& a, double x, double y) {
-  return (x < 0) | (x > a.width_d) | (y > a.height_d) | (y < 0);
+  return (x < 0) | (x > sfc::width_d) | (y > sfc::height_d) | (y < 0);
 }
 
 // Game::resetShip (SRC/game.cpp:133-149).  The accepted (x, y, angle) of the rejection loop over
@@ -155,7 +192,7 @@ __device__ __forceinline__ void new_game(const SfKernelArgs& a, Lane& L) {
   L.time = 0;
   L.death_t = L.fire_t = L.thrust_t = L.left_t = L.right_t = 0;
   L.fort_t = L.fort_death_t = 0;
-  L.fort_vuln_t = a.vuln_time;  // :78 adds to a never-initialised member; defined as 0 + 250
+  L.fort_vuln_t = sfc::vuln_time;  // :78 adds to a never-initialised member; defined as 0 + 250
   L.mmask = L.smask = 0;
 }
 
@@ -245,10 +282,10 @@ __device__ __forceinline__ Extras compute_extras(const SfKernelArgs& a, const La
   // atan2(-(fy-sy), fx-sx) = atan2(dy, -dx) = +-pi - a_pos: derived from a_pos (observation-only
   // value, differs from a second libm call by <= 1 ulp of pi).
   {
-    const double dy = L.sy - a.fort_y;
+    const double dy = L.sy - sfc::fort_y;
     double ov;
     if (dy == 0)  // on the fortress row the two calls sit on different branch cuts: call it
-      ov = atan2(-(a.fort_y - L.sy), a.fort_x - L.sx);
+      ov = atan2(-(sfc::fort_y - L.sy), sfc::fort_x - L.sx);
     else
       ov = dy < 0 ? (-M_PI - a_pos) : (M_PI - a_pos);
     double diff = a_vel - ov;
@@ -258,8 +295,8 @@ __device__ __forceinline__ Extras compute_extras(const SfKernelArgs& a, const La
   }
   // fdist, ndist (SRC/game.cpp:310-311): the y term of the reference subtracts the ship from
   // itself, so fdist = sqrt(dx^2 + 0) = |dx|.
-  const double fdist = fabs(L.sx - a.fort_x);
-  e.ndist = -1 + (fdist - a.ndist_a) / a.ndist_b;
+  const double fdist = fabs(L.sx - sfc::fort_x);
+  e.ndist = -1 + (fdist - sfc::ndist_a) / sfc::ndist_b;
   return e;
 }
 
@@ -270,7 +307,7 @@ __device__ __forceinline__ void write_obs(const SfKernelArgs& a, T* o, const Lan
   const int n_shells = a.real_shell_count ? __popc(L.smask) : n_missiles;  // SRC/pymodule.cpp:131-134
   // ENV:148 reads the vulnerability timer through a getter with undefined behaviour
   // (SRC/pymodule.cpp:44-45); the intended predicate is used.
-  const int kill_ready = (L.vlner > 10 && L.fort_vuln_t < a.vuln_time) ? 1 : 0;
+  const int kill_ready = (L.vlner > 10 && L.fort_vuln_t < sfc::vuln_time) ? 1 : 0;
   const int n_keys_t = a.obs_dim - 15;
   const int timers[4] = {L.fire_t, L.thrust_t, L.left_t, L.right_t};  // SRC/pymodule.cpp:98-105
   const bool ship_alive = L.fl & SF_FL_SHIP_ALIVE, fort_alive = L.fl & SF_FL_FORT_ALIVE;
@@ -288,8 +325,8 @@ __device__ __forceinline__ void write_obs(const SfKernelArgs& a, T* o, const Lan
   } else if (a.obs_type == 1) {  // normalized-features, ENV:109-133
     double f[19];
     f[0] = ship_alive ? 1 : 0;
-    f[1] = L.sx / a.pb_width;
-    f[2] = L.sy / a.pb_height;
+    f[1] = L.sx / sfc::pb_width;
+    f[2] = L.sy / sfc::pb_height;
     f[3] = L.vx / 10;
     f[4] = L.vy / 10;
     f[5] = (double)L.angle / 360;
@@ -311,7 +348,7 @@ __device__ __forceinline__ void write_obs(const SfKernelArgs& a, T* o, const Lan
     f[13] = (double)n_missiles / SF_MAX_MISSILES_D;
     f[14] = (double)n_shells / SF_MAX_MISSILES_D;
 #pragma unroll
-    for (int k = 0; k < 4; k++) f[15 + k] = (double)timers[k] / a.max_ticks;
+    for (int k = 0; k < 4; k++) f[15 + k] = (double)timers[k] / sfc::max_ticks;
 #pragma unroll
     for (int k = 0; k < 19; k++) {
       if (k < 15 + n_keys_t) {
@@ -342,27 +379,32 @@ __device__ __forceinline__ void write_obs(const SfKernelArgs& a, T* o, const Lan
   }
 }
 
-// The block's observation rows sit in LDS as [lane][obs_dim]; global memory wants exactly the
-// same order ([N, obs_dim] row-major), so the block's rows form one contiguous span: copy it
-// with 16-byte lanes-consecutive stores instead of obs_dim strided 4-byte stores per lane.
+// A wave's 64 observation rows sit in ITS OWN piece of LDS as [lane][obs_dim]; global memory wants
+// exactly the same order ([N, obs_dim] row-major), so the wave's rows form one contiguous span:
+// copy it with 16-byte lanes-consecutive stores instead of obs_dim strided 4-byte stores per lane.
+// Wave-private on purpose: no workgroup barrier, so a fast wave never waits for the divergence
+// tail of a slower one (LDS is in-order per wave; the fence only pins the compiler).
 template <typename T>
-__device__ __forceinline__ void flush_obs_block(const SfKernelArgs& a, const T* stage, T* obs, bool vec_ok) {
-  const long base = (long)blockIdx.x * SF_BLOCK;
-  long rows = (long)a.n_envs - base;
-  if (rows > SF_BLOCK) rows = SF_BLOCK;
+__device__ __forceinline__ void flush_obs_wave(const SfKernelArgs& a, const T* stage_w, T* obs, unsigned wave_env0,
+                                               unsigned lane, bool vec_ok) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  long rows = (long)a.n_envs - (long)wave_env0;
+  if (rows > 64) rows = 64;
   if (rows <= 0) return;
   const int total = (int)rows * a.obs_dim;
-  T* dst = obs + base * a.obs_dim;
+  T* dst = obs + (size_t)wave_env0 * a.obs_dim;
   constexpr int V = 16 / (int)sizeof(T);
   int done_elems = 0;
   if (vec_ok) {
     typedef T vec_t __attribute__((ext_vector_type(V)));
     const int nvec = total / V;
-    for (int v = threadIdx.x; v < nvec; v += SF_BLOCK)
-      reinterpret_cast<vec_t*>(dst)[v] = reinterpret_cast<const vec_t*>(stage)[v];
+    for (int v = lane; v < nvec; v += 64)
+      reinterpret_cast<vec_t*>(dst)[v] = reinterpret_cast<const vec_t*>(stage_w)[v];
     done_elems = nvec * V;
   }
-  for (int t = done_elems + threadIdx.x; t < total; t += SF_BLOCK) dst[t] = stage[t];
+  for (int t = done_elems + lane; t < total; t += 64) dst[t] = stage_w[t];
 }
 
 }  // namespace
@@ -390,7 +432,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
   zero_counters(tb, o);
   if (obs != nullptr && i < (unsigned)a.n_envs && a.obs_type != 3) {
     // the reference's extras are stale heap until the first tick; defined as computeExtra(spawn)
-    Extras e = compute_extras(a, L, atan2(L.sy - a.fort_y, L.sx - a.fort_x), atan2(L.vy, L.vx));
+    Extras e = compute_extras(a, L, atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x), atan2(L.vy, L.vx));
     if (a.obs_f64)
       write_obs<double>(a, (double*)obs + (size_t)i * a.obs_dim, L, e);
     else
@@ -399,7 +441,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <bool AUTOTURN>
+template <bool AUTOTURN, bool SHAPED>
 __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const void* actions, int act_type,
                                                           void* obs, int obs_vec_ok, int32_t* reward_out,
                                                           uint8_t* done_out, uint8_t* info_out) {
@@ -431,10 +473,15 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   }
   Lane L;
   load_lane(tb, o, L);
-  // constant block (cos/sin table + hexagon edges): SF_LDS_DOUBLES = 3 doubles per thread
+  // cos/sin table: 720 doubles = 360 16-byte pieces, six per lane (the last one partial)
+  typedef double d2_t __attribute__((ext_vector_type(2)));
   const unsigned char* cb = (const unsigned char*)a.consts;
-  const double c0 = SF_LD(double, cb, tid * 8u), c1 = SF_LD(double, cb, (tid + SF_BLOCK) * 8u);
-  const double c2 = SF_LD(double, cb, (tid + 2 * SF_BLOCK) * 8u);
+  d2_t cst[SF_TRIG_PIECES];
+#pragma unroll
+  for (int k = 0; k < SF_TRIG_PIECES; k++) {
+    cst[k] = d2_t{0, 0};
+    if (tid + k * SF_BLOCK < SF_LDS_DOUBLES / 2) cst[k] = SF_LD(d2_t, cb, (tid + k * SF_BLOCK) * 16u);
+  }
   SF_STAMP(1, false);
   SF_STAMP(2, true);
 
@@ -487,10 +534,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   }
 
   // cos/sin table -> LDS (the loads were issued in round trip 1)
-  lds[tid] = c0;
-  lds[tid + SF_BLOCK] = c1;
-  lds[tid + 2 * SF_BLOCK] = c2;
-  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SF_TRIG_PIECES; k++)
+    if (tid + k * SF_BLOCK < SF_LDS_DOUBLES / 2) reinterpret_cast<d2_t*>(lds)[tid + k * SF_BLOCK] = cst[k];
+  __syncthreads();  // the only workgroup barrier of the kernel
   const double* trig = lds;
   SF_STAMP(3, false);
 
@@ -504,7 +551,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
 
   // ================= Game::stepOneTick (SRC/game.cpp:473-485) =================
   float rew = 0;        // mReward = 0
-  L.time += a.tick_ms;  // updateTime
+  L.time += sfc::tick_ms;  // updateTime
   const unsigned cursor0 = L.cursor;
 
   // ---- processKeyState (SRC/game.cpp:218-272); the wrapper sends FIRE, THRUST, (LEFT, RIGHT)
@@ -519,7 +566,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         if (slot < SF_NSLOT) {
           new_m_slot = slot;
           L.mmask |= 1u << slot;
-          score(-a.missile_penalty, rew, L);
+          score(-sfc::Score<SHAPED>::missile_penalty, rew, L);
         }
       }
       L.fl |= SF_FL_FIRE;
@@ -562,7 +609,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   const int new_m_angle = L.angle;
 
   // ---- monitorShipRespawn (SRC/game.cpp:151-157)
-  if (!(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= a.explode_duration) {
+  if (!(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration) {
     spawn_ship(a, L);
     L.fort_t = 0;
   }
@@ -571,7 +618,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   if (L.fl & SF_FL_SHIP_ALIVE) {
     if (AUTOTURN) {
       // stdAngle(ceil(angleTo(ship, fortress)))  (SRC/vector.cpp:42-52)
-      double t = atan2(a.fort_y - L.sy, a.fort_x - L.sx);
+      double t = atan2(sfc::fort_y - L.sy, sfc::fort_x - L.sx);
       if (t < 0) t += M_PI * 2;
       double c = ceil(rad2deg(t));  // in [0, 360]
       int ia = (int)c;
@@ -580,32 +627,32 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     } else {
       const bool left = L.fl & SF_FL_LEFT, right = L.fl & SF_FL_RIGHT;
       if (left && !right) {  // TURN_LEFT: stdAngle(angle - turnSpeed)
-        L.angle -= a.turn_speed;
+        L.angle -= sfc::turn_speed;
         if (L.angle < 0) L.angle += 360;
       } else if (right && !left) {  // TURN_RIGHT
-        L.angle += a.turn_speed;
+        L.angle += sfc::turn_speed;
         if (L.angle >= 360) L.angle -= 360;
       }
     }
     if (L.fl & SF_FL_THRUST) {
-      L.vx += a.ship_accel * trig[2 * L.angle];
-      L.vy += a.ship_accel * trig[2 * L.angle + 1];
+      L.vx += sfc::ship_accel * trig[2 * L.angle];
+      L.vy += sfc::ship_accel * trig[2 * L.angle + 1];
     }
     L.sx += L.vx;
     L.sy += L.vy;
     // `if (!big.isInside) ... else if (small.isInside) ...` (:337-349), counters branch-free
-    const int out_big = !hex_inside(lds + SF_LDS_BIGHEX, L.sx, L.sy);
-    const int in_small = !out_big && hex_inside(lds + SF_LDS_SMALLHEX, L.sx, L.sy);
+    const int out_big = !inside_big_hex(L.sx, L.sy);
+    const int in_small = !out_big & inside_small_hex(L.sx, L.sy);
     if (out_big | in_small) {
       kill_ship(L, S);
-      score(-a.death_penalty, rew, L);
+      score(-sfc::Score<SHAPED>::death_penalty, rew, L);
     }
     S.big_hex_deaths += out_big;
     S.small_hex_deaths += in_small;
   }
 
   // the two bearings the rest of the tick and the observation need, side by side (ILP)
-  double a_pos = atan2(L.sy - a.fort_y, L.sx - a.fort_x);
+  double a_pos = atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
   double a_vel = atan2(L.vy, L.vx);
 
   // ---- updateFortress (SRC/game.cpp:194-216)
@@ -614,12 +661,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   {
     double ats = rad2deg(a_pos);  // stdAngle: in [-180, 180], only the sign fix applies
     if (ats < 0) ats += 360;
-    if (!(L.fl & SF_FL_FORT_ALIVE) && L.fort_death_t > 1000) {
+    if (!(L.fl & SF_FL_FORT_ALIVE) && L.fort_death_t > sfc::fort_respawn) {
       L.fort_t = 0;
       L.fl |= SF_FL_FORT_ALIVE;
     }
     if (L.fl & SF_FL_SHIP_ALIVE) {
-      double q = ceil(ats / a.sector_size) * a.sector_size;  // in [0, 360]
+      double q = ceil(ats / sfc::sector_size) * sfc::sector_size;  // in [0, 360]
       int fa = (int)q;
       if (fa >= 360) fa -= 360;
       L.fort_angle = fa;
@@ -627,15 +674,15 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         L.fort_last = fa;
         L.fort_t = 0;
       }
-      if (L.fort_t >= a.lock_time && (L.fl & SF_FL_FORT_ALIVE)) {
+      if (L.fort_t >= sfc::lock_time && (L.fl & SF_FL_FORT_ALIVE)) {
         // fireShell (SRC/game.cpp:159-173): a non-integer heading, so real sin/cos
         int slot = __ffs(~L.smask) - 1;
         if (slot < SF_NSLOT) {
           new_s_slot = slot;
           L.smask |= 1u << slot;
           double r = deg2rad(ats);
-          new_s_vx = a.shell_speed * cos(r);
-          new_s_vy = a.shell_speed * sin(r);
+          new_s_vx = sfc::shell_speed * cos(r);
+          new_s_vy = sfc::shell_speed * sin(r);
         }
         L.fort_t = 0;
       }
@@ -654,13 +701,13 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       for (int s = 0; s < SF_SPF; s++) {
         const bool isnew = (s == new_s_slot);
         const double vx = isnew ? new_s_vx : shvx[s], vy = isnew ? new_s_vy : shvy[s];
-        nx[s] = (isnew ? a.fort_x : shx[s]) + vx;
-        ny[s] = (isnew ? a.fort_y : shy[s]) + vy;
+        nx[s] = (isnew ? sfc::fort_x : shx[s]) + vx;
+        ny[s] = (isnew ? sfc::fort_y : shy[s]) + vy;
         // Object::collided (SRC/object.cpp:12-15): sqrt(dx^2+dy^2) <= r.  With a correctly
         // rounded sqrt and r an integer, RN(sqrt(s)) <= r  <=>  s <= r^2 (r^2 is exactly
         // representable and the next double above r^2 has a root that rounds above r).
         const double dx = nx[s] - L.sx, dy = ny[s] - L.sy;
-        col |= (unsigned)(dx * dx + dy * dy <= a.shell_hit_r2) << s;
+        col |= (unsigned)(dx * dx + dy * dy <= sfc::shell_hit_r2) << s;
         out |= (unsigned)outside_area(a, nx[s], ny[s]) << s;
         if (isnew) {
           SF_ST(double, SF_SLOT(a, shell_vx, double, s), o.o8, vx);
@@ -676,7 +723,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         const unsigned k = col & (0u - col);  // lowest colliding slot
         dead |= k;
         kill_ship(L, S);
-        score(-a.death_penalty, rew, L);
+        score(-sfc::Score<SHAPED>::death_penalty, rew, L);
         S.shell_deaths += 1;
       }
       L.smask &= ~dead;
@@ -696,8 +743,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         if (live) {
           double x, y, vx, vy;
           if (s == new_s_slot) {
-            x = a.fort_x;
-            y = a.fort_y;
+            x = sfc::fort_x;
+            y = sfc::fort_y;
             vx = new_s_vx;
             vy = new_s_vy;
             SF_ST(double, SF_SLOT(a, shell_vx, double, s), o.o8, vx);
@@ -713,10 +760,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
           bool dead = false;
           if (L.fl & SF_FL_SHIP_ALIVE) {
             const double dx = x - L.sx, dy = y - L.sy;
-            if (dx * dx + dy * dy <= a.shell_hit_r2) {
+            if (dx * dx + dy * dy <= sfc::shell_hit_r2) {
               dead = true;
               kill_ship(L, S);
-              score(-a.death_penalty, rew, L);
+              score(-sfc::Score<SHAPED>::death_penalty, rew, L);
               S.shell_deaths += 1;
             }
           }
@@ -739,11 +786,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     unsigned ev_hit = 0, ev_out = 0;
     auto m_move = [&](int s, double x, double y, int ang, bool isnew) __attribute__((always_inline)) {
       // velocity = missileSpeed * (cos, sin)(deg2rad(angle)) with an integer angle: table
-      const double nx = x + a.missile_speed * trig[2 * ang];
-      const double ny = y + a.missile_speed * trig[2 * ang + 1];
-      const double dx = nx - a.fort_x, dy = ny - a.fort_y;
+      const double nx = x + sfc::missile_speed * trig[2 * ang];
+      const double ny = y + sfc::missile_speed * trig[2 * ang + 1];
+      const double dx = nx - sfc::fort_x, dy = ny - sfc::fort_y;
       const bool live = (L.mmask >> s) & 1u;
-      const bool hit = live & (dx * dx + dy * dy <= a.missile_hit_r2);  // collided(mFortress), see shells
+      const bool hit = live & (dx * dx + dy * dy <= sfc::missile_hit_r2);  // collided(mFortress), see shells
       const bool out = live & !hit & outside_area(a, nx, ny);
       ev_hit |= (unsigned)hit << s;
       ev_out |= (unsigned)out << s;
@@ -794,16 +841,16 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         ev &= ~bit;
         if (ev_hit & bit) {
           if (L.fl & SF_FL_FORT_ALIVE) {
-            if (L.fort_vuln_t >= a.vuln_time) {
+            if (L.fort_vuln_t >= sfc::vuln_time) {
               L.vlner += 1;
               S.vlner_incs += 1;
               if (L.vlner > S.max_vlner) S.max_vlner = L.vlner;
             } else {
-              const int destroy = L.vlner >= a.vuln_threshold + 1;
+              const int destroy = L.vlner >= sfc::vuln_threshold + 1;
               if (destroy) {
                 L.fl &= ~SF_FL_FORT_ALIVE;
                 L.fort_death_t = 0;
-                score(a.destroy_reward, rew, L);
+                score(sfc::Score<SHAPED>::destroy_reward, rew, L);
               }
               S.destroyed += destroy;
               S.resets += 1 - destroy;
@@ -812,7 +859,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
             L.fort_vuln_t = 0;
           }
         } else {
-          score(-a.miss_penalty, rew, L);
+          score(-sfc::Score<SHAPED>::miss_penalty, rew, L);
           S.missed += 1;
         }
       }
@@ -821,10 +868,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   SF_STAMP(6, false);
 
   // ---- stepTimers (SRC/game.cpp:425-451)
-  L.fort_t += a.tick_ms;
-  L.fort_death_t += a.tick_ms;
-  L.fort_vuln_t += a.tick_ms;
-  L.death_t += a.tick_ms;
+  L.fort_t += sfc::tick_ms;
+  L.fort_death_t += sfc::tick_ms;
+  L.fort_vuln_t += sfc::tick_ms;
+  L.death_t += sfc::tick_ms;
   L.fire_t += (L.fl & SF_FL_FIRE) ? 1 : -1;
   L.thrust_t += (L.fl & SF_FL_THRUST) ? 1 : -1;
   L.left_t += (L.fl & SF_FL_LEFT) ? 1 : -1;
@@ -834,14 +881,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
 
   // ================= SSF_Env.step epilogue (ENV:233-253) =================
   const int fort_kill = r > 0;
-  if (a.shaped) {
+  if (SHAPED) {
     const int vlner_change = L.vlner - L.prev_vlner;
     if (L.vlner <= 10 && !fort_kill) r += vlner_change;
     r = r > 1 ? 1 : (r < -1 ? -1 : r);
     r = r + 2 * fort_kill;
     L.prev_vlner = L.vlner;
   }
-  const int done = L.time >= a.game_time;  // Game::isGameOver (SRC/game.cpp:487-489)
+  const int done = L.time >= sfc::game_time;  // Game::isGameOver (SRC/game.cpp:487-489)
 
   // ================= statistics and the vec-env worker's auto-reset (rl/train.py:80-88) ======
   if (done && a.auto_reset) {
@@ -862,7 +909,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     }
     new_game(a, L);
     zero_counters(tb, o);
-    a_pos = atan2(L.sy - a.fort_y, L.sx - a.fort_x);
+    a_pos = atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
     a_vel = atan2(L.vy, L.vx);
   } else {
     // no-return atomics, executed at the memory side: the counters are never loaded
@@ -909,13 +956,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     if (a.obs_f64) {
       double* stage = lds + SF_LDS_DOUBLES;
       write_obs<double>(a, stage + tid * a.obs_dim, L, e);
-      __syncthreads();
-      flush_obs_block<double>(a, stage, (double*)obs, obs_vec_ok);
+      flush_obs_wave<double>(a, stage + (tid & ~63u) * a.obs_dim, (double*)obs, i & ~63u, lane, obs_vec_ok);
     } else {
       float* stage = reinterpret_cast<float*>(lds + SF_LDS_DOUBLES);
       write_obs<float>(a, stage + tid * a.obs_dim, L, e);
-      __syncthreads();
-      flush_obs_block<float>(a, stage, (float*)obs, obs_vec_ok);
+      flush_obs_wave<float>(a, stage + (tid & ~63u) * a.obs_dim, (float*)obs, i & ~63u, lane, obs_vec_ok);
     }
   }
   SF_STAMP(8, false);
@@ -924,7 +969,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   stamp_[13] = __builtin_amdgcn_s_memrealtime();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (a.dbg != nullptr && (tid & 63) == 0) {
-    unsigned long long* d = a.dbg + ((size_t)blockIdx.x * (SF_BLOCK / 64) + (tid >> 6)) * 16;
+    unsigned long long* d = a.dbg + (size_t)(i >> 6) * 16;
 #pragma unroll
     for (int k = 0; k < 14; k++) d[k] = (k < 10 || k >= 12) ? stamp_[k] : 0ull;
   }
@@ -982,17 +1027,21 @@ hipError_t sf_launch_reset(const SfKernelArgs& a, int first, unsigned cursor0, u
   return hipGetLastError();
 }
 
-hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, const void* actions, int act_type, void* obs,
+hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, const void* actions, int act_type, void* obs,
                           int32_t* reward, uint8_t* done, uint8_t* info, hipStream_t stream) {
   const unsigned grid = (unsigned)(a.lanes / SF_BLOCK);
   const size_t elem = a.obs_f64 ? sizeof(double) : sizeof(float);
   const size_t lds_bytes = SF_LDS_DOUBLES * sizeof(double) + (size_t)SF_BLOCK * a.obs_dim * elem;
   const int vec_ok = ((uintptr_t)obs & 15u) == 0;
-  if (autoturn)
-    hipLaunchKernelGGL(sf_step_kernel<true>, dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a, actions, act_type,
-                       obs, vec_ok, reward, done, info);
-  else
-    hipLaunchKernelGGL(sf_step_kernel<false>, dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a, actions, act_type,
-                       obs, vec_ok, reward, done, info);
+#define SF_GO(AT, SH)                                                                                     \
+  hipLaunchKernelGGL((sf_step_kernel<AT, SH>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a, actions, \
+                     act_type, obs, vec_ok, reward, done, info)
+  // the four presets of SRC/configs.cpp:51-89 are exactly (autoTurn) x (shaped scoring)
+  if (autoturn) {
+    if (shaped) SF_GO(true, true); else SF_GO(true, false);
+  } else {
+    if (shaped) SF_GO(false, true); else SF_GO(false, false);
+  }
+#undef SF_GO
   return hipGetLastError();
 }

@@ -112,7 +112,42 @@ constexpr long tile_offset(int f, int s = 0) {
 #define SF_LDS_BIGHEX 720
 #define SF_LDS_SMALLHEX 744
 #define SF_CONST_DOUBLES 768
-#define SF_LDS_DOUBLES 768 /* the whole block is staged: exactly 3 doubles per thread of a 256-block */
+#define SF_LDS_DOUBLES 720 /* what a wave stages into LDS: the cos/sin table (indexed per lane) */
+
+// The 12 hexagon edges as Hexagon::isInside forms them (SRC/hexagon.cpp:38-42), X(nx, ny, px, py),
+// for radius 200 / 40 (bigHex / smallHex of every preset, SRC/configs.cpp:34-35).  Compiled into the
+// kernels as immediates; sf_create checks them bit for bit against what Hexagon::setRadius's
+// arithmetic (sf_host.cpp, host libm) gives.  Note the floor-induced asymmetry 174/173, 35/34.
+#define SF_BIG_HEX_EDGES(X)                                                                          \
+  X(174.0, 100.0, 155.0, 315.0) X(-0.0, 200.0, 255.0, 141.0) X(-174.0, 100.0, 455.0, 141.0)          \
+  X(-173.0, -100.0, 555.0, 315.0) X(-0.0, -200.0, 455.0, 488.0) X(173.0, -100.0, 255.0, 488.0)
+#define SF_SMALL_HEX_EDGES(X)                                                                        \
+  X(35.0, 20.0, 315.0, 315.0) X(-0.0, 40.0, 335.0, 280.0) X(-35.0, 20.0, 375.0, 280.0)               \
+  X(-34.0, -20.0, 395.0, 315.0) X(-0.0, -40.0, 375.0, 349.0) X(34.0, -20.0, 335.0, 349.0)
+
+// baseConfig (SRC/configs.cpp:3-49) and the wrapper's constants (ENV:57-61,165): identical in all
+// four presets, so they are compile-time constants of the kernels (immediates, not kernel-argument
+// loads a lone wave would have to wait for).  sf_create checks every preset against them.
+namespace sfc {
+constexpr int game_time = 180000, tick_ms = 34, sector_size = 10, lock_time = 1000, vuln_time = 250,
+              vuln_threshold = 10, explode_duration = 1000, turn_speed = 6, missile_speed = 20, shell_speed = 6,
+              fort_respawn = 1000 /* literal at SRC/game.cpp:199 */;
+constexpr double width_d = 710, height_d = 626;         // compared as doubles (SRC/game.cpp:130)
+constexpr double fort_x = 355, fort_y = 315;            // SRC/game.cpp:38-39
+constexpr double ship_accel = 0.3;
+constexpr double missile_hit_r2 = 23.0 * 23.0;          // (missile 5 + fortress 18)^2, see the sqrt-free test
+constexpr double shell_hit_r2 = 13.0 * 13.0;            // (shell 3 + ship 10)^2
+constexpr double ndist_a = 40, ndist_b = (200 - 40) / 2.0;  // normDist, SRC/game.cpp:282-284
+constexpr double pb_width = 90, pb_height = 92, max_ticks = 5294;  // ENV:57-58,165
+// the scoring triple: "autoturn"/"youturn" (SRC/configs.cpp:57-59,68-70) vs the test-* presets (:8-10)
+template <bool SHAPED>
+struct Score {
+  static constexpr float missile_penalty = SHAPED ? 0.05f : 2.0f;  // (float)0.05, penalize(float) :104,187
+  static constexpr float death_penalty = SHAPED ? 1.0f : 100.0f;   // :339,345,415
+  static constexpr float destroy_reward = SHAPED ? 1.0f : 100.0f;  // + mDestroyFortressExtraPoints = 0 (:47,380)
+  static constexpr float miss_penalty = 0.0f;                      // :397
+};
+}  // namespace sfc
 
 // Everything the kernels need that is uniform across lanes; passed by value (kernarg -> SGPRs).
 struct SfKernelArgs {
@@ -124,20 +159,9 @@ struct SfKernelArgs {
   unsigned spawn_mask;       // spawn_len - 1
   unsigned long long action_keys; // 4 bits per action index, up to 16 actions
   int n_actions;
-  // preset (SRC/configs.cpp)
-  int width, height, game_time, tick_ms;
-  int sector_size, lock_time, vuln_time, vuln_threshold;
-  int explode_duration, turn_speed, shaped;
-  int missile_speed, shell_speed;
-  float missile_penalty, death_penalty, destroy_reward, miss_penalty;
-  double ship_accel, start_vx, start_vy;
-  double missile_hit_r2, shell_hit_r2; // (r1+r2)^2: see sf_kernels.hip on the sqrt-free test
-  double fort_x, fort_y;
-  double width_d, height_d;  // width/height as the doubles the comparisons promote them to
-  double ndist_a, ndist_b;   // small_hex and (big_hex-small_hex)/2.0 of normDist (SRC/game.cpp:282-284)
+  double start_vx, start_vy; // cos/sin(deg2rad(-60)) as the host's libm gives them (SRC/configs.cpp:43-44)
   // observation
   int obs_type, obs_f64, real_shell_count, obs_dim, auto_reset;
-  double pb_width, pb_height, max_ticks; // ENV:57-58,165
   // episode accumulators / error counter (device)
   unsigned long long* acc;   // SF_EPISODE_STATS_LEN + 1 words; [8] = bad-action count
   unsigned long long* dbg;   // SF_STAMPS diagnostic builds only: [wave][16] clock stamps; else null
