@@ -46,8 +46,9 @@
 #define SF_BLOCK 256
 #define SF_TRIG_PIECES ((SF_LDS_DOUBLES / 2 + SF_BLOCK - 1) / SF_BLOCK)
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
-#define SF_MPF 8 /* missile slots prefetched into registers; higher slots take the slow loop */
-#define SF_SPF 3 /* shell slots prefetched */
+#define SF_MPF 12 /* missile slots prefetched into registers; higher slots take the slow loop */
+#define SF_MGROUPS 4
+#define SF_SPF 6 /* shell slots prefetched (groups of 3) */
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -168,15 +169,18 @@ __device__ __forceinline__ bool outside_area(const SfKernelArgs& a, double x, do
 // Game::resetShip (SRC/game.cpp:133-149).  The accepted (x, y, angle) of the rejection loop over
 // libc rand() is a fixed sequence per seed: the host precomputed it (sf_spawn_table) and each
 // lane walks it with its own cursor.
-__device__ __forceinline__ void spawn_ship(const SfKernelArgs& a, Lane& L) {
-  const int16_t* e = a.spawn + 4 * (size_t)(L.cursor & a.spawn_mask);
+// `e` = the lane's next table entry, packed (x, y, angle, 0) as four int16
+__device__ __forceinline__ void spawn_ship_from(const SfKernelArgs& a, Lane& L, unsigned long long e) {
   L.cursor += 1;
-  L.sx = (double)e[0];
-  L.sy = (double)e[1];
-  L.angle = e[2];
+  L.sx = (double)(int16_t)(e & 0xFFFFu);
+  L.sy = (double)(int16_t)((e >> 16) & 0xFFFFu);
+  L.angle = (int16_t)((e >> 32) & 0xFFFFu);
   L.vx = a.start_vx;
   L.vy = a.start_vy;
   L.fl |= SF_FL_SHIP_ALIVE;
+}
+__device__ __forceinline__ void spawn_ship(const SfKernelArgs& a, Lane& L) {
+  spawn_ship_from(a, L, *reinterpret_cast<const unsigned long long*>(a.spawn + 4 * (size_t)(L.cursor & a.spawn_mask)));
 }
 
 // Game::Game (SRC/game.cpp:18-82); statistics and episode sums are zeroed by the caller
@@ -486,7 +490,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   SF_STAMP(2, true);
 
   // ================= round trip 2: live projectile slots, predicated by the alive masks ======
-  // Slot groups {0,1} {2,3} {4..7}: a wave ballot skips a group no lane uses.
+  // Slot groups (missiles {0,1} {2,3} {4..7} {8..11}, shells {0,1,2} {3,4,5}): a wave ballot
+  // skips a group no lane uses.  The kernel lasts as long as its slowest wave, so the groups reach
+  // well past the common case: the dependent-load loop behind them is for slots hardly ever used.
+  constexpr int kMgLo[SF_MGROUPS] = {0, 2, 4, 8}, kMgN[SF_MGROUPS] = {2, 2, 4, 4};
   double mx[SF_MPF], my[SF_MPF];
   int mang[SF_MPF];
   double shx[SF_SPF], shy[SF_SPF], shvx[SF_SPF], shvy[SF_SPF];
@@ -498,38 +505,45 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   }
 #pragma unroll
   for (int s = 0; s < SF_SPF; s++) shx[s] = shy[s] = shvx[s] = shvy[s] = 0;
+  // a dead ship whose explosion is over respawns this tick (SRC/game.cpp:151-157): fetch its
+  // entry of the spawn sequence now, not in the middle of the arithmetic
+  const bool will_respawn = !(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration;
+  unsigned long long spawn_e = 0;
   {
-    auto m_load = [&](int s) __attribute__((always_inline)) {
-      if ((L.mmask >> s) & 1u) {
-        mx[s] = SF_LD(double, SF_SLOT(a, missile_x, double, s), o.o8);
-        my[s] = SF_LD(double, SF_SLOT(a, missile_y, double, s), o.o8);
-        mang[s] = SF_LD(int16_t, SF_SLOT(a, missile_angle, int16_t, s), o.o2);
-      }
-    };
-    if (__ballot((L.mmask & 0x03u) != 0u) != 0ull) {
-      m_load(0);
-      m_load(1);
-    }
-    if (__ballot((L.mmask & 0x0Cu) != 0u) != 0ull) {
-      m_load(2);
-      m_load(3);
-    }
-    if (__ballot((L.mmask & 0xF0u) != 0u) != 0ull) {
-      m_load(4);
-      m_load(5);
-      m_load(6);
-      m_load(7);
-    }
-    if (__ballot((L.smask & 0x07u) != 0u) != 0ull) {
 #pragma unroll
-      for (int s = 0; s < SF_SPF; s++) {
-        if ((L.smask >> s) & 1u) {
-          shx[s] = SF_LD(double, SF_SLOT(a, shell_x, double, s), o.o8);
-          shy[s] = SF_LD(double, SF_SLOT(a, shell_y, double, s), o.o8);
-          shvx[s] = SF_LD(double, SF_SLOT(a, shell_vx, double, s), o.o8);
-          shvy[s] = SF_LD(double, SF_SLOT(a, shell_vy, double, s), o.o8);
+    for (int g = 0; g < SF_MGROUPS; g++) {
+      const unsigned gm = ((1u << kMgN[g]) - 1u) << kMgLo[g];
+      if (__ballot((L.mmask & gm) != 0u) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k < kMgN[g]) {
+            const int s = kMgLo[g] + k;
+            if ((L.mmask >> s) & 1u) {
+              mx[s] = SF_LD(double, SF_SLOT(a, missile_x, double, s), o.o8);
+              my[s] = SF_LD(double, SF_SLOT(a, missile_y, double, s), o.o8);
+              mang[s] = SF_LD(int16_t, SF_SLOT(a, missile_angle, int16_t, s), o.o2);
+            }
+          }
         }
       }
+    }
+#pragma unroll
+    for (int g = 0; g < SF_SPF / 3; g++) {
+      if (__ballot((L.smask & (0x7u << (3 * g))) != 0u) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int s = 3 * g + k;
+          if ((L.smask >> s) & 1u) {
+            shx[s] = SF_LD(double, SF_SLOT(a, shell_x, double, s), o.o8);
+            shy[s] = SF_LD(double, SF_SLOT(a, shell_y, double, s), o.o8);
+            shvx[s] = SF_LD(double, SF_SLOT(a, shell_vx, double, s), o.o8);
+            shvy[s] = SF_LD(double, SF_SLOT(a, shell_vy, double, s), o.o8);
+          }
+        }
+      }
+    }
+    if (__ballot(will_respawn) != 0ull) {
+      if (will_respawn) spawn_e = *reinterpret_cast<const unsigned long long*>(a.spawn + 4 * (size_t)(L.cursor & a.spawn_mask));
     }
   }
 
@@ -609,8 +623,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   const int new_m_angle = L.angle;
 
   // ---- monitorShipRespawn (SRC/game.cpp:151-157)
-  if (!(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration) {
-    spawn_ship(a, L);
+  if (will_respawn) {  // !alive && deathTimer >= shipExplodeDuration, evaluated (and fetched) above
+    spawn_ship_from(a, L, spawn_e);
     L.fort_t = 0;
   }
 
@@ -675,14 +689,19 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         L.fort_t = 0;
       }
       if (L.fort_t >= sfc::lock_time && (L.fl & SF_FL_FORT_ALIVE)) {
-        // fireShell (SRC/game.cpp:159-173): a non-integer heading, so real sin/cos
+        // fireShell (SRC/game.cpp:159-173): vel = shellSpeed * (cos, sin)(deg2rad(angle_to_ship)).
+        // angle_to_ship is the bearing of d = ship - fortress, so (cos, sin) = d / |d|: one sqrt
+        // and two divisions instead of a device sincos with argument reduction.  Shell velocity
+        // was never bit-exact against glibc's sin/cos anyway; both forms sit within a few 1e-15
+        // of the true direction (shell positions are tested to 1e-9).
         int slot = __ffs(~L.smask) - 1;
         if (slot < SF_NSLOT) {
           new_s_slot = slot;
           L.smask |= 1u << slot;
-          double r = deg2rad(ats);
-          new_s_vx = sfc::shell_speed * cos(r);
-          new_s_vy = sfc::shell_speed * sin(r);
+          const double ddx = L.sx - sfc::fort_x, ddy = L.sy - sfc::fort_y;
+          const double nrm = sqrt(ddx * ddx + ddy * ddy);
+          new_s_vx = sfc::shell_speed * (ddx / nrm);
+          new_s_vy = sfc::shell_speed * (ddy / nrm);
         }
         L.fort_t = 0;
       }
@@ -694,44 +713,49 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   // ---- updateShells (SRC/game.cpp:404-423).  Ballistics of the prefetched slots first, as
   //      straight-line code; then the (ship-alive dependent) outcome in slot order.
   {
-    if (__ballot((L.smask & 0x07u) != 0u) != 0ull) {
-      unsigned col = 0, out = 0;
-      double nx[SF_SPF], ny[SF_SPF];
 #pragma unroll
-      for (int s = 0; s < SF_SPF; s++) {
+    for (int g = 0; g < SF_SPF / 3; g++) {
+      const unsigned gmask = 0x7u << (3 * g);
+      if (__ballot((L.smask & gmask) != 0u) == 0ull) continue;
+      unsigned col = 0, out = 0;
+      double nx[3], ny[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int s = 3 * g + k;
         const bool isnew = (s == new_s_slot);
         const double vx = isnew ? new_s_vx : shvx[s], vy = isnew ? new_s_vy : shvy[s];
-        nx[s] = (isnew ? sfc::fort_x : shx[s]) + vx;
-        ny[s] = (isnew ? sfc::fort_y : shy[s]) + vy;
+        nx[k] = (isnew ? sfc::fort_x : shx[s]) + vx;
+        ny[k] = (isnew ? sfc::fort_y : shy[s]) + vy;
         // Object::collided (SRC/object.cpp:12-15): sqrt(dx^2+dy^2) <= r.  With a correctly
         // rounded sqrt and r an integer, RN(sqrt(s)) <= r  <=>  s <= r^2 (r^2 is exactly
         // representable and the next double above r^2 has a root that rounds above r).
-        const double dx = nx[s] - L.sx, dy = ny[s] - L.sy;
+        const double dx = nx[k] - L.sx, dy = ny[k] - L.sy;
         col |= (unsigned)(dx * dx + dy * dy <= sfc::shell_hit_r2) << s;
-        out |= (unsigned)outside_area(a, nx[s], ny[s]) << s;
+        out |= (unsigned)outside_area(a, nx[k], ny[k]) << s;
         if (isnew) {
           SF_ST(double, SF_SLOT(a, shell_vx, double, s), o.o8, vx);
           SF_ST(double, SF_SLOT(a, shell_vy, double, s), o.o8, vy);
         }
       }
-      const unsigned live = L.smask & 0x07u;
+      const unsigned live = L.smask & gmask;
       col &= live;
       // slot order: the first colliding shell kills a live ship; every other shell only
       // leaves by flying out (`if (alive && collided) ... else if (outside)`, :410-420)
       unsigned dead = out & live;
       if ((L.fl & SF_FL_SHIP_ALIVE) && col) {
-        const unsigned k = col & (0u - col);  // lowest colliding slot
-        dead |= k;
+        const unsigned kbit = col & (0u - col);  // lowest colliding slot
+        dead |= kbit;
         kill_ship(L, S);
         score(-sfc::Score<SHAPED>::death_penalty, rew, L);
         S.shell_deaths += 1;
       }
       L.smask &= ~dead;
 #pragma unroll
-      for (int s = 0; s < SF_SPF; s++) {
+      for (int k = 0; k < 3; k++) {
+        const int s = 3 * g + k;
         if ((L.smask >> s) & 1u) {
-          SF_ST(double, SF_SLOT(a, shell_x, double, s), o.o8, nx[s]);
-          SF_ST(double, SF_SLOT(a, shell_y, double, s), o.o8, ny[s]);
+          SF_ST(double, SF_SLOT(a, shell_x, double, s), o.o8, nx[k]);
+          SF_ST(double, SF_SLOT(a, shell_y, double, s), o.o8, ny[k]);
         }
       }
     }
@@ -804,19 +828,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       const bool isnew = (s == new_m_slot);
       m_move(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], isnew ? new_m_angle : mang[s], isnew);
     };
-    if (__ballot((L.mmask & 0x03u) != 0u) != 0ull) {
-      m_pref(0);
-      m_pref(1);
-    }
-    if (__ballot((L.mmask & 0x0Cu) != 0u) != 0ull) {
-      m_pref(2);
-      m_pref(3);
-    }
-    if (__ballot((L.mmask & 0xF0u) != 0u) != 0ull) {
-      m_pref(4);
-      m_pref(5);
-      m_pref(6);
-      m_pref(7);
+#pragma unroll
+    for (int g = 0; g < SF_MGROUPS; g++) {
+      const unsigned gm = ((1u << kMgN[g]) - 1u) << kMgLo[g];
+      if (__ballot((L.mmask & gm) != 0u) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k < kMgN[g]) m_pref(kMgLo[g] + k);
+      }
     }
     if (__ballot((L.mmask >> SF_MPF) != 0u) != 0ull) {  // rare: a lane with more than SF_MPF missiles
 #pragma unroll 1

@@ -65,7 +65,12 @@ def main():
     for k, nm in enumerate(names):
         print("  %-45s %7.0f %7.0f  (%4.1f%%)" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 90),
                                                 100 * np.median(d[:, k]) / np.median(tot)))
-    print("  %-45s %7.0f %7.0f" % ("wave total", np.median(tot), np.percentile(tot, 90)))
+    print("  %-45s %7.0f %7.0f   p99 %.0f  max %.0f" % ("wave total", np.median(tot), np.percentile(tot, 90),
+                                                   np.percentile(tot, 99), tot.max()))
+    slow = np.argsort(tot)[-8:]
+    print("  slowest waves, cycles per phase:")
+    for w in slow:
+        print("   wave %4d total %6d :" % (w, tot[w]), " ".join("%5d" % x for x in d[w]))
     rt = buf[:, 12:14].astype(np.int64)  # 100 MHz
     print("real time: first wave start -> last wave end %.2f us; median wave life %.2f us; start spread %.2f us" % (
         (rt[:, 1].max() - rt[:, 0].min()) / 100.0, np.median(rt[:, 1] - rt[:, 0]) / 100.0,
