@@ -215,6 +215,122 @@ def test_missile_slots_exhausted(sfa, oracle_mod):
     env.close()
 
 
+def test_many_shells_and_kill_order(sfa, oracle_mod):
+    """More live shells than the prefetched groups hold (constructed; slots up to 11), several of
+    them overlapping the ship in the same tick: only the lowest colliding slot kills the ship
+    (SRC/game.cpp:410-420), the others fly on; shells on the area border leave."""
+    O = oracle_mod
+    n = 6
+    base = O.OracleVecEnv("youturn", n).snapshots()
+    rng = np.random.default_rng(3)
+    for i in range(n):
+        sx, sy = float(base["ship_x"][i]), float(base["ship_y"][i])
+        vx, vy = float(base["ship_vx"][i]), float(base["ship_vy"][i])
+        live = {0: [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], 1: [2, 5, 9], 2: [0, 4, 7, 13, 19], 3: list(range(20)),
+                4: [1], 5: [3, 6, 8]}[i]
+        for s in live:
+            base["shell_alive"][i, s] = 1
+            base["shell_vx"][i, s] = rng.uniform(-6, 6)
+            base["shell_vy"][i, s] = rng.uniform(-6, 6)
+            base["shell_x"][i, s] = rng.uniform(5, 705)
+            base["shell_y"][i, s] = rng.uniform(5, 620)
+        # shells that will sit on the ship after both have moved this tick
+        for s in {0: [4, 7, 10], 1: [5, 9], 2: [13, 19], 3: [6, 2, 15], 4: [], 5: [8]}[i]:
+            base["shell_x"][i, s] = sx + vx - base["shell_vx"][i, s] + rng.uniform(-3, 3)
+            base["shell_y"][i, s] = sy + vy - base["shell_vy"][i, s] + rng.uniform(-3, 3)
+        # shells about to leave the area
+        for s in {0: [1], 1: [2], 2: [0], 3: [19, 0], 4: [1], 5: [3]}[i]:
+            base["shell_x"][i, s] = 709.5
+            base["shell_vx"][i, s] = 5.0
+    env, orc = _load_both(sfa, O, "youturn", base)
+    acts = np.zeros((3, n), np.uint8)
+    obs, rew, done, info = run_device(env, acts)
+    for t in range(len(acts)):
+        oo, orw, od, oi = orc.step(acts[t].astype(np.int32))
+        assert np.array_equal(rew[t], orw), t
+        assert obs_close(obs[t], oo, True).all(), t
+    sn = orc.snapshots()
+    assert sn["stats"][:, 2].sum() >= 4  # shell deaths really happened
+    assert not compare_state(env.state_dict(), sn)
+    env.close()
+
+
+@pytest.mark.parametrize("gametype", ["youturn", "autoturn", "test-youturn"])
+def test_fuzzed_states(sfa, oracle_mod, gametype):
+    """Random CONSTRUCTED states (not reachable by play): ships anywhere in the area, arbitrary
+    velocities and timers, up to 20 missiles and 20 shells per lane, fortress dead or alive, any
+    vulnerability -- loaded into both engines, then 40 random ticks in lock-step."""
+    O = oracle_mod
+    n, T = 1024, 40
+    rng = np.random.default_rng(len(gametype) * 7)
+    base = O.OracleVecEnv(gametype, n).snapshots()
+    tab = np.load(os.path.join(GOLDEN, "tables.npz"))["missile_vel_by_angle"]
+    base["ship_alive"] = rng.integers(0, 2, n)
+    base["ship_x"] = np.where(rng.random(n) < 0.5, rng.integers(150, 560, n), rng.uniform(150, 560, n))
+    base["ship_y"] = np.where(rng.random(n) < 0.5, rng.integers(135, 495, n), rng.uniform(135, 495, n))
+    base["ship_vx"] = rng.uniform(-4, 4, n) * (rng.random(n) < 0.9)
+    base["ship_vy"] = rng.uniform(-4, 4, n) * (rng.random(n) < 0.9)
+    base["ship_angle"] = rng.integers(0, 360, n)
+    base["ship_death_timer"] = rng.integers(0, 1200, n)
+    for k in ("fire_timer", "thrust_timer", "left_timer", "right_timer"):
+        base[k] = rng.integers(-50, 50, n)
+    for k in ("fire_flag", "thrust_flag", "left_flag", "right_flag"):
+        base[k] = rng.integers(0, 2, n)
+    if gametype != "youturn" and gametype != "test-youturn":
+        base["left_flag"] = 0
+        base["right_flag"] = 0
+    base["fort_alive"] = rng.random(n) < 0.8
+    base["fort_angle"] = rng.integers(0, 36, n) * 10
+    base["fort_last_angle"] = rng.integers(0, 36, n) * 10
+    base["fort_timer"] = rng.integers(0, 1100, n)
+    base["fort_death_timer"] = rng.integers(0, 1100, n)
+    base["fort_vuln_timer"] = rng.integers(0, 400, n)
+    base["vlner"] = rng.integers(0, 14, n)
+    base["points"] = rng.integers(0, 5, n).astype(np.float32) * np.float32(0.05)
+    base["raw_points"] = base["points"] - np.float32(1.0)
+    base["time"] = rng.integers(0, 5000, n) * 34
+    base["tick"] = base["time"] // 34
+    base["stats"] = rng.integers(0, 50, (n, 13))
+    nm = rng.integers(0, 21, n)
+    ns = rng.integers(0, 21, n)
+    for i in range(n):
+        ms = rng.choice(20, nm[i], replace=False)
+        base["missile_alive"][i, ms] = 1
+        ss = rng.choice(20, ns[i], replace=False)
+        base["shell_alive"][i, ss] = 1
+    base["missile_x"] = rng.uniform(-10, 720, (n, 20))
+    base["missile_y"] = rng.uniform(-10, 636, (n, 20))
+    near = rng.random((n, 20)) < 0.25  # a quarter of the missiles about to hit the fortress
+    ang = rng.integers(0, 360, (n, 20))
+    base["missile_angle"] = ang
+    base["missile_vx"] = tab[ang, 0]
+    base["missile_vy"] = tab[ang, 1]
+    base["missile_x"] = np.where(near, 355 - tab[ang, 0] + rng.uniform(-25, 25, (n, 20)), base["missile_x"])
+    base["missile_y"] = np.where(near, 315 - tab[ang, 1] + rng.uniform(-25, 25, (n, 20)), base["missile_y"])
+    base["shell_x"] = rng.uniform(-5, 715, (n, 20))
+    base["shell_y"] = rng.uniform(-5, 631, (n, 20))
+    base["shell_vx"] = rng.uniform(-6, 6, (n, 20))
+    base["shell_vy"] = rng.uniform(-6, 6, (n, 20))
+    hit = rng.random((n, 20)) < 0.15  # some shells about to hit the ship
+    base["shell_x"] = np.where(hit, (base["ship_x"] + base["ship_vx"])[:, None] - base["shell_vx"] + rng.uniform(-14, 14, (n, 20)), base["shell_x"])
+    base["shell_y"] = np.where(hit, (base["ship_y"] + base["ship_vy"])[:, None] - base["shell_vy"] + rng.uniform(-14, 14, (n, 20)), base["shell_y"])
+    pv = rng.integers(0, 14, n)
+    env, orc = _load_both(sfa, O, gametype, base, prev_vlner=pv)
+    acts = rng.integers(0, env.n_actions, (T, n)).astype(np.uint8)
+    cps = {}
+    obs, rew, done, info = run_device(env, acts, state_every=10, state_cb=lambda t, sd: cps.__setitem__(t, sd))
+    for t in range(T):
+        oo, orw, od, oi = orc.step(acts[t].astype(np.int32))
+        assert np.array_equal(rew[t], orw), (t, np.flatnonzero(rew[t] != orw)[:5])
+        assert np.array_equal(done[t], od) and np.array_equal(info[t], oi), t
+        ok = obs_close(obs[t], oo, True)
+        assert ok.all(), (t, np.argwhere(~ok)[:5])
+        if t in cps:
+            bad = compare_state(cps[t], orc.snapshots())
+            assert not bad, (t, bad)
+    env.close()
+
+
 def test_autoturn_heading_on_the_spawn_lattice(sfa, oracle_mod):
     """autoturn rounds atan2 up to an integer degree (SRC/game.cpp:317-319).  A spawned ship sits on
     integer coordinates, where the exact heading can BE an integer (axes, diagonals): the device
