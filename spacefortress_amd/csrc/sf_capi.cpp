@@ -311,12 +311,6 @@ extern "C" int sf_field_id(const char* name) {
   return SF_ERR_FIELD;
 }
 
-static long field_offset_per_lane(int f) {
-  long o = 0;
-  for (int i = 0; i < f; i++) o += (long)sfl::kFields[i].elem_size * sfl::kFields[i].count;
-  return o;
-}
-
 // The tiled device layout never leaves the library: a small kernel gathers the field into (or
 // scatters it from) a linear [count][n_envs] staging buffer, which is what the host sees.
 static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host) {
@@ -334,8 +328,7 @@ static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host
   DeviceGuard guard(b->device);
   HIP_TRY(hipDeviceSynchronize());
   if (!to_host) HIP_TRY(hipMemcpy(b->d_scratch, host, total, hipMemcpyHostToDevice));
-  HIP_TRY(sf_launch_field_copy(b->d_state, b->n_envs, field_offset_per_lane(f), m.elem_size, m.count,
-                               b->d_scratch, to_host ? 1 : 0, nullptr));
+  HIP_TRY(sf_launch_field_copy(b->d_state, b->n_envs, f, b->d_scratch, to_host ? 1 : 0, nullptr));
   HIP_TRY(hipDeviceSynchronize());
   if (to_host) HIP_TRY(hipMemcpy(host, b->d_scratch, total, hipMemcpyDeviceToHost));
   return SF_OK;

@@ -13,8 +13,8 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
                           int32_t* reward, uint8_t* done, uint8_t* info, hipStream_t stream);
 
 // gather (to_linear) / scatter one field between the tiled state and a linear [count][n_envs] buffer
-hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, long offset_per_lane, int elem_size, int count,
-                                unsigned char* linear, int to_linear, hipStream_t stream);
+hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, unsigned char* linear, int to_linear,
+                                hipStream_t stream);
 
 // sf_host.cpp (no HIP calls: usable and tested without a GPU)
 void sf_host_fill_consts(const sf_preset& p, double* consts /* SF_CONST_DOUBLES */);

@@ -70,16 +70,15 @@
 #endif
 
 // Field access inside the wave's tile (sf_layout.h): `tb` is the tile base -- wave-uniform, one
-// SGPR pair for the whole state -- the field/slot offset is a compile-time constant and the lane
-// contributes a 32-bit byte offset (one VGPR per element size).
-#define SF_BASE(a, name) (tb + sfl::tile_offset(SF_F_##name))
-#define SF_SLOT(a, name, T, s) \
-  (tb + sfl::offset_per_lane(SF_F_##name) * sfl::kTileLanes + (size_t)(s) * (sfl::kTileLanes * sizeof(T)))
+// SGPR pair for the whole state -- the group/slot offset is a compile-time constant and the lane
+// contributes a 32-bit byte offset (one VGPR per chunk size: 16, 8, 4 or 2 bytes).
+#define SF_CHUNK(group, s)                                   \
+  (tb + sfl::chunk_offset(SF_G_##group, 0) +                 \
+   (size_t)(s) * (size_t)(sfl::kGroups[SF_G_##group].chunk * sfl::kTileLanes))
 #define SF_LD(T, base, off) (*reinterpret_cast<const T*>((base) + (off)))
-// SF_STORE_MODE (A/B switch, default set below): 0 plain stores (stay dirty in L2 until the
-// end-of-kernel write-back), 1 non-temporal (`nt`), 2 agent-scope relaxed atomic stores (`sc1`
-// write-through: the bytes leave L2 while the kernel still runs, so the kernel boundary has
-// nothing left to flush).
+// SF_STORE_MODE (A/B switch): 0 plain stores, 1 non-temporal.  (Write-through `sc1` stores were
+// also tried to empty the end-of-kernel L2 write-back: +1 %, plain vs nt within 1.3 % -- the
+// kernel boundary is not dominated by the dirty bytes.)
 #ifndef SF_STORE_MODE
 #define SF_STORE_MODE 0
 #endif
@@ -87,25 +86,15 @@ template <typename T>
 __device__ __forceinline__ void sf_store(T* p, T v) {
 #if SF_STORE_MODE == 1
   __builtin_nontemporal_store(v, p);
-#elif SF_STORE_MODE == 2
-  if constexpr (sizeof(T) == 8) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else if constexpr (sizeof(T) == 4) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  } else if constexpr (sizeof(T) == 2) {
-    __hip_atomic_store(reinterpret_cast<unsigned short*>(p), __builtin_bit_cast(unsigned short, v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    __hip_atomic_store(reinterpret_cast<unsigned char*>(p), __builtin_bit_cast(unsigned char, v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  }
 #else
   *p = v;
 #endif
 }
 #define SF_ST(T, base, off, v) sf_store<T>(reinterpret_cast<T*>((base) + (off)), (T)(v))
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+typedef int i2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -131,8 +120,8 @@ struct StatDelta {
   int max_vlner = 0;  // candidate for counter 12 (a running maximum)
 };
 
-struct Off {  // 32-bit byte offsets of this lane for 8-, 4-, 2- and 1-byte fields
-  unsigned o8, o4, o2, o1;
+struct Off {  // 32-bit byte offsets of this lane into rows of 16-, 8-, 4-, 2- and 1-byte chunks
+  unsigned o16, o8, o4, o2, o1;
 };
 
 __device__ __forceinline__ double rad2deg(double a) { return a / M_PI * 180; }  // SRC/vector.cpp:38-40
@@ -208,64 +197,58 @@ __device__ __forceinline__ void kill_ship(Lane& L, StatDelta& S) {  // SRC/game.
   }
 }
 
+// The fixed part of a lane: six 16-byte chunks and one 8-byte chunk (sf_layout.h).
 __device__ __forceinline__ void load_lane(const unsigned char* tb, const Off& o, Lane& L) {
-  L.mmask = SF_LD(uint32_t, SF_BASE(a, missile_mask), o.o4);  // first: the prefetch waits on these
-  L.smask = SF_LD(uint32_t, SF_BASE(a, shell_mask), o.o4);
-  L.sx = SF_LD(double, SF_BASE(a, ship_x), o.o8);
-  L.sy = SF_LD(double, SF_BASE(a, ship_y), o.o8);
-  L.vx = SF_LD(double, SF_BASE(a, ship_vx), o.o8);
-  L.vy = SF_LD(double, SF_BASE(a, ship_vy), o.o8);
-  L.angle = SF_LD(int16_t, SF_BASE(a, ship_angle), o.o2);
-  L.fl = SF_LD(uint8_t, SF_BASE(a, flags), o.o1);
-  L.death_t = SF_LD(int32_t, SF_BASE(a, ship_death_timer), o.o4);
-  L.fire_t = SF_LD(int32_t, SF_BASE(a, fire_timer), o.o4);
-  L.thrust_t = SF_LD(int32_t, SF_BASE(a, thrust_timer), o.o4);
-  L.left_t = SF_LD(int32_t, SF_BASE(a, left_timer), o.o4);
-  L.right_t = SF_LD(int32_t, SF_BASE(a, right_timer), o.o4);
-  L.fort_t = SF_LD(int32_t, SF_BASE(a, fort_timer), o.o4);
-  L.fort_death_t = SF_LD(int32_t, SF_BASE(a, fort_death_timer), o.o4);
-  L.fort_vuln_t = SF_LD(int32_t, SF_BASE(a, fort_vuln_timer), o.o4);
-  L.fort_angle = SF_LD(int16_t, SF_BASE(a, fort_angle), o.o2);
-  L.fort_last = SF_LD(int16_t, SF_BASE(a, fort_last_angle), o.o2);
-  L.points = SF_LD(float, SF_BASE(a, points), o.o4);
-  L.raw = SF_LD(float, SF_BASE(a, raw_points), o.o4);
-  L.vlner = SF_LD(int32_t, SF_BASE(a, vlner), o.o4);
-  L.time = SF_LD(int32_t, SF_BASE(a, time), o.o4);
-  L.prev_vlner = SF_LD(int32_t, SF_BASE(a, prev_vlner), o.o4);
-  L.cursor = SF_LD(uint32_t, SF_BASE(a, spawn_cursor), o.o4);
+  const i4_t mi = SF_LD(i4_t, SF_CHUNK(misc, 0), o.o16);  // first: the projectile prefetch waits on the masks
+  const d2_t p = SF_LD(d2_t, SF_CHUNK(ship_pos, 0), o.o16);
+  const d2_t v = SF_LD(d2_t, SF_CHUNK(ship_vel, 0), o.o16);
+  const i4_t ta = SF_LD(i4_t, SF_CHUNK(timers_a, 0), o.o16);
+  const i4_t tc = SF_LD(i4_t, SF_CHUNK(timers_b, 0), o.o16);
+  const i4_t sc = SF_LD(i4_t, SF_CHUNK(score, 0), o.o16);
+  const i2_t sm = SF_LD(i2_t, SF_CHUNK(small, 0), o.o8);
+  L.prev_vlner = mi.x;
+  L.cursor = (unsigned)mi.y;
+  L.mmask = (unsigned)mi.z;
+  L.smask = (unsigned)mi.w;
+  L.sx = p.x;
+  L.sy = p.y;
+  L.vx = v.x;
+  L.vy = v.y;
+  L.death_t = ta.x;
+  L.fire_t = ta.y;
+  L.thrust_t = ta.z;
+  L.left_t = ta.w;
+  L.right_t = tc.x;
+  L.fort_t = tc.y;
+  L.fort_death_t = tc.z;
+  L.fort_vuln_t = tc.w;
+  L.points = __int_as_float(sc.x);
+  L.raw = __int_as_float(sc.y);
+  L.vlner = sc.z;
+  L.time = sc.w;
+  L.angle = (int16_t)(sm.x & 0xFFFF);
+  L.fort_angle = (int16_t)((unsigned)sm.x >> 16);
+  L.fort_last = (int16_t)(sm.y & 0xFFFF);
+  L.fl = ((unsigned)sm.y >> 16) & 0xFFu;
 }
 
 __device__ __forceinline__ void store_lane(unsigned char* tb, const Off& o, const Lane& L) {
-  SF_ST(double, SF_BASE(a, ship_x), o.o8, L.sx);
-  SF_ST(double, SF_BASE(a, ship_y), o.o8, L.sy);
-  SF_ST(double, SF_BASE(a, ship_vx), o.o8, L.vx);
-  SF_ST(double, SF_BASE(a, ship_vy), o.o8, L.vy);
-  SF_ST(int16_t, SF_BASE(a, ship_angle), o.o2, (int16_t)L.angle);
-  SF_ST(uint8_t, SF_BASE(a, flags), o.o1, (uint8_t)L.fl);
-  SF_ST(int32_t, SF_BASE(a, ship_death_timer), o.o4, L.death_t);
-  SF_ST(int32_t, SF_BASE(a, fire_timer), o.o4, L.fire_t);
-  SF_ST(int32_t, SF_BASE(a, thrust_timer), o.o4, L.thrust_t);
-  SF_ST(int32_t, SF_BASE(a, left_timer), o.o4, L.left_t);
-  SF_ST(int32_t, SF_BASE(a, right_timer), o.o4, L.right_t);
-  SF_ST(int32_t, SF_BASE(a, fort_timer), o.o4, L.fort_t);
-  SF_ST(int32_t, SF_BASE(a, fort_death_timer), o.o4, L.fort_death_t);
-  SF_ST(int32_t, SF_BASE(a, fort_vuln_timer), o.o4, L.fort_vuln_t);
-  SF_ST(int16_t, SF_BASE(a, fort_angle), o.o2, (int16_t)L.fort_angle);
-  SF_ST(int16_t, SF_BASE(a, fort_last_angle), o.o2, (int16_t)L.fort_last);
-  SF_ST(float, SF_BASE(a, points), o.o4, L.points);
-  SF_ST(float, SF_BASE(a, raw_points), o.o4, L.raw);
-  SF_ST(int32_t, SF_BASE(a, vlner), o.o4, L.vlner);
-  SF_ST(int32_t, SF_BASE(a, time), o.o4, L.time);
-  SF_ST(int32_t, SF_BASE(a, prev_vlner), o.o4, L.prev_vlner);
-  SF_ST(uint32_t, SF_BASE(a, missile_mask), o.o4, L.mmask);
-  SF_ST(uint32_t, SF_BASE(a, shell_mask), o.o4, L.smask);
+  SF_ST(d2_t, SF_CHUNK(ship_pos, 0), o.o16, (d2_t{L.sx, L.sy}));
+  SF_ST(d2_t, SF_CHUNK(ship_vel, 0), o.o16, (d2_t{L.vx, L.vy}));
+  SF_ST(i4_t, SF_CHUNK(timers_a, 0), o.o16, (i4_t{L.death_t, L.fire_t, L.thrust_t, L.left_t}));
+  SF_ST(i4_t, SF_CHUNK(timers_b, 0), o.o16, (i4_t{L.right_t, L.fort_t, L.fort_death_t, L.fort_vuln_t}));
+  SF_ST(i4_t, SF_CHUNK(score, 0), o.o16, (i4_t{__float_as_int(L.points), __float_as_int(L.raw), L.vlner, L.time}));
+  SF_ST(i4_t, SF_CHUNK(misc, 0), o.o16, (i4_t{L.prev_vlner, (int)L.cursor, (int)L.mmask, (int)L.smask}));
+  SF_ST(i2_t, SF_CHUNK(small, 0), o.o8,
+        (i2_t{(int)((unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16)),
+              (int)((unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFu) << 16))}));
 }
 
 __device__ __forceinline__ void zero_counters(unsigned char* tb, const Off& o) {
 #pragma unroll
-  for (int k = 0; k < SF_NSTAT; k++) SF_ST(int32_t, SF_SLOT(a, stats, int32_t, k), o.o4, 0);
-  SF_ST(int32_t, SF_BASE(a, ep_return), o.o4, 0);
-  SF_ST(int32_t, SF_BASE(a, ep_kills), o.o4, 0);
+  for (int k = 0; k < SF_NSTAT; k++) SF_ST(int32_t, SF_CHUNK(stats, k), o.o4, 0);
+  SF_ST(int32_t, SF_CHUNK(ep_return, 0), o.o4, 0);
+  SF_ST(int32_t, SF_CHUNK(ep_kills, 0), o.o4, 0);
 }
 
 // ExtraGameValues of Game::computeExtra (SRC/game.cpp:282-312).  They are a pure function of the
@@ -421,18 +404,18 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
   const unsigned i = blockIdx.x * SF_BLOCK + threadIdx.x;
   const unsigned lane = threadIdx.x & 63u;
   unsigned char* const tb = a.state + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * sfl::kTileBytes;
-  const Off o = {lane * 8u, lane * 4u, lane * 2u, lane};
+  const Off o = {lane * 16u, lane * 8u, lane * 4u, lane * 2u, lane};
   Lane L;
   if (first) {
     L.prev_vlner = 0;
     L.cursor = cursor0 + cursor_stride * i;
   } else {
-    L.prev_vlner = SF_LD(int32_t, SF_BASE(a, prev_vlner), o.o4);
-    L.cursor = SF_LD(uint32_t, SF_BASE(a, spawn_cursor), o.o4);
+    const i4_t mi = SF_LD(i4_t, SF_CHUNK(misc, 0), o.o16);
+    L.prev_vlner = mi.x;
+    L.cursor = (unsigned)mi.y;
   }
   new_game(a, L);
   store_lane(tb, o, L);
-  SF_ST(uint32_t, SF_BASE(a, spawn_cursor), o.o4, L.cursor);
   zero_counters(tb, o);
   if (obs != nullptr && i < (unsigned)a.n_envs && a.obs_type != 3) {
     // the reference's extras are stale heap until the first tick; defined as computeExtra(spawn)
@@ -455,8 +438,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   const unsigned lane = tid & 63u;
   // this wave's tile: wave-uniform by construction, made scalar for the compiler
   unsigned char* const tb = a.state + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * sfl::kTileBytes;
-  const Off o = {lane * 8u, lane * 4u, lane * 2u, lane};  // lane offsets inside the tile's rows
-  const Off g = {i * 8u, i * 4u, i * 2u, i};              // env offsets into the caller's arrays
+  const Off o = {lane * 16u, lane * 8u, lane * 4u, lane * 2u, lane};  // lane offsets inside the tile's rows
+  const Off g = {i * 16u, i * 8u, i * 4u, i * 2u, i};     // env offsets into the caller's arrays
   const bool real = i < (unsigned)a.n_envs;  // lanes in [n_envs, lanes) are padding: they run NOOPs
 #ifdef SF_STAMPS
   unsigned long long stamp_[16];
@@ -478,7 +461,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   Lane L;
   load_lane(tb, o, L);
   // cos/sin table: 720 doubles = 360 16-byte pieces, six per lane (the last one partial)
-  typedef double d2_t __attribute__((ext_vector_type(2)));
   const unsigned char* cb = (const unsigned char*)a.consts;
   d2_t cst[SF_TRIG_PIECES];
 #pragma unroll
@@ -519,9 +501,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
           if (k < kMgN[g]) {
             const int s = kMgLo[g] + k;
             if ((L.mmask >> s) & 1u) {
-              mx[s] = SF_LD(double, SF_SLOT(a, missile_x, double, s), o.o8);
-              my[s] = SF_LD(double, SF_SLOT(a, missile_y, double, s), o.o8);
-              mang[s] = SF_LD(int16_t, SF_SLOT(a, missile_angle, int16_t, s), o.o2);
+              const d2_t m = SF_LD(d2_t, SF_CHUNK(missile_pos, s), o.o16);
+              mx[s] = m.x;
+              my[s] = m.y;
+              mang[s] = SF_LD(int16_t, SF_CHUNK(missile_ang, s), o.o2);
             }
           }
         }
@@ -534,10 +517,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         for (int k = 0; k < 3; k++) {
           const int s = 3 * g + k;
           if ((L.smask >> s) & 1u) {
-            shx[s] = SF_LD(double, SF_SLOT(a, shell_x, double, s), o.o8);
-            shy[s] = SF_LD(double, SF_SLOT(a, shell_y, double, s), o.o8);
-            shvx[s] = SF_LD(double, SF_SLOT(a, shell_vx, double, s), o.o8);
-            shvy[s] = SF_LD(double, SF_SLOT(a, shell_vy, double, s), o.o8);
+            const d2_t sp = SF_LD(d2_t, SF_CHUNK(shell_pos, s), o.o16);
+            const d2_t sv = SF_LD(d2_t, SF_CHUNK(shell_vel, s), o.o16);
+            shx[s] = sp.x;
+            shy[s] = sp.y;
+            shvx[s] = sv.x;
+            shvy[s] = sv.y;
           }
         }
       }
@@ -566,7 +551,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   // ================= Game::stepOneTick (SRC/game.cpp:473-485) =================
   float rew = 0;        // mReward = 0
   L.time += sfc::tick_ms;  // updateTime
-  const unsigned cursor0 = L.cursor;
 
   // ---- processKeyState (SRC/game.cpp:218-272); the wrapper sends FIRE, THRUST, (LEFT, RIGHT)
   //      press-or-release every step (ENV:213-229), so each key is one edge test.
@@ -732,10 +716,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         const double dx = nx[k] - L.sx, dy = ny[k] - L.sy;
         col |= (unsigned)(dx * dx + dy * dy <= sfc::shell_hit_r2) << s;
         out |= (unsigned)outside_area(a, nx[k], ny[k]) << s;
-        if (isnew) {
-          SF_ST(double, SF_SLOT(a, shell_vx, double, s), o.o8, vx);
-          SF_ST(double, SF_SLOT(a, shell_vy, double, s), o.o8, vy);
-        }
+        if (isnew) SF_ST(d2_t, SF_CHUNK(shell_vel, s), o.o16, (d2_t{vx, vy}));
       }
       const unsigned live = L.smask & gmask;
       col &= live;
@@ -753,10 +734,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const int s = 3 * g + k;
-        if ((L.smask >> s) & 1u) {
-          SF_ST(double, SF_SLOT(a, shell_x, double, s), o.o8, nx[k]);
-          SF_ST(double, SF_SLOT(a, shell_y, double, s), o.o8, ny[k]);
-        }
+        if ((L.smask >> s) & 1u) SF_ST(d2_t, SF_CHUNK(shell_pos, s), o.o16, (d2_t{nx[k], ny[k]}));
       }
     }
     if (__ballot((L.smask >> SF_SPF) != 0u) != 0ull) {  // rare: more than SF_SPF shells in some lane
@@ -771,13 +749,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
             y = sfc::fort_y;
             vx = new_s_vx;
             vy = new_s_vy;
-            SF_ST(double, SF_SLOT(a, shell_vx, double, s), o.o8, vx);
-            SF_ST(double, SF_SLOT(a, shell_vy, double, s), o.o8, vy);
+            SF_ST(d2_t, SF_CHUNK(shell_vel, s), o.o16, (d2_t{vx, vy}));
           } else {
-            x = SF_LD(double, SF_SLOT(a, shell_x, double, s), o.o8);
-            y = SF_LD(double, SF_SLOT(a, shell_y, double, s), o.o8);
-            vx = SF_LD(double, SF_SLOT(a, shell_vx, double, s), o.o8);
-            vy = SF_LD(double, SF_SLOT(a, shell_vy, double, s), o.o8);
+            const d2_t sp = SF_LD(d2_t, SF_CHUNK(shell_pos, s), o.o16);
+            const d2_t sv = SF_LD(d2_t, SF_CHUNK(shell_vel, s), o.o16);
+            x = sp.x;
+            y = sp.y;
+            vx = sv.x;
+            vy = sv.y;
           }
           x += vx;
           y += vy;
@@ -795,8 +774,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
           if (dead) {
             L.smask &= ~(1u << s);
           } else {
-            SF_ST(double, SF_SLOT(a, shell_x, double, s), o.o8, x);
-            SF_ST(double, SF_SLOT(a, shell_y, double, s), o.o8, y);
+            SF_ST(d2_t, SF_CHUNK(shell_pos, s), o.o16, (d2_t{x, y}));
           }
         }
       }
@@ -818,11 +796,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       const bool out = live & !hit & outside_area(a, nx, ny);
       ev_hit |= (unsigned)hit << s;
       ev_out |= (unsigned)out << s;
-      if (live & !hit & !out) {
-        SF_ST(double, SF_SLOT(a, missile_x, double, s), o.o8, nx);
-        SF_ST(double, SF_SLOT(a, missile_y, double, s), o.o8, ny);
-      }
-      if (isnew) SF_ST(int16_t, SF_SLOT(a, missile_angle, int16_t, s), o.o2, (int16_t)ang);
+      if (live & !hit & !out) SF_ST(d2_t, SF_CHUNK(missile_pos, s), o.o16, (d2_t{nx, ny}));
+      if (isnew) SF_ST(int16_t, SF_CHUNK(missile_ang, s), o.o2, (int16_t)ang);
     };
     auto m_pref = [&](int s) __attribute__((always_inline)) {
       const bool isnew = (s == new_m_slot);
@@ -845,10 +820,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         if (live) {
           if (s == new_m_slot)
             m_move(s, new_m_x, new_m_y, new_m_angle, true);
-          else
-            m_move(s, SF_LD(double, SF_SLOT(a, missile_x, double, s), o.o8),
-                   SF_LD(double, SF_SLOT(a, missile_y, double, s), o.o8),
-                   SF_LD(int16_t, SF_SLOT(a, missile_angle, int16_t, s), o.o2), false);
+          else {
+            const d2_t m = SF_LD(d2_t, SF_CHUNK(missile_pos, s), o.o16);
+            m_move(s, m.x, m.y, SF_LD(int16_t, SF_CHUNK(missile_ang, s), o.o2), false);
+          }
         }
       }
     }
@@ -912,10 +887,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   // ================= statistics and the vec-env worker's auto-reset (rl/train.py:80-88) ======
   if (done && a.auto_reset) {
     // episode totals = what previous launches accumulated + this tick's share
-    const int ep_ret = SF_LD(int32_t, SF_BASE(a, ep_return), o.o4) + r;
-    const int ep_kil = SF_LD(int32_t, SF_BASE(a, ep_kills), o.o4) + fort_kill;
-    const int deaths = SF_LD(int32_t, SF_SLOT(a, stats, int32_t, SF_ST_SHIP_DEATHS), o.o4) + S.ship_deaths;
-    const int shots = SF_LD(int32_t, SF_SLOT(a, stats, int32_t, SF_ST_SHOTS), o.o4) + S.shots;
+    const int ep_ret = SF_LD(int32_t, SF_CHUNK(ep_return, 0), o.o4) + r;
+    const int ep_kil = SF_LD(int32_t, SF_CHUNK(ep_kills, 0), o.o4) + fort_kill;
+    const int deaths = SF_LD(int32_t, SF_CHUNK(stats, SF_ST_SHIP_DEATHS), o.o4) + S.ship_deaths;
+    const int shots = SF_LD(int32_t, SF_CHUNK(stats, SF_ST_SHOTS), o.o4) + S.shots;
     if (real) {
       atomicAdd(&a.acc[0], 1ull);
       atomicAdd(&a.acc[1], (unsigned long long)(long long)ep_ret);
@@ -934,7 +909,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     // no-return atomics, executed at the memory side: the counters are never loaded
 #define SF_FLUSH(idx, v)                                                                      \
   if (__ballot((v) != 0) != 0ull) {                                                           \
-    if ((v) != 0) atomicAdd(reinterpret_cast<int*>(SF_SLOT(a, stats, int32_t, idx) + o.o4), (v)); \
+    if ((v) != 0) atomicAdd(reinterpret_cast<int*>(SF_CHUNK(stats, idx) + o.o4), (v)); \
   }
     SF_FLUSH(SF_ST_BIG_HEX_DEATHS, S.big_hex_deaths)
     SF_FLUSH(SF_ST_SMALL_HEX_DEATHS, S.small_hex_deaths)
@@ -951,18 +926,17 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
 #undef SF_FLUSH
     if (__ballot(S.max_vlner != 0) != 0ull) {
       if (S.max_vlner != 0)
-        atomicMax(reinterpret_cast<int*>(SF_SLOT(a, stats, int32_t, SF_ST_MAX_VLNER) + o.o4), S.max_vlner);
+        atomicMax(reinterpret_cast<int*>(SF_CHUNK(stats, SF_ST_MAX_VLNER) + o.o4), S.max_vlner);
     }
     if (__ballot(r != 0) != 0ull) {
-      if (r != 0) atomicAdd(reinterpret_cast<int*>(SF_BASE(a, ep_return) + o.o4), r);
+      if (r != 0) atomicAdd(reinterpret_cast<int*>(SF_CHUNK(ep_return, 0) + o.o4), r);
     }
     if (__ballot(fort_kill != 0) != 0ull) {
-      if (fort_kill) atomicAdd(reinterpret_cast<int*>(SF_BASE(a, ep_kills) + o.o4), 1);
+      if (fort_kill) atomicAdd(reinterpret_cast<int*>(SF_CHUNK(ep_kills, 0) + o.o4), 1);
     }
   }
 
   store_lane(tb, o, L);
-  if (__ballot(L.cursor != cursor0) != 0ull) SF_ST(uint32_t, SF_BASE(a, spawn_cursor), o.o4, L.cursor);
 
   if (real) {
     if (reward_out) SF_ST(int32_t, (unsigned char*)reward_out, g.o4, r);
@@ -999,38 +973,44 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
 // sf_get_field / sf_set_field: one field between the tiled state and a linear [count][n_envs]
 // buffer (not on the hot path).
 template <typename T>
-__global__ __launch_bounds__(SF_BLOCK) void sf_field_copy_kernel(unsigned char* state, int n_envs, long off_per_lane,
-                                                                int count, T* linear, int to_linear) {
+__global__ __launch_bounds__(SF_BLOCK) void sf_field_copy_kernel(unsigned char* state, int n_envs, long tile_off,
+                                                                int lane_stride, int slot_stride, int count,
+                                                                T* linear, int to_linear) {
   const long e = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
   if (e >= n_envs) return;
-  T* tile = reinterpret_cast<T*>(state + (e >> 6) * sfl::kTileBytes + off_per_lane * sfl::kTileLanes) + (e & 63);
+  unsigned char* lane0 = state + (e >> 6) * sfl::kTileBytes + tile_off + (e & 63) * lane_stride;
   for (int c = 0; c < count; c++) {
+    T* p = reinterpret_cast<T*>(lane0 + (long)c * slot_stride);
     if (to_linear)
-      linear[(long)c * n_envs + e] = tile[(long)c * sfl::kTileLanes];
+      linear[(long)c * n_envs + e] = *p;
     else
-      tile[(long)c * sfl::kTileLanes] = linear[(long)c * n_envs + e];
+      *p = linear[(long)c * n_envs + e];
   }
 }
 
-hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, long off, int elem_size, int count,
-                                unsigned char* linear, int to_linear, hipStream_t stream) {
+hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, unsigned char* linear, int to_linear,
+                                hipStream_t stream) {
+  const sfl::FieldMeta& m = sfl::kFields[field];
+  const int lane_stride = sfl::kGroups[m.group].chunk, slot_stride = lane_stride * sfl::kTileLanes;
+  const long off = sfl::group_offset(m.group) + m.byte_in_chunk;
+  const int elem_size = m.elem_size, count = m.count;
   const unsigned grid = (unsigned)((n_envs + SF_BLOCK - 1) / SF_BLOCK);
   switch (elem_size) {
     case 1:
       hipLaunchKernelGGL(sf_field_copy_kernel<uint8_t>, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, off,
-                         count, (uint8_t*)linear, to_linear);
+                         lane_stride, slot_stride, count, (uint8_t*)linear, to_linear);
       break;
     case 2:
       hipLaunchKernelGGL(sf_field_copy_kernel<uint16_t>, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, off,
-                         count, (uint16_t*)linear, to_linear);
+                         lane_stride, slot_stride, count, (uint16_t*)linear, to_linear);
       break;
     case 4:
       hipLaunchKernelGGL(sf_field_copy_kernel<uint32_t>, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, off,
-                         count, (uint32_t*)linear, to_linear);
+                         lane_stride, slot_stride, count, (uint32_t*)linear, to_linear);
       break;
     default:
       hipLaunchKernelGGL(sf_field_copy_kernel<uint64_t>, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, off,
-                         count, (uint64_t*)linear, to_linear);
+                         lane_stride, slot_stride, count, (uint64_t*)linear, to_linear);
       break;
   }
   return hipGetLastError();

@@ -1,63 +1,93 @@
 // sf_layout.h -- world state of a batch in HBM, shared by the kernels and the C-ABI host code.
 //
-// Struct-of-arrays per WAVE TILE: the batch is cut into tiles of 64 envs (one wavefront);
-// a tile is one contiguous block of kTileBytes holding, field after field, the 64 lanes'
-// values: [field][slot][64 lanes].  So
-//   * lane l of a wave reads  tile_base + C(field, slot) + l*elem : 64 consecutive elements,
-//     a fully coalesced row of 64*elem bytes, aligned to its own size;
-//   * C(field, slot) is a COMPILE-TIME constant: the whole state of a wave is addressed from
-//     one scalar base (an SGPR pair) plus one per-lane byte offset per element size -- no
-//     per-field base arithmetic (the first, batch-wide SoA version of this kernel spent a
-//     quarter of its instructions on 64-bit address math and SGPR spills);
+// One contiguous block per WAVE TILE: the batch is cut into tiles of 64 envs (one wavefront);
+// inside a tile the state is a sequence of GROUPS, each stored [slot][64 lanes][chunk], where a
+// chunk is what ONE lane reads or writes with ONE memory instruction:
+//   * 16-byte chunks pack the fields that always travel together -- (x, y), (vx, vy), four
+//     int32 timers, ... -- so lane l issues one `global_load_dwordx4` at
+//     tile_base + C(group, slot) + 16*l and the wave moves 1 KiB of consecutive bytes: the
+//     widest, fully coalesced access the hardware has (the guide's 16 B/lane rule);
+//   * C(group, slot) is a COMPILE-TIME constant: the whole state of a wave hangs off one
+//     scalar base (an SGPR pair) plus one per-lane offset per chunk size;
+//   * counters touched only by rare events (statistics, episode sums) stay 4-byte rows: they
+//     are never loaded on the hot path, events add to them with atomics;
 //   * a wave's working set is one 74 KB block: page- and channel-local.
+// History: batch-wide [field][N] arrays -> a quarter of the instructions
+// were per-field 64-bit address math and SGPR spills; per-tile [field][64] rows -> 24 loads and
+// 23 stores of 1-8 bytes per lane and step; this layout -> 7 + 7.
 // The batch is padded to a multiple of 256 envs (4 tiles = one workgroup).  The reference keeps
-// the same data as one 2568-byte `Game` object per env (SRC/game.hh:84-143).
+// the same data as one 2568-byte `Game` object per env (SRC/game.hh:84-143).  The layout never
+// leaves the library: sf_get_field / sf_set_field gather and scatter by field name.
 #pragma once
 #include <stdint.h>
 
 #define SF_NSLOT 20 /* SRC/game.hh:3-4 */
 #define SF_NSTAT 13 /* SRC/game.hh:29-43 */
 
-// X(name, ctype, count, is_float) -- ordered by decreasing element size so that every
-// array stays naturally aligned.  Reference members in the comments.
-#define SF_FIELDS(X)                                                                         \
-  X(ship_x, double, 1, 1)         /* mShip.mPos.mX            SRC/object.hh:5 */             \
-  X(ship_y, double, 1, 1)         /* mShip.mPos.mY */                                        \
-  X(ship_vx, double, 1, 1)        /* mShip.mVel.mX */                                        \
-  X(ship_vy, double, 1, 1)        /* mShip.mVel.mY */                                        \
-  X(missile_x, double, SF_NSLOT, 1) /* mMissiles[i].mPos      SRC/game.hh:90 */              \
-  X(missile_y, double, SF_NSLOT, 1)                                                          \
-  X(shell_x, double, SF_NSLOT, 1)  /* mShells[i].mPos, mVel   SRC/game.hh:91 */              \
-  X(shell_y, double, SF_NSLOT, 1)                                                            \
-  X(shell_vx, double, SF_NSLOT, 1)                                                           \
-  X(shell_vy, double, SF_NSLOT, 1)                                                           \
-  X(ship_death_timer, int32_t, 1, 0) /* mShip.mDeathTimer     SRC/game.hh:60-64 */           \
-  X(fire_timer, int32_t, 1, 0)                                                               \
-  X(thrust_timer, int32_t, 1, 0)                                                             \
-  X(left_timer, int32_t, 1, 0)                                                               \
-  X(right_timer, int32_t, 1, 0)                                                              \
-  X(fort_timer, int32_t, 1, 0)       /* mFortress.mTimer      SRC/game.hh:77 */              \
-  X(fort_death_timer, int32_t, 1, 0)                                                         \
-  X(fort_vuln_timer, int32_t, 1, 0)                                                          \
-  X(points, float, 1, 1)             /* mScore                SRC/game.hh:49-52 */           \
-  X(raw_points, float, 1, 1)                                                                 \
-  X(vlner, int32_t, 1, 0)                                                                    \
-  X(time, int32_t, 1, 0)             /* mTime (mTick = mTime / tick_ms) SRC/game.hh:93 */    \
-  X(stats, int32_t, SF_NSTAT, 0)     /* mStats                SRC/game.hh:29-43 */           \
-  X(prev_vlner, int32_t, 1, 0)       /* SSF_Env.prev_vlner    ENV:92,244 */                  \
-  X(spawn_cursor, uint32_t, 1, 0)    /* position in the process's rand() spawn sequence */   \
-  X(missile_mask, uint32_t, 1, 0)    /* bit i = mMissiles[i].mAlive */                       \
-  X(shell_mask, uint32_t, 1, 0)      /* bit i = mShells[i].mAlive */                         \
-  X(ep_return, int32_t, 1, 0)        /* running sum of wrapper rewards (rl/train.py:84) */   \
-  X(ep_kills, int32_t, 1, 0)         /* running sum of info (rl/train.py:81) */              \
-  X(ship_angle, int16_t, 1, 0)       /* mShip.mAngle: always an integer in [0,360) */        \
-  X(fort_angle, int16_t, 1, 0)       /* mFortress.mAngle: multiple of the sector size */     \
-  X(fort_last_angle, int16_t, 1, 0)  /* mFortress.mLastAngle */                              \
-  X(missile_angle, int16_t, SF_NSLOT, 0) /* mMissiles[i].mAngle (velocity = 20*(cos,sin)) */ \
-  X(flags, uint8_t, 1, 0)            /* SF_FL_* bits */
+// G(group, chunk_bytes, slots)
+#define SF_GROUPS(G)                                                                            \
+  G(ship_pos, 16, 1)              /* ship_x, ship_y */                                          \
+  G(ship_vel, 16, 1)              /* ship_vx, ship_vy */                                        \
+  G(timers_a, 16, 1)              /* ship_death, fire, thrust, left timers */                   \
+  G(timers_b, 16, 1)              /* right, fort, fort_death, fort_vuln timers */               \
+  G(score, 16, 1)                 /* points, raw_points, vlner, time */                         \
+  G(misc, 16, 1)                  /* prev_vlner, spawn_cursor, missile_mask, shell_mask */      \
+  G(small, 8, 1)                  /* ship_angle, fort_angle, fort_last_angle (i16), flags (u8) */ \
+  G(missile_pos, 16, SF_NSLOT)    /* missile_x, missile_y */                                    \
+  G(missile_ang, 2, SF_NSLOT)     /* missile_angle */                                           \
+  G(shell_pos, 16, SF_NSLOT)      /* shell_x, shell_y */                                        \
+  G(shell_vel, 16, SF_NSLOT)      /* shell_vx, shell_vy */                                      \
+  G(stats, 4, SF_NSTAT)           /* the 13 counters: atomics only */                           \
+  G(ep_return, 4, 1)                                                                            \
+  G(ep_kills, 4, 1)
+
+enum SfGroupId {
+#define G(name, chunk, slots) SF_G_##name,
+  SF_GROUPS(G)
+#undef G
+      SF_G_COUNT
+};
+
+// X(name, ctype, count, is_float, group, byte offset inside the lane's chunk)
+// `count` = elements per env (= the group's slot count).  Reference members in the comments.
+#define SF_FIELDS(X)                                                                                        \
+  X(ship_x, double, 1, 1, ship_pos, 0)           /* mShip.mPos.mX            SRC/object.hh:5 */            \
+  X(ship_y, double, 1, 1, ship_pos, 8)           /* mShip.mPos.mY */                                       \
+  X(ship_vx, double, 1, 1, ship_vel, 0)          /* mShip.mVel.mX */                                       \
+  X(ship_vy, double, 1, 1, ship_vel, 8)          /* mShip.mVel.mY */                                       \
+  X(missile_x, double, SF_NSLOT, 1, missile_pos, 0) /* mMissiles[i].mPos      SRC/game.hh:90 */            \
+  X(missile_y, double, SF_NSLOT, 1, missile_pos, 8)                                                        \
+  X(shell_x, double, SF_NSLOT, 1, shell_pos, 0)  /* mShells[i].mPos, mVel    SRC/game.hh:91 */             \
+  X(shell_y, double, SF_NSLOT, 1, shell_pos, 8)                                                            \
+  X(shell_vx, double, SF_NSLOT, 1, shell_vel, 0)                                                           \
+  X(shell_vy, double, SF_NSLOT, 1, shell_vel, 8)                                                           \
+  X(ship_death_timer, int32_t, 1, 0, timers_a, 0) /* mShip.mDeathTimer       SRC/game.hh:60-64 */          \
+  X(fire_timer, int32_t, 1, 0, timers_a, 4)                                                                \
+  X(thrust_timer, int32_t, 1, 0, timers_a, 8)                                                              \
+  X(left_timer, int32_t, 1, 0, timers_a, 12)                                                               \
+  X(right_timer, int32_t, 1, 0, timers_b, 0)                                                               \
+  X(fort_timer, int32_t, 1, 0, timers_b, 4)      /* mFortress.mTimer         SRC/game.hh:77 */             \
+  X(fort_death_timer, int32_t, 1, 0, timers_b, 8)                                                          \
+  X(fort_vuln_timer, int32_t, 1, 0, timers_b, 12)                                                          \
+  X(points, float, 1, 1, score, 0)               /* mScore                   SRC/game.hh:49-52 */          \
+  X(raw_points, float, 1, 1, score, 4)                                                                     \
+  X(vlner, int32_t, 1, 0, score, 8)                                                                        \
+  X(time, int32_t, 1, 0, score, 12)              /* mTime (mTick = mTime / tick_ms) SRC/game.hh:93 */      \
+  X(stats, int32_t, SF_NSTAT, 0, stats, 0)       /* mStats                   SRC/game.hh:29-43 */          \
+  X(prev_vlner, int32_t, 1, 0, misc, 0)          /* SSF_Env.prev_vlner       ENV:92,244 */                 \
+  X(spawn_cursor, uint32_t, 1, 0, misc, 4)       /* position in the process's rand() spawn sequence */     \
+  X(missile_mask, uint32_t, 1, 0, misc, 8)       /* bit i = mMissiles[i].mAlive */                         \
+  X(shell_mask, uint32_t, 1, 0, misc, 12)        /* bit i = mShells[i].mAlive */                           \
+  X(ep_return, int32_t, 1, 0, ep_return, 0)      /* running sum of wrapper rewards (rl/train.py:84) */     \
+  X(ep_kills, int32_t, 1, 0, ep_kills, 0)        /* running sum of info (rl/train.py:81) */                \
+  X(ship_angle, int16_t, 1, 0, small, 0)         /* mShip.mAngle: always an integer in [0,360) */          \
+  X(fort_angle, int16_t, 1, 0, small, 2)         /* mFortress.mAngle: multiple of the sector size */       \
+  X(fort_last_angle, int16_t, 1, 0, small, 4)    /* mFortress.mLastAngle */                                \
+  X(missile_angle, int16_t, SF_NSLOT, 0, missile_ang, 0) /* mMissiles[i].mAngle (vel = 20*(cos,sin)) */    \
+  X(flags, uint8_t, 1, 0, small, 6)              /* SF_FL_* bits */
 
 enum SfFieldId {
-#define X(name, ctype, count, isf) SF_F_##name,
+#define X(name, ctype, count, isf, group, off) SF_F_##name,
   SF_FIELDS(X)
 #undef X
       SF_F_COUNT
@@ -79,40 +109,48 @@ enum {
 };
 
 namespace sfl {
+constexpr int kTileLanes = 64;  // one wavefront
+
+struct GroupMeta {
+  int chunk, slots;
+};
+constexpr GroupMeta kGroups[SF_G_COUNT] = {
+#define G(name, chunk, slots) {chunk, slots},
+    SF_GROUPS(G)
+#undef G
+};
+// byte offset, inside a tile, of (group g, slot 0, lane 0)
+constexpr long group_offset(int g) {
+  long o = 0;
+  for (int i = 0; i < g; i++) o += (long)kGroups[i].chunk * kGroups[i].slots * kTileLanes;
+  return o;
+}
+constexpr long kTileBytes = group_offset(SF_G_COUNT);          // 74 496 B
+constexpr long kBytesPerLane = kTileBytes / kTileLanes;        // 1164 B
+// byte offset, inside a tile, of lane 0's chunk of (group g, slot s)
+constexpr long chunk_offset(int g, int s = 0) { return group_offset(g) + (long)s * kGroups[g].chunk * kTileLanes; }
+
 struct FieldMeta {
   const char* name;
-  int elem_size, count, is_float;
+  int elem_size, count, is_float, group, byte_in_chunk;
 };
 constexpr FieldMeta kFields[SF_F_COUNT] = {
-#define X(name, ctype, count, isf) {#name, (int)sizeof(ctype), count, isf},
+#define X(name, ctype, count, isf, group, off) {#name, (int)sizeof(ctype), count, isf, SF_G_##group, off},
     SF_FIELDS(X)
 #undef X
 };
-// bytes per lane that precede field f
-constexpr long offset_per_lane(int f) {
-  long o = 0;
-  for (int i = 0; i < f; i++) o += (long)kFields[i].elem_size * kFields[i].count;
-  return o;
-}
-constexpr long kBytesPerLane = offset_per_lane(SF_F_COUNT);
-constexpr int kTileLanes = 64;                          // one wavefront
-constexpr long kTileBytes = kBytesPerLane * kTileLanes;  // 74 432 B
-// byte offset, inside a tile, of lane 0 of (field f, slot s)
-constexpr long tile_offset(int f, int s = 0) {
-  return offset_per_lane(f) * kTileLanes + (long)s * kTileLanes * kFields[f].elem_size;
-}
 }  // namespace sfl
 
 // Host-built constant block (doubles):
 //   [0, 720)    cos/sin(deg2rad(k)) interleaved, k = 0..359 -- indexed per lane, so every
 //               workgroup stages it into LDS (SF_LDS_DOUBLES)
 //   [720, 744)  big hexagon: per edge (nx, ny, px, py)   SRC/hexagon.cpp:36-48
-//   [744, 768)  small hexagon, same -- uniform, so they travel as kernel arguments (SGPRs)
+//   [744, 768)  small hexagon, same -- checked against the constants compiled into the kernels
 #define SF_LDS_TRIG 0
 #define SF_LDS_BIGHEX 720
 #define SF_LDS_SMALLHEX 744
 #define SF_CONST_DOUBLES 768
-#define SF_LDS_DOUBLES 720 /* what a wave stages into LDS: the cos/sin table (indexed per lane) */
+#define SF_LDS_DOUBLES 720 /* what a workgroup stages into LDS: the cos/sin table (indexed per lane) */
 
 // The 12 hexagon edges as Hexagon::isInside forms them (SRC/hexagon.cpp:38-42), X(nx, ny, px, py),
 // for radius 200 / 40 (bigHex / smallHex of every preset, SRC/configs.cpp:34-35).  Compiled into the
@@ -151,10 +189,10 @@ struct Score {
 
 // Everything the kernels need that is uniform across lanes; passed by value (kernarg -> SGPRs).
 struct SfKernelArgs {
-  unsigned char* state;      // base of the SoA block
+  unsigned char* state;      // base of the tiled state block
   long lanes;                // padded lane count (multiple of 256)
   int n_envs;                // real lanes
-  const double* consts;      // SF_LDS_DOUBLES doubles in HBM
+  const double* consts;      // SF_CONST_DOUBLES doubles in HBM
   const int16_t* spawn;      // [spawn_len][4] (x, y, angle, 0)
   unsigned spawn_mask;       // spawn_len - 1
   unsigned long long action_keys; // 4 bits per action index, up to 16 actions
