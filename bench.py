@@ -74,8 +74,8 @@ def pmc_traffic(gametype, envs, obs_type):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=12000, help="timed launches (default spans two episode rollovers: 5295 steps each)")
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--gametype", default="youturn")
     ap.add_argument("--obs-type", default="features")
@@ -181,10 +181,13 @@ def main():
                     "note": "numpy int64 actions in, numpy obs/reward/done/info out every step (PCIe both ways)"}
     if os.environ.get("SF_PMC_CALIB"):
         # known-byte calibration dispatches for the rocprofv3 --pmc passes (tools/pmc_report.py):
-        # the field gather kernel reads n*count*elem bytes in the step kernel's own access pattern
-        # (8 / 4 / 2 bytes per lane, 64-lane rows) and writes the same number linearly
-        for name in ("missile_x", "shell_vx", "stats", "missile_angle", "ship_x", "time"):
-            env.get_field(name)
+        # sf_group_copy_kernel reads n*20*16 bytes in the step kernel's own access pattern
+        # (16 bytes per lane, 64-lane rows) and writes the same number linearly
+        import ctypes
+        from spacefortress_amd import _lib
+        for which in (0, 1, 0, 1):
+            nb = ctypes.c_size_t()
+            _lib.check(_lib.lib().sf_calibration_copy(env._h, which, ctypes.byref(nb)))
 
     if rank == 0:
         total_steps = float(n) * args.steps * world

@@ -142,6 +142,12 @@ int sf_set_field(sf_batch* b, int field_id, const void* host, size_t bytes);
 #define SF_EPISODE_STATS_LEN 8
 int sf_episode_stats(sf_batch* b, int64_t* out, int clear, void* stream);
 
+/* ---- diagnostics: reads (and writes linearly) *bytes_moved bytes of state with the step kernel's
+ *      own access pattern -- 16 B per lane, 64-lane rows -- so that rocprofv3's FETCH_SIZE /
+ *      WRITE_SIZE counters can be calibrated on a known byte count (tools/pmc_report.py).
+ *      which: 0 or 1 (two different 16-byte groups).  Synchronous. ---- */
+int sf_calibration_copy(sf_batch* b, int which, size_t* bytes_moved);
+
 /* ---- host-only helpers (usable without a GPU) ---- */
 typedef struct {
   int32_t width, height, game_time;

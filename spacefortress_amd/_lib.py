@@ -69,6 +69,7 @@ SYMBOLS = {
     "sf_get_field": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "sf_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "sf_episode_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sf_calibration_copy": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "sf_preset_get": (C.c_int, [C.c_char_p, C.POINTER(Preset)]),
     "sf_action_table": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p]),
     "sf_spawn_table": (C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),

@@ -137,7 +137,7 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   HIP_TRY_FREE(hipMalloc((void**)&b->d_consts, consts.size() * sizeof(double)));
   HIP_TRY_FREE(hipMalloc((void**)&b->d_spawn, spawn.size() * sizeof(int16_t)));
   HIP_TRY_FREE(hipMalloc((void**)&b->d_acc, sizeof(kAccInit)));
-  HIP_TRY_FREE(hipMalloc((void**)&b->d_scratch, (size_t)p->n_envs * SF_NSLOT * sizeof(double)));
+  HIP_TRY_FREE(hipMalloc((void**)&b->d_scratch, (size_t)p->n_envs * SF_NSLOT * 16));
   HIP_TRY_FREE(hipMemcpy(b->d_consts, consts.data(), consts.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY_FREE(hipMemcpy(b->d_spawn, spawn.data(), spawn.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   HIP_TRY_FREE(hipMemcpy(b->d_acc, kAccInit, sizeof(kAccInit), hipMemcpyHostToDevice));
@@ -331,6 +331,24 @@ static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host
   HIP_TRY(sf_launch_field_copy(b->d_state, b->n_envs, f, b->d_scratch, to_host ? 1 : 0, nullptr));
   HIP_TRY(hipDeviceSynchronize());
   if (to_host) HIP_TRY(hipMemcpy(host, b->d_scratch, total, hipMemcpyDeviceToHost));
+  return SF_OK;
+}
+
+// Diagnostics: move a known number of bytes with the step kernel's own access pattern (whole
+// 16-byte chunks, 64-lane rows) so rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated.
+extern "C" int sf_calibration_copy(sf_batch* b, int which, size_t* bytes_moved) {
+  if (!b) return SF_ERR_ARG;
+  const int groups[2] = {SF_G_shell_pos, SF_G_missile_pos};
+  if (which < 0 || which > 1) {
+    sf_set_error("sf_calibration_copy: which must be 0 or 1");
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  const int g = groups[which];
+  static_assert(sfl::kGroups[SF_G_shell_pos].chunk == 16 && sfl::kGroups[SF_G_missile_pos].chunk == 16, "chunk");
+  HIP_TRY(sf_launch_group_copy(b->d_state, b->n_envs, g, b->d_scratch, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  if (bytes_moved) *bytes_moved = (size_t)b->n_envs * sfl::kGroups[g].slots * 16;
   return SF_OK;
 }
 

@@ -16,6 +16,9 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
 hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, unsigned char* linear, int to_linear,
                                 hipStream_t stream);
 
+hipError_t sf_launch_group_copy(const unsigned char* state, int n_envs, int group, unsigned char* linear,
+                                hipStream_t stream);
+
 // sf_host.cpp (no HIP calls: usable and tested without a GPU)
 void sf_host_fill_consts(const sf_preset& p, double* consts /* SF_CONST_DOUBLES */);
 void sf_set_error(const char* fmt, ...);

@@ -988,6 +988,25 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_field_copy_kernel(unsigned char* 
   }
 }
 
+// PMC calibration (sf_calibration_copy): copy whole 16-byte chunks of one group to the linear
+// buffer -- 16 B per lane, 1 KiB per wave-instruction, exactly the step kernel's access pattern.
+__global__ __launch_bounds__(SF_BLOCK) void sf_group_copy_kernel(const unsigned char* state, int n_envs, long tile_off,
+                                                                int slots, i4_t* linear) {
+  const long e = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
+  if (e >= n_envs) return;
+  const unsigned char* lane0 = state + (e >> 6) * sfl::kTileBytes + tile_off + (e & 63) * 16;
+  for (int c = 0; c < slots; c++)
+    linear[(long)c * n_envs + e] = *reinterpret_cast<const i4_t*>(lane0 + (long)c * 16 * sfl::kTileLanes);
+}
+
+hipError_t sf_launch_group_copy(const unsigned char* state, int n_envs, int group, unsigned char* linear,
+                                hipStream_t stream) {
+  const unsigned grid = (unsigned)((n_envs + SF_BLOCK - 1) / SF_BLOCK);
+  hipLaunchKernelGGL(sf_group_copy_kernel, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs,
+                     sfl::group_offset(group), sfl::kGroups[group].slots, (i4_t*)linear);
+  return hipGetLastError();
+}
+
 hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, unsigned char* linear, int to_linear,
                                 hipStream_t stream) {
   const sfl::FieldMeta& m = sfl::kFields[field];

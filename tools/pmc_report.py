@@ -8,9 +8,9 @@ MI355X_MICROARCH.md prescribes) of bench.py into HBM bytes per sf_step_kernel la
 
 gfx950 correction (guide, HBM section): FETCH_SIZE counts 64 B per 128-B request, i.e. half the
 bytes of a coalesced stream.  It is calibrated here, not assumed: with SF_PMC_CALIB=1 bench.py
-also dispatches the field-gather kernel on fields of known size, in the step kernel's own access
-pattern (8/4/2 bytes per lane in 64-lane rows); the read factor is fitted on those, the write
-counter is checked to be exact on them.  Counter unit: KiB.
+also dispatches sf_group_copy_kernel (sfmi.h: sf_calibration_copy) on groups of known size, in the
+step kernel's own access pattern (16 bytes per lane, 64-lane rows); the read factor is fitted on
+those, the write counter is checked to be exact on them.  Counter unit: KiB.
 """
 import argparse
 import collections
@@ -19,10 +19,7 @@ import glob
 import json
 import os
 
-CALIB = [  # (kernel template arg, bytes per env) in the order bench.py dispatches them
-    ("unsigned long", 20 * 8), ("unsigned long", 20 * 8), ("unsigned int", 13 * 4),
-    ("unsigned short", 20 * 2), ("unsigned long", 8), ("unsigned int", 4),
-]
+CALIB_BYTES_PER_ENV = 20 * 16  # sf_group_copy_kernel: 20 slots x one 16-byte chunk
 
 
 def load(d):
@@ -46,27 +43,15 @@ def main():
     fe, wr = load(a.fetch_dir), load(a.write_dir)
 
     def calib(by):
-        seq = []
-        for k, v in by.items():
-            if "sf_field_copy_kernel" in k:
-                seq.append((k, v))
         out = []
-        order = collections.defaultdict(list)
-        for k, v in seq:
-            for t, _ in CALIB:
-                if "<" + t + ">" in k:
-                    order[t] = v
-        idx = collections.defaultdict(int)
-        for t, bpe in CALIB:
-            v = order[t][idx[t]]
-            idx[t] += 1
-            out.append((t, bpe * a.envs, v * 1024))
+        for k, v in by.items():
+            if "sf_group_copy_kernel" in k:
+                out += [("16B chunk rows", CALIB_BYTES_PER_ENV * a.envs, x * 1024) for x in v]
         return out
 
     cf, cw = calib(fe), calib(wr)
-    big = [(b, m) for _, b, m in cf if b >= (1 << 20)]
-    read_factor = sum(b for b, m in big) / sum(m for b, m in big)
-    write_factor = sum(b for _, b, m in cw if b >= (1 << 20)) / sum(m for _, b, m in cw if b >= (1 << 20))
+    read_factor = sum(b for _, b, m in cf) / sum(m for _, b, m in cf)
+    write_factor = sum(b for _, b, m in cw) / sum(m for _, b, m in cw)
     step_f = [v for k, v in fe.items() if "sf_step_kernel" in k][0]
     step_w = [v for k, v in wr.items() if "sf_step_kernel" in k][0]
     fetch_kib = sum(step_f) / len(step_f)
