@@ -76,16 +76,24 @@
   (tb + sfl::chunk_offset(SF_G_##group, 0) +                 \
    (size_t)(s) * (size_t)(sfl::kGroups[SF_G_##group].chunk * sfl::kTileLanes))
 #define SF_LD(T, base, off) (*reinterpret_cast<const T*>((base) + (off)))
-// SF_STORE_MODE (A/B switch): 0 plain stores, 1 non-temporal.  (Write-through `sc1` stores were
-// also tried to empty the end-of-kernel L2 write-back: +1 %, plain vs nt within 1.3 % -- the
-// kernel boundary is not dominated by the dirty bytes.)
+// SF_STORE_MODE (A/B switch, tools/ab.py on one device, 65 536 envs): 0 plain stores 11.20 us per
+// launch, 1 non-temporal 11.01, 2 write-through (`sc1`) for the 16-byte chunks 10.83 -- the bytes
+// leave L2 while the kernel still runs, so the end-of-kernel write-back has less to flush.  (With
+// the earlier 1-8-byte rows `sc1` LOST 1 %: narrow write-through stores are one fabric write each.)
+// Nothing stored this way is read again inside the launch.
 #ifndef SF_STORE_MODE
-#define SF_STORE_MODE 0
+#define SF_STORE_MODE 2
 #endif
 template <typename T>
 __device__ __forceinline__ void sf_store(T* p, T v) {
 #if SF_STORE_MODE == 1
   __builtin_nontemporal_store(v, p);
+#elif SF_STORE_MODE == 2
+  if constexpr (sizeof(T) == 16) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  } else {
+    *p = v;
+  }
 #else
   *p = v;
 #endif
@@ -446,6 +454,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   stamp_[12] = __builtin_amdgcn_s_memrealtime();
 #endif
   SF_STAMP(0, false);
+#ifdef SF_REP  // diagnostic only: run the whole step SF_REP times in one launch (cold vs warm caches)
+  for (int rep_ = 0; rep_ < SF_REP; rep_++) {
+  if (rep_ < 2) stamp_[10 + rep_] = __builtin_amdgcn_s_memtime();
+#endif
 
   // ================= round trip 1: every unconditional load =================
   int act = 0;
@@ -956,6 +968,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       flush_obs_wave<float>(a, stage + (tid & ~63u) * a.obs_dim, (float*)obs, i & ~63u, lane, obs_vec_ok);
     }
   }
+#ifdef SF_REP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  }
+#endif
   SF_STAMP(8, false);
   SF_STAMP(9, true);
 #ifdef SF_STAMPS
@@ -964,7 +981,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   if (a.dbg != nullptr && (tid & 63) == 0) {
     unsigned long long* d = a.dbg + (size_t)(i >> 6) * 16;
 #pragma unroll
-    for (int k = 0; k < 14; k++) d[k] = (k < 10 || k >= 12) ? stamp_[k] : 0ull;
+    for (int k = 0; k < 14; k++) d[k] = stamp_[k];
   }
 #endif
 }
