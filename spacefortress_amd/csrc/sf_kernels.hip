@@ -56,7 +56,7 @@
 
 // Diagnostic build only (-DSF_STAMPS, tools/stamps.py): shader-clock stamps at phase boundaries,
 // with forced waits so each phase owns its memory latency.  The product build has none of it.
-#ifdef SF_STAMPS
+#if defined(SF_STAMPS) && !defined(SF_STAMPS_LITE)
 #define SF_STAMP(k, drain)                                                 \
   do {                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                     \

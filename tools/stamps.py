@@ -19,11 +19,14 @@ sys.path.insert(0, ROOT)
 DIAG = os.path.join(ROOT, "build", "diag", "libsfmi_stamps.so")
 
 
-def build():
+def build(lite=False):
+    global DIAG
+    if lite:
+        DIAG = DIAG.replace("_stamps.so", "_stamps_lite.so")
     os.makedirs(os.path.dirname(DIAG), exist_ok=True)
     csrc = os.path.join(ROOT, "spacefortress_amd", "csrc")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-DSF_STAMPS", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+           "-ffp-contract=off", "-fno-fast-math", "-DSF_STAMPS"] + (["-DSF_STAMPS_LITE"] if lite else []) + ["-I" + os.path.join(ROOT, "include"), "-I" + csrc,
            os.path.join(csrc, "sf_kernels.hip"), os.path.join(csrc, "sf_capi.cpp"), os.path.join(csrc, "sf_host.cpp"),
            "-o", DIAG]
     subprocess.check_call(cmd)
@@ -35,9 +38,15 @@ def main():
     ap.add_argument("--gametype", default="youturn")
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--lite", action="store_true", help="only real-time start/end per wave (no forced waits): "
+                    "first-wave-start -> last-wave-end span of an otherwise unperturbed kernel")
     a = ap.parse_args()
+    global DIAG
+    if a.lite:
+        DIAG = DIAG.replace("_stamps.so", "_stamps_lite.so")
     if not os.path.exists(DIAG) or a.build_only:
-        build()
+        DIAG = DIAG.replace("_stamps_lite.so", "_stamps.so")
+        build(a.lite)
     if a.build_only:
         return
     os.environ["SFMI_LIB_PATH"] = DIAG
@@ -55,6 +64,14 @@ def main():
     buf = np.zeros((n_waves, 16), np.uint64)
     L.sf_debug_read.argtypes = [C.c_void_p, C.c_void_p]
     assert L.sf_debug_read(env._h, buf.ctypes.data_as(C.c_void_p)) == 0
+    if a.lite:
+        rt = buf[:, 12:14].astype(np.int64)
+        life = (rt[:, 1] - rt[:, 0]) / 100.0
+        print("lite: %d waves; span first start -> last end %.2f us; wave life median %.2f p90 %.2f max %.2f us; "
+              "start spread %.2f us; end spread (last - median end) %.2f us" % (
+                  n_waves, (rt[:, 1].max() - rt[:, 0].min()) / 100.0, np.median(life), np.percentile(life, 90), life.max(),
+                  (rt[:, 0].max() - rt[:, 0].min()) / 100.0, (rt[:, 1].max() - np.median(rt[:, 1])) / 100.0))
+        return
     s = buf[:, :10].astype(np.int64)
     names = ["issue loads (round trip 1)", "wait round trip 1", "prefetch issue + LDS stage + barrier",
              "keys/ship/atan2 x2/fortress", "wait projectile prefetch", "shells + missiles",
