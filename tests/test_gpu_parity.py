@@ -331,6 +331,54 @@ def test_fuzzed_states(sfa, oracle_mod, gametype):
     env.close()
 
 
+@pytest.mark.parametrize("n,f64", [(1, False), (63, True), (65, False), (1000, False), (257, True)])
+def test_odd_batch_sizes_and_unaligned_outputs(sfa, oracle_mod, n, f64):
+    """Batch sizes that are not multiples of the 64-lane tile / 256-lane workgroup, observation
+    buffers that are not 16-byte aligned (views into a bigger tensor), and NULL output pointers:
+    the padded lanes must stay invisible and the obs flush must take its scalar tail path."""
+    import ctypes as C
+    from spacefortress_amd import _lib
+
+    O = oracle_mod
+    T = 120
+    rng = np.random.default_rng(n)
+    dt = torch.float64 if f64 else torch.float32
+    env = sfa.SFVecEnv(n, gametype="youturn", spawn_stride=2, obs_dtype=dt)
+    orc = O.OracleVecEnv("youturn", n, spawn_stride=2)
+    acts = rng.integers(0, 5, (T, n)).astype(np.int32)
+    dev = env.device
+    a = torch.from_numpy(acts).to(dev)
+    # one big buffer, rows offset by 1 element so that most rows are NOT 16-byte aligned
+    big = torch.zeros(T * (n * env.obs_dim + 1) + 8, dtype=dt, device=dev)
+    rew = torch.empty((T, n), dtype=torch.int32, device=dev)
+    done = torch.empty((T, n), dtype=torch.uint8, device=dev)
+    info = torch.empty((T, n), dtype=torch.uint8, device=dev)
+    views = []
+    for t in range(T):
+        off = 1 + t * (n * env.obs_dim + 1)
+        v = big[off:off + n * env.obs_dim].view(n, env.obs_dim)
+        views.append(v)
+        env.step_tensors(a[t], out=(v, rew[t], done[t], info[t]))
+    torch.cuda.synchronize()
+    assert any(v.data_ptr() % 16 for v in views)
+    for t in range(T):
+        oo, orw, od, oi = orc.step(acts[t])
+        assert np.array_equal(rew[t].cpu().numpy(), orw), t
+        assert obs_close(views[t].cpu().numpy(), oo, f64).all(), t
+    # nothing was written between or after the rows
+    gaps = [float(big[t * (n * env.obs_dim + 1)]) for t in range(T)]
+    assert not any(gaps) and not big[-8:].any()
+    assert not compare_state(env.state_dict(), orc.snapshots())
+    # every output pointer may be NULL (sfmi.h)
+    L = _lib.lib()
+    rc = L.sf_step(env._h, C.c_void_p(a[0].data_ptr()), 4, None, None, None, None, env._stream())
+    assert rc == 0
+    orc.step(acts[0])
+    torch.cuda.synchronize()
+    assert not compare_state(env.state_dict(), orc.snapshots())
+    env.close()
+
+
 def test_autoturn_heading_on_the_spawn_lattice(sfa, oracle_mod):
     """autoturn rounds atan2 up to an integer degree (SRC/game.cpp:317-319).  A spawned ship sits on
     integer coordinates, where the exact heading can BE an integer (axes, diagonals): the device
