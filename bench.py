@@ -113,7 +113,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SF_BENCH_FORCE_DIST"):  # SF_BENCH_FORCE_DIST: rehearse the RCCL path on one rank
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
