@@ -113,6 +113,16 @@ int sf_reset(sf_batch* b, void* obs_dev, void* stream);
 int sf_step(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
             uint8_t* done_dev, uint8_t* info_dev, void* stream);
 
+/* ---- K VecEnv.step calls whose actions are all known up front (open-loop rollouts: random-action
+ *      benchmarks, replaying recorded action sequences, evaluating fixed plans), fused into ONE
+ *      launch: each wave keeps its environments in registers between ticks, so a tick costs
+ *      neither the state round trips through HBM nor a kernel boundary.  Bit-identical to n_steps
+ *      consecutive sf_step calls.  actions_dev [n_steps][n_envs]; obs_dev [n_steps][n_envs][obs_dim];
+ *      reward_dev / done_dev / info_dev [n_steps][n_envs]; any output may be NULL.
+ *      n_steps * n_envs * 8 must stay below 2^32. ---- */
+int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, void* obs_dev,
+               int32_t* reward_dev, uint8_t* done_dev, uint8_t* info_dev, void* stream);
+
 /* Out-of-range actions are executed as NOOP and counted on the device; this reads and clears the
  * count (synchronises `stream`).  Returns SF_ERR_ACTION if any were seen since the last call. */
 int sf_check_actions(sf_batch* b, void* stream);

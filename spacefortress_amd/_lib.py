@@ -62,6 +62,7 @@ SYMBOLS = {
     "sf_max_ticks": (C.c_int, [C.c_void_p]),
     "sf_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_check_actions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sf_n_fields": (C.c_int, []),
     "sf_field_info": (C.c_int, [C.c_int, C.POINTER(FieldDesc)]),

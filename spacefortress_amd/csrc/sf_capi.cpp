@@ -256,7 +256,27 @@ extern "C" int sf_step(sf_batch* b, const void* actions_dev, int act_type, void*
   }
   DeviceGuard guard(b->device);
   HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev,
-                         (hipStream_t)stream));
+                         1, false, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, void* obs_dev,
+                          int32_t* reward_dev, uint8_t* done_dev, uint8_t* info_dev, void* stream) {
+  if (!b || !actions_dev) {
+    sf_set_error("sf_rollout: null batch or actions");
+    return SF_ERR_ARG;
+  }
+  if (act_type != SF_ACT_U8 && act_type != SF_ACT_I32 && act_type != SF_ACT_I64) {
+    sf_set_error("sf_rollout: act_type must be 1, 4 or 8 (got %d)", act_type);
+    return SF_ERR_ARG;
+  }
+  if (n_steps <= 0 || (double)n_steps * b->n_envs * 8.0 >= 4294967296.0) {
+    sf_set_error("sf_rollout: n_steps must be positive and n_steps * n_envs * 8 < 2^32 (got %d)", n_steps);
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev,
+                         n_steps, true, (hipStream_t)stream));
   return SF_OK;
 }
 

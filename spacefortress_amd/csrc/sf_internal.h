@@ -10,7 +10,7 @@
 hipError_t sf_launch_reset(const SfKernelArgs& a, int first, unsigned cursor0, unsigned stride, void* obs,
                            hipStream_t stream);
 hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, const void* actions, int act_type, void* obs,
-                          int32_t* reward, uint8_t* done, uint8_t* info, hipStream_t stream);
+                          int32_t* reward, uint8_t* done, uint8_t* info, int n_steps, bool fused, hipStream_t stream);
 
 // gather (to_linear) / scatter one field between the tiled state and a linear [count][n_envs] buffer
 hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, unsigned char* linear, int to_linear,

@@ -252,11 +252,32 @@ __device__ __forceinline__ void store_lane(unsigned char* tb, const Off& o, cons
               (int)((unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFu) << 16))}));
 }
 
+// Agent-scope (L2-coherent, L1-bypassing) accesses for the few places where one launch may read
+// back what it wrote earlier or mixes plain stores with atomics on the same word: the counter
+// rows (atomics + the zeroing at a new game) and the dependent-load slow path of the projectile
+// slots beyond the prefetched groups (a fused launch reads in tick k+1 what tick k stored).
+__device__ __forceinline__ int ld_coherent_i32(const unsigned char* p) {
+  return __hip_atomic_load(reinterpret_cast<const int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_coherent_i16(const unsigned char* p) {
+  return (int16_t)__hip_atomic_load(reinterpret_cast<const unsigned short*>(p), __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ d2_t ld_coherent_d2(const unsigned char* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return d2_t{__longlong_as_double((long long)x), __longlong_as_double((long long)y)};
+}
+__device__ __forceinline__ void st_coherent_i32(unsigned char* p, int v) {
+  __hip_atomic_store(reinterpret_cast<int*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void zero_counters(unsigned char* tb, const Off& o) {
 #pragma unroll
-  for (int k = 0; k < SF_NSTAT; k++) SF_ST(int32_t, SF_CHUNK(stats, k), o.o4, 0);
-  SF_ST(int32_t, SF_CHUNK(ep_return, 0), o.o4, 0);
-  SF_ST(int32_t, SF_CHUNK(ep_kills, 0), o.o4, 0);
+  for (int k = 0; k < SF_NSTAT; k++) st_coherent_i32(SF_CHUNK(stats, k) + o.o4, 0);
+  st_coherent_i32(SF_CHUNK(ep_return, 0) + o.o4, 0);
+  st_coherent_i32(SF_CHUNK(ep_kills, 0) + o.o4, 0);
 }
 
 // ExtraGameValues of Game::computeExtra (SRC/game.cpp:282-312).  They are a pure function of the
@@ -436,10 +457,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <bool AUTOTURN, bool SHAPED>
+// FUSED = false: one tick per launch (sf_step, the VecEnv.step path).
+// FUSED = true:  n_steps ticks per launch with the actions of all of them given up front
+// (sf_rollout): the wave keeps its state in registers between ticks, so a tick costs neither the
+// two memory round trips nor a kernel boundary.  Same body, bit-identical results.
+template <bool AUTOTURN, bool SHAPED, bool FUSED>
 __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const void* actions, int act_type,
                                                           void* obs, int obs_vec_ok, int32_t* reward_out,
-                                                          uint8_t* done_out, uint8_t* info_out) {
+                                                          uint8_t* done_out, uint8_t* info_out, int n_steps) {
   extern __shared__ double lds[];  // [SF_LDS_DOUBLES] cos/sin table, then the obs staging rows
   const unsigned tid = threadIdx.x;
   const unsigned i = blockIdx.x * SF_BLOCK + tid;  // env index: actions and outputs
@@ -454,22 +479,17 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   stamp_[12] = __builtin_amdgcn_s_memrealtime();
 #endif
   SF_STAMP(0, false);
-#ifdef SF_REP  // diagnostic only: run the whole step SF_REP times in one launch (cold vs warm caches)
-  for (int rep_ = 0; rep_ < SF_REP; rep_++) {
-  if (rep_ < 2) stamp_[10 + rep_] = __builtin_amdgcn_s_memtime();
-#endif
 
   // ================= round trip 1: every unconditional load =================
-  int act = 0;
-  if (real) {  // ENV:211-212
+  auto load_action = [&](int step) __attribute__((always_inline)) -> int {  // ENV:211-212
+    if (!real) return 0;
     const unsigned char* ab = (const unsigned char*)actions;
-    if (act_type == 8)
-      act = (int)SF_LD(long long, ab, g.o8);
-    else if (act_type == 4)
-      act = SF_LD(int, ab, g.o4);
-    else
-      act = SF_LD(unsigned char, ab, g.o1);
-  }
+    const unsigned e = (unsigned)step * (unsigned)a.n_envs + i;
+    if (act_type == 8) return (int)SF_LD(long long, ab, e * 8u);
+    if (act_type == 4) return SF_LD(int, ab, e * 4u);
+    return SF_LD(unsigned char, ab, e);
+  };
+  int act_next = load_action(0);
   Lane L;
   load_lane(tb, o, L);
   // cos/sin table: 720 doubles = 360 16-byte pieces, six per lane (the last one partial)
@@ -501,7 +521,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   for (int s = 0; s < SF_SPF; s++) shx[s] = shy[s] = shvx[s] = shvy[s] = 0;
   // a dead ship whose explosion is over respawns this tick (SRC/game.cpp:151-157): fetch its
   // entry of the spawn sequence now, not in the middle of the arithmetic
-  const bool will_respawn = !(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration;
+  bool will_respawn = !(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration;
   unsigned long long spawn_e = 0;
   {
 #pragma unroll
@@ -551,6 +571,18 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   __syncthreads();  // the only workgroup barrier of the kernel
   const double* trig = lds;
   SF_STAMP(3, false);
+
+  const int n_iter = FUSED ? n_steps : 1;
+  for (int step = 0; step < n_iter; step++) {
+  int act = act_next;
+  if (FUSED) {
+    if (step + 1 < n_iter) act_next = load_action(step + 1);  // in flight while this tick computes
+    if (step > 0) {
+      will_respawn = !(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration;
+      if (will_respawn) spawn_e = *reinterpret_cast<const unsigned long long*>(a.spawn + 4 * (size_t)(L.cursor & a.spawn_mask));
+    }
+  }
+  const size_t so = (size_t)step * (size_t)a.n_envs;  // this tick's row of the output arrays
 
   if (act < 0 || act >= a.n_actions) {
     atomicAdd(&a.acc[8], 1ull);  // reference: IndexError; here NOOP + counted (sf_check_actions)
@@ -729,6 +761,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         col |= (unsigned)(dx * dx + dy * dy <= sfc::shell_hit_r2) << s;
         out |= (unsigned)outside_area(a, nx[k], ny[k]) << s;
         if (isnew) SF_ST(d2_t, SF_CHUNK(shell_vel, s), o.o16, (d2_t{vx, vy}));
+        if (FUSED) {  // the registers carry the shell into the next tick
+          shx[s] = nx[k];
+          shy[s] = ny[k];
+          shvx[s] = vx;
+          shvy[s] = vy;
+        }
       }
       const unsigned live = L.smask & gmask;
       col &= live;
@@ -763,8 +801,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
             vy = new_s_vy;
             SF_ST(d2_t, SF_CHUNK(shell_vel, s), o.o16, (d2_t{vx, vy}));
           } else {
-            const d2_t sp = SF_LD(d2_t, SF_CHUNK(shell_pos, s), o.o16);
-            const d2_t sv = SF_LD(d2_t, SF_CHUNK(shell_vel, s), o.o16);
+            const d2_t sp = ld_coherent_d2(SF_CHUNK(shell_pos, s) + o.o16);
+            const d2_t sv = ld_coherent_d2(SF_CHUNK(shell_vel, s) + o.o16);
             x = sp.x;
             y = sp.y;
             vx = sv.x;
@@ -798,10 +836,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   //      as bitmasks and replayed in slot order afterwards.
   {
     unsigned ev_hit = 0, ev_out = 0;
-    auto m_move = [&](int s, double x, double y, int ang, bool isnew) __attribute__((always_inline)) {
+    auto m_move = [&](int s, double x, double y, int ang, bool isnew, double& nx, double& ny)
+                      __attribute__((always_inline)) {
       // velocity = missileSpeed * (cos, sin)(deg2rad(angle)) with an integer angle: table
-      const double nx = x + sfc::missile_speed * trig[2 * ang];
-      const double ny = y + sfc::missile_speed * trig[2 * ang + 1];
+      nx = x + sfc::missile_speed * trig[2 * ang];
+      ny = y + sfc::missile_speed * trig[2 * ang + 1];
       const double dx = nx - sfc::fort_x, dy = ny - sfc::fort_y;
       const bool live = (L.mmask >> s) & 1u;
       const bool hit = live & (dx * dx + dy * dy <= sfc::missile_hit_r2);  // collided(mFortress), see shells
@@ -813,7 +852,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     };
     auto m_pref = [&](int s) __attribute__((always_inline)) {
       const bool isnew = (s == new_m_slot);
-      m_move(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], isnew ? new_m_angle : mang[s], isnew);
+      const int ang = isnew ? new_m_angle : mang[s];
+      double nx, ny;
+      m_move(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], ang, isnew, nx, ny);
+      if (FUSED) {  // the registers carry the missile into the next tick
+        mx[s] = nx;
+        my[s] = ny;
+        mang[s] = ang;
+      }
     };
 #pragma unroll
     for (int g = 0; g < SF_MGROUPS; g++) {
@@ -830,11 +876,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         const bool live = (L.mmask >> s) & 1u;
         if (__ballot(live) == 0ull) continue;
         if (live) {
+          double nx, ny;
           if (s == new_m_slot)
-            m_move(s, new_m_x, new_m_y, new_m_angle, true);
+            m_move(s, new_m_x, new_m_y, new_m_angle, true, nx, ny);
           else {
-            const d2_t m = SF_LD(d2_t, SF_CHUNK(missile_pos, s), o.o16);
-            m_move(s, m.x, m.y, SF_LD(int16_t, SF_CHUNK(missile_ang, s), o.o2), false);
+            const d2_t m = ld_coherent_d2(SF_CHUNK(missile_pos, s) + o.o16);
+            m_move(s, m.x, m.y, ld_coherent_i16(SF_CHUNK(missile_ang, s) + o.o2), false, nx, ny);
           }
         }
       }
@@ -899,10 +946,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   // ================= statistics and the vec-env worker's auto-reset (rl/train.py:80-88) ======
   if (done && a.auto_reset) {
     // episode totals = what previous launches accumulated + this tick's share
-    const int ep_ret = SF_LD(int32_t, SF_CHUNK(ep_return, 0), o.o4) + r;
-    const int ep_kil = SF_LD(int32_t, SF_CHUNK(ep_kills, 0), o.o4) + fort_kill;
-    const int deaths = SF_LD(int32_t, SF_CHUNK(stats, SF_ST_SHIP_DEATHS), o.o4) + S.ship_deaths;
-    const int shots = SF_LD(int32_t, SF_CHUNK(stats, SF_ST_SHOTS), o.o4) + S.shots;
+    const int ep_ret = ld_coherent_i32(SF_CHUNK(ep_return, 0) + o.o4) + r;
+    const int ep_kil = ld_coherent_i32(SF_CHUNK(ep_kills, 0) + o.o4) + fort_kill;
+    const int deaths = ld_coherent_i32(SF_CHUNK(stats, SF_ST_SHIP_DEATHS) + o.o4) + S.ship_deaths;
+    const int shots = ld_coherent_i32(SF_CHUNK(stats, SF_ST_SHOTS) + o.o4) + S.shots;
     if (real) {
       atomicAdd(&a.acc[0], 1ull);
       atomicAdd(&a.acc[1], (unsigned long long)(long long)ep_ret);
@@ -948,12 +995,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     }
   }
 
-  store_lane(tb, o, L);
+  if (!FUSED) store_lane(tb, o, L);
 
   if (real) {
-    if (reward_out) SF_ST(int32_t, (unsigned char*)reward_out, g.o4, r);
-    if (done_out) SF_ST(uint8_t, (unsigned char*)done_out, g.o1, (uint8_t)done);
-    if (info_out) SF_ST(uint8_t, (unsigned char*)info_out, g.o1, (uint8_t)fort_kill);
+    if (reward_out) SF_ST(int32_t, (unsigned char*)(reward_out + so), g.o4, r);
+    if (done_out) SF_ST(uint8_t, (unsigned char*)(done_out + so), g.o1, (uint8_t)done);
+    if (info_out) SF_ST(uint8_t, (unsigned char*)(info_out + so), g.o1, (uint8_t)fort_kill);
   }
   SF_STAMP(7, false);
   if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid
@@ -961,18 +1008,17 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     if (a.obs_f64) {
       double* stage = lds + SF_LDS_DOUBLES;
       write_obs<double>(a, stage + tid * a.obs_dim, L, e);
-      flush_obs_wave<double>(a, stage + (tid & ~63u) * a.obs_dim, (double*)obs, i & ~63u, lane, obs_vec_ok);
+      flush_obs_wave<double>(a, stage + (tid & ~63u) * a.obs_dim, (double*)obs + so * a.obs_dim, i & ~63u, lane,
+                             obs_vec_ok);
     } else {
       float* stage = reinterpret_cast<float*>(lds + SF_LDS_DOUBLES);
       write_obs<float>(a, stage + tid * a.obs_dim, L, e);
-      flush_obs_wave<float>(a, stage + (tid & ~63u) * a.obs_dim, (float*)obs, i & ~63u, lane, obs_vec_ok);
+      flush_obs_wave<float>(a, stage + (tid & ~63u) * a.obs_dim, (float*)obs + so * a.obs_dim, i & ~63u, lane,
+                            obs_vec_ok);
     }
   }
-#ifdef SF_REP
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-  }
-#endif
+  }  // tick loop
+  if (FUSED) store_lane(tb, o, L);
   SF_STAMP(8, false);
   SF_STAMP(9, true);
 #ifdef SF_STAMPS
@@ -1063,19 +1109,26 @@ hipError_t sf_launch_reset(const SfKernelArgs& a, int first, unsigned cursor0, u
 }
 
 hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, const void* actions, int act_type, void* obs,
-                          int32_t* reward, uint8_t* done, uint8_t* info, hipStream_t stream) {
+                          int32_t* reward, uint8_t* done, uint8_t* info, int n_steps, bool fused, hipStream_t stream) {
   const unsigned grid = (unsigned)(a.lanes / SF_BLOCK);
   const size_t elem = a.obs_f64 ? sizeof(double) : sizeof(float);
   const size_t lds_bytes = SF_LDS_DOUBLES * sizeof(double) + (size_t)SF_BLOCK * a.obs_dim * elem;
-  const int vec_ok = ((uintptr_t)obs & 15u) == 0;
-#define SF_GO(AT, SH)                                                                                     \
-  hipLaunchKernelGGL((sf_step_kernel<AT, SH>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a, actions, \
-                     act_type, obs, vec_ok, reward, done, info)
+  // 16-byte obs stores need every tick's row of the output to start 16-byte aligned
+  const int vec_ok = ((uintptr_t)obs & 15u) == 0 && (!fused || ((size_t)a.n_envs * a.obs_dim * elem) % 16 == 0);
+#define SF_GO(AT, SH, FU)                                                                                   \
+  hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a, actions, \
+                     act_type, obs, vec_ok, reward, done, info, n_steps)
   // the four presets of SRC/configs.cpp:51-89 are exactly (autoTurn) x (shaped scoring)
-  if (autoturn) {
-    if (shaped) SF_GO(true, true); else SF_GO(true, false);
-  } else {
-    if (shaped) SF_GO(false, true); else SF_GO(false, false);
+  const int sel = (autoturn ? 4 : 0) | (shaped ? 2 : 0) | (fused ? 1 : 0);
+  switch (sel) {
+    case 0: SF_GO(false, false, false); break;
+    case 1: SF_GO(false, false, true); break;
+    case 2: SF_GO(false, true, false); break;
+    case 3: SF_GO(false, true, true); break;
+    case 4: SF_GO(true, false, false); break;
+    case 5: SF_GO(true, false, true); break;
+    case 6: SF_GO(true, true, false); break;
+    default: SF_GO(true, true, true); break;
   }
 #undef SF_GO
   return hipGetLastError();

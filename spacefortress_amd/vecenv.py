@@ -117,6 +117,31 @@ class SFVecEnv:
                                    C.c_void_p(info.data_ptr()), self._stream()))
         return obs, rew, done, info
 
+    def rollout(self, actions, out=None, want_obs=True):
+        """K steps whose actions are all known up front, fused into one launch (sfmi.h: sf_rollout).
+        `actions`: contiguous uint8/int32/int64 tensor [K, N] on this device.  Returns
+        (obs [K, N, obs_dim] or None, reward int32 [K, N], done uint8 [K, N], info uint8 [K, N]);
+        bit-identical to K `step_tensors` calls."""
+        if actions.device != self.device or not actions.is_contiguous() or actions.dim() != 2 \
+                or actions.shape[1] != self.num_envs:
+            raise ValueError("actions must be a contiguous [K, %d] tensor on %s" % (self.num_envs, self.device))
+        at = _ACT_TYPES.get(actions.dtype)
+        if at is None:
+            raise TypeError("actions dtype must be uint8, int32 or int64 (got %s)" % (actions.dtype,))
+        K, n = actions.shape
+        if out is not None:
+            obs, rew, done, info = out
+        else:
+            obs = torch.empty((K, n, self.obs_dim), dtype=self.obs_dtype, device=self.device) if want_obs else None
+            rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
+            done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
+            info = torch.empty((K, n), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.sf_rollout(self._h, C.c_void_p(actions.data_ptr()), at, int(K),
+                                      C.c_void_p(obs.data_ptr()) if obs is not None else None,
+                                      C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
+                                      C.c_void_p(info.data_ptr()), self._stream()))
+        return obs, rew, done, info
+
     def step_async(self, actions):
         if torch.is_tensor(actions):
             self._pending = (self.step_tensors(actions), False)

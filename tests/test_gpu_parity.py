@@ -177,7 +177,8 @@ def test_episode_rollover_and_stats(sfa, oracle_mod):
 def _load_both(sfa, O, gametype, snaps, prev_vlner=None, **kw):
     n = len(snaps)
     env = sfa.SFVecEnv(n, gametype=gametype, obs_dtype=torch.float64, **kw)
-    orc = O.OracleVecEnv(gametype, n, **{k: v for k, v in kw.items() if k in ("action_set", "obs_type")})
+    orc = O.OracleVecEnv(gametype, n, **{k: v for k, v in kw.items()
+                                         if k in ("action_set", "obs_type", "spawn_stride", "spawn_skip")})
     orc.load_snapshots(snaps, prev_vlner)
     for k, v in snapshots_to_fields(snaps).items():
         env.set_field(k, v)
@@ -377,6 +378,79 @@ def test_odd_batch_sizes_and_unaligned_outputs(sfa, oracle_mod, n, f64):
     torch.cuda.synchronize()
     assert not compare_state(env.state_dict(), orc.snapshots())
     env.close()
+
+
+@pytest.mark.parametrize("gametype,obs_type,f64", [("youturn", "features", False), ("autoturn", "features", True),
+                                                  ("test-youturn", "normalized-features", False)])
+def test_fused_rollout_equals_single_steps(sfa, oracle_mod, gametype, obs_type, f64):
+    """sf_rollout (K ticks in one launch, state in registers) against K sf_step launches from the
+    same start state -- every output and the final state bit-identical -- and against the oracle.
+    The start state is constructed so that the fused loop crosses an episode end (auto-reset inside
+    the launch), and some lanes carry more projectiles than the register-resident groups hold."""
+    O = oracle_mod
+    n, K = 1500, 96
+    rng = np.random.default_rng(11)
+    dt = torch.float64 if f64 else torch.float32
+    base = O.OracleVecEnv(gametype, n, obs_type=obs_type, spawn_stride=1).snapshots()
+    base["time"] = np.where(np.arange(n) % 3 == 0, 180000 - 34 * rng.integers(1, 60, n), 34 * rng.integers(0, 3000, n))
+    base["tick"] = base["time"] // 34
+    tab = np.load(os.path.join(GOLDEN, "tables.npz"))["missile_vel_by_angle"]
+    crowd = np.flatnonzero(np.arange(n) % 5 == 0)
+    ang = rng.integers(0, 360, (n, 20))
+    base["missile_angle"] = ang
+    base["missile_vx"] = tab[ang, 0]
+    base["missile_vy"] = tab[ang, 1]
+    base["missile_x"] = rng.uniform(100, 600, (n, 20))
+    base["missile_y"] = rng.uniform(100, 520, (n, 20))
+    base["shell_x"] = rng.uniform(50, 650, (n, 20))
+    base["shell_y"] = rng.uniform(50, 570, (n, 20))
+    base["shell_vx"] = rng.uniform(-4, 4, (n, 20))
+    base["shell_vy"] = rng.uniform(-4, 4, (n, 20))
+    for i in crowd:
+        base["missile_alive"][i, rng.choice(20, rng.integers(10, 21), replace=False)] = 1
+        base["shell_alive"][i, rng.choice(20, rng.integers(5, 16), replace=False)] = 1
+    acts = rng.integers(0, 5 if "you" in gametype else 3, (K, n)).astype(np.uint8)
+    envs = []
+    for _ in range(2):
+        env, orc = _load_both(sfa, O, gametype, base, obs_type=obs_type, spawn_stride=1)
+        env.close()
+        env = sfa.SFVecEnv(n, gametype=gametype, obs_type=obs_type, spawn_stride=1, obs_dtype=dt)
+        for k, v in snapshots_to_fields(base).items():
+            env.set_field(k, v)
+        envs.append(env)
+    single, fused = envs
+    obs1, rew1, done1, info1 = run_device(single, acts)
+    d_acts = torch.from_numpy(acts).to(fused.device)
+    o2, r2, d2, i2 = fused.rollout(d_acts)
+    torch.cuda.synchronize()
+    fused.check_actions()
+    assert np.array_equal(o2.cpu().numpy(), obs1)
+    assert np.array_equal(r2.cpu().numpy(), rew1)
+    assert np.array_equal(d2.cpu().numpy().astype(bool), done1) and np.array_equal(i2.cpu().numpy().astype(bool), info1)
+    assert done1.any() and not done1.all()
+    s1, s2 = single.state_dict(), fused.state_dict()
+    live_m = lambda sd: ((sd["missile_mask"][None, :] >> np.arange(20, dtype=np.uint32)[:, None]) & 1).astype(bool)
+    live_s = lambda sd: ((sd["shell_mask"][None, :] >> np.arange(20, dtype=np.uint32)[:, None]) & 1).astype(bool)
+    for k in s1:
+        a_, b_ = s1[k], s2[k]
+        if k.startswith("missile_") and k != "missile_mask":
+            a_, b_ = a_[live_m(s1)], b_[live_m(s2)]
+        if k.startswith("shell_") and k != "shell_mask":
+            a_, b_ = a_[live_s(s1)], b_[live_s(s2)]
+        assert np.array_equal(a_, b_), k
+    # and both equal the oracle
+    _, orc = _load_both(sfa, O, gametype, base, obs_type=obs_type, spawn_stride=1)
+    for t in range(K):
+        oo, orw, od, oi = orc.step(acts[t].astype(np.int32))
+        assert np.array_equal(rew1[t], orw), t
+        assert obs_close(obs1[t], oo, f64).all(), t
+    assert not compare_state(s2, orc.snapshots())
+    # a second rollout continues from the registers' final state written back
+    o3, r3, d3, i3 = fused.rollout(d_acts[:7])
+    obs4, rew4, _, _ = run_device(single, acts[:7])
+    assert np.array_equal(o3.cpu().numpy(), obs4) and np.array_equal(r3.cpu().numpy(), rew4)
+    for e in envs:
+        e.close()
 
 
 def test_autoturn_heading_on_the_spawn_lattice(sfa, oracle_mod):
