@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="baseline processes (0 = this box's share, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timing-launches", type=int, default=200)
+    ap.add_argument("--rollout-k", type=int, default=64, metavar="K",
+                    help="also time the fused open-loop path (sf_rollout: K ticks per launch, all actions known up "
+                         "front, same per-tick outputs); reported as rollout_fused, never as value; 0 = skip")
     ap.add_argument("--numpy-api", type=int, default=0, metavar="K",
                     help="also time K steps through the host-buffer (numpy) API: actions H2D, results D2H every "
                          "step -- the PCIe-inclusive rate, reported as host_api, never as value")
@@ -169,6 +172,32 @@ def main():
     kern_ms = float(np.mean(per))
     kern_ms_med = per[len(per) // 2]
     env.check_actions()
+    fused = None
+    if args.rollout_k > 0:
+        K = min(args.rollout_k, ring)
+        ro_acts = actions[:K].contiguous()
+        ro_out = (torch.empty((K, n, env.obs_dim), dtype=env.obs_dtype, device=dev),
+                  torch.empty((K, n), dtype=torch.int32, device=dev),
+                  torch.empty((K, n), dtype=torch.uint8, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev))
+        launches = max(2, args.steps // K)
+        for _ in range(2):
+            env.rollout(ro_acts, out=ro_out)
+        barrier()
+        tf = time.perf_counter()
+        for _ in range(launches):
+            env.rollout(ro_acts, out=ro_out)
+        barrier()
+        dtf = time.perf_counter() - tf
+        if dist is not None:
+            tt = torch.tensor([dtf], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtf = float(tt.item())
+        fused = {"value": float(n) * K * launches * world / dtf, "unit": "env-steps/s", "ticks_per_launch": K,
+                 "launches": launches, "us_per_tick": dtf / (K * launches) * 1e6,
+                 "note": "sf_rollout: K ticks fused into one launch (state stays in registers), actions of all K "
+                         "ticks resident up front, obs/reward/done/info written for every tick; bit-identical to K "
+                         "sf_step launches (tests/test_gpu_parity.py::test_fused_rollout_equals_single_steps)"}
+        del ro_out
     host_api = None
     if args.numpy_api > 0 and rank == 0:
         np_actions = actions.cpu().numpy().astype(np.int64)  # what rl/train.py:79 hands over
@@ -218,6 +247,7 @@ def main():
                          "kernel_ms_event_pair_mean": kern_ms, "kernel_ms_event_pair_median": kern_ms_med,
                          "algorithmic_bytes_per_launch": algo, "launches_timed": k},
             "cpu_baseline": base,
+            "rollout_fused": fused,
             "host_api": host_api,
             "episode_stats": summarize(stats.cpu()),
         }
