@@ -145,7 +145,16 @@ __device__ __forceinline__ void score(float amount, float& rew, Lane& L) {
 
 // Hexagon::isInside (SRC/hexagon.cpp:36-48).  The edges (nx, ny, px, py) are compile-time
 // constants (sf_layout.h: both radii are the same in every preset), so they are immediates.
-#define SF_EDGE_TEST(nx, ny, px, py) in = in & !((nx) * (x - (px)) + (ny) * (y - (py)) < 0);
+// For the two horizontal edges of each hexagon nx is -0.0, so  nx*dx + ny*dy < 0  is exactly
+// ny*dy < 0 (adding a zero changes nothing, a zero product is not < 0), i.e. a plain comparison
+// of y against the edge: y < py for ny > 0, y > py for ny < 0 (the sign of a difference of two
+// doubles is exact, and scaling by |ny| >= 1 cannot flush it to zero).  Eight multiplies, eight
+// subtractions and four additions less per ship and tick, same truth value for every finite y.
+#define SF_EDGE_TEST(nx, ny, px, py)                                     \
+  if ((nx) == 0.0)                                                       \
+    in = in & !((ny) > 0 ? (y < (py)) : (y > (py)));                     \
+  else                                                                   \
+    in = in & !((nx) * (x - (px)) + (ny) * (y - (py)) < 0);
 __device__ __forceinline__ bool inside_big_hex(double x, double y) {
   bool in = true;
   SF_BIG_HEX_EDGES(SF_EDGE_TEST)
@@ -597,52 +606,35 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   L.time += sfc::tick_ms;  // updateTime
 
   // ---- processKeyState (SRC/game.cpp:218-272); the wrapper sends FIRE, THRUST, (LEFT, RIGHT)
-  //      press-or-release every step (ENV:213-229), so each key is one edge test.
+  //      press-or-release every step (ENV:213-229), so each key is one edge test.  Branch-free:
+  //      the flag bits of `fl` sit in key order (FIRE, THRUST, LEFT, RIGHT = bits 2..5), so the
+  //      new flags are the key mask itself, an edge is key XOR flag, a press edge is key AND NOT
+  //      flag; an edge zeroes that key's timer (:227,231,235,244,250,253,257,261), a press edge
+  //      counts (:228,232,236,245).
   int new_m_slot = -1;
   {
-    const bool k_fire = keys & 1u, k_thrust = keys & 2u;
-    if (k_fire && !(L.fl & SF_FL_FIRE)) {
-      // fireMissile (SRC/game.cpp:175-192): before this tick's turn and move
-      if (L.fl & SF_FL_SHIP_ALIVE) {
-        int slot = __ffs(~L.mmask) - 1;
-        if (slot < SF_NSLOT) {
-          new_m_slot = slot;
-          L.mmask |= 1u << slot;
-          score(-sfc::Score<SHAPED>::missile_penalty, rew, L);
-        }
-      }
-      L.fl |= SF_FL_FIRE;
-      L.fire_t = 0;
-      S.shots += 1;
-    } else if (!k_fire && (L.fl & SF_FL_FIRE)) {
-      L.fl &= ~SF_FL_FIRE;
-      L.fire_t = 0;
-    }
-    if (k_thrust && !(L.fl & SF_FL_THRUST)) {
-      L.fl |= SF_FL_THRUST;
-      L.thrust_t = 0;
-      S.thrusts += 1;
-    } else if (!k_thrust && (L.fl & SF_FL_THRUST)) {
-      L.fl &= ~SF_FL_THRUST;
-      L.thrust_t = 0;
-    }
+    const unsigned kmask = AUTOTURN ? 0x3u : 0xFu;  // autoturn games send two keys (ENV:221)
+    const unsigned old = (L.fl >> 2) & kmask, now = keys & kmask;
+    const unsigned edge = old ^ now, press = now & ~old;
+    L.fl = (L.fl & ~(kmask << 2)) | (now << 2);
+    L.fire_t = (edge & 1u) ? 0 : L.fire_t;
+    L.thrust_t = (edge & 2u) ? 0 : L.thrust_t;
+    S.shots += (int)(press & 1u);
+    S.thrusts += (int)((press >> 1) & 1u);
     if (!AUTOTURN) {
-      const bool k_left = keys & 4u, k_right = keys & 8u;
-      if (k_left && !(L.fl & SF_FL_LEFT)) {
-        L.fl |= SF_FL_LEFT;
-        L.left_t = 0;
-        S.lefts += 1;
-      } else if (!k_left && (L.fl & SF_FL_LEFT)) {
-        L.fl &= ~SF_FL_LEFT;
-        L.left_t = 0;
-      }
-      if (k_right && !(L.fl & SF_FL_RIGHT)) {
-        L.fl |= SF_FL_RIGHT;
-        L.right_t = 0;
-        S.rights += 1;
-      } else if (!k_right && (L.fl & SF_FL_RIGHT)) {
-        L.fl &= ~SF_FL_RIGHT;
-        L.right_t = 0;
+      L.left_t = (edge & 4u) ? 0 : L.left_t;
+      L.right_t = (edge & 8u) ? 0 : L.right_t;
+      S.lefts += (int)((press >> 2) & 1u);
+      S.rights += (int)((press >> 3) & 1u);
+    }
+    // FIRE press edge: fireMissile (SRC/game.cpp:175-192,237-238) before this tick's turn and
+    // move; the shot is counted and the timer zeroed even if nothing could be created
+    if ((press & 1u) && (L.fl & SF_FL_SHIP_ALIVE)) {
+      const int slot = __ffs(~L.mmask) - 1;
+      if (slot < SF_NSLOT) {
+        new_m_slot = slot;
+        L.mmask |= 1u << slot;
+        score(-sfc::Score<SHAPED>::missile_penalty, rew, L);
       }
     }
   }
