@@ -52,9 +52,22 @@ def cpu_baseline(gametype, seconds, cores):
     kind = kinds.pop() if len(kinds) == 1 else "port"
     what = ("reference C++ engine (oracle/_ref: Game::pressKey/releaseKey + stepOneTick(34) loop, new Game at game over)"
             if kind == "reference" else "C restatement of the engine (oracle/sf_oracle.c), same loop")
-    return {"value": total, "unit": "env-steps/s", "cores": cores, "kind": kind,
-            "sample": "%s, %s, uniform random actions, one process per core x %d, %.0f s each; "
-                      "bare engine only (no Python wrapper, no IPC)" % (what, gametype, cores, seconds)}
+    out = {"value": total, "unit": "env-steps/s", "cores": cores, "kind": kind,
+           "sample": "%s, %s, uniform random actions, one process per core x %d, %.0f s each; "
+                     "bare engine only (no Python wrapper, no IPC)" % (what, gametype, cores, seconds)}
+    # the reference's actual shape: SubprocVecEnv (one process per env, Pipe IPC, Python wrapper, rl/train.py:30-32)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "subproc_bench.py"), "--procs", str(cores),
+                            "--gametype", gametype, "--seconds", str(max(2.0, seconds / 2))],
+                           stdout=subprocess.PIPE, text=True, timeout=120)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        out["subproc_vecenv"] = {"value": j["steps"] / j["seconds"], "unit": "env-steps/s", "procs": j["procs"],
+                                 "sample": "SubprocVecEnv-shaped harness (oracle/subproc_bench.py): one process per env, "
+                                           "multiprocessing.Pipe, per-env wrapper step + features obs, reset on done; "
+                                           "the C restatement inside each worker"}
+    except Exception as e:  # the baseline is informative, never fatal
+        out["subproc_vecenv"] = {"error": str(e)}
+    return out
 
 
 def pmc_traffic(gametype, envs, obs_type):
