@@ -59,6 +59,13 @@ typedef enum {
 #define SF_OBS_NORMALIZED 1 /* ENV:109-133 */
 #define SF_OBS_MONITORS 2   /* ENV:96-108: 10 values */
 #define SF_OBS_NONE 3       /* skip the observation epilogue */
+#define SF_OBS_IMAGE 4      /* ENV:203-206 + rl/envs.py:28-30: uint8 [1][84][84], what the trainer's VecEnv yields */
+#define SF_OBS_IMAGE_RAW 5  /* ENV:203-206 alone: uint8 [92][90], SSF_Env's own `game_state` */
+
+/* image geometry (ENV:57-58, rl/envs.py:29) */
+#define SF_IMAGE_W 90
+#define SF_IMAGE_H 92
+#define SF_IMAGE_OUT 84
 
 /* flags */
 #define SF_FLAG_OBS_F64 1u          /* write observations as float64 (the reference's dtype) instead of float32 */
@@ -122,6 +129,17 @@ int sf_step(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, i
  *      n_steps * n_envs * 8 must stay below 2^32. ---- */
 int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, void* obs_dev,
                int32_t* reward_dev, uint8_t* done_dev, uint8_t* info_dev, void* stream);
+
+/* ---- Game.draw() + pb_pixels -> grey frame (SRC/pymodule.cpp:243-254, SRC/draw.cpp:257-270,
+ *      ENV:203-206), optionally followed by the trainer's 84x84 INTER_AREA shrink (rl/envs.py:28-30),
+ *      for the CURRENT state of every env: what `render()` / `_draw()` give in the reference,
+ *      whatever obs_type the batch was created with.  mode SF_OBS_IMAGE: frames_dev uint8
+ *      [n_envs][84][84]; SF_OBS_IMAGE_RAW: uint8 [n_envs][92][90].  frames_dev must be 4-byte
+ *      aligned.  With obs_type SF_OBS_IMAGE / SF_OBS_IMAGE_RAW, sf_reset and sf_step write these
+ *      frames to obs_dev themselves (sf_obs_dim = 7056 / 8280 bytes per env); sf_rollout then
+ *      takes obs_dev = NULL only.  Pixel-level anti-aliasing is this library's own model: see
+ *      DESIGN.md "image observation". ---- */
+int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, void* stream);
 
 /* Out-of-range actions are executed as NOOP and counted on the device; this reads and clears the
  * count (synchronises `stream`).  Returns SF_ERR_ACTION if any were seen since the last call. */
@@ -189,6 +207,14 @@ int sf_spawn_table(uint32_t seed, int n, int16_t* out);
 int sf_trig_table(double* out);
 /* hexagon vertices (SRC/hexagon.cpp:13-34): out is double[6][2] */
 int sf_hex_points(int radius, double* out);
+
+/* the part of every frame that never changes: both hexagons stroked on black (SRC/draw.cpp:131-143,
+ * 230-231, 262-263) as 8-bit grey: out is uint8[92][90] */
+int sf_image_background(uint8_t* out);
+/* cv2.resize(..., INTER_AREA) taps for one axis, ssize -> dsize with dsize <= ssize < 2*dsize
+ * (rl/envs.py:29: 90 -> 84 and 92 -> 84): destination i reads source cells first[i] .. first[i] +
+ * count[i] - 1 with weights alpha[4*i ..]; alpha is float[dsize][4] */
+int sf_resize_area_tab(int ssize, int dsize, int32_t* first, int32_t* count, float* alpha);
 
 const char* sf_last_error(void);
 int sf_version(void);

@@ -11,8 +11,8 @@ of the reference) when `gym` is importable, and always exposes
 from spacefortress_amd.env import SSF_Env
 from spacefortress_amd.vecenv import SFVecEnv
 
-# id -> constructor kwargs, as registered by the reference (obs_type 'image' there; the image
-# observation is not built yet, so the ids resolve to the symbolic 'features' observation here)
+# id -> constructor kwargs, as registered by the reference (obs_type 'image' there; pass
+# obs_type="image" for that, the default here stays the symbolic 'features' observation)
 ENV_IDS = {
     "SpaceFortress-youturn-image-v0": {"gametype": "youturn"},
     "SpaceFortress-autoturn-image-v0": {"gametype": "autoturn"},
@@ -40,6 +40,7 @@ def make_env(env_id, seed, rank, obs_type="features", **kw):
 
 def make_vec_env(env_id, num_envs, obs_type="features", spawn_skip=1, **kw):
     """The whole `SubprocVecEnv([make_env(id, seed, i) for i in range(N)])` as one device batch.
+    obs_type="image" yields what rl/envs.py:19-30 wraps each worker into: uint8 [N, 1, 84, 84].
     spawn_skip=1 reproduces the trainer: the parent built one throw-away env before forking
     (rl/train.py:17), so every worker's first Game is the second spawn of the libc stream."""
     return SFVecEnv(num_envs, obs_type=obs_type, spawn_skip=spawn_skip, **_resolve(env_id), **kw)

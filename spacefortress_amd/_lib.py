@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("SFMI_LIB_PATH") or os.path.join(HERE, "libsfmi.so")
 
 SF_OK = 0
 SF_ERR_PRESET, SF_ERR_ARG, SF_ERR_HIP, SF_ERR_NO_DEVICE, SF_ERR_ACTION, SF_ERR_FIELD = -1, -2, -3, -4, -5, -6
-OBS_TYPES = {"features": 0, "normalized-features": 1, "monitors": 2, "none": 3}
+OBS_TYPES = {"features": 0, "normalized-features": 1, "monitors": 2, "none": 3, "image": 4, "image-raw": 5}
+IMAGE_W, IMAGE_H, IMAGE_OUT = 90, 92, 84
 FLAG_OBS_F64 = 1
 FLAG_REAL_SHELL_COUNT = 2
 FLAG_NO_AUTO_RESET = 4
@@ -76,6 +77,9 @@ SYMBOLS = {
     "sf_spawn_table": (C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
     "sf_trig_table": (C.c_int, [C.c_void_p]),
     "sf_hex_points": (C.c_int, [C.c_int, C.c_void_p]),
+    "sf_render": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "sf_image_background": (C.c_int, [C.c_void_p]),
+    "sf_resize_area_tab": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_last_error": (C.c_char_p, []),
     "sf_version": (C.c_int, []),
 }

@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfmi.so")
-SOURCES = ["sf_kernels.hip", "sf_capi.cpp", "sf_host.cpp"]
-HEADERS = ["sf_layout.h", "sf_internal.h", os.path.join(ROOT, "include", "sfmi.h")]
+SOURCES = ["sf_kernels.hip", "sf_render.hip", "sf_capi.cpp", "sf_host.cpp", "sf_image.cpp"]
+HEADERS = ["sf_layout.h", "sf_internal.h", "sf_raster.h", os.path.join(ROOT, "include", "sfmi.h")]
 
 
 def needs_build():

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "sf_internal.h"
+#include "sf_raster.h"
 
 struct sf_batch {
   SfKernelArgs args;
@@ -24,6 +25,9 @@ struct sf_batch {
   int16_t* d_spawn;
   unsigned long long* d_acc;
   unsigned char* d_scratch;  // linear staging for sf_get_field / sf_set_field (largest field)
+  int obs_mode;              // the caller's SF_OBS_*; args.obs_type is SF_OBS_NONE for the image modes
+  uint32_t* d_bg;            // image observation: static background, 92*90 bytes
+  uint32_t* d_tabs;          // INTER_AREA taps, 2*84 x {first, a0, a1, a2}
 };
 
 namespace {
@@ -69,8 +73,8 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
     sf_set_error("sf_create: n_envs must be positive (got %d)", p->n_envs);
     return SF_ERR_ARG;
   }
-  if (p->obs_type < SF_OBS_FEATURES || p->obs_type > SF_OBS_NONE) {
-    // ENV:51 assert obs_type in (...); 'image' is not built yet
+  if (p->obs_type < SF_OBS_FEATURES || p->obs_type > SF_OBS_IMAGE_RAW) {
+    // ENV:51 assert obs_type in ('image', 'features', 'normalized-features', 'monitors')
     sf_set_error("sf_create: unsupported obs_type %d", p->obs_type);
     return SF_ERR_ARG;
   }
@@ -141,6 +145,30 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   HIP_TRY_FREE(hipMemcpy(b->d_consts, consts.data(), consts.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY_FREE(hipMemcpy(b->d_spawn, spawn.data(), spawn.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   HIP_TRY_FREE(hipMemcpy(b->d_acc, kAccInit, sizeof(kAccInit), hipMemcpyHostToDevice));
+  {
+    // image observation tables (sf_image.cpp): 11 KB, built for every batch so that sf_render works
+    // whatever obs_type the batch steps with (the reference's render(), ENV:190-193)
+    static_assert(SF_IMG_W == SF_IMAGE_W && SF_IMG_H == SF_IMAGE_H && SF_OUT == SF_IMAGE_OUT, "sfmi.h vs sf_raster.h");
+    static_assert(SF_IMG_W == (int)sfc::pb_width && SF_IMG_H == (int)sfc::pb_height, "ENV:57-58");
+    std::vector<uint8_t> bg(SF_IMG_W * SF_IMG_H);
+    sf_image_background(bg.data());
+    std::vector<uint32_t> tabs(2 * SF_OUT * 4);
+    const int ssize[2] = {SF_IMG_W, SF_IMG_H};
+    for (int ax = 0; ax < 2; ax++) {
+      int32_t first[SF_OUT], count[SF_OUT];
+      float alpha[SF_OUT * 4];
+      sf_resize_area_tab(ssize[ax], SF_OUT, first, count, alpha);
+      for (int i = 0; i < SF_OUT; i++) {
+        uint32_t* t = &tabs[4 * (ax * SF_OUT + i)];
+        t[0] = (uint32_t)first[i];
+        memcpy(t + 1, alpha + 4 * i, 3 * sizeof(float));
+      }
+    }
+    HIP_TRY_FREE(hipMalloc((void**)&b->d_bg, bg.size()));
+    HIP_TRY_FREE(hipMalloc((void**)&b->d_tabs, tabs.size() * sizeof(uint32_t)));
+    HIP_TRY_FREE(hipMemcpy(b->d_bg, bg.data(), bg.size(), hipMemcpyHostToDevice));
+    HIP_TRY_FREE(hipMemcpy(b->d_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
 
   SfKernelArgs& a = b->args;
   a.state = b->d_state;
@@ -184,11 +212,13 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
       return SF_ERR_ARG;
     }
   }
-  a.obs_type = p->obs_type;
+  b->obs_mode = p->obs_type;
+  const bool image = p->obs_type == SF_OBS_IMAGE || p->obs_type == SF_OBS_IMAGE_RAW;
+  a.obs_type = image ? SF_OBS_NONE : p->obs_type;  // frames come from sf_render, after the step kernel
   a.obs_f64 = (p->flags & SF_FLAG_OBS_F64) ? 1 : 0;
   a.real_shell_count = (p->flags & SF_FLAG_REAL_SHELL_COUNT) ? 1 : 0;
   a.auto_reset = (p->flags & SF_FLAG_NO_AUTO_RESET) ? 0 : 1;
-  a.obs_dim = p->obs_type == SF_OBS_MONITORS ? 10 : (p->obs_type == SF_OBS_NONE ? 0 : 15 + preset.n_keys);
+  a.obs_dim = p->obs_type == SF_OBS_MONITORS ? 10 : ((p->obs_type == SF_OBS_NONE || image) ? 0 : 15 + preset.n_keys);
   static_assert(sfc::pb_width == (double)(int)(450 * .2) && sfc::pb_height == (double)(int)(460 * .2), "ENV:57-58");
   static_assert(sfc::max_ticks == (double)(sfc::game_time / sfc::tick_ms), "ENV:165");
   a.acc = b->d_acc;
@@ -213,6 +243,8 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_spawn) (void)hipFree(b->d_spawn);
   if (b->d_acc) (void)hipFree(b->d_acc);
   if (b->d_scratch) (void)hipFree(b->d_scratch);
+  if (b->d_bg) (void)hipFree(b->d_bg);
+  if (b->d_tabs) (void)hipFree(b->d_tabs);
   if (b->args.dbg) (void)hipFree(b->args.dbg);
   delete b;
   return SF_OK;
@@ -229,10 +261,39 @@ extern "C" int sf_debug_read(sf_batch* b, unsigned long long* host) {
 #endif
 
 extern "C" int sf_n_envs(const sf_batch* b) { return b ? b->n_envs : SF_ERR_ARG; }
-extern "C" int sf_obs_dim(const sf_batch* b) { return b ? b->args.obs_dim : SF_ERR_ARG; }
+extern "C" int sf_obs_dim(const sf_batch* b) {
+  if (!b) return SF_ERR_ARG;
+  if (b->obs_mode == SF_OBS_IMAGE) return SF_OUT * SF_OUT;
+  if (b->obs_mode == SF_OBS_IMAGE_RAW) return SF_IMG_W * SF_IMG_H;
+  return b->args.obs_dim;
+}
 extern "C" int sf_n_actions(const sf_batch* b) { return b ? b->act_count : SF_ERR_ARG; }
 extern "C" int sf_tick_ms(const sf_batch* b) { return b ? sfc::tick_ms : SF_ERR_ARG; }
 extern "C" int sf_max_ticks(const sf_batch* b) { return b ? (int)sfc::max_ticks : SF_ERR_ARG; }
+
+static bool is_image(const sf_batch* b) { return b->obs_mode == SF_OBS_IMAGE || b->obs_mode == SF_OBS_IMAGE_RAW; }
+
+static int render(sf_batch* b, int mode, uint8_t* frames_dev, hipStream_t stream) {
+  if (((uintptr_t)frames_dev & 3) != 0) {
+    sf_set_error("image frames must be 4-byte aligned");
+    return SF_ERR_ARG;
+  }
+  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_tabs, frames_dev, mode == SF_OBS_IMAGE ? 1 : 0, stream));
+  return SF_OK;
+}
+
+extern "C" int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, void* stream) {
+  if (!b || !frames_dev) {
+    sf_set_error("sf_render: null batch or output");
+    return SF_ERR_ARG;
+  }
+  if (mode != SF_OBS_IMAGE && mode != SF_OBS_IMAGE_RAW) {
+    sf_set_error("sf_render: mode must be SF_OBS_IMAGE or SF_OBS_IMAGE_RAW (got %d)", mode);
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  return render(b, mode, frames_dev, (hipStream_t)stream);
+}
 
 extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
   if (!b) {
@@ -240,7 +301,9 @@ extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
     return SF_ERR_ARG;
   }
   DeviceGuard guard(b->device);
-  HIP_TRY(sf_launch_reset(b->args, 0, 0, 0, obs_dev, (hipStream_t)stream));
+  const bool image = is_image(b);
+  HIP_TRY(sf_launch_reset(b->args, 0, 0, 0, image ? nullptr : obs_dev, (hipStream_t)stream));
+  if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, (hipStream_t)stream);
   return SF_OK;
 }
 
@@ -255,8 +318,10 @@ extern "C" int sf_step(sf_batch* b, const void* actions_dev, int act_type, void*
     return SF_ERR_ARG;
   }
   DeviceGuard guard(b->device);
-  HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev,
-                         1, false, (hipStream_t)stream));
+  const bool image = is_image(b);
+  HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, image ? nullptr : obs_dev,
+                         reward_dev, done_dev, info_dev, 1, false, (hipStream_t)stream));
+  if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, (hipStream_t)stream);
   return SF_OK;
 }
 
@@ -268,6 +333,11 @@ extern "C" int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, in
   }
   if (act_type != SF_ACT_U8 && act_type != SF_ACT_I32 && act_type != SF_ACT_I64) {
     sf_set_error("sf_rollout: act_type must be 1, 4 or 8 (got %d)", act_type);
+    return SF_ERR_ARG;
+  }
+  if (is_image(b) && obs_dev) {
+    sf_set_error("sf_rollout: image observations are rendered from the state in HBM, one frame per sf_step; "
+                 "pass obs_dev = NULL");
     return SF_ERR_ARG;
   }
   if (n_steps <= 0 || (double)n_steps * b->n_envs * 8.0 >= 4294967296.0) {

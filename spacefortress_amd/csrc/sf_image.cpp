@@ -1,0 +1,109 @@
+// sf_image.cpp -- host-side tables of the image observation (no HIP calls; tested without a GPU):
+//   * the static background: the two hexagons, which the reference strokes first on every frame
+//     (SRC/draw.cpp:131-143,230-231) and which never change, as 8-bit coverage of a 92x90 surface;
+//   * the INTER_AREA resampling tables of cv2.resize(frame, (84, 84)) (rl/envs.py:29).
+// cv2 (OpenCV) is a dependency of the reference that is not vendored in /root/reference and not
+// installed in this image; the table follows OpenCV's published algorithm (modules/imgproc/src/
+// resize.cpp, computeResizeAreaTab, the general non-integer-scale area path).  See sf_raster.h for
+// what is and is not pinned about pixel values.
+#include <math.h>
+#include <string.h>
+
+#include "sf_internal.h"
+#include "sf_raster.h"
+
+namespace {
+
+// user space -> device space: cairo_scale(.2) then cairo_translate(-130, -80), SRC/draw.cpp:259-260
+inline double dev_x(double x) { return (x - SF_VP_X) * SF_SCALE; }
+inline double dev_y(double y) { return (y - SF_VP_Y) * SF_SCALE; }
+
+// vertices of the polygon whose edges are the hexagon's edges moved by `off` along their outward
+// normals: the outline (off > 0) / inline (off < 0) of a closed stroke with miter joins
+void offset_polygon(const double* p /* [6][2] */, double off, double* qx, double* qy) {
+  double area2 = 0;
+  for (int i = 0; i < 6; i++) {
+    const int j = (i + 1) % 6;
+    area2 += p[2 * i] * p[2 * j + 1] - p[2 * j] * p[2 * i + 1];
+  }
+  const double orient = area2 > 0 ? 1.0 : -1.0;
+  // edge i: from p[i] to p[i+1]; outward unit normal n_i; offset line: n_i . x = n_i . p[i] + off
+  double nx[6], ny[6], c[6];
+  for (int i = 0; i < 6; i++) {
+    const int j = (i + 1) % 6;
+    const double ex = p[2 * j] - p[2 * i], ey = p[2 * j + 1] - p[2 * i + 1];
+    const double len = sqrt(ex * ex + ey * ey);
+    nx[i] = orient * ey / len;
+    ny[i] = -orient * ex / len;
+    c[i] = nx[i] * p[2 * i] + ny[i] * p[2 * i + 1] + off;
+  }
+  // vertex i of the offset polygon = intersection of offset edges i-1 and i
+  for (int i = 0; i < 6; i++) {
+    const int h = (i + 5) % 6;
+    const double det = nx[h] * ny[i] - ny[h] * nx[i];
+    qx[i] = (c[h] * ny[i] - ny[h] * c[i]) / det;
+    qy[i] = (nx[h] * c[i] - c[h] * nx[i]) / det;
+  }
+}
+
+}  // namespace
+
+extern "C" int sf_image_background(uint8_t* out) {
+  if (!out) {
+    sf_set_error("sf_image_background: null output");
+    return SF_ERR_ARG;
+  }
+  memset(out, 0, SF_IMG_W * SF_IMG_H);  // cairo_paint of black, SRC/draw.cpp:262-263
+  const int radii[2] = {200, 40};       // bigHex, smallHex (SRC/configs.cpp:34-35), drawn in this order
+  for (int h = 0; h < 2; h++) {
+    double p[12], ox[6], oy[6], ix[6], iy[6];
+    sf_hex_points(radii[h], p);
+    offset_polygon(p, SF_LINE_W / 2, ox, oy);
+    offset_polygon(p, -SF_LINE_W / 2, ix, iy);
+    for (int i = 0; i < 6; i++) {
+      ox[i] = dev_x(ox[i]);
+      oy[i] = dev_y(oy[i]);
+      ix[i] = dev_x(ix[i]);
+      iy[i] = dev_y(iy[i]);
+    }
+    for (int y = 0; y < SF_IMG_H; y++)
+      for (int x = 0; x < SF_IMG_W; x++) {
+        // ring = outline minus inline; both convex, the inline inside the outline
+        double a = sfr::clip_area<double>(ox, oy, 6, (double)x, (double)y) -
+                   sfr::clip_area<double>(ix, iy, 6, (double)x, (double)y);
+        if (a <= 0) continue;
+        if (a > 1) a = 1;
+        const int m = (int)(a * 255.0 + 0.5);
+        out[y * SF_IMG_W + x] = (uint8_t)sfr::over_un8(out[y * SF_IMG_W + x], 255, m);  // white, :133-136
+      }
+  }
+  return SF_OK;
+}
+
+extern "C" int sf_resize_area_tab(int ssize, int dsize, int32_t* first, int32_t* count, float* alpha) {
+  if (ssize <= 0 || dsize <= 0 || dsize > ssize || ssize >= 2 * dsize || !first || !count || !alpha) {
+    sf_set_error("sf_resize_area_tab: need dsize <= ssize < 2*dsize and non-null outputs");
+    return SF_ERR_ARG;
+  }
+  const double inv_scale = (double)dsize / (double)ssize;
+  const double scale = 1.0 / inv_scale;
+  for (int dx = 0; dx < dsize; dx++) {
+    const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    const double cell = fmin(scale, ssize - fsx1);
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    if (sx2 > ssize - 1) sx2 = ssize - 1;
+    if (sx1 > sx2) sx1 = sx2;
+    int k = 0, f = sx1;
+    float* a = alpha + 4 * dx;
+    a[0] = a[1] = a[2] = a[3] = 0.f;
+    if (sx1 - fsx1 > 1e-3) {
+      f = sx1 - 1;
+      a[k++] = (float)((sx1 - fsx1) / cell);
+    }
+    for (int sx = sx1; sx < sx2; sx++) a[k++] = (float)(1.0 / cell);
+    if (fsx2 - sx2 > 1e-3) a[k++] = (float)(fmin(fmin(fsx2 - sx2, 1.0), cell) / cell);
+    first[dx] = f;
+    count[dx] = k;  // <= 3 because ssize < 2*dsize
+  }
+  return SF_OK;
+}

@@ -21,9 +21,9 @@ class SSF_Env(_Base):
     def __init__(self, gametype="youturn", scale=.2, viewport=(130, 80, 450, 460), ls=3, action_set=1,
                  obs_type="image", device=None, seed=1):
         assert obs_type in ("image", "features", "normalized-features", "monitors")  # ENV:51
-        if obs_type == "image":
-            raise NotImplementedError("image observations (SURVEY 8f rank 1) are not built yet; "
-                                      "use obs_type='features'")
+        if (scale, tuple(viewport), ls) != (.2, (130, 80, 450, 460), 3):
+            # the renderer's geometry (90x92 surface, 0.6-pixel strokes) is compiled into the kernel
+            raise ValueError("only the default scale=.2, viewport=(130,80,450,460), ls=3 are built")
         self.obs_type = obs_type
         self.gametype = gametype
         self.viewport = viewport
@@ -32,12 +32,17 @@ class SSF_Env(_Base):
         self.h = int(viewport[3] * scale)
         self.action_set = action_set
         self.last_action = None
-        self._vec = SFVecEnv(1, gametype=gametype, obs_type=obs_type, action_set=action_set, device=device,
+        # 'image' here is the bare [92, 90] grey frame (ENV:171); the 84x84 shrink is the trainer's wrapper
+        self._vec = SFVecEnv(1, gametype=gametype, obs_type="image-raw" if obs_type == "image" else obs_type,
+                             action_set=action_set, device=device,
                              seed=seed, obs_dtype=__import__("torch").float64, auto_reset=False)
         self.tickdur = self._vec.tickdur
         self.max_ticks = float(self._vec.max_ticks)
         self.action_space = self._vec.action_space
         self.observation_space = self._vec.observation_space
+        if obs_type == "image":  # ENV:169 declares (h, w, 3) although the observation is the grey (h, w) frame
+            from .spaces import Box
+            self.observation_space = Box(0, 255, (self.h, self.w, 3), np.uint8)
         self.actions_taken = {i: 0 for i in range(self.action_space.n)}  # ENV:91
         # ENV:93: __init__ ends with reset(), i.e. the first Game -- sf_create already made it
 
@@ -54,7 +59,15 @@ class SSF_Env(_Base):
         return obs[0], int(r[0]), bool(d[0]), bool(i[0])
 
     def render(self, mode="human", close=False):
-        raise NotImplementedError("rendering is outside the env.step() hot path")
+        """ENV:180-198.  'rgb_array' returns game_gray_rgb, the grey frame replicated to [92, 90, 3];
+        the pyglet window of mode 'human' is not part of this library."""
+        if close:
+            return None
+        if mode != "rgb_array":
+            raise NotImplementedError("render(mode='human') opens a pyglet window in the reference; "
+                                      "use mode='rgb_array'")
+        frame = self._vec.render("image-raw")[0].cpu().numpy()
+        return np.repeat(frame[:, :, None], 3, axis=2)  # cv2.COLOR_GRAY2RGB
 
     def close(self):
         self._vec.close()

@@ -36,8 +36,6 @@ class SFVecEnv:
     def __init__(self, num_envs, gametype="youturn", obs_type="features", action_set=1, device=None,
                  seed=1, spawn_skip=0, spawn_stride=0, obs_dtype=torch.float32, faithful_bugs=True,
                  auto_reset=True, spawn_table_len=0, reuse_buffers=False):
-        if obs_type == "image":
-            raise NotImplementedError("image observations (SURVEY 8f rank 1) are not built yet")
         if obs_type not in _lib.OBS_TYPES:
             raise AssertionError("obs_type %r" % (obs_type,))  # ENV:51
         self._L = _lib.lib()
@@ -69,12 +67,22 @@ class SFVecEnv:
         self.obs_type = obs_type
         self.obs_dtype = obs_dtype
         self.obs_dim = self._L.sf_obs_dim(h)
+        # 'image': what the trainer's VecEnv yields, WrapPyTorch's [1, 84, 84] uint8 (rl/envs.py:19-30);
+        # 'image-raw': SSF_Env's own [92, 90] grey frame (ENV:171)
+        self.is_image = obs_type in ("image", "image-raw")
+        self.obs_shape = {"image": (1, _lib.IMAGE_OUT, _lib.IMAGE_OUT),
+                          "image-raw": (_lib.IMAGE_H, _lib.IMAGE_W)}.get(obs_type, (self.obs_dim,))
         self.n_actions = self._L.sf_n_actions(h)
         self.tickdur = self._L.sf_tick_ms(h)      # ENV:61
         self.max_ticks = self._L.sf_max_ticks(h)  # ENV:165
         self.action_space = Discrete(self.n_actions)  # ENV:90
         # ENV:175 declares dtype uint8 for the feature Box; the values are floats
-        self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32 if obs_dtype == torch.float32 else np.float64)
+        if self.is_image:
+            self.obs_dtype = torch.uint8
+            self.observation_space = Box(0, 255, self.obs_shape, np.uint8)  # rl/envs.py:22-26
+        else:
+            self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,),
+                                         np.float32 if obs_dtype == torch.float32 else np.float64)
         self.reuse_buffers = reuse_buffers
         self._bufs = None
         self._pending = None
@@ -88,7 +96,7 @@ class SFVecEnv:
         if self.reuse_buffers and self._bufs is not None:
             return self._bufs
         n = self.num_envs
-        bufs = (torch.empty((n, self.obs_dim), dtype=self.obs_dtype, device=self.device),
+        bufs = (torch.empty((n,) + self.obs_shape, dtype=self.obs_dtype, device=self.device),
                 torch.empty(n, dtype=torch.int32, device=self.device),
                 torch.empty(n, dtype=torch.uint8, device=self.device),
                 torch.empty(n, dtype=torch.uint8, device=self.device))
@@ -132,7 +140,10 @@ class SFVecEnv:
         if out is not None:
             obs, rew, done, info = out
         else:
-            obs = torch.empty((K, n, self.obs_dim), dtype=self.obs_dtype, device=self.device) if want_obs else None
+            if self.is_image and want_obs:
+                raise ValueError("rollout() keeps the state in registers between ticks; image frames are rendered "
+                                 "from the state in HBM, one per step(): pass want_obs=False")
+            obs = torch.empty((K, n) + self.obs_shape, dtype=self.obs_dtype, device=self.device) if want_obs else None
             rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
             done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
             info = torch.empty((K, n), dtype=torch.uint8, device=self.device)
@@ -178,6 +189,17 @@ class SFVecEnv:
             self.close()
         except Exception:
             pass
+
+    def render(self, mode="image-raw", out=None):
+        """Frames of the CURRENT state of every env, whatever obs_type the batch steps with (the
+        reference's `render()`, ENV:180-198): uint8 [N, 92, 90] ('image-raw') or [N, 1, 84, 84] ('image')."""
+        if mode not in ("image", "image-raw"):
+            raise ValueError("mode must be 'image' or 'image-raw'")
+        shape = (1, _lib.IMAGE_OUT, _lib.IMAGE_OUT) if mode == "image" else (_lib.IMAGE_H, _lib.IMAGE_W)
+        if out is None:
+            out = torch.empty((self.num_envs,) + shape, dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.sf_render(self._h, _lib.OBS_TYPES[mode], C.c_void_p(out.data_ptr()), self._stream()))
+        return out
 
     # ------------------------------------------------------------------ extras
     def check_actions(self):

@@ -1,0 +1,204 @@
+"""The image observation on the GPU (sf_render behind SFVecEnv / SSF_Env) against the numpy
+restatement of the same rendering model (oracle/render_np.py), on states recorded from the real
+reference engine (tests/golden/*.npz) and on oracle lock-step runs.
+
+Bar: every pixel within 2 grey levels (the kernel computes coverage in float32 from edge integrals,
+the restatement in float64 from polygon clipping; a coverage that lands on a rounding boundary moves
+one level, compositing two strokes can move two), and at least 99.5 % of the pixels identical.
+Pixel parity with cairo + cv2 themselves is UNPINNED (see oracle/render_np.py); geometry-level
+checks -- the ship lights up where the state says it is -- are below."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def sfa():
+    import spacefortress_amd as m
+    from spacefortress_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "libsfmi.so not built: the GPU tests never fall back"
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return m
+
+
+@pytest.fixture(scope="module")
+def model():
+    from oracle import render_np as R
+
+    z = np.load(os.path.join(GOLDEN, "tables.npz"))
+    hb, hs = z["hex_points"][:12], z["hex_points"][12:]  # big, small: recorded from the reference
+    return R, hb, hs, R.background(hb, hs)
+
+
+def frames_close(got, want, what):
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 2, (what, int(d.max()), np.argwhere(d > 2)[:5])
+    assert (d == 0).mean() >= 0.995, (what, float((d == 0).mean()))
+
+
+@pytest.mark.parametrize("name,stride", [
+    ("autoturn_destroy", 7), ("youturn_hunter", 61), ("youturn_deaths", 13), ("youturn_rapid_fire", 11),
+    ("youturn_random_short", 9),
+])
+def test_frames_vs_model_on_reference_states(sfa, model, name, stride):
+    """Replay a recorded reference run on the GPU; at every `stride`-th tick render both sizes and
+    compare with the model's rendering of the state the REFERENCE had at that tick."""
+    R, hb, hs, bg = model
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    assert meta["snap_every"] == 1
+    N = 2
+    env = sfa.SFVecEnv(N, gametype=meta["gametype"], action_set=meta["action_set"], seed=meta["seed"],
+                       spawn_skip=meta["spawn_skip"], obs_type="image")
+    acts = torch.from_numpy(np.repeat(z["actions"][:, None], N, 1).astype(np.uint8)).to(env.device)
+    done = z["done"].astype(bool)
+    # no reset(): the recording starts from the first Game of the process, which sf_create made
+    obs0 = env.render("image")
+    assert obs0.shape == (N, 1, 84, 84) and obs0.dtype == torch.uint8
+    seen = dict(explosion=0, missiles=0, shells=0, kill_bar=0)
+    T = min(len(acts), 1500)
+    for t in range(T):
+        obs, rew, dn, info = env.step_tensors(acts[t])
+        if t % stride or done[t]:
+            continue
+        snap = z["snaps"][t]
+        raw = env.render("image-raw").cpu().numpy()
+        small = obs.cpu().numpy()
+        want_raw = R.render_raw(snap, hb, hs, bg=bg)
+        frames_close(raw[0], want_raw, (name, t, "raw"))
+        assert np.array_equal(raw[0], raw[1])
+        frames_close(small[0, 0], R.resize_area(want_raw), (name, t, "84"))
+        # the shrink itself, isolated from coverage rounding: resample the kernel's own raw frame
+        d = np.abs(small[0, 0].astype(int) - R.resize_area(raw[0]).astype(int))
+        assert d.max() <= 1 and (d == 0).mean() > 0.999, (name, t, int(d.max()))
+        seen["explosion"] += int(not snap["ship_alive"] or not snap["fort_alive"])
+        seen["missiles"] += int(snap["missile_alive"].sum() > 0)
+        seen["shells"] += int(snap["shell_alive"].sum() > 0)
+        seen["kill_bar"] += int(snap["vlner"] > 10)
+    env.close()
+    if name == "autoturn_destroy":
+        assert seen["explosion"] and seen["missiles"] and seen["kill_bar"], seen
+    if name == "youturn_deaths":
+        assert seen["explosion"] and seen["shells"], seen
+
+
+def test_frames_vs_model_random_lanes(sfa, oracle_mod, model):
+    """Different lanes in different states (spawn offsets, random actions), lock-step with the CPU
+    oracle; every lane's frame at a few checkpoints."""
+    R, hb, hs, bg = model
+    O = oracle_mod
+    N, T = 48, 420
+    rng = np.random.default_rng(11)
+    env = sfa.SFVecEnv(N, gametype="youturn", obs_type="image-raw", spawn_stride=5, spawn_skip=1)
+    orc = O.OracleVecEnv("youturn", N, spawn_stride=5, spawn_skip=1)
+    acts = rng.integers(0, 5, (T, N)).astype(np.uint8)
+    a = torch.from_numpy(acts).to(env.device)
+    obs = env.reset()
+    orc.reset()
+    assert obs.shape == (N, 92, 90)
+    for t in range(T):
+        obs, rew, dn, info = env.step_tensors(a[t])
+        orc.step(acts[t].astype(np.int32))
+        if t % 70 == 69:
+            got = obs.cpu().numpy()
+            snaps = orc.snapshots()
+            for i in range(N):
+                frames_close(got[i], R.render_raw(snaps[i], hb, hs, bg=bg), (t, i))
+    env.close()
+
+
+def test_ship_lights_up_where_the_state_says(sfa, model):
+    """Geometry, independent of the model: the pixels that differ from the static background and are
+    not text / bar / fortress have their centroid at the ship's device position."""
+    R, hb, hs, bg = model
+    N = 256
+    env = sfa.SFVecEnv(N, gametype="youturn", obs_type="features", spawn_stride=1)
+    env.reset()
+    a = torch.full((N,), 0, dtype=torch.uint8, device=env.device)
+    for _ in range(3):
+        env.step_tensors(a)
+    raw = env.render("image-raw").cpu().numpy().astype(np.int32)
+    sx, sy = env.get_field("ship_x"), env.get_field("ship_y")
+    ys, xs = np.mgrid[0:92, 0:90]
+    checked = 0
+    for i in range(N):
+        ex, ey = (sx[i] - 130) * 0.2, (sy[i] - 80) * 0.2
+        if abs(ex - 45) < 13 and abs(ey - 47) < 13:
+            continue  # too close to the fortress to tell their pixels apart
+        checked += 1
+        diff = np.abs(raw[i] - bg.astype(np.int32))
+        diff[:8] = 0          # score text
+        diff[86:] = 0         # vulnerability bar
+        diff[41:54, 38:54] = 0  # fortress wireframe
+        assert diff.sum() > 0
+        cx, cy = (diff * (xs + 0.5)).sum() / diff.sum(), (diff * (ys + 0.5)).sum() / diff.sum()
+        # the wireframe's centroid sits within its own extent (36 user units = 7 px) of the position
+        assert abs(cx - ex) < 3.0 and abs(cy - ey) < 3.0, (i, cx, cy, ex, ey)
+    assert checked > N // 2
+    env.close()
+
+
+def test_image_env_surfaces(sfa):
+    """SSF_Env(obs_type='image') returns the [92, 90] grey frame, declares (92, 90, 3) like ENV:169,
+    render('rgb_array') replicates it; the vec env's 'image' observation is [N, 1, 84, 84] uint8 with
+    the WrapPyTorch Box (rl/envs.py:22-26); rollout refuses image observations."""
+    e = sfa.SSF_Env(gametype="autoturn", obs_type="image")
+    f0 = e.reset()
+    assert f0.shape == (92, 90) and f0.dtype == np.uint8
+    assert e.observation_space.shape == (92, 90, 3)
+    f1, r, d, i = e.step(1)
+    assert f1.shape == (92, 90) and isinstance(r, int) and isinstance(d, bool) and isinstance(i, bool)
+    rgb = e.render("rgb_array")
+    assert rgb.shape == (92, 90, 3) and np.array_equal(rgb[:, :, 0], f1) and np.array_equal(rgb[:, :, 2], f1)
+    with pytest.raises(NotImplementedError):
+        e.render("human")
+    e.close()
+    with pytest.raises(ValueError):
+        sfa.SSF_Env(scale=.5)
+
+    v = sfa.SFVecEnv(5, obs_type="image")
+    assert v.observation_space.shape == (1, 84, 84) and v.observation_space.dtype == np.uint8
+    o, r, d, i = v.step(np.zeros(5, np.int64))
+    assert o.shape == (5, 1, 84, 84) and o.dtype == np.uint8 and r.dtype == np.int64
+    assert np.array_equal(o, v.render("image").cpu().numpy())
+    with pytest.raises(ValueError):
+        v.rollout(torch.zeros((4, 5), dtype=torch.uint8, device=v.device))
+    ob, rw, dn, inf = v.rollout(torch.zeros((4, 5), dtype=torch.uint8, device=v.device), want_obs=False)
+    assert ob is None and rw.shape == (4, 5)
+    v.close()
+
+
+def test_image_full_batch_properties(sfa):
+    """65 536 envs: identical lanes give identical frames (one wave per env, no cross-talk), the
+    static background is where it should be in every frame, and frames follow the state through
+    the auto-reset at the end of the episode."""
+    N = 65536
+    env = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", reuse_buffers=True)
+    rng = np.random.default_rng(5)
+    obs = env.reset()
+    first = obs[0].clone()
+    assert bool((obs == first).all())
+    for t in range(40):
+        a = torch.full((N,), int(rng.integers(0, 5)), dtype=torch.uint8, device=env.device)
+        obs, rew, dn, info = env.step_tensors(a)
+    assert bool((obs == obs[0]).all()) and not bool((obs[0] == first).all())
+    # different actions per lane from here on: frames must now differ between lanes, yet every
+    # frame keeps the hexagon pixels (nothing ever draws darker than the white hexagon)
+    a = torch.from_numpy(rng.integers(0, 5, N).astype(np.uint8)).to(env.device)
+    for t in range(30):
+        obs, rew, dn, info = env.step_tensors(a)
+    assert int((obs != obs[0]).any(dim=(1, 2, 3)).sum()) > N // 2
+    hexmask = (first[0] >= 250)  # explosions (.5 / .75 grey) may be drawn over it, nothing darker
+    hexmask[:6] = False
+    assert int(hexmask.sum()) > 100
+    assert bool((obs[:, 0][:, hexmask] >= 120).all())
+    env.close()
