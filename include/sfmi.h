@@ -134,7 +134,7 @@ int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, 
  *      ENV:203-206), optionally followed by the trainer's 84x84 INTER_AREA shrink (rl/envs.py:28-30),
  *      for the CURRENT state of every env: what `render()` / `_draw()` give in the reference,
  *      whatever obs_type the batch was created with.  mode SF_OBS_IMAGE: frames_dev uint8
- *      [n_envs][84][84]; SF_OBS_IMAGE_RAW: uint8 [n_envs][92][90].  frames_dev must be 4-byte
+ *      [n_envs][84][84]; SF_OBS_IMAGE_RAW: uint8 [n_envs][92][90].  frames_dev must be 16-byte
  *      aligned.  With obs_type SF_OBS_IMAGE / SF_OBS_IMAGE_RAW, sf_reset and sf_step write these
  *      frames to obs_dev themselves (sf_obs_dim = 7056 / 8280 bytes per env); sf_rollout then
  *      takes obs_dev = NULL only.  Pixel-level anti-aliasing is this library's own model: see
@@ -211,10 +211,18 @@ int sf_hex_points(int radius, double* out);
 /* the part of every frame that never changes: both hexagons stroked on black (SRC/draw.cpp:131-143,
  * 230-231, 262-263) as 8-bit grey: out is uint8[92][90] */
 int sf_image_background(uint8_t* out);
+/* the background plus the overlays the render kernel starts from when they are static: variant bit 0 =
+ * the score text "0000000", bit 1 = the vulnerability bar at 0 (drawScore / drawVlner, SRC/draw.cpp:
+ * 190-225); out is uint8[92][90] */
+int sf_image_static(int variant, uint8_t* out);
 /* cv2.resize(..., INTER_AREA) taps for one axis, ssize -> dsize with dsize <= ssize < 2*dsize
  * (rl/envs.py:29: 90 -> 84 and 92 -> 84): destination i reads source cells first[i] .. first[i] +
  * count[i] - 1 with weights alpha[4*i ..]; alpha is float[dsize][4] */
 int sf_resize_area_tab(int ssize, int dsize, int32_t* first, int32_t* count, float* alpha);
+/* cv2.resize(src, (dw, dh), interpolation=INTER_AREA) for 8-bit grey frames and a shrink below 2x per
+ * axis, with OpenCV's float arithmetic and rounding: the library's own resampling of the static
+ * background; host memory, row-major */
+int sf_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
 
 const char* sf_last_error(void);
 int sf_version(void);

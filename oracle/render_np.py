@@ -17,8 +17,8 @@ What the reference draws, where, in which order and in which grey comes from its
 PARITY UNPINNED at the pixel level: cairo, freetype and cv2 are not in this image and the
 reference ships no frame fixtures (rl/imgs/screens.png is a full-colour screenshot at another
 scale), so how a 0.6-pixel stroke turns into grey levels is a MODEL here -- exact area coverage of
-each stroke's rectangles, 8-bit OVER compositing, seven-segment digits for the score text, chords
-for the explosion arcs; INTER_AREA follows OpenCV's published algorithm (imgproc/resize.cpp,
+each stroke's rectangles, 8-bit OVER compositing, seven-segment digits for the score text, one chord
+per explosion arc and a 12-gon ring for its circle; INTER_AREA follows OpenCV's published algorithm (imgproc/resize.cpp,
 computeResizeAreaTab + resizeArea_).  This file restates that model independently of the HIP
 kernel (float64, polygon clipping instead of the kernel's edge integrals) so that the kernel can be
 checked against it; geometry-level checks (where the ship is, what lights up) are in the tests.
@@ -123,8 +123,20 @@ def explosion(fb, pos):
         grey = 191 if radius < 60 else 128
         for angle in range(0, 360, 30):
             _arc(fb, pos, radius, angle + ofs, angle + ofs + 10, grey)
-    for angle in range(0, 360, 30):  # the radius-7 circle, as twelve chords
-        _arc(fb, pos, 7, angle, angle + 30, 191)
+    # the radius-7 circle: ONE stroke (cairo_arc 0..2pi + cairo_stroke), modelled as the ring between
+    # two regular 12-gons of circumradius 7 -/+ half the line width
+    gons = []
+    for r in (7 + LINE_W / 2, 7 - LINE_W / 2):
+        gons.append(_dev([(pos[0] + r * math.cos(math.radians(30 * k)), pos[1] + r * math.sin(math.radians(30 * k)))
+                          for k in range(12)]))
+    x0, y0 = np.floor(gons[0].min(0)).astype(int)
+    x1, y1 = np.ceil(gons[0].max(0)).astype(int)
+    for py in range(max(y0, 0), min(y1, H)):
+        for px in range(max(x0, 0), min(x1, W)):
+            a = min(max(pixel_area(gons[0], px, py) - pixel_area(gons[1], px, py), 0.0), 1.0)
+            m = int(a * 255.0 + 0.5)
+            if m > 0:
+                fb[py, px] = mul_un8(191, m) + mul_un8(int(fb[py, px]), 255 - m)
 
 
 def _arc(fb, pos, r, a0, a1, grey):

@@ -79,7 +79,9 @@ SYMBOLS = {
     "sf_hex_points": (C.c_int, [C.c_int, C.c_void_p]),
     "sf_render": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "sf_image_background": (C.c_int, [C.c_void_p]),
+    "sf_image_static": (C.c_int, [C.c_int, C.c_void_p]),
     "sf_resize_area_tab": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_resize_area_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "sf_last_error": (C.c_char_p, []),
     "sf_version": (C.c_int, []),
 }

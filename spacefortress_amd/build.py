@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfmi.so")
 SOURCES = ["sf_kernels.hip", "sf_render.hip", "sf_capi.cpp", "sf_host.cpp", "sf_image.cpp"]
-HEADERS = ["sf_layout.h", "sf_internal.h", "sf_raster.h", os.path.join(ROOT, "include", "sfmi.h")]
+HEADERS = ["sf_layout.h", "sf_internal.h", "sf_raster.h", "sf_render_tables.h", os.path.join(ROOT, "include", "sfmi.h")]
 
 
 def needs_build():

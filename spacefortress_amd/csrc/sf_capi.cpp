@@ -2,6 +2,7 @@
 // Host code only; the kernels are in sf_kernels.hip.  There is no CPU implementation of the
 // path in this library: every entry point that computes needs a HIP device.
 #include <limits.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,7 +28,8 @@ struct sf_batch {
   unsigned char* d_scratch;  // linear staging for sf_get_field / sf_set_field (largest field)
   int obs_mode;              // the caller's SF_OBS_*; args.obs_type is SF_OBS_NONE for the image modes
   uint32_t* d_bg;            // image observation: static background, 92*90 bytes
-  uint32_t* d_tabs;          // INTER_AREA taps, 2*84 x {first, a0, a1, a2}
+  uint32_t* d_bg84;          // ... resampled to 84x84
+  uint32_t* d_tabs;          // INTER_AREA taps (sf_raster.h)
 };
 
 namespace {
@@ -150,20 +152,39 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
     // whatever obs_type the batch steps with (the reference's render(), ENV:190-193)
     static_assert(SF_IMG_W == SF_IMAGE_W && SF_IMG_H == SF_IMAGE_H && SF_OUT == SF_IMAGE_OUT, "sfmi.h vs sf_raster.h");
     static_assert(SF_IMG_W == (int)sfc::pb_width && SF_IMG_H == (int)sfc::pb_height, "ENV:57-58");
-    std::vector<uint8_t> bg(SF_IMG_W * SF_IMG_H);
-    sf_image_background(bg.data());
-    std::vector<uint32_t> tabs(2 * SF_OUT * 4);
-    const int ssize[2] = {SF_IMG_W, SF_IMG_H};
-    for (int ax = 0; ax < 2; ax++) {
-      int32_t first[SF_OUT], count[SF_OUT];
-      float alpha[SF_OUT * 4];
-      sf_resize_area_tab(ssize[ax], SF_OUT, first, count, alpha);
-      for (int i = 0; i < SF_OUT; i++) {
-        uint32_t* t = &tabs[4 * (ax * SF_OUT + i)];
-        t[0] = (uint32_t)first[i];
-        memcpy(t + 1, alpha + 4 * i, 3 * sizeof(float));
+    std::vector<uint8_t> bg(4 * SF_BG_STRIDE, 0), bg84(4 * SF_OUT * SF_OUT);
+    for (int v = 0; v < 4; v++) {  // static background variants: sf_raster.h
+      sf_image_static(v, bg.data() + v * SF_BG_STRIDE);
+      sf_resize_area_u8(bg.data() + v * SF_BG_STRIDE, SF_IMG_W, SF_IMG_H, bg84.data() + v * SF_OUT * SF_OUT, SF_OUT, SF_OUT);
+    }
+    // device layout of the INTER_AREA tables: sf_raster.h
+    std::vector<uint32_t> tabs(SF_TAB_WORDS, 0u);
+    {
+      const int ssize[2] = {SF_IMG_W, SF_IMG_H};
+      bool ok = true;
+      for (int ax = 0; ax < 2; ax++) {
+        int32_t first[SF_OUT], count[SF_OUT];
+        float alpha[SF_OUT * 4];
+        sf_resize_area_tab(ssize[ax], SF_OUT, first, count, alpha);
+        for (int i = 0; i < SF_OUT; i++) {
+          // what the kernel's sparse resampling assumes: two column taps; <= three row taps; and the
+          // windows where its dirty-box arithmetic expects them (first in [i*s - 1, i*s], s = 15/14, 23/21)
+          const double lo = (double)i * ssize[ax] / SF_OUT;
+          ok = ok && count[i] <= (ax == 0 ? 2 : 3) && first[i] >= (int)floor(lo) - 1 && first[i] <= (int)floor(lo) &&
+               first[i] + count[i] <= ssize[ax];
+          uint32_t* t = &tabs[4 * (ax * SF_OUT + i)];
+          t[0] = (uint32_t)first[i];
+          memcpy(t + 1, alpha + 4 * i, 3 * sizeof(float));
+        }
+      }
+      if (!ok) {
+        sf_set_error("sf_create: INTER_AREA table does not have the structure the render kernel assumes");
+        sf_destroy(b);
+        return SF_ERR_ARG;
       }
     }
+    HIP_TRY_FREE(hipMalloc((void**)&b->d_bg84, bg84.size()));
+    HIP_TRY_FREE(hipMemcpy(b->d_bg84, bg84.data(), bg84.size(), hipMemcpyHostToDevice));
     HIP_TRY_FREE(hipMalloc((void**)&b->d_bg, bg.size()));
     HIP_TRY_FREE(hipMalloc((void**)&b->d_tabs, tabs.size() * sizeof(uint32_t)));
     HIP_TRY_FREE(hipMemcpy(b->d_bg, bg.data(), bg.size(), hipMemcpyHostToDevice));
@@ -245,6 +266,7 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_scratch) (void)hipFree(b->d_scratch);
   if (b->d_bg) (void)hipFree(b->d_bg);
   if (b->d_tabs) (void)hipFree(b->d_tabs);
+  if (b->d_bg84) (void)hipFree(b->d_bg84);
   if (b->args.dbg) (void)hipFree(b->args.dbg);
   delete b;
   return SF_OK;
@@ -274,11 +296,11 @@ extern "C" int sf_max_ticks(const sf_batch* b) { return b ? (int)sfc::max_ticks 
 static bool is_image(const sf_batch* b) { return b->obs_mode == SF_OBS_IMAGE || b->obs_mode == SF_OBS_IMAGE_RAW; }
 
 static int render(sf_batch* b, int mode, uint8_t* frames_dev, hipStream_t stream) {
-  if (((uintptr_t)frames_dev & 3) != 0) {
-    sf_set_error("image frames must be 4-byte aligned");
+  if (((uintptr_t)frames_dev & 15) != 0) {
+    sf_set_error("image frames must be 16-byte aligned");
     return SF_ERR_ARG;
   }
-  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_tabs, frames_dev, mode == SF_OBS_IMAGE ? 1 : 0, stream));
+  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, mode == SF_OBS_IMAGE ? 1 : 0, stream));
   return SF_OK;
 }
 

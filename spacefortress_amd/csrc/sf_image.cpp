@@ -9,6 +9,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <vector>
+
 #include "sf_internal.h"
 #include "sf_raster.h"
 
@@ -105,5 +107,61 @@ extern "C" int sf_resize_area_tab(int ssize, int dsize, int32_t* first, int32_t*
     first[dx] = f;
     count[dx] = k;  // <= 3 because ssize < 2*dsize
   }
+  return SF_OK;
+}
+
+extern "C" int sf_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
+  // OpenCV's resizeArea_<uchar, float>: for every row-table entry (dy, sy, beta) the source row is first
+  // reduced horizontally, buf[dx] = sum alpha * S[sx] in column-table order, then sum[dx] (+)= beta * buf[dx];
+  // a destination row is written when the next one starts: saturate_cast<uchar>(sum) = round half to even.
+  if (!src || !dst || dw > 4096 || dh > 4096) {
+    sf_set_error("sf_resize_area_u8: bad argument");
+    return SF_ERR_ARG;
+  }
+  std::vector<int32_t> xf(dw), xc(dw), yf(dh), yc(dh);
+  std::vector<float> xa(4 * (size_t)dw), ya(4 * (size_t)dh);
+  int rc = sf_resize_area_tab(sw, dw, xf.data(), xc.data(), xa.data());
+  if (rc != SF_OK) return rc;
+  rc = sf_resize_area_tab(sh, dh, yf.data(), yc.data(), ya.data());
+  if (rc != SF_OK) return rc;
+  std::vector<float> buf(dw), sum(dw);
+  for (int dy = 0; dy < dh; dy++) {
+    for (int k = 0; k < yc[dy]; k++) {
+      const uint8_t* S = src + (size_t)(yf[dy] + k) * sw;
+      const float beta = ya[4 * dy + k];
+      for (int dx = 0; dx < dw; dx++) {
+        float b = 0.f;
+        for (int j = 0; j < xc[dx]; j++) b += (float)S[xf[dx] + j] * xa[4 * dx + j];
+        buf[dx] = b;
+      }
+      for (int dx = 0; dx < dw; dx++) sum[dx] = k == 0 ? beta * buf[dx] : sum[dx] + beta * buf[dx];
+    }
+    for (int dx = 0; dx < dw; dx++) {
+      float r = nearbyintf(sum[dx]);
+      dst[(size_t)dy * dw + dx] = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+    }
+  }
+  return SF_OK;
+}
+
+extern "C" int sf_image_static(int variant, uint8_t* out) {
+  // the static background plus what the kernel may take as given (sf_render.hip): bit 0 the score text
+  // "0000000", bit 1 the vulnerability bar at 0 -- drawn with the kernel's own per-pixel arithmetic
+  if (variant < 0 || variant > 3 || !out) {
+    sf_set_error("sf_image_static: variant must be 0..3 and out non-null");
+    return SF_ERR_ARG;
+  }
+  int rc = sf_image_background(out);
+  if (rc != SF_OK) return rc;
+  if (variant & 1) {
+    const unsigned long long masks = sfr::score_masks(0);
+    for (int y = SF_TXT_BOX_Y0; y < SF_TXT_BOX_Y1; y++)
+      for (int x = SF_TXT_BOX_X0; x < SF_TXT_BOX_X1; x++)
+        out[y * SF_IMG_W + x] = (uint8_t)sfr::text_pixel(x, y, masks, out[y * SF_IMG_W + x]);
+  }
+  if (variant & 2)
+    for (int y = SF_BAR_BOX_Y0; y < SF_BAR_BOX_Y1; y++)
+      for (int x = SF_BAR_BOX_X0; x < SF_BAR_BOX_X1; x++)
+        out[y * SF_IMG_W + x] = (uint8_t)sfr::bar_pixel(x, y, 0, 168, out[y * SF_IMG_W + x]);
   return SF_OK;
 }

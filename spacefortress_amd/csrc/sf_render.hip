@@ -11,8 +11,10 @@
 // 8-bit arithmetic, like the image backend does.  The quads of one draw phase are built one per
 // lane (<= 64 per round); the wave then walks the live ones in order (ballot + readlane, no LDS
 // list) and, for each, its lanes take the pixels of its bounding box: exact area coverage from an
-// edge integral (no arrays, no scratch).  The epilogue resamples 90x92 -> 84x84 from LDS with the
-// INTER_AREA tables (four output bytes per lane and store) or copies the raw frame out.
+// edge integral (no arrays, no scratch).  The 84x84 frame is kept in LDS too: it starts as the
+// resampled background (host-made) and after every object the wave re-evaluates INTER_AREA only for
+// the output pixels whose footprint the object's bounding box touches -- a frame is a few dozen
+// changed pixels on a static picture.  The epilogue copies 7 KB (or the raw 8 KB) out, 16 B a lane.
 //
 // Pixel values: what is drawn where, in which order and grey follows the reference; the
 // anti-aliasing model is ours (cairo is not in this image).  Pixel parity with cairo + cv2 is
@@ -22,12 +24,19 @@
 #include "sf_internal.h"
 #include "sf_raster.h"
 
+// diagnostic builds only (tools/render_ablate.py): bit 0 ship+fortress, 1 missiles+shells, 2 score,
+// 3 bar, 4 the resampling -- each bit removes that phase so its cost can be read off
+#ifndef SF_RENDER_SKIP
+#define SF_RENDER_SKIP 0
+#endif
+
 namespace {
 
 constexpr int kFbBytes = SF_IMG_W * SF_IMG_H;          // 8280
 constexpr int kFbWords = kFbBytes / 4;                 // 2070
 constexpr int kFbPadWords = (SF_IMG_W * (SF_IMG_H + 1) + 3) / 4 + 1;  // one spare row for zero-weight taps
-constexpr int kTabWords = 2 * SF_OUT * 4;              // x and y taps: {first, a0, a1, a2}
+constexpr int kFbVec = kFbBytes / 16;                  // 517 (+ 8 bytes)
+constexpr int kOutBytes = SF_OUT * SF_OUT;             // 7056 = 441 * 16
 
 struct d2_t {
   double x, y;
@@ -49,9 +58,18 @@ __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 
 __device__ __forceinline__ float ramp_mean(float ya, float yb) {
   float lo = fminf(ya, yb), d = fabsf(yb - ya);  // the mean does not depend on the direction
   if (d < 1e-6f) return clamp01(lo + 0.5f * d);
-  const float inv = 1.0f / d;
+  const float inv = __builtin_amdgcn_rcpf(d);  // 1 ulp: moves a coverage by 1e-7, far below one grey level
   const float ta = clamp01(-lo * inv), tb = clamp01((1.0f - lo) * inv);
   return (1.0f - tb) + (tb - ta) * (lo + 0.5f * d * (ta + tb));
+}
+
+// one directed edge's share of the integral of clamp(y, 0, 1) dx over the pixel at the origin
+__device__ __forceinline__ float edge_term(float x0, float y0, float x1, float y1) {
+  const float xa = clamp01(x0), xb = clamp01(x1);
+  const float w = xb - xa;
+  if (w == 0.f) return 0.f;
+  const float slope = (y1 - y0) * __builtin_amdgcn_rcpf(x1 - x0);
+  return w * ramp_mean(y0 + (xa - x0) * slope, y0 + (xb - x0) * slope);
 }
 
 // area of quad /\ pixel [px,px+1]x[py,py+1]:  | sum over edges of the integral of clamp(y,0,1) dx |
@@ -60,70 +78,146 @@ __device__ __forceinline__ float quad_cover(const Quad& q, float px, float py) {
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const int f = (e + 1) & 3;
-    const float x0 = q.x[e] - px, y0 = q.y[e] - py, x1 = q.x[f] - px, y1 = q.y[f] - py;
-    const float xa = clamp01(x0), xb = clamp01(x1);
-    const float w = xb - xa;
-    if (w != 0.f) {
-      const float slope = (y1 - y0) / (x1 - x0);
-      const float ya = y0 + (xa - x0) * slope, yb = y0 + (xb - x0) * slope;
-      s += w * ramp_mean(ya, yb);
-    }
+    s += edge_term(q.x[e] - px, q.y[e] - py, q.x[f] - px, q.y[f] - py);
   }
   return fabsf(s);
 }
+
+using sfr::cover_to_mask;
+using sfr::dev_x;
+using sfr::dev_y;
 
 __device__ __forceinline__ float bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-// Composite this round's quads (one per lane, `valid` lanes only) in lane order.
-__device__ __forceinline__ void draw_quads(uint8_t* fb, const Quad& mine, int grey, bool valid, int lane) {
-  unsigned long long live = __ballot(valid);
-  while (live) {
-    const int src = __builtin_ctzll(live);
-    live &= live - 1;
-    Quad q;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      q.x[k] = bcast(mine.x[k], src);
-      q.y[k] = bcast(mine.y[k], src);
-    }
-    const int c = __builtin_amdgcn_readlane(grey, src);
-    const float fx0 = fminf(fminf(q.x[0], q.x[1]), fminf(q.x[2], q.x[3]));
-    const float fx1 = fmaxf(fmaxf(q.x[0], q.x[1]), fmaxf(q.x[2], q.x[3]));
-    const float fy0 = fminf(fminf(q.y[0], q.y[1]), fminf(q.y[2], q.y[3]));
-    const float fy1 = fmaxf(fmaxf(q.y[0], q.y[1]), fmaxf(q.y[2], q.y[3]));
-    // clip the bounding box to the surface (also rejects NaN / far-away geometry)
-    if (!(fx1 > 0.f && fy1 > 0.f && fx0 < (float)SF_IMG_W && fy0 < (float)SF_IMG_H)) continue;
-    const int bx0 = (int)floorf(fmaxf(fx0, 0.f)), by0 = (int)floorf(fmaxf(fy0, 0.f));
-    const int bx1 = (int)ceilf(fminf(fx1, (float)SF_IMG_W)), by1 = (int)ceilf(fminf(fy1, (float)SF_IMG_H));
-    const int bw = bx1 - bx0, n = bw * (by1 - by0);
-    for (int base = 0; base < n; base += 64) {
-      const int i = base + lane;
-      if (i < n) {
-        const int ry = i / bw, rx = i - ry * bw;
-        const int px = bx0 + rx, py = by0 + ry;
-        float area = quad_cover(q, (float)px, (float)py);
-        area = fminf(area, 1.f);
-        const int m = (int)(area * 255.f + 0.5f);
-        if (m > 0) {
-          uint8_t* p = fb + py * SF_IMG_W + px;
-          *p = (uint8_t)sfr::over_un8(*p, c, m);
-        }
-      }
+struct Box {  // pixel rectangle [x0, x1) x [y0, y1) of the 90x92 surface
+  int x0, y0, x1, y1;
+  __device__ __forceinline__ void clear() { x0 = y0 = 1 << 20; x1 = y1 = -1; }
+  __device__ __forceinline__ bool empty() const { return x1 <= x0 || y1 <= y0; }
+  __device__ __forceinline__ void add(int ax0, int ay0, int ax1, int ay1) {
+    x0 = min(x0, ax0); y0 = min(y0, ay0); x1 = max(x1, ax1); y1 = max(y1, ay1);
+  }
+  __device__ __forceinline__ bool meets(const Box& o) const { return x0 < o.x1 && o.x0 < x1 && y0 < o.y1 && o.y0 < y1; }
+};
+
+// pixel box of a quad, clipped to the surface (empty for NaN / far-away geometry)
+__device__ __forceinline__ Box quad_box(const Quad& q) {
+  const float fx0 = fminf(fminf(q.x[0], q.x[1]), fminf(q.x[2], q.x[3]));
+  const float fx1 = fmaxf(fmaxf(q.x[0], q.x[1]), fmaxf(q.x[2], q.x[3]));
+  const float fy0 = fminf(fminf(q.y[0], q.y[1]), fminf(q.y[2], q.y[3]));
+  const float fy1 = fmaxf(fmaxf(q.y[0], q.y[1]), fmaxf(q.y[2], q.y[3]));
+  Box b;
+  b.clear();
+  if (fx1 > 0.f && fy1 > 0.f && fx0 < (float)SF_IMG_W && fy0 < (float)SF_IMG_H) {
+    b.x0 = (int)floorf(fmaxf(fx0, 0.f));
+    b.y0 = (int)floorf(fmaxf(fy0, 0.f));
+    b.x1 = (int)ceilf(fminf(fx1, (float)SF_IMG_W));
+    b.y1 = (int)ceilf(fminf(fy1, (float)SF_IMG_H));
+  }
+  return b;
+}
+
+// everything an explosion draws lies within 63 + 1.5 user units of its centre
+__device__ __forceinline__ Box explosion_box(float cx, float cy) {
+  const float gx = dev_x(cx), gy = dev_y(cy), ext = 64.5f * (float)SF_SCALE;
+  Box b;
+  b.x0 = max((int)floorf(gx - ext), 0);
+  b.y0 = max((int)floorf(gy - ext), 0);
+  b.x1 = min((int)ceilf(gx + ext), SF_IMG_W);
+  b.y1 = min((int)ceilf(gy + ext), SF_IMG_H);
+  return b;
+}
+
+// The frame of one env: the 90x92 surface and (RESIZE) its 84x84 INTER_AREA image, both in LDS.
+template <bool RESIZE>
+struct Frame {
+  uint8_t* fb;
+  uint8_t* obuf;
+  const uint32_t* tab;  // LDS copy of the tap tables (sf_raster.h)
+  int lane;
+
+  // cv2.resize(..., INTER_AREA) restricted to the destination pixels that read source pixels of `b`
+  // (OpenCV's resizeArea_ arithmetic: per source row buf = sum alpha * S, then sum += beta * buf in
+  // table order, saturate_cast<uchar>).  Destination column dx reads source columns first, first+1
+  // with first in [dx*15/14 - 1, dx*15/14]; row dy reads up to three rows from first in
+  // [dy*23/21 - 1, dy*23/21] -- hence the conservative bounds below.
+  __device__ __forceinline__ void resample(const Box& b) const {
+    if (!RESIZE || (SF_RENDER_SKIP & 16) || b.empty()) return;
+    const int ox0 = max(((b.x0 - 1) * 14) / 15, 0), ox1 = min((b.x1 * 14) / 15 + 1, SF_OUT);
+    const int oy0 = max(((b.y0 - 2) * 21) / 23, 0), oy1 = min((b.y1 * 21) / 23 + 1, SF_OUT);
+    const int ow = ox1 - ox0, n = ow * (oy1 - oy0);
+    const float* tabf = reinterpret_cast<const float*>(tab);
+    for (int i = lane; i < n; i += 64) {
+      const int ry = i / ow, rx = i - ry * ow;
+      const int dx = ox0 + rx, dy = oy0 + ry;
+      const int fx = (int)tab[4 * dx];
+      const float a0 = tabf[4 * dx + 1], a1 = tabf[4 * dx + 2];
+      const int fy = (int)tab[4 * (SF_OUT + dy)];
+      const float b0 = tabf[4 * (SF_OUT + dy) + 1], b1 = tabf[4 * (SF_OUT + dy) + 2], b2 = tabf[4 * (SF_OUT + dy) + 3];
+      const uint8_t* r0 = fb + fy * SF_IMG_W + fx;
+      const uint8_t* r1 = r0 + SF_IMG_W;
+      const uint8_t* r2 = r1 + SF_IMG_W;
+      const float h0 = (float)r0[0] * a0 + (float)r0[1] * a1;
+      const float h1 = (float)r1[0] * a0 + (float)r1[1] * a1;
+      const float h2 = (float)r2[0] * a0 + (float)r2[1] * a1;
+      const float sum = (b0 * h0 + b1 * h1) + b2 * h2;  // a two-row entry has b2 = 0: adds +0
+      int v = (int)rintf(sum);                            // saturate_cast<uchar>: round half to even, clamp
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      obuf[dy * SF_OUT + dx] = (uint8_t)v;
     }
     __builtin_amdgcn_wave_barrier();
   }
-}
 
-// user space -> device space (SRC/draw.cpp:259-260)
-__device__ __forceinline__ float dev_x(float x) { return (x - (float)SF_VP_X) * (float)SF_SCALE; }
-__device__ __forceinline__ float dev_y(float y) { return (y - (float)SF_VP_Y) * (float)SF_SCALE; }
+  // Composite this round's quads (one per lane, `valid` lanes only) in lane order; lanes
+  // [k*per, (k+1)*per) belong to one object, whose pixels are resampled when it is complete.
+  __device__ __forceinline__ void draw_quads(const Quad& mine, int grey, bool valid, int per) const {
+    unsigned long long live = __ballot(valid);
+    Box dirty;
+    dirty.clear();
+    int obj = -1;
+    while (live) {
+      const int src = __builtin_ctzll(live);
+      live &= live - 1;
+      if (src / per != obj) {
+        resample(dirty);
+        dirty.clear();
+        obj = src / per;
+      }
+      Quad q;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        q.x[k] = bcast(mine.x[k], src);
+        q.y[k] = bcast(mine.y[k], src);
+      }
+      const int c = __builtin_amdgcn_readlane(grey, src);
+      const Box qb = quad_box(q);
+      if (qb.empty()) continue;
+      const int bx0 = qb.x0, by0 = qb.y0;
+      dirty.add(qb.x0, qb.y0, qb.x1, qb.y1);
+      const int bw = qb.x1 - qb.x0, n = bw * (qb.y1 - qb.y0);
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        if (i < n) {
+          const int ry = i / bw, rx = i - ry * bw;
+          const int px = bx0 + rx, py = by0 + ry;
+          const int m = cover_to_mask(quad_cover(q, (float)px, (float)py));
+          if (m > 0) {
+            uint8_t* p = fb + py * SF_IMG_W + px;
+            *p = (uint8_t)sfr::over_un8(*p, c, m);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    resample(dirty);
+  }
+};
 
 // Stroke of the segment A-B (wireframe coordinates), butt caps, width SF_LINE_W, under
 // translate(pos) rotate(angle) (drawWireFrame, SRC/draw.cpp:112-129)
-__device__ __forceinline__ Quad line_quad(float ax, float ay, float bx, float by, float ca, float sa, float posx,
-                                          float posy) {
+__device__ __forceinline__ Quad line_quad(const float* ln, float ca, float sa, float posx, float posy) {
+  const float ax = ln[0], ay = ln[1], bx = ln[2], by = ln[3];
   const float ux = bx - ax, uy = by - ay;
   const float inv = (float)(SF_LINE_W / 2) / sqrtf(ux * ux + uy * uy);
   const float nx = -uy * inv, ny = ux * inv;
@@ -138,15 +232,6 @@ __device__ __forceinline__ Quad line_quad(float ax, float ay, float bx, float by
   return q;
 }
 
-__device__ __forceinline__ Quad rect_quad(float x0, float y0, float x1, float y1) {
-  Quad q;
-  q.x[0] = dev_x(x0); q.y[0] = dev_y(y0);
-  q.x[1] = dev_x(x1); q.y[1] = dev_y(y0);
-  q.x[2] = dev_x(x1); q.y[2] = dev_y(y1);
-  q.x[3] = dev_x(x0); q.y[3] = dev_y(y1);
-  return q;
-}
-
 __device__ __forceinline__ void sincos_deg(float deg, float* s, float* c) {
   sincosf(deg * 0.017453292519943295f, s, c);
 }
@@ -157,45 +242,106 @@ __constant__ float kFortLines[4][4] = {{0, 0, 36, 0}, {0, -18, 18, -18}, {18, -1
 __constant__ float kMissileLines[3][4] = {{0, 0, -25, 0}, {0, 0, -5, 5}, {0, 0, -5, -5}};
 __constant__ float kShellLines[4][4] = {{-8, 0, 0, -6}, {0, -6, 16, 0}, {16, 0, 0, 6}, {0, 6, -8, 0}};
 
-// seven-segment masks (bit 0 = A top, clockwise, bit 6 = G middle) for 0-9 and '-'
-__constant__ unsigned char kSegs[11] = {0x3F, 0x06, 0x5B, 0x4F, 0x66, 0x6D, 0x7D, 0x07, 0x7F, 0x6F, 0x40};
+// drawExplosion (SRC/draw.cpp:145-175): 7 rings (radius 15 + 8i) of twelve 10-degree arcs starting at
+// 30k + 3(i+1) degrees, each its own stroke, then one radius-7 circle.  An arc is one chord quad
+// between radius -/+ half the line width; the circle is ONE stroke: the ring between two regular
+// 12-gons.  cos/sin of every angle involved are compile-time constants.
+#include "sf_render_tables.h"  // kArcs[7][12], kGon[12]
 
-// drawExplosion (SRC/draw.cpp:145-175): 7 rings of twelve 10-degree arcs, then a radius-7 circle.
-// Piece p of 96: one chord quad per arc / per 30 degrees of the circle.
-__device__ __forceinline__ Quad explosion_quad(int p, float cx, float cy, int* grey) {
-  float r, a0, a1;
-  if (p < 84) {
-    const int ring = p / 12, k = p - ring * 12;
-    const int radius = 15 + 8 * ring;
-    a0 = (float)(30 * k + 3 * (ring + 1));
-    a1 = a0 + 10.f;
-    r = (float)radius;
-    *grey = radius < 60 ? 191 : 128;  // .75 / .5
-  } else {
-    a0 = (float)(30 * (p - 84));
-    a1 = a0 + 30.f;
-    r = 7.f;
-    *grey = 191;
-  }
-  float s0, c0, s1, c1;
-  sincos_deg(a0, &s0, &c0);
-  sincos_deg(a1, &s1, &c1);
-  const float ri = r - (float)(SF_LINE_W / 2), ro = r + (float)(SF_LINE_W / 2);
+__device__ __forceinline__ Quad arc_quad(const ArcCS& t, float radius, float cx, float cy) {
+  const float ri = radius - (float)(SF_LINE_W / 2), ro = radius + (float)(SF_LINE_W / 2);
   Quad q;
-  q.x[0] = dev_x(cx + ri * c0); q.y[0] = dev_y(cy + ri * s0);
-  q.x[1] = dev_x(cx + ro * c0); q.y[1] = dev_y(cy + ro * s0);
-  q.x[2] = dev_x(cx + ro * c1); q.y[2] = dev_y(cy + ro * s1);
-  q.x[3] = dev_x(cx + ri * c1); q.y[3] = dev_y(cy + ri * s1);
+  q.x[0] = dev_x(cx + ri * t.c0); q.y[0] = dev_y(cy + ri * t.s0);
+  q.x[1] = dev_x(cx + ro * t.c0); q.y[1] = dev_y(cy + ro * t.s0);
+  q.x[2] = dev_x(cx + ro * t.c1); q.y[2] = dev_y(cy + ro * t.s1);
+  q.x[3] = dev_x(cx + ri * t.c1); q.y[3] = dev_y(cy + ri * t.s1);
   return q;
 }
 
-__device__ __forceinline__ void draw_explosion(uint8_t* fb, float cx, float cy, int lane) {
-  for (int round = 0; round < 2; round++) {
-    const int p = round * 64 + lane;
-    int grey = 0;
-    const Quad q = explosion_quad(p < 96 ? p : 0, cx, cy, &grey);
-    draw_quads(fb, q, grey, p < 96, lane);
+// area of the regular 12-gon (centre (gx, gy), circumradius r, device pixels) inside the pixel at (px, py)
+__device__ __forceinline__ float gon_cover(float gx, float gy, float r, float px, float py) {
+  float s = 0.f;
+  float x0 = gx + r * kGon[0][0] - px, y0 = gy + r * kGon[0][1] - py;
+#pragma unroll
+  for (int k = 1; k <= 12; k++) {
+    const float x1 = gx + r * kGon[k % 12][0] - px, y1 = gy + r * kGon[k % 12][1] - py;
+    s += edge_term(x0, y0, x1, y1);
+    x0 = x1;
+    y0 = y1;
   }
+  return fabsf(s);
+}
+
+__device__ __forceinline__ bool quad_misses_pixel(const Quad& q, float px, float py) {
+  const float fx0 = fminf(fminf(q.x[0], q.x[1]), fminf(q.x[2], q.x[3]));
+  const float fx1 = fmaxf(fmaxf(q.x[0], q.x[1]), fmaxf(q.x[2], q.x[3]));
+  const float fy0 = fminf(fminf(q.y[0], q.y[1]), fminf(q.y[2], q.y[3]));
+  const float fy1 = fmaxf(fmaxf(q.y[0], q.y[1]), fmaxf(q.y[2], q.y[3]));
+  return fx1 <= px || fx0 >= px + 1.f || fy1 <= py || fy0 >= py + 1.f;
+}
+
+// The 96 strokes in the reference's order, without walking them one by one:
+//   * ring 0 (whose arcs lie less than a pixel apart) and the circle: a lane per pixel of the 8x8
+//     box around the centre; it composites the ring-0 arcs that touch it in arc order, then the
+//     circle.  Rings 1..6 never share a pixel with the circle, so the circle may come before them.
+//   * rings 1..6 in order; inside a ring the arcs are >= 1.49 px apart (chord of 20 degrees at the
+//     inner radius 21.5 * .2) and cannot touch the same pixel: twelve arcs at once, five lanes each.
+template <bool RESIZE>
+__device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, float cx, float cy) {
+  uint8_t* fb = F.fb;
+  const int lane = F.lane;
+  const float gx = dev_x(cx), gy = dev_y(cy);
+  {
+    const int bx0 = (int)floorf(gx - 16.5f * (float)SF_SCALE), by0 = (int)floorf(gy - 16.5f * (float)SF_SCALE);
+    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+    if (px >= 0 && px < SF_IMG_W && py >= 0 && py < SF_IMG_H) {
+      const float fpx = (float)px, fpy = (float)py;
+      int d = fb[py * SF_IMG_W + px];
+      const int d0 = d;
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        const Quad q = arc_quad(kArcs[0][k], 15.f, cx, cy);
+        if (quad_misses_pixel(q, fpx, fpy)) continue;
+        const int m = cover_to_mask(quad_cover(q, fpx, fpy));
+        if (m > 0) d = sfr::over_un8(d, 191, m);
+      }
+      const float ro = 8.5f * (float)SF_SCALE, ri = 5.5f * (float)SF_SCALE;  // radius 7 -/+ half the line width
+      if (fabsf(fpx + 0.5f - gx) < ro + 0.5f && fabsf(fpy + 0.5f - gy) < ro + 0.5f) {
+        const float area = gon_cover(gx, gy, ro, fpx, fpy) - gon_cover(gx, gy, ri, fpx, fpy);
+        const int m = cover_to_mask(fmaxf(area, 0.f));
+        if (m > 0) d = sfr::over_un8(d, 191, m);
+      }
+      if (d != d0) fb[py * SF_IMG_W + px] = (uint8_t)d;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const int arc = lane / 5, sub = lane - arc * 5;
+  for (int ring = 1; ring < 7; ring++) {
+    const int radius = 15 + 8 * ring;
+    const int grey = radius < 60 ? 191 : 128;  // .75 / .5
+    const Quad q = arc_quad(kArcs[ring][arc < 12 ? arc : 0], (float)radius, cx, cy);
+    const Box qb = quad_box(q);
+    int n = 0, bx0 = 0, by0 = 0, bw = 1;
+    if (arc < 12 && !qb.empty()) {
+      bx0 = qb.x0;
+      by0 = qb.y0;
+      bw = qb.x1 - qb.x0;
+      n = bw * (qb.y1 - qb.y0);
+    }
+    for (int i = sub; __any(i < n); i += 5) {
+      if (i < n) {
+        const int ry = i / bw, rx = i - ry * bw;
+        const int px = bx0 + rx, py = by0 + ry;
+        const int m = cover_to_mask(quad_cover(q, (float)px, (float)py));
+        if (m > 0) {
+          uint8_t* p = fb + py * SF_IMG_W + px;
+          *p = (uint8_t)sfr::over_un8(*p, grey, m);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  F.resample(explosion_box(cx, cy));
 }
 
 }  // namespace
@@ -203,22 +349,26 @@ __device__ __forceinline__ void draw_explosion(uint8_t* fb, float cx, float cy, 
 struct SfRenderArgs {
   const unsigned char* state;
   int n_envs;
-  const uint32_t* bg;    // kFbWords
-  const uint32_t* tabs;  // kTabWords: x taps [84] then y taps [84], each {first, a0, a1, a2}
+  const uint32_t* bg;    // four variants of the static 92x90 background, SF_BG_STRIDE bytes apart:
+                         // bit 0 = with the score 0000000, bit 1 = with the empty vulnerability bar
+  const uint32_t* bg84;  // ... and their 84x84 INTER_AREA images, 7056 bytes apart
+  const uint32_t* tabs;  // SF_TAB_WORDS, layout in sf_raster.h
   uint8_t* out;
-  int resize;            // 1: [n][84][84], 0: [n][92][90]
 };
 
+template <bool RESIZE>
 __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
-  __shared__ uint32_t fbw[kFbPadWords];
-  __shared__ uint32_t tabw[kTabWords];
+  __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
+  __shared__ __attribute__((aligned(16))) uint32_t obufw[RESIZE ? kOutBytes / 4 : 4];
+  __shared__ __attribute__((aligned(16))) uint32_t tabw[RESIZE ? SF_TAB_WORDS : 4];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int env = blockIdx.x, lane = threadIdx.x;
 
-  for (int i = lane; i < kFbWords; i += 64) fbw[i] = a.bg[i];
-  for (int i = kFbWords + lane; i < kFbPadWords; i += 64) fbw[i] = 0;
-  if (a.resize)
-    for (int i = lane; i < kTabWords; i += 64) tabw[i] = a.tabs[i];
+  if (RESIZE) {
+    const uint4* tsrc = reinterpret_cast<const uint4*>(a.tabs);
+    uint4* tdst = reinterpret_cast<uint4*>(tabw);
+    for (int i = lane; i < SF_TAB_WORDS / 4; i += 64) tdst[i] = tsrc[i];
+  }
 
   // this env's lane of its wave tile
   const unsigned char* tile = a.state + (long)(env >> 6) * sfl::kTileBytes;
@@ -231,148 +381,178 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   const int ship_angle = R_LD(int16_t, R_CHUNK(small, 0), o8);
   const int fort_angle = R_LD(int16_t, R_CHUNK(small, 0), o8 + 2);
   const unsigned flags = R_LD(uint8_t, R_CHUNK(small, 0), o8 + 6);
-  const unsigned mmask = (unsigned)mi.z, smask = (unsigned)mi.w;
-  const float points = __int_as_float(sc.x);
+  const unsigned mmask = (SF_RENDER_SKIP & 2) ? 0u : (unsigned)mi.z, smask = (SF_RENDER_SKIP & 2) ? 0u : (unsigned)mi.w;
+  const int pnts = (int)__int_as_float(sc.x);  // drawScore takes mScore.mPoints as an int (SRC/draw.cpp:190,266)
   const int vlner = sc.z;
   const int fort_vuln_timer = tb.w;
-  __syncthreads();
-
   const float ship_x = (float)sp.x, ship_y = (float)sp.y;
+  const bool ship_alive = flags & SF_FL_SHIP_ALIVE;
 
-  // ---- ship (SRC/draw.cpp:233-237)
-  if (flags & SF_FL_SHIP_ALIVE) {
-    float s, c;
-    sincos_deg((float)ship_angle, &s, &c);
-    const int k = lane < 3 ? lane : 0;
-    const Quad q = line_quad(kShipLines[k][0], kShipLines[k][1], kShipLines[k][2], kShipLines[k][3], c, s, ship_x, ship_y);
-    draw_quads(fb, q, 255, lane < 3, lane);
-  } else {
-    draw_explosion(fb, ship_x, ship_y, lane);
-  }
-  // ---- fortress (:238-242)
-  if (flags & SF_FL_FORT_ALIVE) {
-    float s, c;
-    sincos_deg((float)fort_angle, &s, &c);
-    const int k = lane < 4 ? lane : 0;
-    const Quad q = line_quad(kFortLines[k][0], kFortLines[k][1], kFortLines[k][2], kFortLines[k][3], c, s,
-                             (float)sfc::fort_x, (float)sfc::fort_y);
-    draw_quads(fb, q, 255, lane < 4, lane);
-  } else {
-    draw_explosion(fb, (float)sfc::fort_x, (float)sfc::fort_y, lane);
-  }
-  // ---- missiles (:243-247): slot order, three segments each
+  // ---- projectile strokes first: one lane per wireframe segment (missiles: slot*3 + k; shells: two
+  // rounds of slot*4 + k), because what they touch decides which background variant the frame
+  // starts from
+  Quad mq = {}, sq[2] = {{}, {}};
+  bool mvalid = false, svalid[2] = {false, false};
   if (mmask) {
     const int slot = lane / 3, k = lane - slot * 3;
-    const bool valid = lane < 3 * SF_NSLOT && ((mmask >> slot) & 1u);
-    Quad q = {};
-    if (valid) {
+    mvalid = lane < 3 * SF_NSLOT && ((mmask >> slot) & 1u);
+    if (mvalid) {
       const d2_t m = R_LD(d2_t, R_CHUNK(missile_pos, slot), o16);
       const int ang = R_LD(int16_t, R_CHUNK(missile_ang, slot), o2);
       float s, c;
       sincos_deg((float)ang, &s, &c);
-      q = line_quad(kMissileLines[k][0], kMissileLines[k][1], kMissileLines[k][2], kMissileLines[k][3], c, s, (float)m.x,
-                    (float)m.y);
+      mq = line_quad(kMissileLines[k], c, s, (float)m.x, (float)m.y);
     }
-    draw_quads(fb, q, 255, valid, lane);
   }
-  // ---- shells (:248-253): only once they are more than 21 away from the fortress
   if (smask) {
+#pragma unroll
     for (int round = 0; round < 2; round++) {
       const int p = round * 64 + lane;
       const int slot = p >> 2, k = p & 3;
       bool valid = p < 4 * SF_NSLOT && ((smask >> slot) & 1u);
-      Quad q = {};
       if (valid) {
         const d2_t s = R_LD(d2_t, R_CHUNK(shell_pos, slot), o16);
         const d2_t v = R_LD(d2_t, R_CHUNK(shell_vel, slot), o16);
         const double dx = s.x - sfc::fort_x, dy = s.y - sfc::fort_y;
-        valid = sqrt(dx * dx + dy * dy) > 21.0;
+        valid = sqrt(dx * dx + dy * dy) > 21.0;  // drawn only once clear of the fortress (SRC/draw.cpp:249-250)
         // mAngle = stdAngle(rad2deg(atan2(dy, dx))) at launch (SRC/game.cpp:263); the velocity kept in
         // the state has that direction.  drawWireFrame takes it as an int (truncation).
         double ang = atan2(v.y, v.x) * 180.0 / M_PI;
         if (ang < 0) ang += 360.0;
         float sn, cs;
         sincos_deg((float)(int)ang, &sn, &cs);
-        q = line_quad(kShellLines[k][0], kShellLines[k][1], kShellLines[k][2], kShellLines[k][3], cs, sn, (float)s.x,
-                      (float)s.y);
+        sq[round] = line_quad(kShellLines[k], cs, sn, (float)s.x, (float)s.y);
       }
-      draw_quads(fb, q, 255, valid, lane);
+      svalid[round] = valid;
     }
   }
-  // ---- score (drawScore, :190-203): "%07d" of (int)points, grey .5, as seven-segment digits
-  {
-    int pnts = (int)points;
-    const bool neg = pnts < 0;
-    unsigned mag = neg ? (unsigned)(-(long)pnts) : (unsigned)pnts;
-    // character d (0 = leftmost of 7): digits right-aligned, zero padded; a sign takes the first cell
-    const int cell = lane / 7, seg = lane - cell * 7;
-    unsigned div = 1;
-    for (int i = 0; i < 6 - cell; i++) div *= 10;
-    const int digit = (int)((mag / div) % 10);
-    const int glyph = (neg && cell == 0) ? 10 : digit;
-    const bool valid = lane < 49 && ((kSegs[glyph] >> seg) & 1);
-    const float gx = SF_TXT_X0 + SF_TXT_ADV * cell + SF_TXT_PAD, gy = SF_TXT_TOP;
-    const float W = SF_TXT_W, H = SF_TXT_H, T = SF_TXT_T, m0 = 0.5f * (SF_TXT_H - SF_TXT_T), m1 = 0.5f * (SF_TXT_H + SF_TXT_T);
-    float x0, y0, x1, y1;
-    switch (seg) {
-      case 0: x0 = 0; x1 = W; y0 = 0; y1 = T; break;          // A top
-      case 1: x0 = W - T; x1 = W; y0 = T; y1 = m0; break;     // B upper right
-      case 2: x0 = W - T; x1 = W; y0 = m1; y1 = H - T; break; // C lower right
-      case 3: x0 = 0; x1 = W; y0 = H - T; y1 = H; break;      // D bottom
-      case 4: x0 = 0; x1 = T; y0 = m1; y1 = H - T; break;     // E lower left
-      case 5: x0 = 0; x1 = T; y0 = T; y1 = m0; break;         // F upper left
-      default: x0 = 0; x1 = W; y0 = m0; y1 = m1; break;       // G middle
-    }
-    const Quad q = rect_quad(gx + x0, gy + y0, gx + x1, gy + y1);
-    draw_quads(fb, q, 128, valid, lane);
+
+  // ---- background variant.  The score and the bar are drawn LAST (SRC/draw.cpp:266-268); when they
+  // show 0000000 / an empty bar and nothing drawn before them reaches their pixels, the result is the
+  // static picture the host baked (same arithmetic, sf_raster.h).  A live ship and the fortress never
+  // reach them (the ship is inside the big hexagon, rows 12.2 .. 81.6 +- 5.4 px).
+  const Box tbox{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1};
+  const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
+  bool near_text = false, near_bar = false;
+  if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
+    const Box eb = explosion_box(ship_x, ship_y);
+    near_text = eb.meets(tbox);
+    near_bar = eb.meets(bbox);
   }
-  // ---- vulnerability bar (drawVlner, :205-225)
   {
+    bool t = false, b = false;
+    if (mvalid) {
+      const Box qb = quad_box(mq);
+      t = t || qb.meets(tbox);
+      b = b || qb.meets(bbox);
+    }
+#pragma unroll
+    for (int round = 0; round < 2; round++)
+      if (svalid[round]) {
+        const Box qb = quad_box(sq[round]);
+        t = t || qb.meets(tbox);
+        b = b || qb.meets(bbox);
+      }
+    near_text = near_text || __any(t);
+    near_bar = near_bar || __any(b);
+  }
+  const bool baked_text = pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4);
+  const bool baked_bar = vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8);
+  const int variant = (baked_text ? 1 : 0) | (baked_bar ? 2 : 0);
+  {
+    const uint32_t* bgv = a.bg + variant * (SF_BG_STRIDE / 4);
+    const uint4* src = reinterpret_cast<const uint4*>(bgv);
+    uint4* dst = reinterpret_cast<uint4*>(fbw);
+    for (int i = lane; i < kFbVec; i += 64) dst[i] = src[i];
+    for (int i = 4 * kFbVec + lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bgv[i] : 0u;
+  }
+  if (RESIZE) {
+    const uint4* src = reinterpret_cast<const uint4*>(a.bg84 + variant * (kOutBytes / 4));
+    uint4* dst = reinterpret_cast<uint4*>(obufw);
+    for (int i = lane; i < kOutBytes / 16; i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const Frame<RESIZE> F{fb, reinterpret_cast<uint8_t*>(obufw), tabw, lane};
+
+  // ---- ship (SRC/draw.cpp:233-237)
+  if (SF_RENDER_SKIP & 1) {
+  } else if (ship_alive) {
+    float s, c;
+    sincos_deg((float)ship_angle, &s, &c);
+    const Quad q = line_quad(kShipLines[lane < 3 ? lane : 0], c, s, ship_x, ship_y);
+    F.draw_quads(q, 255, lane < 3, 64);
+  } else {
+    draw_explosion(F, ship_x, ship_y);
+  }
+  // ---- fortress (:238-242)
+  if (SF_RENDER_SKIP & 1) {
+  } else if (flags & SF_FL_FORT_ALIVE) {
+    float s, c;
+    sincos_deg((float)fort_angle, &s, &c);
+    const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
+    F.draw_quads(q, 255, lane < 4, 64);
+  } else {
+    draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);
+  }
+  // ---- missiles (:243-247), shells (:248-253): slot order
+  if (mmask) F.draw_quads(mq, 255, mvalid, 3);
+  if (smask) {
+    F.draw_quads(sq[0], 255, svalid[0], 4);
+    F.draw_quads(sq[1], 255, svalid[1], 4);
+  }
+  // ---- score (drawScore, :190-203): "%07d", grey .5, seven-segment digits; a lane per pixel of the box
+  if (!baked_text && !(SF_RENDER_SKIP & 4)) {
+    const unsigned long long masks = sfr::score_masks(pnts);
+    constexpr int w = SF_TXT_BOX_X1 - SF_TXT_BOX_X0, h = SF_TXT_BOX_Y1 - SF_TXT_BOX_Y0;
+    static_assert(SF_TXT_BOX_X0 <= (SF_TXT_X0 + SF_TXT_PAD - SF_VP_X) * SF_SCALE &&
+                  SF_TXT_BOX_X1 >= (SF_TXT_X0 + 6 * SF_TXT_ADV + SF_TXT_PAD + SF_TXT_W - SF_VP_X) * SF_SCALE &&
+                  SF_TXT_BOX_Y0 <= (SF_TXT_TOP - SF_VP_Y) * SF_SCALE &&
+                  SF_TXT_BOX_Y1 >= (SF_TXT_TOP + SF_TXT_H - SF_VP_Y) * SF_SCALE, "text box");
+    for (int i = lane; i < w * h; i += 64) {
+      const int ry = i / w, rx = i - ry * w;
+      uint8_t* p = fb + (SF_TXT_BOX_Y0 + ry) * SF_IMG_W + SF_TXT_BOX_X0 + rx;
+      *p = (uint8_t)sfr::text_pixel(SF_TXT_BOX_X0 + rx, SF_TXT_BOX_Y0 + ry, masks, *p);
+    }
+    __builtin_amdgcn_wave_barrier();
+    F.resample(tbox);
+  }
+  // ---- vulnerability bar (drawVlner, :205-225): two filled rectangles, a lane per pixel of the box
+  if (!baked_bar && !(SF_RENDER_SKIP & 8)) {
     const bool kill = vlner > 10 && fort_vuln_timer < sfc::vuln_time;  // :268
     const int v = vlner > 10 ? 10 : vlner;
-    const Quad q = lane == 0 ? rect_quad(255.f, 522.f, 455.f, 532.f) : rect_quad(255.f, 522.f, 255.f + 20.f * (float)v, 532.f);
-    draw_quads(fb, q, lane == 0 ? 84 : (kill ? 255 : 168), lane == 0 || (lane == 1 && v > 0), lane);
+    const int vg = kill ? 255 : 168;
+    constexpr int w = SF_BAR_BOX_X1 - SF_BAR_BOX_X0, h = SF_BAR_BOX_Y1 - SF_BAR_BOX_Y0;
+    static_assert(SF_BAR_BOX_X0 == (int)((255 - SF_VP_X) * SF_SCALE) && SF_BAR_BOX_X1 == (int)((455 - SF_VP_X) * SF_SCALE) &&
+                  SF_BAR_BOX_Y0 <= (522 - SF_VP_Y) * SF_SCALE && SF_BAR_BOX_Y1 >= (532 - SF_VP_Y) * SF_SCALE, "bar box");
+    for (int i = lane; i < w * h; i += 64) {
+      const int ry = i / w, rx = i - ry * w;
+      uint8_t* p = fb + (SF_BAR_BOX_Y0 + ry) * SF_IMG_W + SF_BAR_BOX_X0 + rx;
+      *p = (uint8_t)sfr::bar_pixel(SF_BAR_BOX_X0 + rx, SF_BAR_BOX_Y0 + ry, v, vg, *p);
+    }
+    __builtin_amdgcn_wave_barrier();
+    F.resample(bbox);
   }
   __syncthreads();
 
-  // ---- epilogue
-  if (!a.resize) {
-    uint32_t* out = reinterpret_cast<uint32_t*>(a.out + (size_t)env * kFbBytes);
-    for (int i = lane; i < kFbWords; i += 64) out[i] = fbw[i];
-    return;
-  }
-  const float* tabf = reinterpret_cast<const float*>(tabw);
-  uint32_t* out = reinterpret_cast<uint32_t*>(a.out + (size_t)env * (SF_OUT * SF_OUT));
-  for (int d = lane; d < SF_OUT * SF_OUT / 4; d += 64) {
-    const int dy = d / (SF_OUT / 4), q4 = d - dy * (SF_OUT / 4);
-    const int fy = (int)tabw[4 * (SF_OUT + dy)];
-    const float b0 = tabf[4 * (SF_OUT + dy) + 1], b1 = tabf[4 * (SF_OUT + dy) + 2], b2 = tabf[4 * (SF_OUT + dy) + 3];
-    uint32_t packed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int dx = 4 * q4 + j;
-      const int fx = (int)tabw[4 * dx];
-      const float a0 = tabf[4 * dx + 1], a1 = tabf[4 * dx + 2], a2 = tabf[4 * dx + 3];
-      const uint8_t* r0 = fb + fy * SF_IMG_W + fx;
-      const uint8_t* r1 = r0 + SF_IMG_W;
-      const uint8_t* r2 = r1 + SF_IMG_W;
-      // resizeArea_: per source row buf = sum alpha*S, then sum += beta*buf, in table order
-      const float h0 = ((float)r0[0] * a0 + (float)r0[1] * a1) + (float)r0[2] * a2;
-      const float h1 = ((float)r1[0] * a0 + (float)r1[1] * a1) + (float)r1[2] * a2;
-      const float h2 = ((float)r2[0] * a0 + (float)r2[1] * a1) + (float)r2[2] * a2;
-      const float sum = (b0 * h0 + b1 * h1) + b2 * h2;
-      int v = (int)rintf(sum);  // saturate_cast<uchar>(float): round half to even, clamp
-      v = v < 0 ? 0 : (v > 255 ? 255 : v);
-      packed |= (uint32_t)v << (8 * j);
-    }
-    out[d] = packed;
+  // ---- epilogue: the frame leaves LDS in 16-byte pieces (raw: 8280 = 1035 * 8)
+  if (RESIZE) {
+    const uint4* src = reinterpret_cast<const uint4*>(obufw);
+    uint4* out = reinterpret_cast<uint4*>(a.out + (size_t)env * kOutBytes);
+    for (int i = lane; i < kOutBytes / 16; i += 64) out[i] = src[i];
+  } else {
+    const uint2* src = reinterpret_cast<const uint2*>(fbw);
+    uint2* out = reinterpret_cast<uint2*>(a.out + (size_t)env * kFbBytes);
+    for (int i = lane; i < kFbBytes / 8; i += 64) out[i] = src[i];
   }
 }
 
-hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* tabs,
-                            uint8_t* out, int resize, hipStream_t stream) {
+hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
+                            const uint32_t* tabs, uint8_t* out, int resize, hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
-  SfRenderArgs a{state, n_envs, bg, tabs, out, resize};
-  hipLaunchKernelGGL(sf_render_kernel, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
+  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out};
+  if (resize)
+    hipLaunchKernelGGL(sf_render_kernel<true>, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL(sf_render_kernel<false>, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
   return hipGetLastError();
 }

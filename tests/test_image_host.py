@@ -59,6 +59,19 @@ def test_resize_tables_follow_opencv_area():
                                 i32.ctypes.data_as(C.c_void_p)) < 0  # scale >= 2: not this table's path
 
 
+def test_host_resize_matches_model():
+    """The library's own INTER_AREA (used for the static background) against the numpy model."""
+    from oracle import render_np as R
+    L = _lib()
+    rng = np.random.default_rng(3)
+    bg = np.zeros((92, 90), np.uint8)
+    L.sf_image_background(bg.ctypes.data_as(C.c_void_p))
+    for img in (bg, rng.integers(0, 256, (92, 90)).astype(np.uint8), np.full((92, 90), 255, np.uint8)):
+        out = np.zeros((84, 84), np.uint8)
+        assert L.sf_resize_area_u8(img.ctypes.data_as(C.c_void_p), 90, 92, out.ctypes.data_as(C.c_void_p), 84, 84) == 0
+        assert np.array_equal(out, R.resize_area(img))
+
+
 def test_resize_area_properties():
     from oracle import render_np as R
     rng = np.random.default_rng(0)
@@ -104,3 +117,22 @@ def test_model_draws_what_the_state_says(oracle_mod):
     s["points"] = -12.7
     fn = R.render_raw(s, hb, hs, bg=bg).astype(int)
     assert (fn != f).any()
+
+
+def test_static_variants_match_model():
+    """The baked backgrounds the kernel starts from (score 0000000 / empty bar) equal what the model
+    draws stroke by stroke on the bare background."""
+    from oracle import render_np as R
+    L = _lib()
+    hb, hs = _hex()
+    bg = R.background(hb, hs)
+    for v in range(4):
+        out = np.zeros((92, 90), np.uint8)
+        assert L.sf_image_static(v, out.ctypes.data_as(C.c_void_p)) == 0
+        want = bg.copy()
+        if v & 1:
+            R.score_text(want, 0)
+        if v & 2:
+            R.over(want, R.rect_poly(255, 522, 455, 532), 84)
+        assert np.array_equal(out, want), v
+    assert L.sf_image_static(4, bg.ctypes.data_as(C.c_void_p)) < 0

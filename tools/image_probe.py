@@ -8,7 +8,7 @@ from spacefortress_amd import SFVecEnv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-for mode in ("image", "image-raw"):
+for mode in (sys.argv[3:] or ["image", "image-raw"]):
     env = SFVecEnv(n, gametype="youturn", obs_type=mode, spawn_stride=1, reuse_buffers=True)
     env.reset()
     acts = torch.randint(0, 5, (64, n), device=env.device, dtype=torch.uint8)
