@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--numpy-api", type=int, default=0, metavar="K",
                     help="also time K steps through the host-buffer (numpy) API: actions H2D, results D2H every "
                          "step -- the PCIe-inclusive rate, reported as host_api, never as value")
+    ap.add_argument("--image-envs", type=int, default=16384, metavar="N",
+                    help="also time N envs stepping with the image observation (BASELINE cfg 5: sf_step + sf_render, "
+                         "uint8 [N,1,84,84] per step); reported as image_obs, never as value; 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -221,6 +224,30 @@ def main():
         dt = time.perf_counter() - th
         host_api = {"value": n * args.numpy_api / dt, "unit": "env-steps/s", "ms_per_step": dt / args.numpy_api * 1e3,
                     "note": "numpy int64 actions in, numpy obs/reward/done/info out every step (PCIe both ways)"}
+    image_obs = None
+    if args.image_envs > 0 and rank == 0:
+        ni = args.image_envs
+        ienv = SFVecEnv(ni, gametype=args.gametype, obs_type="image", device=dev, spawn_stride=1, reuse_buffers=True)
+        ienv.reset()
+        iacts = actions[:, :ni].contiguous() if ni <= n else torch.randint(0, ienv.n_actions, (ring, ni), device=dev,
+                                                                           dtype=torch.uint8, generator=g)
+        isteps = max(50, min(1000, args.steps // 4))
+        for t in range(400):  # into mid-episode states: missiles, shells, explosions on screen
+            ienv.step_tensors(iacts[t % ring])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for t in range(isteps):
+            ienv.step_tensors(iacts[t % ring])
+        e1.record()
+        torch.cuda.synchronize()
+        ims = e0.elapsed_time(e1) / isteps
+        image_obs = {"value": ni / ims * 1e3, "unit": "env-steps/s", "envs": ni, "steps": isteps, "us_per_step": ims * 1e3,
+                     "frame_bytes_per_step": ni * 84 * 84, "frames_GBps": ni * 84 * 84 / ims / 1e6,
+                     "note": "obs_type='image' (SURVEY 8f rank 1): sf_step + sf_render per step, one wave per env "
+                             "rasterises the 90x92 frame in LDS and writes uint8 [N,1,84,84] (INTER_AREA); HIP events; "
+                             "pixel model pinned to oracle/render_np.py, not to cairo/cv2 (DESIGN.md)"}
+        ienv.close()
     if os.environ.get("SF_PMC_CALIB"):
         # known-byte calibration dispatches for the rocprofv3 --pmc passes (tools/pmc_report.py):
         # sf_group_copy_kernel reads n*20*16 bytes in the step kernel's own access pattern
@@ -262,6 +289,7 @@ def main():
             "cpu_baseline": base,
             "rollout_fused": fused,
             "host_api": host_api,
+            "image_obs": image_obs,
             "episode_stats": summarize(stats.cpu()),
         }
         print(json.dumps(out))

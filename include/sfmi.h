@@ -135,11 +135,13 @@ int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, 
  *      for the CURRENT state of every env: what `render()` / `_draw()` give in the reference,
  *      whatever obs_type the batch was created with.  mode SF_OBS_IMAGE: frames_dev uint8
  *      [n_envs][84][84]; SF_OBS_IMAGE_RAW: uint8 [n_envs][92][90].  frames_dev must be 16-byte
- *      aligned.  With obs_type SF_OBS_IMAGE / SF_OBS_IMAGE_RAW, sf_reset and sf_step write these
+ *      aligned.  env_stride = bytes from one env's frame to the next (0 = dense); a larger
+ *      stride writes straight into one slot of a [n_envs][num_stack][84][84] frame stack
+ *      (rl/train.py:39,51-56), multiple of 16 (raw: 8).  With obs_type SF_OBS_IMAGE / SF_OBS_IMAGE_RAW, sf_reset and sf_step write these
  *      frames to obs_dev themselves (sf_obs_dim = 7056 / 8280 bytes per env); sf_rollout then
  *      takes obs_dev = NULL only.  Pixel-level anti-aliasing is this library's own model: see
  *      DESIGN.md "image observation". ---- */
-int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, void* stream);
+int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, void* stream);
 
 /* Out-of-range actions are executed as NOOP and counted on the device; this reads and clears the
  * count (synchronises `stream`).  Returns SF_ERR_ACTION if any were seen since the last call. */

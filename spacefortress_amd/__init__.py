@@ -7,7 +7,7 @@ environment does, and fails loudly if the extension or the device is missing.
 """
 from ._lib import SfmiError, lib  # noqa: F401
 
-__all__ = ["SFVecEnv", "SSF_Env", "SfmiError", "lib"]
+__all__ = ["SFVecEnv", "SSF_Env", "FrameStack", "SfmiError", "lib"]
 
 
 def __getattr__(name):
@@ -17,4 +17,7 @@ def __getattr__(name):
     if name == "SSF_Env":
         from .env import SSF_Env
         return SSF_Env
+    if name == "FrameStack":
+        from .framestack import FrameStack
+        return FrameStack
     raise AttributeError(name)

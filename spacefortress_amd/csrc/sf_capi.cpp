@@ -295,16 +295,20 @@ extern "C" int sf_max_ticks(const sf_batch* b) { return b ? (int)sfc::max_ticks 
 
 static bool is_image(const sf_batch* b) { return b->obs_mode == SF_OBS_IMAGE || b->obs_mode == SF_OBS_IMAGE_RAW; }
 
-static int render(sf_batch* b, int mode, uint8_t* frames_dev, hipStream_t stream) {
-  if (((uintptr_t)frames_dev & 15) != 0) {
-    sf_set_error("image frames must be 16-byte aligned");
+static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, hipStream_t stream) {
+  const size_t frame = mode == SF_OBS_IMAGE ? (size_t)SF_OUT * SF_OUT : (size_t)SF_IMG_W * SF_IMG_H;
+  if (env_stride == 0) env_stride = frame;
+  if (((uintptr_t)frames_dev & 15) != 0 || env_stride < frame || (env_stride & (mode == SF_OBS_IMAGE ? 15 : 7)) != 0) {
+    sf_set_error("image frames must be 16-byte aligned, env_stride >= the frame size and a multiple of %d",
+                 mode == SF_OBS_IMAGE ? 16 : 8);
     return SF_ERR_ARG;
   }
-  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, mode == SF_OBS_IMAGE ? 1 : 0, stream));
+  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride,
+                           mode == SF_OBS_IMAGE ? 1 : 0, stream));
   return SF_OK;
 }
 
-extern "C" int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, void* stream) {
+extern "C" int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, void* stream) {
   if (!b || !frames_dev) {
     sf_set_error("sf_render: null batch or output");
     return SF_ERR_ARG;
@@ -314,7 +318,7 @@ extern "C" int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, void* strea
     return SF_ERR_ARG;
   }
   DeviceGuard guard(b->device);
-  return render(b, mode, frames_dev, (hipStream_t)stream);
+  return render(b, mode, frames_dev, env_stride, (hipStream_t)stream);
 }
 
 extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
@@ -325,7 +329,7 @@ extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
   DeviceGuard guard(b->device);
   const bool image = is_image(b);
   HIP_TRY(sf_launch_reset(b->args, 0, 0, 0, image ? nullptr : obs_dev, (hipStream_t)stream));
-  if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, (hipStream_t)stream);
+  if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
   return SF_OK;
 }
 
@@ -343,7 +347,7 @@ extern "C" int sf_step(sf_batch* b, const void* actions_dev, int act_type, void*
   const bool image = is_image(b);
   HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, image ? nullptr : obs_dev,
                          reward_dev, done_dev, info_dev, 1, false, (hipStream_t)stream));
-  if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, (hipStream_t)stream);
+  if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
   return SF_OK;
 }
 

@@ -354,6 +354,7 @@ struct SfRenderArgs {
   const uint32_t* bg84;  // ... and their 84x84 INTER_AREA images, 7056 bytes apart
   const uint32_t* tabs;  // SF_TAB_WORDS, layout in sf_raster.h
   uint8_t* out;
+  size_t out_stride;     // bytes from one env's frame to the next (>= the frame size, multiple of 16)
 };
 
 template <bool RESIZE>
@@ -537,19 +538,19 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   // ---- epilogue: the frame leaves LDS in 16-byte pieces (raw: 8280 = 1035 * 8)
   if (RESIZE) {
     const uint4* src = reinterpret_cast<const uint4*>(obufw);
-    uint4* out = reinterpret_cast<uint4*>(a.out + (size_t)env * kOutBytes);
+    uint4* out = reinterpret_cast<uint4*>(a.out + (size_t)env * a.out_stride);
     for (int i = lane; i < kOutBytes / 16; i += 64) out[i] = src[i];
   } else {
     const uint2* src = reinterpret_cast<const uint2*>(fbw);
-    uint2* out = reinterpret_cast<uint2*>(a.out + (size_t)env * kFbBytes);
+    uint2* out = reinterpret_cast<uint2*>(a.out + (size_t)env * a.out_stride);
     for (int i = lane; i < kFbBytes / 8; i += 64) out[i] = src[i];
   }
 }
 
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
-                            const uint32_t* tabs, uint8_t* out, int resize, hipStream_t stream) {
+                            const uint32_t* tabs, uint8_t* out, size_t out_stride, int resize, hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
-  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out};
+  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride};
   if (resize)
     hipLaunchKernelGGL(sf_render_kernel<true>, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
   else

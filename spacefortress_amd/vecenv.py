@@ -198,7 +198,11 @@ class SFVecEnv:
         shape = (1, _lib.IMAGE_OUT, _lib.IMAGE_OUT) if mode == "image" else (_lib.IMAGE_H, _lib.IMAGE_W)
         if out is None:
             out = torch.empty((self.num_envs,) + shape, dtype=torch.uint8, device=self.device)
-        _lib.check(self._L.sf_render(self._h, _lib.OBS_TYPES[mode], C.c_void_p(out.data_ptr()), self._stream()))
+        # `out` may be a view whose env stride is larger than a frame (one slot of a frame stack)
+        if out.shape != (self.num_envs,) + shape or out.dtype != torch.uint8 or not out[0].is_contiguous():
+            raise ValueError("out must be uint8 %s with contiguous frames" % (((self.num_envs,) + shape),))
+        stride = out.stride(0) if self.num_envs > 1 else 0
+        _lib.check(self._L.sf_render(self._h, _lib.OBS_TYPES[mode], C.c_void_p(out.data_ptr()), stride, self._stream()))
         return out
 
     # ------------------------------------------------------------------ extras

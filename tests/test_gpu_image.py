@@ -208,3 +208,38 @@ def test_image_full_batch_properties(sfa):
     assert int(hexmask.sum()) > 100
     assert bool((obs[:, 0][:, hexmask] >= 45).all())
     env.close()
+
+
+def test_frame_stack_matches_the_trainers_shift(sfa):
+    """FrameStack (device ring, frames rendered straight into a slot) against the trainer's own
+    update: shift by one frame, zero finished envs, newest last (rl/train.py:51-56,92-97)."""
+    N, S = 64, 4
+    # episodes end at step 5295 in every lane; start late in the episode so that a reset is inside
+    env = sfa.SFVecEnv(N, gametype="autoturn", obs_type="image", spawn_stride=2)
+    twin = sfa.SFVecEnv(N, gametype="autoturn", obs_type="image", spawn_stride=2)
+    for e in (env, twin):
+        e.set_field("time", np.full(N, 34 * 5285, np.int32))
+    fs = sfa.FrameStack(env, S)
+    rng = np.random.default_rng(2)
+    ref = torch.zeros((N, S, 84, 84), dtype=torch.uint8, device=env.device)
+    # no reset(): start both from the state just set
+    env.render("image", out=fs.ring[:, fs.head:fs.head + 1])
+    ref[:, -1:] = twin.render("image")
+    assert torch.equal(fs.stacked(), ref)
+    saw_done = False
+    for t in range(25):
+        a = torch.from_numpy(rng.integers(0, 3, N).astype(np.uint8)).to(env.device)
+        rew, done, info = fs.step(a)
+        obs, r2, d2, i2 = twin.step_tensors(a)
+        assert torch.equal(rew, r2) and torch.equal(done, d2.bool())
+        ref *= (1 - d2)[:, None, None, None]
+        ref[:, :-1] = ref[:, 1:].clone()
+        ref[:, -1:] = obs
+        assert torch.equal(fs.stacked(), ref), t
+        saw_done = saw_done or bool(done.any())
+    assert saw_done
+    # a stack straight after reset(): three empty frames and the first observation
+    st = fs.reset()
+    assert st.shape == (N, S, 84, 84) and int(st[:, :-1].sum()) == 0 and int(st[:, -1].sum()) > 0
+    env.close()
+    twin.close()
