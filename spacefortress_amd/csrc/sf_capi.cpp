@@ -30,6 +30,7 @@ struct sf_batch {
   uint32_t* d_bg;            // image observation: static background, 92*90 bytes
   uint32_t* d_bg84;          // ... resampled to 84x84
   uint32_t* d_tabs;          // INTER_AREA taps (sf_raster.h)
+  unsigned char* d_xcache;   // explosion cache, SF_XC_BYTES per env; allocated by the first render
 };
 
 namespace {
@@ -266,6 +267,7 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_scratch) (void)hipFree(b->d_scratch);
   if (b->d_bg) (void)hipFree(b->d_bg);
   if (b->d_tabs) (void)hipFree(b->d_tabs);
+  if (b->d_xcache) (void)hipFree(b->d_xcache);
   if (b->d_bg84) (void)hipFree(b->d_bg84);
   if (b->args.dbg) (void)hipFree(b->args.dbg);
   delete b;
@@ -303,7 +305,13 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
                  mode == SF_OBS_IMAGE ? 16 : 8);
     return SF_ERR_ARG;
   }
-  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride,
+  if (!b->d_xcache && !getenv("SFMI_NO_EXPLOSION_CACHE")) {
+    // first frame of this batch: the per-env explosion cache (feature-only batches never pay for it)
+    const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES;
+    HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes));
+    HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes, stream));
+  }
+  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache,
                            mode == SF_OBS_IMAGE ? 1 : 0, stream));
   return SF_OK;
 }

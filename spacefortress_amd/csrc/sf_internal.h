@@ -21,7 +21,8 @@ hipError_t sf_launch_group_copy(const unsigned char* state, int n_envs, int grou
 
 // sf_render.hip: one wave per env; bg = 92*90 bytes, bg84 = its 84*84 INTER_AREA image, tabs = SF_TAB_WORDS
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
-                            const uint32_t* tabs, uint8_t* out, size_t out_stride, int resize, hipStream_t stream);
+                            const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache, int resize,
+                            hipStream_t stream);
 
 // sf_host.cpp (no HIP calls: usable and tested without a GPU)
 void sf_host_fill_consts(const sf_preset& p, double* consts /* SF_CONST_DOUBLES */);

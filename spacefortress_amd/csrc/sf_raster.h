@@ -40,6 +40,8 @@
 // Device copies of the static background: variant v (bit 0: score 0000000 baked in, bit 1: empty bar
 // baked in) at byte offset v * SF_BG_STRIDE (92x90) and v * 84*84 (resampled)
 #define SF_BG_STRIDE 8288
+// per-env cache of the dead ship's explosion pixels (sf_render.hip: ship_explosion)
+#define SF_XC_BYTES 1600
 
 namespace sfr {
 

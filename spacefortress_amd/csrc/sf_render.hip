@@ -129,6 +129,19 @@ __device__ __forceinline__ Box explosion_box(float cx, float cy) {
   return b;
 }
 
+// Destination pixels of the 84x84 image that read source pixels of `b`.  Destination column dx reads
+// source columns first, first+1 with first in [dx*15/14 - 1, dx*15/14]; row dy reads up to three rows
+// from first in [dy*23/21 - 1, dy*23/21] (checked against the tables in sf_create) -- hence these
+// conservative bounds.
+__device__ __forceinline__ Box out_box(const Box& b) {
+  Box o;
+  o.x0 = max(((b.x0 - 1) * 14) / 15, 0);
+  o.x1 = min((b.x1 * 14) / 15 + 1, SF_OUT);
+  o.y0 = max(((b.y0 - 2) * 21) / 23, 0);
+  o.y1 = min((b.y1 * 21) / 23 + 1, SF_OUT);
+  return o;
+}
+
 // The frame of one env: the 90x92 surface and (RESIZE) its 84x84 INTER_AREA image, both in LDS.
 template <bool RESIZE>
 struct Frame {
@@ -139,14 +152,12 @@ struct Frame {
 
   // cv2.resize(..., INTER_AREA) restricted to the destination pixels that read source pixels of `b`
   // (OpenCV's resizeArea_ arithmetic: per source row buf = sum alpha * S, then sum += beta * buf in
-  // table order, saturate_cast<uchar>).  Destination column dx reads source columns first, first+1
-  // with first in [dx*15/14 - 1, dx*15/14]; row dy reads up to three rows from first in
-  // [dy*23/21 - 1, dy*23/21] -- hence the conservative bounds below.
+  // table order, saturate_cast<uchar>).
   __device__ __forceinline__ void resample(const Box& b) const {
     if (!RESIZE || (SF_RENDER_SKIP & 16) || b.empty()) return;
-    const int ox0 = max(((b.x0 - 1) * 14) / 15, 0), ox1 = min((b.x1 * 14) / 15 + 1, SF_OUT);
-    const int oy0 = max(((b.y0 - 2) * 21) / 23, 0), oy1 = min((b.y1 * 21) / 23 + 1, SF_OUT);
-    const int ow = ox1 - ox0, n = ow * (oy1 - oy0);
+    const Box o = out_box(b);
+    const int ox0 = o.x0, oy0 = o.y0;
+    const int ow = o.x1 - o.x0, n = ow * (o.y1 - o.y0);
     const float* tabf = reinterpret_cast<const float*>(tab);
     for (int i = lane; i < n; i += 64) {
       const int ry = i / ow, rx = i - ry * ow;
@@ -344,6 +355,60 @@ __device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, float cx,
   F.resample(explosion_box(cx, cy));
 }
 
+// ---- A dead ship stays where it died for the 1000 ms of its explosion (30 frames), and the
+// explosion is the first thing drawn on the static background: its pixels -- and the 84x84 pixels
+// that read them -- are a function of the position alone.  Each env keeps them in HBM, keyed by that
+// position: SF_XC_BYTES per env = {x, y (f64 bits), flags, pad; 27 rows x 28 of the surface; 28 rows
+// x 28 of the 84x84 image}.  29 of 30 explosion frames become two small copies.
+constexpr int kXcKey = 0, kXcFlags = 16, kXcFb = 32, kXcRow = 28, kXcFbRows = 27, kXcOut = kXcFb + kXcFbRows * kXcRow + 12,
+              kXcOutRows = 28;
+static_assert(kXcOut % 4 == 0 && kXcOut + kXcOutRows * kXcRow <= SF_XC_BYTES, "explosion cache layout");
+
+template <bool RESIZE>
+__device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned char* xc, double x, double y) {
+  const float cx = (float)x, cy = (float)y;
+  const Box b = explosion_box(cx, cy), o = out_box(b);
+  const int lane = F.lane;
+  const unsigned need = RESIZE ? 3u : 1u;
+  bool hit = false;
+  if (xc) {
+    const double kx = *reinterpret_cast<const double*>(xc + kXcKey), ky = *reinterpret_cast<const double*>(xc + kXcKey + 8);
+    const unsigned fl = *reinterpret_cast<const unsigned*>(xc + kXcFlags);
+    hit = kx == x && ky == y && (fl & need) == need;
+  }
+  const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows;
+  if (hit && fits) {
+    for (int i = lane; i < kXcFbRows * kXcRow; i += 64) {
+      const int r = i / kXcRow, c = i - r * kXcRow;
+      if (r < b.y1 - b.y0 && c < b.x1 - b.x0) F.fb[(b.y0 + r) * SF_IMG_W + b.x0 + c] = xc[kXcFb + i];
+    }
+    if (RESIZE)
+      for (int i = lane; i < kXcOutRows * kXcRow; i += 64) {
+        const int r = i / kXcRow, c = i - r * kXcRow;
+        if (r < o.y1 - o.y0 && c < o.x1 - o.x0) F.obuf[(o.y0 + r) * SF_OUT + o.x0 + c] = xc[kXcOut + i];
+      }
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
+  draw_explosion(F, cx, cy);
+  if (xc && fits) {
+    for (int i = lane; i < kXcFbRows * kXcRow; i += 64) {
+      const int r = i / kXcRow, c = i - r * kXcRow;
+      if (r < b.y1 - b.y0 && c < b.x1 - b.x0) xc[kXcFb + i] = F.fb[(b.y0 + r) * SF_IMG_W + b.x0 + c];
+    }
+    if (RESIZE)
+      for (int i = lane; i < kXcOutRows * kXcRow; i += 64) {
+        const int r = i / kXcRow, c = i - r * kXcRow;
+        if (r < o.y1 - o.y0 && c < o.x1 - o.x0) xc[kXcOut + i] = F.obuf[(o.y0 + r) * SF_OUT + o.x0 + c];
+      }
+    if (lane == 0) {
+      *reinterpret_cast<double*>(xc + kXcKey) = x;
+      *reinterpret_cast<double*>(xc + kXcKey + 8) = y;
+      *reinterpret_cast<unsigned*>(xc + kXcFlags) = need;
+    }
+  }
+}
+
 }  // namespace
 
 struct SfRenderArgs {
@@ -355,6 +420,7 @@ struct SfRenderArgs {
   const uint32_t* tabs;  // SF_TAB_WORDS, layout in sf_raster.h
   uint8_t* out;
   size_t out_stride;     // bytes from one env's frame to the next (>= the frame size, multiple of 16)
+  unsigned char* xcache; // SF_XC_BYTES per env (zero-initialised), or null
 };
 
 template <bool RESIZE>
@@ -436,7 +502,10 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
   bool near_text = false, near_bar = false;
   if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
-    const Box eb = explosion_box(ship_x, ship_y);
+    // 3 pixels wider than what the explosion paints: the 84x84 pixels recomputed (or restored from the
+    // cache) for it read that far, and must not depend on whether the score / bar were baked in
+    Box eb = explosion_box(ship_x, ship_y);
+    eb.x0 -= 3; eb.y0 -= 3; eb.x1 += 3; eb.y1 += 3;
     near_text = eb.meets(tbox);
     near_bar = eb.meets(bbox);
   }
@@ -483,7 +552,7 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
     const Quad q = line_quad(kShipLines[lane < 3 ? lane : 0], c, s, ship_x, ship_y);
     F.draw_quads(q, 255, lane < 3, 64);
   } else {
-    draw_explosion(F, ship_x, ship_y);
+    ship_explosion(F, a.xcache ? a.xcache + (size_t)env * SF_XC_BYTES : nullptr, sp.x, sp.y);
   }
   // ---- fortress (:238-242)
   if (SF_RENDER_SKIP & 1) {
@@ -548,9 +617,10 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
 }
 
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
-                            const uint32_t* tabs, uint8_t* out, size_t out_stride, int resize, hipStream_t stream) {
+                            const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache, int resize,
+                            hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
-  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride};
+  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache};
   if (resize)
     hipLaunchKernelGGL(sf_render_kernel<true>, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
   else

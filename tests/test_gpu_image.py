@@ -243,3 +243,35 @@ def test_frame_stack_matches_the_trainers_shift(sfa):
     assert st.shape == (N, S, 84, 84) and int(st[:, :-1].sum()) == 0 and int(st[:, -1].sum()) > 0
     env.close()
     twin.close()
+
+
+def test_explosion_cache_is_invisible(sfa, monkeypatch):
+    """A dead ship's explosion is drawn once and then restored from the per-env cache for the
+    rest of its 30 frames; frames must be identical to a batch that redraws it every time,
+    in both sizes, through deaths, respawns and a restored state."""
+    N, T = 512, 260
+    rng = np.random.default_rng(9)
+    acts = torch.from_numpy(rng.integers(0, 5, (T, N)).astype(np.uint8)).cuda()
+    monkeypatch.setenv("SFMI_NO_EXPLOSION_CACHE", "1")
+    plain = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=3)
+    plain.render("image")  # the switch is read by a batch's first frame
+    monkeypatch.delenv("SFMI_NO_EXPLOSION_CACHE")
+    cached = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=3)
+    dead_frames = 0
+    for t in range(T):
+        o1, *_ = plain.step_tensors(acts[t])
+        o2, *_ = cached.step_tensors(acts[t])
+        assert torch.equal(o1, o2), t
+        if t % 16 == 0:
+            assert torch.equal(plain.render("image-raw"), cached.render("image-raw")), t
+        dead_frames += int((torch.from_numpy(cached.get_field("flags")) & 1 == 0).sum()) if t % 16 == 0 else 0
+    assert dead_frames > 100
+    # a state restored into the batch: the key is the position, stale entries cannot match by accident
+    sd = plain.state_dict()
+    perm = rng.permutation(N)
+    for e in (plain, cached):
+        e.load_state_dict({k: (v[..., perm] if v.ndim else v) for k, v in sd.items()})
+    assert torch.equal(plain.render("image"), cached.render("image"))
+    assert torch.equal(plain.render("image-raw"), cached.render("image-raw"))
+    plain.close()
+    cached.close()
