@@ -178,6 +178,31 @@ int sf_episode_stats(sf_batch* b, int64_t* out, int clear, void* stream);
  *      which: 0 or 1 (two different 16-byte groups).  Synchronous. ---- */
 int sf_calibration_copy(sf_batch* b, int which, size_t* bytes_moved);
 
+/* ---- gym_vecenv.VecNormalize(envs) (rl/train.py:35-36: applied whenever the observation is 1-D): running
+ *      mean / variance of the observations and of the discounted returns over the batch, observations
+ *      become clip((obs - mean) / sqrt(var + eps), +-clipob), rewards clip(rew / sqrt(ret_var + eps),
+ *      +-cliprew).  gym-vecenv==1.0 (requirements.txt:4) is not in the reference tree: the algorithm is
+ *      OpenAI baselines' vec_normalize.py / running_mean_std.py of that vintage (statistics updated with
+ *      the batch BEFORE it is normalised; `ret = ret * gamma + rew`, never cleared at episode ends). ---- */
+typedef struct {
+  int32_t n_envs, obs_dim, device_id;
+  int32_t obs_f64;                        /* observations are float64 (SF_FLAG_OBS_F64), else float32 */
+  int32_t ob, ret;                        /* VecNormalize(ob=True, ret=True) */
+  double clipob, cliprew, gamma, epsilon; /* 10, 10, 0.99, 1e-8 */
+} sf_normalizer_params;
+typedef struct sf_normalizer sf_normalizer;
+int sf_normalizer_create(const sf_normalizer_params* params, sf_normalizer** out);
+int sf_normalizer_destroy(sf_normalizer* z);
+/* VecNormalize.step_wait (obs + rewards) or .reset (obs only: reward pointers NULL).  obs_dev
+ * [n_envs][obs_dim] -> obs_out_dev (may alias); reward_dev int32[n_envs] -> reward_out_dev float[n_envs].
+ * frozen != 0: normalise with the statistics as they are (evaluation), update nothing. */
+int sf_normalize(sf_normalizer* z, const void* obs_dev, void* obs_out_dev, const int32_t* reward_dev,
+                 float* reward_out_dev, int frozen, void* stream);
+/* statistics as host doubles [2*obs_dim + 4]: ob mean[D], ob var[D], ret mean, ret var, ob count, ret
+ * count; ret_host (may be NULL): the per-env discounted returns [n_envs].  Synchronise `stream`. */
+int sf_normalizer_get_state(sf_normalizer* z, double* host, double* ret_host, void* stream);
+int sf_normalizer_set_state(sf_normalizer* z, const double* host, const double* ret_host, void* stream);
+
 /* ---- host-only helpers (usable without a GPU) ---- */
 typedef struct {
   int32_t width, height, game_time;

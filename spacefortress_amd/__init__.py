@@ -7,7 +7,7 @@ environment does, and fails loudly if the extension or the device is missing.
 """
 from ._lib import SfmiError, lib  # noqa: F401
 
-__all__ = ["SFVecEnv", "SSF_Env", "FrameStack", "SfmiError", "lib"]
+__all__ = ["SFVecEnv", "SSF_Env", "FrameStack", "SFVecNormalize", "SfmiError", "lib"]
 
 
 def __getattr__(name):
@@ -20,4 +20,7 @@ def __getattr__(name):
     if name == "FrameStack":
         from .framestack import FrameStack
         return FrameStack
+    if name == "SFVecNormalize":
+        from .vecnormalize import SFVecNormalize
+        return SFVecNormalize
     raise AttributeError(name)

@@ -77,6 +77,11 @@ SYMBOLS = {
     "sf_spawn_table": (C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
     "sf_trig_table": (C.c_int, [C.c_void_p]),
     "sf_hex_points": (C.c_int, [C.c_int, C.c_void_p]),
+    "sf_normalizer_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "sf_normalizer_destroy": (C.c_int, [C.c_void_p]),
+    "sf_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sf_normalizer_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_normalizer_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_render": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sf_image_background": (C.c_int, [C.c_void_p]),
     "sf_image_static": (C.c_int, [C.c_int, C.c_void_p]),

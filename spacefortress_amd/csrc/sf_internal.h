@@ -24,6 +24,13 @@ hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache, int resize,
                             hipStream_t stream);
 
+// sf_normalize.hip: reduce + apply (two launches); sums / stats are the buffers of this step's parity,
+// *_next the other parity's
+hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, const int32_t* rew, float* rew_out, double* ret,
+                               int n, int dim, double gamma, double eps, double clipob, double cliprew, int do_ob,
+                               int do_ret, double* sums, double* sums_next, const double* stats, double* stats_next,
+                               hipStream_t stream);
+
 // sf_host.cpp (no HIP calls: usable and tested without a GPU)
 void sf_host_fill_consts(const sf_preset& p, double* consts /* SF_CONST_DOUBLES */);
 void sf_set_error(const char* fmt, ...);
