@@ -7,7 +7,7 @@ environment does, and fails loudly if the extension or the device is missing.
 """
 from ._lib import SfmiError, lib  # noqa: F401
 
-__all__ = ["SFVecEnv", "SSF_Env", "FrameStack", "SFVecNormalize", "SfmiError", "lib"]
+__all__ = ["SFVecEnv", "SSF_Env", "FrameStack", "SFVecNormalize", "DeviceRollout", "SfmiError", "lib"]
 
 
 def __getattr__(name):
@@ -23,4 +23,7 @@ def __getattr__(name):
     if name == "SFVecNormalize":
         from .vecnormalize import SFVecNormalize
         return SFVecNormalize
+    if name == "DeviceRollout":
+        from .rollout import DeviceRollout
+        return DeviceRollout
     raise AttributeError(name)

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfmi.so")
-SOURCES = ["sf_kernels.hip", "sf_render.hip", "sf_normalize.hip", "sf_capi.cpp", "sf_norm_capi.cpp", "sf_host.cpp", "sf_image.cpp"]
+SOURCES = ["sf_kernels.hip", "sf_render.hip", "sf_normalize.hip", "sf_rollout_ops.hip", "sf_capi.cpp", "sf_norm_capi.cpp", "sf_host.cpp", "sf_image.cpp"]
 HEADERS = ["sf_layout.h", "sf_internal.h", "sf_raster.h", "sf_render_tables.h", os.path.join(ROOT, "include", "sfmi.h")]
 
 

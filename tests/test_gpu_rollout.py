@@ -1,0 +1,100 @@
+"""The device-side trainer helpers (sf_compute_returns, sf_record_step, DeviceRollout) against fixtures
+recorded from the reference's own rl/storage.py / rl/train.py:82-88 -- BIT-EXACT (float32, same operation
+order, no FMA contraction) -- and an end-to-end rollout against a host-side replay of the same steps."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+TR = os.path.join(GOLDEN, "trainer")
+
+
+@pytest.fixture(scope="module")
+def sfa():
+    import spacefortress_amd as m
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return m
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("name", ["returns_gae", "returns_gae_long", "returns_plain", "returns_one_step"])
+def test_compute_returns_bit_exact(sfa, name):
+    from spacefortress_amd import _lib
+    z = np.load(os.path.join(TR, name + ".npz"))
+    dev = torch.device("cuda")
+    T, n = z["rewards"].shape
+    rewards, vp, masks = (torch.from_numpy(z[k]).to(dev) for k in ("rewards", "value_preds_in", "masks"))
+    nv = torch.from_numpy(z["next_value"]).to(dev)
+    ret = torch.zeros(T + 1, n, device=dev)
+    _lib.check(_lib.lib().sf_compute_returns(T, n, _p(rewards), _p(vp), _p(masks), _p(nv), _p(ret), int(z["use_gae"]),
+                                             float(z["gamma"]), float(z["tau"]), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(ret.cpu().numpy(), z["returns"])
+    assert np.array_equal(vp.cpu().numpy(), z["value_preds_out"])
+
+
+def test_record_step_bit_exact(sfa):
+    from spacefortress_amd import _lib
+    z = np.load(os.path.join(TR, "trainer_bookkeeping.npz"))
+    dev = torch.device("cuda")
+    T, n = z["rewards"].shape
+    ep, fin = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    r_out, m_out = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    for t in range(T):
+        r, d = torch.from_numpy(z["rewards"][t]).to(dev), torch.from_numpy(z["done"][t]).to(dev)
+        _lib.check(_lib.lib().sf_record_step(n, _p(r), _p(d), _p(r_out), _p(m_out), _p(ep), _p(fin), None))
+        assert np.array_equal(m_out.cpu().numpy(), z["masks"][t])
+        assert np.array_equal(r_out.cpu().numpy(), z["rewards"][t].astype(np.float32))
+        assert np.array_equal(ep.cpu().numpy(), z["episode_rewards"][t])
+        assert np.array_equal(fin.cpu().numpy(), z["final_rewards"][t])
+    assert _lib.lib().sf_record_step(0, None, None, None, None, None, None, None) < 0
+
+
+def test_device_rollout_end_to_end(sfa):
+    """A 12-step rollout collected entirely on the device equals the same steps taken one by one with the
+    trainer's host-side bookkeeping; returns equal the oracle's restatement of rl/storage.py."""
+    from oracle import trainer_np as TN
+    N, T = 300, 12
+    env = sfa.SFVecEnv(N, gametype="autoturn", spawn_stride=1)
+    twin = sfa.SFVecEnv(N, gametype="autoturn", spawn_stride=1)
+    for e in (env, twin):  # late in the episode so that `done` happens inside the rollout
+        e.set_field("time", np.full(N, 34 * 5289, np.int32))
+    ro = sfa.DeviceRollout(env, T)
+    g = torch.Generator(device=env.device).manual_seed(0)
+    ro.observations[0].copy_(twin.step_tensors(torch.zeros(N, dtype=torch.uint8, device=env.device))[0])
+    env.step_tensors(torch.zeros(N, dtype=torch.uint8, device=env.device))
+    ep, fin = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    kills = 0
+    for t in range(T):
+        a = torch.randint(0, 3, (N, 1), device=env.device, generator=g)
+        v = torch.randn(N, 1, device=env.device, generator=g)
+        ro.step(t, a, value_pred=v, action_log_prob=-v)
+        o, r, d, i = twin.step_tensors(a.view(-1))
+        _, m, ep, fin = TN.record_step(r.cpu().numpy(), d.cpu().numpy().astype(bool), ep, fin)
+        kills += int(i.sum())
+        assert torch.equal(ro.observations[t + 1], o)
+        assert np.array_equal(ro.rewards[t, :, 0].cpu().numpy(), r.cpu().numpy().astype(np.float32))
+        assert np.array_equal(ro.masks[t + 1, :, 0].cpu().numpy(), m)
+        assert torch.equal(ro.actions[t], a) and torch.equal(ro.value_preds[t], v)
+    assert (ro.masks[1:] == 0).any()
+    assert np.array_equal(ro.episode_rewards[:, 0].cpu().numpy(), ep) and np.array_equal(ro.final_rewards[:, 0].cpu().numpy(), fin)
+    assert int(ro.num_destruction) == kills
+    nv = torch.randn(N, 1, device=env.device, generator=g)
+    vp_in = ro.value_preds[..., 0].cpu().numpy().copy()
+    ro.compute_returns(nv, True, 0.99, 0.95)
+    want, _ = TN.compute_returns(ro.rewards[..., 0].cpu().numpy(), vp_in, ro.masks[..., 0].cpu().numpy(),
+                                 nv[:, 0].cpu().numpy(), True, 0.99, 0.95)
+    assert np.array_equal(ro.returns[..., 0].cpu().numpy(), want)
+    last = ro.observations[-1].clone()
+    ro.after_update()
+    assert torch.equal(ro.observations[0], last) and torch.equal(ro.masks[0], ro.masks[-1])
+    env.close()
+    twin.close()
