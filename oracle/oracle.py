@@ -343,6 +343,14 @@ class RefGame(_GameApi):
     def rollout(self, n_steps, lcg_seed):
         return self.L.sfref_rollout(self.h, n_steps, lcg_seed)
 
+    def dump(self):
+        """Game::dumpState(), the string `Game.dump()` returns (SRC/pymodule.cpp:361-370)."""
+        buf = C.create_string_buffer(8192)
+        self.L.sfref_dump.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        n = self.L.sfref_dump(self.h, buf, len(buf))
+        assert n < len(buf)
+        return buf.value.decode()
+
     def replay(self, keys):
         """Run len(keys) engine ticks of key bits in one call (new Game after game over)."""
         k = np.ascontiguousarray(keys, np.uint8)

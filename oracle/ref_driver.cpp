@@ -110,6 +110,16 @@ int sfref_step_one_tick(void* h, int ms) {
 
 int sfref_is_game_over(void* h) { return ((RefGame*)h)->game->isGameOver() ? 1 : 0; }
 
+// Game::dumpState() (SRC/game.cpp:519-576), what the `dump` method of the Python type returns
+int sfref_dump(void* h, char* buf, int cap) {
+  std::string s = ((RefGame*)h)->game->dumpState();
+  if (buf && cap > 0) {
+    strncpy(buf, s.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
+  }
+  return (int)s.size();
+}
+
 int sfref_sizeof_game(void) { return (int)sizeof(Game); }
 
 /* big hexagon vertices x0,y0..x5,y5 then the small hexagon's (SRC/hexagon.cpp:13-34) */

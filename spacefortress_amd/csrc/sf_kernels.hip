@@ -258,7 +258,7 @@ __device__ __forceinline__ void store_lane(unsigned char* tb, const Off& o, cons
   SF_ST(i4_t, SF_CHUNK(misc, 0), o.o16, (i4_t{L.prev_vlner, (int)L.cursor, (int)L.mmask, (int)L.smask}));
   SF_ST(i2_t, SF_CHUNK(small, 0), o.o8,
         (i2_t{(int)((unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16)),
-              (int)((unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFu) << 16))}));
+              (int)((unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16))}));
 }
 
 // Agent-scope (L2-coherent, L1-bypassing) accesses for the few places where one launch may read
@@ -923,6 +923,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   L.right_t += (L.fl & SF_FL_RIGHT) ? 1 : -1;
 
   int r = (int)rew;  // `return mReward` through `int stepOneTick` (SRC/game.hh:138): truncation
+  // kept for `Game.step_one_tick`'s return value (field last_reward): the spare byte next to the flags
+  L.fl = (L.fl & 0xFFu) | ((unsigned)(r & 0xFF) << 8);
 
   // ================= SSF_Env.step epilogue (ENV:233-253) =================
   const int fort_kill = r > 0;

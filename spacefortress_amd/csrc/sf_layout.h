@@ -32,7 +32,7 @@
   G(timers_b, 16, 1)              /* right, fort, fort_death, fort_vuln timers */               \
   G(score, 16, 1)                 /* points, raw_points, vlner, time */                         \
   G(misc, 16, 1)                  /* prev_vlner, spawn_cursor, missile_mask, shell_mask */      \
-  G(small, 8, 1)                  /* ship_angle, fort_angle, fort_last_angle (i16), flags (u8) */ \
+  G(small, 8, 1)                  /* ship_angle, fort_angle, fort_last_angle (i16), flags (u8), last_reward (i8) */ \
   G(missile_pos, 16, SF_NSLOT)    /* missile_x, missile_y */                                    \
   G(missile_ang, 2, SF_NSLOT)     /* missile_angle */                                           \
   G(shell_pos, 16, SF_NSLOT)      /* shell_x, shell_y */                                        \
@@ -84,7 +84,8 @@ enum SfGroupId {
   X(fort_angle, int16_t, 1, 0, small, 2)         /* mFortress.mAngle: multiple of the sector size */       \
   X(fort_last_angle, int16_t, 1, 0, small, 4)    /* mFortress.mLastAngle */                                \
   X(missile_angle, int16_t, SF_NSLOT, 0, missile_ang, 0) /* mMissiles[i].mAngle (vel = 20*(cos,sin)) */    \
-  X(flags, uint8_t, 1, 0, small, 6)              /* SF_FL_* bits */
+  X(flags, uint8_t, 1, 0, small, 6)              /* SF_FL_* bits */                                        \
+  X(last_reward, int8_t, 1, 0, small, 7)         /* (int)mReward of the last tick = what step_one_tick returned (SRC/game.cpp:484) */
 
 enum SfFieldId {
 #define X(name, ctype, count, isf, group, off) SF_F_##name,

@@ -1,0 +1,276 @@
+"""Game -- a single-lane view of the batched engine with the shape of the reference's CPython type
+`_spacefortress.Game` (SRC/pymodule.cpp:319-411), for scripts that poke `sf.Game` directly and for
+single-lane debugging (SURVEY 8b "optional Game-shaped shim", 8f rank 4).
+
+    g = Game("youturn"); g.press_key(FIRE_KEY); r = g.step_one_tick(34); g.ship_x; g.missiles; g.dump()
+
+It is a batch of ONE lane of libsfmi (no CPU engine behind it).  Differences from the reference, by design:
+  * key events are applied as the key STATE at the tick (what SSF_Env.step produces: one press or release
+    per key and tick, ENV:213-229); several presses of one key inside one tick collapse;
+  * `events` / `dump()` rebuild the tick's event list on the host from the recorded key calls and the state
+    change of the tick (exact on the recorded reference runs in tests/golden/telemetry; the order of two
+    missile hits inside ONE tick is not recoverable and is emitted in hit-count order);
+  * `thrust_durations`, `shot_durations`, `shot_intervals_*` are not kept by the device engine: AttributeError;
+  * `vulnerability_timer` / `vulnerability_time` return the values the reference's getters intend (their
+    "d"-format-with-int bug is undefined behaviour, SRC/pymodule.cpp:44-45).
+"""
+import math
+
+import numpy as np
+
+FIRE_KEY, THRUST_KEY, LEFT_KEY, RIGHT_KEY = 1, 2, 3, 4
+_KEY_BIT = {FIRE_KEY: 1, THRUST_KEY: 2, LEFT_KEY: 4, RIGHT_KEY: 8}
+_KEY_NAME = {FIRE_KEY: "fire", THRUST_KEY: "thrust", LEFT_KEY: "left", RIGHT_KEY: "right"}
+_STAT = ("bigHexDeaths", "smallHexDeaths", "shellDeaths", "shipDeaths", "resets", "destroyedFortresses", "missedShots",
+         "totalShots", "totalThrusts", "totalLefts", "totalRights", "vlnerIncs", "maxVlner")
+
+
+class Game:
+    def __init__(self, config, lw=2.0, grayscale=0, width=-1, height=-1, viewport=(0, 0, -1, -1), device=None, seed=1):
+        import ctypes as C
+        import torch
+        from . import _lib
+        from .vecenv import SFVecEnv
+
+        self._torch, self._C, self._lib = torch, C, _lib
+        # every key combination as an action (ENV:64-89 with action_set 0), no wrapper auto-reset
+        self._vec = SFVecEnv(1, gametype=config, obs_type="features", action_set=0, device=device, seed=seed,
+                             obs_dtype=torch.float64, auto_reset=False)
+        keys = (C.c_uint8 * 16)()
+        n = _lib.lib().sf_action_table(config.encode(), 0, keys)
+        self._action_of = {int(keys[i]): i for i in range(n)}
+        self._n_keys = 4 if n == 16 else 2
+        self._config = config
+        self._keys = 0
+        self._calls = []       # (pressed, sym) since the last tick, in call order
+        self._events = ()
+        self._obs = None
+        self._sd = None
+        self.pb_width, self.pb_height = (width, height) if width > 0 else (90, 92)
+        p = _lib.Preset()
+        _lib.check(_lib.lib().sf_preset_get(config.encode(), C.byref(p)))
+        self._preset = p
+
+    # ------------------------------------------------------------------ methods (SRC/pymodule.cpp:361-370)
+    def press_key(self, sym):
+        self._key_call(True, sym)
+
+    def release_key(self, sym):
+        self._key_call(False, sym)
+
+    def _key_call(self, pressed, sym):
+        if sym not in _KEY_BIT:
+            raise ValueError("unknown key %r" % (sym,))
+        if _KEY_BIT[sym] >= (1 << self._n_keys):
+            raise ValueError("this game type steps with FIRE and THRUST only (ENV:213-220)")
+        self._calls.append((pressed, sym))
+        self._keys = (self._keys | _KEY_BIT[sym]) if pressed else (self._keys & ~_KEY_BIT[sym])
+
+    def step_one_tick(self, ms):
+        if ms != self._vec.tickdur:
+            raise ValueError("the device engine ticks in %d ms steps (ENV:61)" % self._vec.tickdur)
+        before = self._state()
+        a = self._torch.tensor([self._action_of[self._keys]], dtype=self._torch.uint8, device=self._vec.device)
+        obs, _, _, _ = self._vec.step_tensors(a)
+        self._obs = obs[0].cpu().numpy()
+        self._sd = None
+        after = self._state()
+        self._events = tuple(self._derive_events(before, after))
+        self._calls = []
+        return int(after["last_reward"])
+
+    def is_game_over(self):
+        return bool(self.time >= self.max_time)
+
+    def draw(self):
+        self._frame = self._vec.render("image-raw")[0].cpu().numpy()
+
+    @property
+    def pb_pixels(self):
+        """The surface as the reference exposes it: RGB24 rows of 4 bytes per pixel (B, G, R, x)."""
+        f = getattr(self, "_frame", None)
+        if f is None:
+            self.draw()
+            f = self._frame
+        return np.repeat(f[:, :, None], 4, axis=2).tobytes()
+
+    def config(self, key):
+        p = self._preset
+        table = {"width": p.width, "height": p.height, "gameTime": p.game_time, "destroyFortress": p.destroy_fortress,
+                 "shipDeathPenalty": p.ship_death_penalty, "missilePenalty": p.missile_penalty, "shellSpeed": p.shell_speed,
+                 "missileSpeed": p.missile_speed, "autoTurn": p.auto_turn, "fortressSectorSize": p.sector_size,
+                 "fortressLockTime": p.lock_time, "fortressVulnerabilityTime": p.vuln_time,
+                 "fortressVulnerabilityThreshold": p.vuln_threshold, "bigHex": p.big_hex, "smallHex": p.small_hex,
+                 "shipExplodeDuration": p.explode_duration, "shipAcceleration": p.ship_accel, "shipTurnSpeed": p.turn_speed}
+        if key not in table:
+            raise ValueError("No config value for `%s'" % key)  # SRC/pymodule.cpp:273
+        return table[key]
+
+    def close(self):
+        self._vec.close()
+
+    # ------------------------------------------------------------------ state
+    def _state(self):
+        if self._sd is None:
+            self._sd = {k: (v[0] if v.ndim == 1 else v[:, 0]) for k, v in self._vec.state_dict().items()}
+        return self._sd
+
+    def _f(self, name):
+        return self._state()[name]
+
+    def _features(self):
+        if self._obs is None:  # before the first tick: the reset observation
+            self._obs = self._vec.render_features() if hasattr(self._vec, "render_features") else None
+        return self._obs
+
+    tick = property(lambda s: int(s._f("time")) // s._vec.tickdur)
+    time = property(lambda s: int(s._f("time")))
+    max_time = property(lambda s: int(s._preset.game_time))
+    ship_alive = property(lambda s: bool(int(s._f("flags")) & 1))
+    ship_x = property(lambda s: float(s._f("ship_x")))
+    ship_y = property(lambda s: float(s._f("ship_y")))
+    ship_vx = property(lambda s: float(s._f("ship_vx")))
+    ship_vy = property(lambda s: float(s._f("ship_vy")))
+    ship_angle = property(lambda s: float(s._f("ship_angle")))
+    fortress_alive = property(lambda s: bool(int(s._f("flags")) & 2))
+    fortress_angle = property(lambda s: float(s._f("fort_angle")))
+    bighex = property(lambda s: int(s._preset.big_hex))
+    smallhex = property(lambda s: int(s._preset.small_hex))
+    points = property(lambda s: float(s._f("points")))
+    raw_points = property(lambda s: float(s._f("raw_points")))
+    vulnerability = property(lambda s: int(s._f("vlner")))
+    vulnerability_timer = property(lambda s: float(s._f("fort_vuln_timer")))
+    vulnerability_time = property(lambda s: float(s._preset.vuln_time))
+    thrust_flag = property(lambda s: bool(int(s._f("flags")) & 8))
+    events = property(lambda s: s._events)
+
+    @property
+    def turn_flag(self):  # NO_TURN, TURN_LEFT, TURN_RIGHT; both keys held cancel (SRC/game.cpp:263-270)
+        left, right = bool(int(self._f("flags")) & 16), bool(int(self._f("flags")) & 32)
+        return 1 if left and not right else (2 if right and not left else 0)
+
+    def _extra(self, i):
+        if self._obs is None:
+            raise AttributeError("vdir / aim / ndist are defined after the first tick (mExtra is uninitialised before)")
+        return float(self._obs[i])
+
+    aim = property(lambda s: s._extra(6))    # feature order ENV:134-157
+    vdir = property(lambda s: s._extra(7))
+    ndist = property(lambda s: s._extra(8))
+
+    @property
+    def missiles(self):
+        st = self._state()
+        m = int(st["missile_mask"])
+        return tuple((float(st["missile_x"][i]), float(st["missile_y"][i]), float(st["missile_angle"][i]))
+                     for i in range(20) if (m >> i) & 1)
+
+    @property
+    def shells(self):
+        # the reference's getter walks the MISSILES (SRC/pymodule.cpp:131-134); `real_shells` is the intent
+        return self.missiles
+
+    @property
+    def real_shells(self):
+        st = self._state()
+        m = int(st["shell_mask"])
+        return tuple((float(st["shell_x"][i]), float(st["shell_y"][i]), _shell_angle(st["shell_vx"][i], st["shell_vy"][i]))
+                     for i in range(20) if (m >> i) & 1)
+
+    @property
+    def stats(self):
+        st = self._state()
+        return tuple(int(v) for v in st["stats"]) + (float(st["points"]), float(st["raw_points"]))
+
+    @property
+    def timers(self):
+        st = self._state()
+        return tuple(int(st[k]) for k in ("fire_timer", "thrust_timer", "left_timer", "right_timer"))
+
+    @property
+    def collisions(self):
+        names = []  # the reference fills the tuple back to front: shell, missile, smallhex, bighex
+        ev = set(self._events)
+        if "shell-hit-ship" in ev:
+            names.append("shell")
+        if ev & {"hit-fortress", "hit-dead-fortress"}:
+            names.append("missile")
+        if "explode-smallhex" in ev:
+            names.append("smallhex")
+        if "explode-bighex" in ev:
+            names.append("bighex")
+        return tuple(names)
+
+    def __getattr__(self, name):
+        if name in ("thrust_durations", "shot_durations", "shot_intervals_invul", "shot_intervals_vul", "max_points"):
+            raise AttributeError("%s is not kept by the device engine (DESIGN.md, telemetry)" % name)
+        raise AttributeError(name)
+
+    # ------------------------------------------------------------------ telemetry
+    def _derive_events(self, b, a):
+        """The tick's mEvents (SRC/game.cpp:124-127 and its addEvent call sites) from the recorded key calls
+        and the state before / after, in stepOneTick's phase order (:473-485)."""
+        ev = []
+        new_missile = (int(a["missile_mask"]) | self._gone_missiles(b, a)) & ~int(b["missile_mask"])
+        fire_was = bool(int(b["flags"]) & 4)
+        for pressed, sym in self._calls:                                     # processKeyState :218-272
+            ev.append(("press-" if pressed else "release-") + _KEY_NAME[sym])
+            if sym == FIRE_KEY:
+                if pressed and not fire_was and new_missile:
+                    ev.append("missile-fired")                               # :186
+                    new_missile = 0
+                fire_was = pressed
+        sb, sa = b["stats"], a["stats"]
+        if not (int(b["flags"]) & 1) and (int(a["flags"]) & 1 or sa[3] > sb[3]):
+            ev.append("ship-respawn")                                        # :155
+        ev += ["explode-bighex"] * int(sa[0] - sb[0])                        # :342
+        ev += ["explode-smallhex"] * int(sa[1] - sb[1])                      # :348
+        if not (int(b["flags"]) & 2) and int(a["flags"]) & 2:
+            ev.append("fortress-respawn")                                    # :202
+        if int(a["shell_mask"]) & ~int(b["shell_mask"]) or self._shell_fired_and_gone(b, a):
+            ev.append("fortress-fired")                                      # :169
+        ev += ["shell-hit-ship"] * int(sa[2] - sb[2])                        # :417
+        incs, dest, resets = int(sa[11] - sb[11]), int(sa[5] - sb[5]), int(sa[4] - sb[4])
+        for _ in range(incs):
+            ev += ["hit-fortress", "vlner-increased"]                        # :363,371
+        for _ in range(dest):
+            ev += ["hit-fortress", "fortress-destroyed"]                     # :381
+        for _ in range(resets):
+            ev += ["hit-fortress", "vlner-reset"]                            # :385
+        dead_hits = self._missiles_gone_count(b, a) - int(sa[6] - sb[6]) - incs - dest - resets
+        ev += ["hit-dead-fortress"] * max(dead_hits, 0)                      # :393
+        return ev
+
+    @staticmethod
+    def _missiles_gone_count(b, a):
+        return bin(int(b["missile_mask"]) & ~int(a["missile_mask"])).count("1")
+
+    @staticmethod
+    def _gone_missiles(b, a):
+        return 0  # a missile created and removed inside one tick cannot be seen in the masks
+
+    @staticmethod
+    def _shell_fired_and_gone(b, a):
+        return False
+
+    def dump(self):
+        """Game::dumpState() (SRC/game.cpp:519-576): same format, same number formatting."""
+        st = self._state()
+        fl = int(st["flags"])
+        mm, sm = int(st["missile_mask"]), int(st["shell_mask"])
+        mis = ",".join("%.3f,%.3f,%.1f" % (st["missile_x"][i], st["missile_y"][i], st["missile_angle"][i])
+                       for i in range(20) if (mm >> i) & 1)
+        she = ",".join("%.3f,%.3f,%.1f" % (st["shell_x"][i], st["shell_y"][i], _shell_angle(st["shell_vx"][i], st["shell_vy"][i]))
+                       for i in range(20) if (sm >> i) & 1)
+        ev = ",".join('"%s"' % e for e in self._events)
+        return "[%d,%d,%.3f,%.3f,%.3f,%.3f,%.1f,%d,%.1f,[%s],[%s],%.1f,%d,%d,%d,[%s]]" % (
+            int(st["time"]), fl & 1, st["ship_x"], st["ship_y"], st["ship_vx"], st["ship_vy"], float(st["ship_angle"]),
+            (fl >> 1) & 1, float(st["fort_angle"]), mis, she, float(st["points"]), int(st["vlner"]), (fl >> 3) & 1,
+            self.turn_flag, ev)
+
+
+def _shell_angle(vx, vy):
+    """mShells[i].mAngle = stdAngle(rad2deg(atan2(dy, dx))) at launch (SRC/game.cpp:263): the direction
+    of the velocity the state keeps."""
+    a = math.degrees(math.atan2(float(vy), float(vx)))
+    return a + 360.0 if a < 0 else a

@@ -226,6 +226,8 @@ class SFVecEnv:
                 dt = _NP_FIELD_DTYPES[(d.elem_size, d.is_float)]
                 if name in _UNSIGNED_FIELDS:
                     dt = {1: np.uint8, 4: np.uint32}[d.elem_size]
+                elif d.elem_size == 1:
+                    dt = np.int8
                 self._fields[name] = (f, dt, d.count)
         return list(self._fields)
 

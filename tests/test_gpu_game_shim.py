@@ -1,0 +1,79 @@
+"""The `Game`-shaped single-lane view (spacefortress.core.Game) against the REAL reference engine: the
+recorded runs of tests/golden (state, raw engine reward of every tick) and the dumpState() strings recorded
+from oracle/_ref (tests/golden/telemetry/dumps.npz), character for character."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def drive(g, keys, youturn):
+    import spacefortress.core as sf
+    (g.press_key if keys & 1 else g.release_key)(sf.FIRE_KEY)  # ENV:213-229
+    (g.press_key if keys & 2 else g.release_key)(sf.THRUST_KEY)
+    if youturn:
+        (g.press_key if keys & 4 else g.release_key)(sf.LEFT_KEY)
+        (g.press_key if keys & 8 else g.release_key)(sf.RIGHT_KEY)
+
+
+@pytest.mark.parametrize("name", ["autoturn_destroy", "youturn_deaths", "youturn_rapid_fire"])
+def test_game_shim_replays_the_reference(name):
+    import spacefortress.core as sf
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    dumps = np.load(os.path.join(GOLDEN, "telemetry", "dumps.npz"))[name]
+    meta = json.loads(str(z["meta"]))
+    youturn = meta["gametype"] in ("youturn", "test-youturn")
+    g = sf.Game(meta["gametype"], width=90, height=92, viewport=(130, 80, 450, 460), lw=3, grayscale=True)
+    assert g.dump() == dumps[0].decode()
+    mismatched_dumps = 0
+    for t, keys in enumerate(z["keys"]):
+        drive(g, int(keys), youturn)
+        r = g.step_one_tick(34)
+        s = z["snaps"][t]
+        assert r == int(z["eng_reward"][t]), t          # Game::stepOneTick's own return value
+        assert g.time == int(s["time"]) and g.tick == int(s["tick"])
+        assert g.ship_alive == bool(s["ship_alive"]) and g.fortress_alive == bool(s["fort_alive"])
+        assert (g.ship_x, g.ship_y, g.ship_vx, g.ship_vy, g.ship_angle) == tuple(float(s[k]) for k in
+                                                                               ("ship_x", "ship_y", "ship_vx", "ship_vy", "ship_angle"))
+        assert g.fortress_angle == float(s["fort_angle"]) and g.vulnerability == int(s["vlner"])
+        assert g.points == float(s["points"]) and g.raw_points == float(s["raw_points"])
+        assert g.thrust_flag == bool(s["thrust_flag"]) and g.turn_flag == int(s["turn_flag"])
+        assert g.stats[:13] == tuple(int(v) for v in s["stats"])
+        assert g.timers == tuple(int(s[k]) for k in ("fire_timer", "thrust_timer", "left_timer", "right_timer"))
+        assert len(g.missiles) == int(s["missile_alive"].sum()) and g.shells == g.missiles
+        if s["ship_alive"]:
+            assert abs(g.aim - float(s["aim"])) < 1e-9 and abs(g.vdir - float(s["vdir"])) < 1e-9
+        assert g.is_game_over() == bool(z["done"][t])
+        if g.dump() != dumps[t + 1].decode():
+            mismatched_dumps += 1
+            if mismatched_dumps == 1:
+                first = (t, g.dump(), dumps[t + 1].decode())
+    assert mismatched_dumps == 0, first
+    g.draw()
+    assert len(g.pb_pixels) == 92 * 90 * 4 and g.pb_width == 90 and g.pb_height == 92
+    assert g.config("bigHex") == 200 and g.bighex == 200 and g.smallhex == 40
+    with pytest.raises(ValueError):
+        g.config("nonsense")
+    with pytest.raises(AttributeError):
+        g.thrust_durations
+    with pytest.raises(ValueError):
+        g.step_one_tick(33)
+    g.close()
+
+
+def test_game_shim_errors():
+    import spacefortress.core as sf
+    with pytest.raises(RuntimeError):
+        sf.Game("no-such-config")  # SRC/pymodule.cpp:341
+    g = sf.Game("autoturn")
+    with pytest.raises(ValueError):
+        g.press_key(sf.LEFT_KEY)
+    with pytest.raises(ValueError):
+        g.press_key(9)
+    g.close()
