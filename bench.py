@@ -227,26 +227,29 @@ def main():
     image_obs = None
     if args.image_envs > 0 and rank == 0:
         ni = args.image_envs
+        from spacefortress_amd import FrameStack
         ienv = SFVecEnv(ni, gametype=args.gametype, obs_type="image", device=dev, spawn_stride=1, reuse_buffers=True)
-        ienv.reset()
+        stack = FrameStack(ienv, 4)  # BASELINE configs[4]: 84x84 grey raster + 4-frame stack
+        stack.reset()
         iacts = actions[:, :ni].contiguous() if ni <= n else torch.randint(0, ienv.n_actions, (ring, ni), device=dev,
                                                                            dtype=torch.uint8, generator=g)
         isteps = max(50, min(1000, args.steps // 4))
         for t in range(400):  # into mid-episode states: missiles, shells, explosions on screen
-            ienv.step_tensors(iacts[t % ring])
+            stack.step(iacts[t % ring])
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for t in range(isteps):
-            ienv.step_tensors(iacts[t % ring])
+            stack.step(iacts[t % ring])
         e1.record()
         torch.cuda.synchronize()
         ims = e0.elapsed_time(e1) / isteps
         image_obs = {"value": ni / ims * 1e3, "unit": "env-steps/s", "envs": ni, "steps": isteps, "us_per_step": ims * 1e3,
                      "frame_bytes_per_step": ni * 84 * 84, "frames_GBps": ni * 84 * 84 / ims / 1e6,
-                     "note": "obs_type='image' (SURVEY 8f rank 1): sf_step + sf_render per step, one wave per env "
-                             "rasterises the 90x92 frame in LDS and writes uint8 [N,1,84,84] (INTER_AREA); HIP events; "
-                             "pixel model pinned to oracle/render_np.py, not to cairo/cv2 (DESIGN.md)"}
+                     "note": "BASELINE configs[4]: youturn image obs, 84x84 grey raster + 4-frame stack (device ring "
+                             "[N,4,84,84], one new frame per env and step), sf_step + sf_frame_stack_clear + sf_render "
+                             "per step; one wave per env rasterises the 90x92 frame in LDS (INTER_AREA to 84x84); HIP "
+                             "events; pixel model pinned to the numpy restatement, not to cairo/cv2 (DESIGN.md 10)"}
         ienv.close()
     if os.environ.get("SF_PMC_CALIB"):
         # known-byte calibration dispatches for the rocprofv3 --pmc passes (tools/pmc_report.py):

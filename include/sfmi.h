@@ -143,6 +143,10 @@ int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, 
  *      DESIGN.md "image observation". ---- */
 int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, void* stream);
 
+/* `current_obs *= masks` of the trainer's frame stack (rl/train.py:92-93): zero the bytes_per_env bytes of
+ * every env whose done flag is set, touching nothing else.  stack_dev uint8 [n_envs][bytes_per_env]. */
+int sf_frame_stack_clear(uint8_t* stack_dev, size_t bytes_per_env, const uint8_t* done_dev, int n_envs, void* stream);
+
 /* Out-of-range actions are executed as NOOP and counted on the device; this reads and clears the
  * count (synchronises `stream`).  Returns SF_ERR_ACTION if any were seen since the last call. */
 int sf_check_actions(sf_batch* b, void* stream);

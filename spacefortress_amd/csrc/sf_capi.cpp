@@ -329,6 +329,15 @@ extern "C" int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_
   return render(b, mode, frames_dev, env_stride, (hipStream_t)stream);
 }
 
+extern "C" int sf_frame_stack_clear(uint8_t* stack_dev, size_t bytes_per_env, const uint8_t* done_dev, int n_envs, void* stream) {
+  if (!stack_dev || !done_dev || n_envs <= 0 || (bytes_per_env & 15) != 0 || ((uintptr_t)stack_dev & 15) != 0) {
+    sf_set_error("sf_frame_stack_clear: need 16-byte aligned stack, bytes_per_env a multiple of 16, done_dev, n_envs > 0");
+    return SF_ERR_ARG;
+  }
+  HIP_TRY(sf_launch_stack_clear(stack_dev, bytes_per_env, done_dev, n_envs, (hipStream_t)stream));
+  return SF_OK;
+}
+
 extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
   if (!b) {
     sf_set_error("sf_reset: null batch");

@@ -31,6 +31,8 @@ hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, cons
                                int do_ret, double* sums, double* sums_next, const double* stats, double* stats_next,
                                hipStream_t stream);
 
+hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n, hipStream_t stream);
+
 // sf_host.cpp (no HIP calls: usable and tested without a GPU)
 void sf_host_fill_consts(const sf_preset& p, double* consts /* SF_CONST_DOUBLES */);
 void sf_set_error(const char* fmt, ...);

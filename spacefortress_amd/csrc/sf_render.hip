@@ -616,6 +616,21 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   }
 }
 
+// current_obs *= masks (rl/train.py:92-93) for a [n][bytes_per_env] uint8 stack: only finished envs are touched
+__global__ __launch_bounds__(256) void sf_stack_clear_kernel(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n) {
+  const int env = blockIdx.x;
+  if (env >= n || !done[env]) return;
+  uint4* p = reinterpret_cast<uint4*>(stack + (size_t)env * bytes_per_env);
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (size_t i = threadIdx.x; i < bytes_per_env / 16; i += 256) p[i] = z;
+}
+
+hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sf_stack_clear_kernel, dim3((unsigned)n), dim3(256), 0, stream, stack, bytes_per_env, done, n);
+  return hipGetLastError();
+}
+
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache, int resize,
                             hipStream_t stream) {
