@@ -307,11 +307,14 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
   }
   if (!b->d_xcache && !getenv("SFMI_NO_EXPLOSION_CACHE")) {
     // first frame of this batch: the per-env explosion cache (feature-only batches never pay for it)
+    // ... followed by the 36 fortress pictures, drawn here once
     const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES;
-    HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes));
-    HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes, stream));
+    HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes + 36 * SF_FP_BYTES));
+    HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes + 36 * SF_FP_BYTES, stream));
+    HIP_TRY(sf_launch_fort_patches(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes, stream));
   }
-  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache,
+  const unsigned char* fpatch = b->d_xcache ? b->d_xcache + (size_t)b->n_envs * SF_XC_BYTES : nullptr;
+  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache, fpatch,
                            mode == SF_OBS_IMAGE ? 1 : 0, stream));
   return SF_OK;
 }

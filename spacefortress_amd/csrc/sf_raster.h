@@ -42,6 +42,8 @@
 #define SF_BG_STRIDE 8288
 // per-env cache of the dead ship's explosion pixels (sf_render.hip: ship_explosion)
 #define SF_XC_BYTES 1600
+// one fortress picture (sf_render.hip: fort_patch_copy): 16 x 16 of the surface, 18 rows x 20 of the 84x84 image
+#define SF_FP_BYTES 640
 
 namespace sfr {
 

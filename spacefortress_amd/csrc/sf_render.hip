@@ -37,6 +37,7 @@ constexpr int kFbWords = kFbBytes / 4;                 // 2070
 constexpr int kFbPadWords = (SF_IMG_W * (SF_IMG_H + 1) + 3) / 4 + 1;  // one spare row for zero-weight taps
 constexpr int kFbVec = kFbBytes / 16;                  // 517 (+ 8 bytes)
 constexpr int kOutBytes = SF_OUT * SF_OUT;             // 7056 = 441 * 16
+constexpr int kMaskScratch = 256;                      // coverage masks of one small object (draw_objects)
 
 struct d2_t {
   double x, y;
@@ -149,6 +150,8 @@ struct Frame {
   uint8_t* obuf;
   const uint32_t* tab;  // LDS copy of the tap tables (sf_raster.h)
   int lane;
+  float* qscr;          // LDS: 4 quads of the object being drawn (draw_objects)
+  uint8_t* mscr;        // LDS: kMaskScratch coverage masks
 
   // cv2.resize(..., INTER_AREA) restricted to the destination pixels that read source pixels of `b`
   // (OpenCV's resizeArea_ arithmetic: per source row buf = sum alpha * S, then sum += beta * buf in
@@ -222,6 +225,90 @@ struct Frame {
       __builtin_amdgcn_wave_barrier();
     }
     resample(dirty);
+  }
+
+  // Small objects (missiles: 3 strokes, shells: 4) -- lanes [k*per, (k+1)*per) hold the strokes of object k.
+  // A stroke covers a dozen pixels, so walking strokes one by one leaves most of the wave idle.  Per object:
+  //   1. all (stroke, pixel) pairs of the object at once: coverage masks into LDS;
+  //   2. a lane per pixel of the object's box composites the strokes that cover it, in stroke order
+  // -- the same arithmetic in the same order as stroke by stroke, in about a third of the instructions.
+  __device__ __forceinline__ void draw_objects(const Quad& mine, int grey, bool valid, int per) const {
+    const Box myb = quad_box(mine);
+    const int mybw = myb.x1 - myb.x0;
+    const int myn = (valid && !myb.empty()) ? mybw * (myb.y1 - myb.y0) : 0;
+    unsigned long long live = __ballot(myn > 0);
+    while (live) {
+      const int lo = (__builtin_ctzll(live) / per) * per;
+      const unsigned objmask = (unsigned)(live >> lo) & ((1u << per) - 1u);
+      live &= ~((unsigned long long)objmask << lo);
+      // the object's strokes: geometry through LDS (owners write, everybody reads), boxes as scalars
+      int n[4], bx0[4], by0[4], bw[4], bh[4], off[5];
+      off[0] = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool on = k < per && ((objmask >> k) & 1u);
+        const int src = lo + (k < per ? k : 0);
+        n[k] = on ? __builtin_amdgcn_readlane(myn, src) : 0;
+        bx0[k] = __builtin_amdgcn_readlane(myb.x0, src);
+        by0[k] = __builtin_amdgcn_readlane(myb.y0, src);
+        bw[k] = on ? __builtin_amdgcn_readlane(mybw, src) : 1;
+        bh[k] = on ? n[k] / bw[k] : 0;
+        off[k + 1] = off[k] + n[k];
+      }
+      const int total = off[4];
+      if (total > kMaskScratch) {  // cannot happen for a missile or a shell (<= 7 x 7 pixels a stroke); stay correct anyway
+        draw_quads(mine, grey, valid && lane >= lo && lane < lo + per, per);
+        continue;
+      }
+      if (lane >= lo && lane < lo + per) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          qscr[(lane - lo) * 8 + v] = mine.x[v];
+          qscr[(lane - lo) * 8 + 4 + v] = mine.y[v];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < total; i += 64) {
+        const int k = (i >= off[1]) + (i >= off[2]) + (i >= off[3]);
+        const int j = i - (k == 0 ? off[0] : k == 1 ? off[1] : k == 2 ? off[2] : off[3]);
+        const int w = k == 0 ? bw[0] : k == 1 ? bw[1] : k == 2 ? bw[2] : bw[3];
+        const int x0 = k == 0 ? bx0[0] : k == 1 ? bx0[1] : k == 2 ? bx0[2] : bx0[3];
+        const int y0 = k == 0 ? by0[0] : k == 1 ? by0[1] : k == 2 ? by0[2] : by0[3];
+        const int ry = j / w, rx = j - ry * w;
+        Quad q;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          q.x[v] = qscr[k * 8 + v];
+          q.y[v] = qscr[k * 8 + 4 + v];
+        }
+        mscr[i] = (uint8_t)cover_to_mask(quad_cover(q, (float)(x0 + rx), (float)(y0 + ry)));
+      }
+      __builtin_amdgcn_wave_barrier();
+      Box u;
+      u.clear();
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (n[k]) u.add(bx0[k], by0[k], bx0[k] + bw[k], by0[k] + bh[k]);
+      const int uw = u.x1 - u.x0, un = uw * (u.y1 - u.y0);
+      for (int pi = lane; pi < un; pi += 64) {
+        const int ry = pi / uw, rx = pi - ry * uw;
+        const int px = u.x0 + rx, py = u.y0 + ry;
+        uint8_t* p = fb + py * SF_IMG_W + px;
+        int d = *p;
+        const int d0 = d;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int cx = px - bx0[k], cy = py - by0[k];
+          if (n[k] && cx >= 0 && cx < bw[k] && cy >= 0 && cy < bh[k]) {
+            const int m = mscr[off[k] + cy * bw[k] + cx];
+            if (m > 0) d = sfr::over_un8(d, grey, m);
+          }
+        }
+        if (d != d0) *p = (uint8_t)d;
+      }
+      __builtin_amdgcn_wave_barrier();
+      resample(u);
+    }
   }
 };
 
@@ -421,13 +508,47 @@ struct SfRenderArgs {
   uint8_t* out;
   size_t out_stride;     // bytes from one env's frame to the next (>= the frame size, multiple of 16)
   unsigned char* xcache; // SF_XC_BYTES per env (zero-initialised), or null
+  const unsigned char* fpatch;  // 36 x SF_FP_BYTES: the live fortress at 0, 10, ... 350 degrees on the bare background, or null
 };
+
+// The fortress never moves and its heading is a multiple of the 10-degree sector (SRC/game.cpp:205-208):
+// 36 pictures.  sf_fort_patch_kernel draws them once per batch with the frame code below (so they are
+// bit-identical to drawing in place); a frame whose ship / explosion pixels stay clear of the fortress's
+// box then copies 256 + 306 bytes instead of rasterising four strokes.
+constexpr int kFpX0 = 37, kFpX1 = 53, kFpY0 = 39, kFpY1 = 55;  // 355 +- 37.5, 315 +- 37.5 user units, in pixels
+constexpr int kFpOutRow = 20, kFpOutAt = 256;
+static_assert(kFpX0 <= (355 - 37.5 - SF_VP_X) * SF_SCALE && kFpX1 >= (355 + 37.5 - SF_VP_X) * SF_SCALE &&
+              kFpY0 <= (315 - 37.5 - SF_VP_Y) * SF_SCALE && kFpY1 >= (315 + 37.5 - SF_VP_Y) * SF_SCALE, "fortress box");
+
+template <bool RESIZE>
+__device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned char* gp, bool store) {
+  const Box b{kFpX0, kFpY0, kFpX1, kFpY1}, o = out_box(b);
+  const int lane = F.lane;
+  for (int i = lane; i < 256; i += 64) {
+    uint8_t* p = F.fb + (kFpY0 + (i >> 4)) * SF_IMG_W + kFpX0 + (i & 15);
+    if (store) gp[i] = *p; else *p = gp[i];
+  }
+  if (RESIZE) {
+    const int ow = o.x1 - o.x0, oh = o.y1 - o.y0;  // 17 x 18
+    for (int i = lane; i < kFpOutRow * oh; i += 64) {
+      const int r = i / kFpOutRow, c = i - r * kFpOutRow;
+      if (c < ow) {
+        uint8_t* p = F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c;
+        if (store) gp[kFpOutAt + i] = *p; else *p = gp[kFpOutAt + i];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 
 template <bool RESIZE>
 __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
   __shared__ __attribute__((aligned(16))) uint32_t obufw[RESIZE ? kOutBytes / 4 : 4];
   __shared__ __attribute__((aligned(16))) uint32_t tabw[RESIZE ? SF_TAB_WORDS : 4];
+  __shared__ __attribute__((aligned(16))) float qscr[32];
+  __shared__ __attribute__((aligned(16))) uint8_t mscr[kMaskScratch];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int env = blockIdx.x, lane = threadIdx.x;
 
@@ -542,7 +663,7 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
     for (int i = lane; i < kOutBytes / 16; i += 64) dst[i] = src[i];
   }
   __syncthreads();
-  const Frame<RESIZE> F{fb, reinterpret_cast<uint8_t*>(obufw), tabw, lane};
+  const Frame<RESIZE> F{fb, reinterpret_cast<uint8_t*>(obufw), tabw, lane, qscr, mscr};
 
   // ---- ship (SRC/draw.cpp:233-237)
   if (SF_RENDER_SKIP & 1) {
@@ -557,18 +678,30 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   // ---- fortress (:238-242)
   if (SF_RENDER_SKIP & 1) {
   } else if (flags & SF_FL_FORT_ALIVE) {
-    float s, c;
-    sincos_deg((float)fort_angle, &s, &c);
-    const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
-    F.draw_quads(q, 255, lane < 4, 64);
+    // what was drawn before the fortress: the ship (within 25.5 + 1.5 user units of its position) or its explosion
+    Box sb = explosion_box(ship_x, ship_y);
+    if (ship_alive) {
+      const float gx = dev_x(ship_x), gy = dev_y(ship_y), ext = 27.f * (float)SF_SCALE;
+      sb = Box{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
+    }
+    const int sector = fort_angle / 10;
+    if (a.fpatch && fort_angle >= 0 && fort_angle < 360 && sector * 10 == fort_angle &&
+        !sb.meets(Box{kFpX0 - 3, kFpY0 - 3, kFpX1 + 3, kFpY1 + 3})) {  // + what the patch's 84x84 pixels read
+      fort_patch_copy(F, const_cast<unsigned char*>(a.fpatch) + sector * SF_FP_BYTES, false);
+    } else {
+      float s, c;
+      sincos_deg((float)fort_angle, &s, &c);
+      const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
+      F.draw_quads(q, 255, lane < 4, 64);
+    }
   } else {
     draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);
   }
   // ---- missiles (:243-247), shells (:248-253): slot order
-  if (mmask) F.draw_quads(mq, 255, mvalid, 3);
+  if (mmask) F.draw_objects(mq, 255, mvalid, 3);
   if (smask) {
-    F.draw_quads(sq[0], 255, svalid[0], 4);
-    F.draw_quads(sq[1], 255, svalid[1], 4);
+    F.draw_objects(sq[0], 255, svalid[0], 4);
+    F.draw_objects(sq[1], 255, svalid[1], 4);
   }
   // ---- score (drawScore, :190-203): "%07d", grey .5, seven-segment digits; a lane per pixel of the box
   if (!baked_text && !(SF_RENDER_SKIP & 4)) {
@@ -616,6 +749,37 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   }
 }
 
+// one workgroup per sector: the live fortress drawn on the bare background, its box of the surface and of the
+// 84x84 image saved for fort_patch_copy
+__global__ __launch_bounds__(64) void sf_fort_patch_kernel(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs,
+                                                           unsigned char* fpatch) {
+  __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
+  __shared__ __attribute__((aligned(16))) uint32_t obufw[kOutBytes / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t tabw[SF_TAB_WORDS];
+  __shared__ __attribute__((aligned(16))) float qscr[32];
+  __shared__ __attribute__((aligned(16))) uint8_t mscr[kMaskScratch];
+  const int lane = threadIdx.x, sector = blockIdx.x;
+  for (int i = lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bg[i] : 0u;
+  for (int i = lane; i < kOutBytes / 4; i += 64) obufw[i] = bg84[i];
+  for (int i = lane; i < SF_TAB_WORDS; i += 64) tabw[i] = tabs[i];
+  __syncthreads();
+  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, lane, qscr, mscr};
+  float s, c;
+  sincos_deg((float)(10 * sector), &s, &c);
+  const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
+  F.draw_quads(q, 255, lane < 4, 64);
+  // (draw_quads has resampled what the strokes touch; the rest of the patch keeps the background's values,
+  //  exactly as when the fortress is drawn in place)
+  __syncthreads();
+  fort_patch_copy(F, fpatch + sector * SF_FP_BYTES, true);
+}
+
+hipError_t sf_launch_fort_patches(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(sf_fort_patch_kernel, dim3(36), dim3(64), 0, stream, bg, bg84, tabs, fpatch);
+  return hipGetLastError();
+}
+
 // current_obs *= masks (rl/train.py:92-93) for a [n][bytes_per_env] uint8 stack: only finished envs are touched
 __global__ __launch_bounds__(256) void sf_stack_clear_kernel(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n) {
   const int env = blockIdx.x;
@@ -632,10 +796,10 @@ hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uin
 }
 
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
-                            const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache, int resize,
-                            hipStream_t stream) {
+                            const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
+                            const unsigned char* fpatch, int resize, hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
-  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache};
+  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch};
   if (resize)
     hipLaunchKernelGGL(sf_render_kernel<true>, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
   else
