@@ -211,12 +211,14 @@ int sf_normalizer_set_state(sf_normalizer* z, const double* host, const double* 
  *      on `stream` of the current device) so that nothing crosses PCIe inside a rollout.
  *      sf_record_step: rl/train.py:82-88 -- reward_out = float(reward), mask_out = 1 - done,
  *      episode_rewards += reward; final_rewards = final_rewards * mask + (1 - mask) * episode_rewards;
- *      episode_rewards *= mask.  Any output / accumulator may be NULL.
+ *      episode_rewards *= mask; actions_out (int64, `rollouts.actions[step]`) = the step's actions.
+ *      Any output / accumulator may be NULL.
  *      sf_compute_returns: RolloutStorage.compute_returns (rl/storage.py:50-63) over rewards [T][n],
  *      value_preds [T+1][n] (row T is overwritten with next_value when use_gae, like the reference),
  *      masks [T+1][n], next_value [n] -> returns [T+1][n]; float32, bit-identical to the reference. ---- */
 int sf_record_step(int n, const int32_t* reward_dev, const uint8_t* done_dev, float* reward_out, float* mask_out,
-                   float* episode_rewards, float* final_rewards, void* stream);
+                   float* episode_rewards, float* final_rewards, const void* actions_dev, int act_type,
+                   int64_t* actions_out, void* stream);
 int sf_compute_returns(int num_steps, int n, const float* rewards, float* value_preds, const float* masks,
                        const float* next_value, float* returns, int use_gae, double gamma, double tau, void* stream);
 

@@ -26,11 +26,12 @@ hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32
 hipError_t sf_launch_fort_patches(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
                                   hipStream_t stream);
 
-// sf_normalize.hip: reduce + apply (two launches); sums / stats are the buffers of this step's parity,
-// *_next the other parity's
+// sf_normalize.hip: reduce + apply (two launches); partials = SF_NORM_GROUPS x 2 (dim + 1) doubles; stats is the
+// buffer of this step's parity, stats_next the other parity's
+#define SF_NORM_GROUPS 256
 hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, const int32_t* rew, float* rew_out, double* ret,
                                int n, int dim, double gamma, double eps, double clipob, double cliprew, int do_ob,
-                               int do_ret, double* sums, double* sums_next, const double* stats, double* stats_next,
+                               int do_ret, double* partials, const double* stats, double* stats_next,
                                hipStream_t stream);
 
 hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n, hipStream_t stream);

@@ -10,7 +10,7 @@ struct sf_normalizer {
   sf_normalizer_params p;
   int parity;
   double* d_ret;       // per-env discounted return (VecNormalize.ret)
-  double* d_sums[2];   // 2 * (D + 1)
+  double* d_partials;  // SF_NORM_GROUPS x 2 * (D + 1), then the ticket counter
   double* d_stats[2];  // 2 * D + 4
 };
 
@@ -74,9 +74,9 @@ extern "C" int sf_normalizer_create(const sf_normalizer_params* p, sf_normalizer
   } while (0)
   TRY_FREE(hipMalloc((void**)&z->d_ret, sizeof(double) * p->n_envs));
   TRY_FREE(hipMemset(z->d_ret, 0, sizeof(double) * p->n_envs));
+  TRY_FREE(hipMalloc((void**)&z->d_partials, sizeof(double) * (n_sums(z) * SF_NORM_GROUPS + 1)));
+  TRY_FREE(hipMemset(z->d_partials, 0, sizeof(double) * (n_sums(z) * SF_NORM_GROUPS + 1)));
   for (int k = 0; k < 2; k++) {
-    TRY_FREE(hipMalloc((void**)&z->d_sums[k], sizeof(double) * n_sums(z)));
-    TRY_FREE(hipMemset(z->d_sums[k], 0, sizeof(double) * n_sums(z)));
     TRY_FREE(hipMalloc((void**)&z->d_stats[k], sizeof(double) * n_stats(z)));
     TRY_FREE(hipMemcpy(z->d_stats[k], st.data(), sizeof(double) * n_stats(z), hipMemcpyHostToDevice));
   }
@@ -89,8 +89,8 @@ extern "C" int sf_normalizer_destroy(sf_normalizer* z) {
   if (!z) return SF_OK;
   DeviceGuard guard(z->p.device_id);
   if (z->d_ret) (void)hipFree(z->d_ret);
+  if (z->d_partials) (void)hipFree(z->d_partials);
   for (int k = 0; k < 2; k++) {
-    if (z->d_sums[k]) (void)hipFree(z->d_sums[k]);
     if (z->d_stats[k]) (void)hipFree(z->d_stats[k]);
   }
   delete z;
@@ -113,8 +113,8 @@ extern "C" int sf_normalize(sf_normalizer* z, const void* obs_dev, void* obs_out
   HIP_TRY(sf_launch_normalize(z->p.ob ? obs_dev : nullptr, z->p.ob ? obs_out_dev : nullptr, z->p.obs_f64,
                               z->p.ret ? reward_dev : nullptr, z->p.ret ? reward_out_dev : nullptr, z->d_ret, z->p.n_envs,
                               z->p.obs_dim, z->p.gamma, z->p.epsilon, z->p.clipob, z->p.cliprew, do_ob, do_ret,
-                              z->d_sums[k], z->d_sums[k ^ 1], z->d_stats[k], z->d_stats[k ^ 1], (hipStream_t)stream));
-  z->parity = k ^ 1;
+                              z->d_partials, z->d_stats[k], z->d_stats[k ^ 1], (hipStream_t)stream));
+  if (do_ob || do_ret) z->parity = k ^ 1;
   return SF_OK;
 }
 

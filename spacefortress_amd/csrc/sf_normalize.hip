@@ -11,14 +11,17 @@
 // (mean over envs, population variance over envs, n_envs); mean 0, var 1, count 1e-4 initially.
 // Parity is pinned only to the numpy restatement of that algorithm (oracle/vecnorm_np.py).
 //
-// Two launches per step, both tiny and HBM-streaming:
-//   sf_norm_reduce_kernel  a wave stages 64 rows of observations through LDS (coalesced reads), lane f
-//                          sums feature f and its square in float64; lane-per-env return update and
-//                          its two sums; one float64 atomic per feature and wave;
-//   sf_norm_apply_kernel   every workgroup merges the running statistics with the batch sums (19 values:
-//                          cheaper than a third launch), then normalises and clips its rows; workgroup
-//                          0 stores the merged statistics.  Statistics and sums are double-buffered by
-//                          step parity, so nothing is read while it is written.
+// Three small launches per step:
+//   sf_norm_reduce_kernel  256 workgroups; a wave stages 64 rows of observations through LDS (coalesced
+//                          reads), three groups of 19 lanes sum feature f and its square in float64 over
+//                          every third row; lane-per-env return update and its two sums; one row of
+//                          partial sums per workgroup (no atomics on the sums: 1024 waves adding into the
+//                          same 40 addresses serialise in L2 -- measured 45 us);
+//   sf_norm_merge_kernel   one workgroup adds the 256 rows up, merges them into the running statistics
+//                          (RunningMeanStd.update) and stores those for the other step parity;
+//   sf_norm_apply_kernel   reads the 40 merged values, normalises and clips.
+// Statistics are double-buffered by step parity so that nothing is read while it is written; sums are
+// added in a fixed order: run-to-run deterministic.
 #include <hip/hip_runtime.h>
 
 #include "sf_internal.h"
@@ -27,49 +30,8 @@ namespace {
 
 constexpr int kMaxDim = 24;  // 19 / 17 / 10 on this path; bounds the LDS staging buffer
 
-template <typename T>
-__global__ __launch_bounds__(256) void sf_norm_reduce_kernel(const T* obs, const int32_t* rew, double* ret, int n, int dim,
-                                                             double gamma, int do_ob, int do_ret, double* sums) {
-  __shared__ T stage[4][64 * kMaxDim];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long n_chunks = ((long)n + 63) / 64;
-  for (long chunk = (long)blockIdx.x * 4 + wave; chunk < n_chunks; chunk += (long)gridDim.x * 4) {
-    const long row0 = chunk * 64;
-    const int rows = (int)min((long)64, (long)n - row0);
-    if (do_ob) {
-      const T* src = obs + row0 * dim;
-      for (int i = lane; i < rows * dim; i += 64) stage[wave][i] = src[i];
-      __builtin_amdgcn_wave_barrier();
-      if (lane < dim) {
-        double s = 0, q = 0;
-        for (int r = 0; r < rows; r++) {
-          const double v = (double)stage[wave][r * dim + lane];
-          s += v;
-          q += v * v;
-        }
-        atomicAdd(&sums[lane], s);
-        atomicAdd(&sums[dim + 1 + lane], q);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (do_ret && rew) {
-      double v = 0;
-      if (lane < rows) {
-        v = ret[row0 + lane] * gamma + (double)rew[row0 + lane];
-        ret[row0 + lane] = v;
-      }
-      double s = v, q = v * v;
-      for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o);
-        q += __shfl_xor(q, o);
-      }
-      if (lane == 0) {
-        atomicAdd(&sums[dim], s);
-        atomicAdd(&sums[2 * dim + 1], q);
-      }
-    }
-  }
-}
+static_assert(SF_NORM_GROUPS == 256, "sf_internal.h");
+constexpr int kReduceGroups = SF_NORM_GROUPS;  // workgroups of the reduction = rows of partial sums
 
 // RunningMeanStd.update with batch (sum, sumsq, n): returns merged mean/var/count
 __device__ __forceinline__ void merge(double mean, double var, double count, double sum, double sumsq, double n,
@@ -84,46 +46,126 @@ __device__ __forceinline__ void merge(double mean, double var, double count, dou
   *ncount = tot;
 }
 
+// stats: [0,D) mean, [D,2D) var, [2D] ret mean, [2D+1] ret var, [2D+2] ob count, [2D+3] ret count
+// partials: [kReduceGroups][2 * (dim + 1)] doubles -- per workgroup: sum per feature, sum of returns, sum of
+// squares per feature, sum of squared returns
+template <typename T>
+__global__ __launch_bounds__(256) void sf_norm_reduce_kernel(const T* obs, const int32_t* rew, double* ret, int n, int dim,
+                                                             double gamma, int do_ob, int do_ret, double* partials) {
+  __shared__ T stage[4][64 * kMaxDim];
+  __shared__ double wsum[4][2 * (kMaxDim + 1)];
+  __shared__ double fold[4][2][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long n_chunks = ((long)n + 63) / 64;
+  const int groups = 64 / dim;
+  double s = 0, q = 0;    // lane g*dim + f: feature f, rows g, g + groups, ...
+  double rs = 0, rq = 0;  // every lane: its envs' returns
+  for (long chunk = (long)blockIdx.x * 4 + wave; chunk < n_chunks; chunk += (long)gridDim.x * 4) {
+    const long row0 = chunk * 64;
+    const int rows = (int)min((long)64, (long)n - row0);
+    if (do_ob) {
+      const T* src = obs + row0 * dim;
+      for (int i = lane; i < rows * dim; i += 64) stage[wave][i] = src[i];
+      __builtin_amdgcn_wave_barrier();
+      if (lane < groups * dim)
+        for (int r = lane / dim; r < rows; r += groups) {
+          const double v = (double)stage[wave][r * dim + lane % dim];
+          s += v;
+          q += v * v;
+        }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (do_ret && lane < rows) {
+      const double v = ret[row0 + lane] * gamma + (double)rew[row0 + lane];
+      ret[row0 + lane] = v;
+      rs += v;
+      rq += v * v;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    rs += __shfl_xor(rs, o);
+    rq += __shfl_xor(rq, o);
+  }
+  fold[wave][0][lane] = s;
+  fold[wave][1][lane] = q;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < dim) {
+    double ts = 0, tq = 0;
+    for (int g = 0; g < groups; g++) {
+      ts += fold[wave][0][g * dim + lane];
+      tq += fold[wave][1][g * dim + lane];
+    }
+    wsum[wave][lane] = ts;
+    wsum[wave][dim + 1 + lane] = tq;
+  }
+  if (lane == 0) {
+    wsum[wave][dim] = rs;
+    wsum[wave][2 * dim + 1] = rq;
+  }
+  __syncthreads();
+  const int t = threadIdx.x, width = 2 * (dim + 1);
+  // column-major: partials[c][workgroup], so that the merge reads each column as one contiguous row
+  if (t < width) partials[(size_t)t * kReduceGroups + blockIdx.x] = (wsum[0][t] + wsum[1][t]) + (wsum[2][t] + wsum[3][t]);
+}
+
+// One workgroup: column c of the partial sums is 256 contiguous doubles; wave w takes the columns c = w, w + 4,
+// ...: a lane adds four of them, a butterfly the 64 lanes -- a fixed order, so the statistics are run-to-run
+// deterministic -- then RunningMeanStd.update per feature and for the returns.  (Folding this into the
+// reduction behind a "last workgroup" ticket was tried: 256 atomics on one address cost 11 us.)
+__global__ __launch_bounds__(256) void sf_norm_merge_kernel(const double* partials, int n, int dim, int do_ob, int do_ret,
+                                                            const double* stats, double* stats_next) {
+  __shared__ double total[2 * (kMaxDim + 1)];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = threadIdx.x, width = 2 * (dim + 1);
+  for (int c = wave; c < width; c += 4) {
+    const double* col = partials + (size_t)c * kReduceGroups;
+    double v = (col[lane] + col[lane + 64]) + (col[lane + 128] + col[lane + 192]);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) total[c] = v;
+  }
+  __syncthreads();
+  if (t <= dim) {
+    const bool is_ret = t == dim;
+    const bool upd = is_ret ? do_ret != 0 : do_ob != 0;
+    double mean = is_ret ? stats[2 * dim] : stats[t], var = is_ret ? stats[2 * dim + 1] : stats[dim + t];
+    double count = stats[2 * dim + 2 + (is_ret ? 1 : 0)];
+    if (upd) merge(mean, var, count, total[t], total[dim + 1 + t], (double)n, &mean, &var, &count);
+    if (is_ret) {
+      stats_next[2 * dim] = mean;
+      stats_next[2 * dim + 1] = var;
+      stats_next[2 * dim + 3] = count;
+    } else {
+      stats_next[t] = mean;
+      stats_next[dim + t] = var;
+      if (t == 0) stats_next[2 * dim + 2] = count;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sf_norm_apply_kernel(const T* obs, T* obs_out, const int32_t* rew, float* rew_out,
                                                             int n, int dim, double eps, double clipob, double cliprew,
-                                                            int do_ob, int do_ret, const double* sums, double* sums_next,
-                                                            const double* stats, double* stats_next) {
+                                                            const double* stats) {
   __shared__ double s_mean[kMaxDim + 1], s_inv[kMaxDim + 1];
   const int t = threadIdx.x;
-  // stats: [0,D) mean, [D,2D) var, [2D] ret mean, [2D+1] ret var, [2D+2] ob count, [2D+3] ret count
   if (t <= dim) {
     const bool is_ret = t == dim;
-    const bool upd = is_ret ? (do_ret && rew) : do_ob;
-    double mean = is_ret ? stats[2 * dim] : stats[t], var = is_ret ? stats[2 * dim + 1] : stats[dim + t];
-    double count = stats[2 * dim + 2 + (is_ret ? 1 : 0)];
-    if (upd) merge(mean, var, count, sums[t], sums[dim + 1 + t], (double)n, &mean, &var, &count);
-    s_mean[t] = mean;
-    s_inv[t] = 1.0 / sqrt(var + eps);
-    if (blockIdx.x == 0) {
-      if (is_ret) {
-        stats_next[2 * dim] = mean;
-        stats_next[2 * dim + 1] = var;
-        stats_next[2 * dim + 3] = count;
-      } else {
-        stats_next[t] = mean;
-        stats_next[dim + t] = var;
-        if (t == 0) stats_next[2 * dim + 2] = count;
-      }
-      // the other parity's sums are idle now: clear them for the next step's reduction
-      sums_next[t] = 0;
-      sums_next[dim + 1 + t] = 0;
-    }
+    s_mean[t] = is_ret ? stats[2 * dim] : stats[t];
+    s_inv[t] = 1.0 / sqrt((is_ret ? stats[2 * dim + 1] : stats[dim + t]) + eps);
   }
   __syncthreads();
-  const long total = (long)n * dim;
-  if (obs_out)
-    for (long i = (long)blockIdx.x * 256 + t; i < total; i += (long)gridDim.x * 256) {
-      const int f = (int)(i % dim);
-      double v = ((double)obs[i] - s_mean[f]) * s_inv[f];
+  if (obs_out) {
+    // a thread walks a column of the flattened [n][dim] array in steps of the grid size, which is a
+    // multiple of dim: its feature index never changes (no modulo in the loop)
+    const long total = (long)n * dim, stride = (long)gridDim.x * 256;
+    const long first = (long)blockIdx.x * 256 + t;
+    const int f = (int)(first % dim);
+    const double mean = s_mean[f], inv = s_inv[f];
+    for (long i = first; i < total; i += stride) {
+      double v = ((double)obs[i] - mean) * inv;
       v = v < -clipob ? -clipob : (v > clipob ? clipob : v);
       obs_out[i] = (T)v;
     }
+  }
   if (rew && rew_out)
     for (long i = (long)blockIdx.x * 256 + t; i < n; i += (long)gridDim.x * 256) {
       double v = (double)rew[i] * s_inv[dim];  // rews / sqrt(ret_rms.var + eps): no mean subtraction
@@ -136,21 +178,31 @@ __global__ __launch_bounds__(256) void sf_norm_apply_kernel(const T* obs, T* obs
 
 hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, const int32_t* rew, float* rew_out, double* ret,
                                int n, int dim, double gamma, double eps, double clipob, double cliprew, int do_ob,
-                               int do_ret, double* sums, double* sums_next, const double* stats, double* stats_next,
+                               int do_ret, double* partials, const double* stats, double* stats_next,
                                hipStream_t stream) {
   if (n <= 0 || dim <= 0 || dim > kMaxDim) return hipErrorInvalidValue;
-  const int chunks = (n + 63) / 64;
-  const int g1 = min((chunks + 3) / 4, 1024), g2 = (int)min(((long)n * dim + 255) / 256, (long)2048);
+  const bool update = do_ob || do_ret;
+  const double* use = update ? stats_next : stats;  // frozen: normalise with the statistics as they are
+  // the apply grid is a multiple of dim workgroups so that (grid * 256) % dim == 0
+  long g2 = ((long)n * dim + 255) / 256;
+  g2 = g2 > 2048 ? 2048 : g2;
+  g2 = (g2 + dim - 1) / dim * dim;
   if (obs_f64) {
-    hipLaunchKernelGGL(sf_norm_reduce_kernel<double>, dim3(g1), dim3(256), 0, stream, (const double*)obs, rew, ret, n, dim,
-                       gamma, do_ob, do_ret, sums);
-    hipLaunchKernelGGL(sf_norm_apply_kernel<double>, dim3(g2), dim3(256), 0, stream, (const double*)obs, (double*)obs_out, rew,
-                       rew_out, n, dim, eps, clipob, cliprew, do_ob, do_ret, sums, sums_next, stats, stats_next);
+    if (update) {
+      hipLaunchKernelGGL(sf_norm_reduce_kernel<double>, dim3(kReduceGroups), dim3(256), 0, stream, (const double*)obs, rew,
+                         ret, n, dim, gamma, do_ob, do_ret, partials);
+      hipLaunchKernelGGL(sf_norm_merge_kernel, dim3(1), dim3(256), 0, stream, partials, n, dim, do_ob, do_ret, stats, stats_next);
+    }
+    hipLaunchKernelGGL(sf_norm_apply_kernel<double>, dim3((unsigned)g2), dim3(256), 0, stream, (const double*)obs,
+                       (double*)obs_out, rew, rew_out, n, dim, eps, clipob, cliprew, use);
   } else {
-    hipLaunchKernelGGL(sf_norm_reduce_kernel<float>, dim3(g1), dim3(256), 0, stream, (const float*)obs, rew, ret, n, dim,
-                       gamma, do_ob, do_ret, sums);
-    hipLaunchKernelGGL(sf_norm_apply_kernel<float>, dim3(g2), dim3(256), 0, stream, (const float*)obs, (float*)obs_out, rew,
-                       rew_out, n, dim, eps, clipob, cliprew, do_ob, do_ret, sums, sums_next, stats, stats_next);
+    if (update) {
+      hipLaunchKernelGGL(sf_norm_reduce_kernel<float>, dim3(kReduceGroups), dim3(256), 0, stream, (const float*)obs, rew, ret,
+                         n, dim, gamma, do_ob, do_ret, partials);
+      hipLaunchKernelGGL(sf_norm_merge_kernel, dim3(1), dim3(256), 0, stream, partials, n, dim, do_ob, do_ret, stats, stats_next);
+    }
+    hipLaunchKernelGGL(sf_norm_apply_kernel<float>, dim3((unsigned)g2), dim3(256), 0, stream, (const float*)obs,
+                       (float*)obs_out, rew, rew_out, n, dim, eps, clipob, cliprew, use);
   }
   return hipGetLastError();
 }

@@ -18,9 +18,14 @@
 namespace {
 
 __global__ __launch_bounds__(256) void sf_record_kernel(int n, const int32_t* reward, const uint8_t* done, float* reward_out,
-                                                        float* mask_out, float* episode_rewards, float* final_rewards) {
+                                                        float* mask_out, float* episode_rewards, float* final_rewards,
+                                                        const void* actions, int act_type, int64_t* actions_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (actions_out)  // rollouts.actions[step].copy_(action): a LongTensor in the reference (rl/storage.py:22-23)
+    actions_out[i] = act_type == 1 ? (int64_t) reinterpret_cast<const uint8_t*>(actions)[i]
+                   : act_type == 4 ? (int64_t) reinterpret_cast<const int32_t*>(actions)[i]
+                                   : reinterpret_cast<const int64_t*>(actions)[i];
   const float r = (float)reward[i];
   const float mask = done[i] ? 0.0f : 1.0f;
   if (reward_out) reward_out[i] = r;
@@ -71,13 +76,18 @@ __global__ __launch_bounds__(256) void sf_returns_kernel(int T, int n, const flo
 }  // namespace
 
 extern "C" int sf_record_step(int n, const int32_t* reward_dev, const uint8_t* done_dev, float* reward_out, float* mask_out,
-                              float* episode_rewards, float* final_rewards, void* stream) {
+                              float* episode_rewards, float* final_rewards, const void* actions_dev, int act_type,
+                              int64_t* actions_out, void* stream) {
   if (n <= 0 || !reward_dev || !done_dev) {
     sf_set_error("sf_record_step: need n > 0, reward_dev and done_dev");
     return SF_ERR_ARG;
   }
+  if (actions_out && (!actions_dev || (act_type != SF_ACT_U8 && act_type != SF_ACT_I32 && act_type != SF_ACT_I64))) {
+    sf_set_error("sf_record_step: actions_out needs actions_dev and act_type 1, 4 or 8");
+    return SF_ERR_ARG;
+  }
   hipLaunchKernelGGL(sf_record_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, reward_dev, done_dev,
-                     reward_out, mask_out, episode_rewards, final_rewards);
+                     reward_out, mask_out, episode_rewards, final_rewards, actions_dev, act_type, actions_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     sf_set_error("sf_record_step: %s", hipGetErrorString(e));

@@ -36,10 +36,11 @@ class DeviceRollout:
         self.masks = torch.ones(T + 1, n, 1, device=dev)
         self.episode_rewards = torch.zeros(n, 1, device=dev)  # rl/train.py:64-65
         self.final_rewards = torch.zeros(n, 1, device=dev)
-        self.num_destruction = torch.zeros((), dtype=torch.long, device=dev)
+        self._kills0 = int(env.episode_stats()[3])
         self._rew = torch.empty(n, dtype=torch.int32, device=dev)
         self._done = torch.empty(n, dtype=torch.uint8, device=dev)
         self._info = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._ptr = None
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.env.device).cuda_stream)
@@ -50,20 +51,39 @@ class DeviceRollout:
         _lib.check(e._L.sf_reset(e._h, _p(self.observations[0]), e._stream()))
         return self.observations[0]
 
+    def _pointers(self):
+        """Raw addresses of every per-step slice, made once: the step loop is host-bound otherwise
+        (a tensor view and its data_ptr() cost about a microsecond each)."""
+        T = self.num_steps
+        vp = C.c_void_p
+        self._ptr = {
+            "obs": [vp(self.observations[t].data_ptr()) for t in range(T + 1)],
+            "rew": [vp(self.rewards[t].data_ptr()) for t in range(T)],
+            "mask": [vp(self.masks[t].data_ptr()) for t in range(T + 1)],
+            "act": [vp(self.actions[t].data_ptr()) for t in range(T)],
+            "r": vp(self._rew.data_ptr()), "d": vp(self._done.data_ptr()), "i": vp(self._info.data_ptr()),
+            "ep": vp(self.episode_rewards.data_ptr()), "fin": vp(self.final_rewards.data_ptr()),
+        }
+
     def step(self, step, action, value_pred=None, action_log_prob=None, state=None):
         """envs.step(action) + the bookkeeping + rollouts.insert(...) of rl/train.py:79-98.
         `action`: [N] or [N, 1] integer tensor on the device."""
         e = self.env
-        a = action.reshape(-1)
+        a = action
         if a.dtype not in (torch.uint8, torch.int32, torch.int64):
             a = a.long()
-        a = a.contiguous()
-        e.step_tensors(a, out=(self.observations[step + 1], self._rew, self._done, self._info))
-        _lib.check(self._L.sf_record_step(e.num_envs, _p(self._rew), _p(self._done), _p(self.rewards[step]),
-                                          _p(self.masks[step + 1]), _p(self.episode_rewards), _p(self.final_rewards),
-                                          self._stream()))
-        self.num_destruction += self._info.sum()  # num_destruction += sum(info), rl/train.py:81
-        self.actions[step].copy_(a.view(-1, 1))
+        if not a.is_contiguous():
+            a = a.contiguous()
+        if a.numel() != e.num_envs or a.device != e.device:
+            raise ValueError("action must hold %d elements on %s" % (e.num_envs, e.device))
+        if self._ptr is None:
+            self._pointers()
+        P = self._ptr
+        stream = self._stream()
+        ap, at = C.c_void_p(a.data_ptr()), a.element_size()
+        _lib.check(self._L.sf_step(e._h, ap, at, P["obs"][step + 1], P["r"], P["d"], P["i"], stream))
+        _lib.check(self._L.sf_record_step(e.num_envs, P["r"], P["d"], P["rew"][step], P["mask"][step + 1], P["ep"], P["fin"],
+                                          ap, at, P["act"][step], stream))
         if value_pred is not None:
             self.value_preds[step].copy_(value_pred)
         if action_log_prob is not None:
@@ -71,6 +91,11 @@ class DeviceRollout:
         if state is not None:
             self.states[step + 1].copy_(state)
         return self.observations[step + 1], self.rewards[step], self.masks[step + 1]
+
+    @property
+    def num_destruction(self):
+        """num_destruction += sum(info) of rl/train.py:81, from the step kernel's own accumulator (synchronises)."""
+        return int(self.env.episode_stats()[3]) - self._kills0
 
     def compute_returns(self, next_value, use_gae, gamma, tau):
         """rl/storage.py:50-63 in one launch."""

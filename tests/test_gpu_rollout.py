@@ -50,12 +50,12 @@ def test_record_step_bit_exact(sfa):
     r_out, m_out = torch.empty(n, device=dev), torch.empty(n, device=dev)
     for t in range(T):
         r, d = torch.from_numpy(z["rewards"][t]).to(dev), torch.from_numpy(z["done"][t]).to(dev)
-        _lib.check(_lib.lib().sf_record_step(n, _p(r), _p(d), _p(r_out), _p(m_out), _p(ep), _p(fin), None))
+        _lib.check(_lib.lib().sf_record_step(n, _p(r), _p(d), _p(r_out), _p(m_out), _p(ep), _p(fin), None, 0, None, None))
         assert np.array_equal(m_out.cpu().numpy(), z["masks"][t])
         assert np.array_equal(r_out.cpu().numpy(), z["rewards"][t].astype(np.float32))
         assert np.array_equal(ep.cpu().numpy(), z["episode_rewards"][t])
         assert np.array_equal(fin.cpu().numpy(), z["final_rewards"][t])
-    assert _lib.lib().sf_record_step(0, None, None, None, None, None, None, None) < 0
+    assert _lib.lib().sf_record_step(0, None, None, None, None, None, None, None, 0, None, None) < 0
 
 
 def test_device_rollout_end_to_end(sfa):
