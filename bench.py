@@ -224,6 +224,21 @@ def main():
         dt = time.perf_counter() - th
         host_api = {"value": n * args.numpy_api / dt, "unit": "env-steps/s", "ms_per_step": dt / args.numpy_api * 1e3,
                     "note": "numpy int64 actions in, numpy obs/reward/done/info out every step (PCIe both ways)"}
+    # a measured ceiling beside the 8 TB/s spec peak: device-to-device copy of 1 GiB, read + write bytes
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * src.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
     image_obs = None
     if args.image_envs > 0 and rank == 0:
         ni = args.image_envs
@@ -285,6 +300,8 @@ def main():
                        "parallelism": "%d independent shard(s), one process per GPU" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "measured_copy_ceiling_GBps": copy_gbs,
+                         "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                          "traffic": pmc_traffic(args.gametype, n, args.obs_type),
                          "kernel": "sf_step_kernel", "kernel_ms_mean": region_ms,
                          "kernel_ms_event_pair_mean": kern_ms, "kernel_ms_event_pair_median": kern_ms_med,

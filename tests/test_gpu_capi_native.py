@@ -1,0 +1,41 @@
+"""The drop-in boundary without Python on top: a C++ program with nothing but HIP buffers and include/sfmi.h
+(tests/capi/demo.cpp) is compiled against libsfmi.so, run, and must print the same numbers as the Python host
+side fed with the same actions."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_native_caller_matches_python_host_side(tmp_path):
+    from spacefortress_amd import SFVecEnv, _lib
+    exe = str(tmp_path / "sfmi_demo")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", os.path.join(ROOT, "tests", "capi", "demo.cpp"), "-I" + os.path.join(ROOT, "include"),
+                           "-L" + libdir, "-lsfmi", "-Wl,-rpath," + libdir, "-o", exe])
+    n, steps = 1000, 300
+    out = subprocess.run([exe, str(n), str(steps)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = dict(kv.split("=") for kv in out.stdout.split())
+    env = SFVecEnv(n, gametype="youturn", spawn_stride=1)
+    env.reset()
+    lcg, rsum = 12345, 0
+    for t in range(steps):
+        a = np.empty(n, np.uint8)
+        for i in range(n):
+            lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
+            a[i] = (lcg >> 16) % 5
+        obs, rew, done, info = env.step_tensors(torch.from_numpy(a).to(env.device))
+        rsum += int(rew.sum())
+    assert int(got["reward_sum"]) == rsum
+    assert int(got["shots"]) == int(env.get_field("stats")[7].sum())
+    assert float(got["ship_x_sum"]) == float(sum(env.get_field("ship_x").tolist()))  # same left-to-right double sum
+    assert abs(float(got["obs_sum"]) - float(obs.cpu().numpy().astype(np.float64).sum())) < 1e-6 * abs(float(got["obs_sum"]))
+    assert int(got["dim"]) == 19 and int(got["n_act"]) == 5
+    env.close()
