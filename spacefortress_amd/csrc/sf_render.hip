@@ -29,6 +29,9 @@
 #ifndef SF_RENDER_SKIP
 #define SF_RENDER_SKIP 0
 #endif
+#ifndef SF_RENDER_TABS_IN_LDS
+#define SF_RENDER_TABS_IN_LDS 0
+#endif
 
 namespace {
 
@@ -143,11 +146,14 @@ __device__ __forceinline__ Box out_box(const Box& b) {
   return o;
 }
 
-// The frame of one env: the 90x92 surface and (RESIZE) its 84x84 INTER_AREA image, both in LDS.
+// The frame of one env: the 90x92 surface in LDS and (RESIZE) its 84x84 INTER_AREA image -- which lives where it
+// is going anyway, in the caller's frame in HBM: it starts as a copy of the resampled background and only the few
+// dozen pixels an object touches are rewritten (byte stores that merge in L2).  Keeping it in LDS too cost 7 of
+// the 18 KB per env, i.e. waves per CU, on a kernel that needs them to hide its LDS round trips.
 template <bool RESIZE>
 struct Frame {
   uint8_t* fb;
-  uint8_t* obuf;
+  uint8_t* obuf;        // 84 x 84, row stride SF_OUT (global memory; LDS in sf_fort_patch_kernel)
   const uint32_t* tab;  // LDS copy of the tap tables (sf_raster.h)
   int lane;
   float* qscr;          // LDS: 4 quads of the object being drawn (draw_objects)
@@ -156,7 +162,10 @@ struct Frame {
   // cv2.resize(..., INTER_AREA) restricted to the destination pixels that read source pixels of `b`
   // (OpenCV's resizeArea_ arithmetic: per source row buf = sum alpha * S, then sum += beta * buf in
   // table order, saturate_cast<uchar>).
-  __device__ __forceinline__ void resample(const Box& b) const {
+  __device__ __forceinline__ void resample(const Box& b) const { resample_into(b, obuf, SF_OUT, 0, 0); }
+
+  // ... written to dst[(dy - y_off) * stride + (dx - x_off)]
+  __device__ __forceinline__ void resample_into(const Box& b, uint8_t* dst, int stride, int x_off, int y_off) const {
     if (!RESIZE || (SF_RENDER_SKIP & 16) || b.empty()) return;
     const Box o = out_box(b);
     const int ox0 = o.x0, oy0 = o.y0;
@@ -178,7 +187,7 @@ struct Frame {
       const float sum = (b0 * h0 + b1 * h1) + b2 * h2;  // a two-row entry has b2 = 0: adds +0
       int v = (int)rintf(sum);                            // saturate_cast<uchar>: round half to even, clamp
       v = v < 0 ? 0 : (v > 255 ? 255 : v);
-      obuf[dy * SF_OUT + dx] = (uint8_t)v;
+      dst[(dy - y_off) * stride + (dx - x_off)] = (uint8_t)v;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -483,11 +492,7 @@ __device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned 
       const int r = i / kXcRow, c = i - r * kXcRow;
       if (r < b.y1 - b.y0 && c < b.x1 - b.x0) xc[kXcFb + i] = F.fb[(b.y0 + r) * SF_IMG_W + b.x0 + c];
     }
-    if (RESIZE)
-      for (int i = lane; i < kXcOutRows * kXcRow; i += 64) {
-        const int r = i / kXcRow, c = i - r * kXcRow;
-        if (r < o.y1 - o.y0 && c < o.x1 - o.x0) xc[kXcOut + i] = F.obuf[(o.y0 + r) * SF_OUT + o.x0 + c];
-      }
+    F.resample_into(b, xc + kXcOut, kXcRow, o.x0, o.y0);  // the same values draw_explosion just gave the frame
     if (lane == 0) {
       *reinterpret_cast<double*>(xc + kXcKey) = x;
       *reinterpret_cast<double*>(xc + kXcKey + 8) = y;
@@ -545,18 +550,24 @@ __device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned
 template <bool RESIZE>
 __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
-  __shared__ __attribute__((aligned(16))) uint32_t obufw[RESIZE ? kOutBytes / 4 : 4];
+#if SF_RENDER_TABS_IN_LDS
   __shared__ __attribute__((aligned(16))) uint32_t tabw[RESIZE ? SF_TAB_WORDS : 4];
+#else
+  const uint32_t* const tabw = a.tabs;  // 2.7 KB read by every wave: L1/L2 resident; LDS is better spent on waves
+#endif
   __shared__ __attribute__((aligned(16))) float qscr[32];
   __shared__ __attribute__((aligned(16))) uint8_t mscr[kMaskScratch];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int env = blockIdx.x, lane = threadIdx.x;
+  uint8_t* const frame_out = a.out + (size_t)env * a.out_stride;
 
+#if SF_RENDER_TABS_IN_LDS
   if (RESIZE) {
     const uint4* tsrc = reinterpret_cast<const uint4*>(a.tabs);
     uint4* tdst = reinterpret_cast<uint4*>(tabw);
     for (int i = lane; i < SF_TAB_WORDS / 4; i += 64) tdst[i] = tsrc[i];
   }
+#endif
 
   // this env's lane of its wave tile
   const unsigned char* tile = a.state + (long)(env >> 6) * sfl::kTileBytes;
@@ -659,11 +670,13 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   }
   if (RESIZE) {
     const uint4* src = reinterpret_cast<const uint4*>(a.bg84 + variant * (kOutBytes / 4));
-    uint4* dst = reinterpret_cast<uint4*>(obufw);
+    uint4* dst = reinterpret_cast<uint4*>(frame_out);
     for (int i = lane; i < kOutBytes / 16; i += 64) dst[i] = src[i];
+    // the byte stores that follow must land on top of these: wait until L2 has them (vmcnt counts stores on gfx9)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  const Frame<RESIZE> F{fb, reinterpret_cast<uint8_t*>(obufw), tabw, lane, qscr, mscr};
+  const Frame<RESIZE> F{fb, frame_out, tabw, lane, qscr, mscr};
 
   // ---- ship (SRC/draw.cpp:233-237)
   if (SF_RENDER_SKIP & 1) {
@@ -737,14 +750,10 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   }
   __syncthreads();
 
-  // ---- epilogue: the frame leaves LDS in 16-byte pieces (raw: 8280 = 1035 * 8)
-  if (RESIZE) {
-    const uint4* src = reinterpret_cast<const uint4*>(obufw);
-    uint4* out = reinterpret_cast<uint4*>(a.out + (size_t)env * a.out_stride);
-    for (int i = lane; i < kOutBytes / 16; i += 64) out[i] = src[i];
-  } else {
+  // ---- epilogue: the 84x84 frame is already where it belongs; the raw one leaves LDS (8280 = 1035 * 8)
+  if (!RESIZE) {
     const uint2* src = reinterpret_cast<const uint2*>(fbw);
-    uint2* out = reinterpret_cast<uint2*>(a.out + (size_t)env * a.out_stride);
+    uint2* out = reinterpret_cast<uint2*>(frame_out);
     for (int i = lane; i < kFbBytes / 8; i += 64) out[i] = src[i];
   }
 }
