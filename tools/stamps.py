@@ -27,8 +27,7 @@ def build(lite=False):
     csrc = os.path.join(ROOT, "spacefortress_amd", "csrc")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-DSF_STAMPS"] + (["-DSF_STAMPS_LITE"] if lite else []) + ["-I" + os.path.join(ROOT, "include"), "-I" + csrc,
-           os.path.join(csrc, "sf_kernels.hip"), os.path.join(csrc, "sf_capi.cpp"), os.path.join(csrc, "sf_host.cpp"),
-           "-o", DIAG]
+           ] + [os.path.join(csrc, f) for f in __import__("spacefortress_amd.build", fromlist=["SOURCES"]).SOURCES] + ["-o", DIAG]
     subprocess.check_call(cmd)
 
 
