@@ -147,6 +147,35 @@ int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, voi
  * every env whose done flag is set, touching nothing else.  stack_dev uint8 [n_envs][bytes_per_env]. */
 int sf_frame_stack_clear(uint8_t* stack_dev, size_t bytes_per_env, const uint8_t* done_dev, int n_envs, void* stream);
 
+/* ---- telemetry: what happened in a tick, per env, as a bitmask -- the reference's per-tick event strings
+ *      (Game::addEvent, SRC/game.cpp:124-127 and its call sites :155,169,186,202,223,342,348,363,371,381,385,
+ *      393,417) without their multiplicity and order.  Key bits are STATE changes (the reference logs every
+ *      press/release call, ENV:213-229 makes one per key and tick).  Once a buffer is set, every sf_step
+ *      writes uint32 [n_envs] and every sf_rollout uint32 [n_steps][n_envs] to it; NULL switches it off. ---- */
+#define SF_EV_PRESS_FIRE 0x1u
+#define SF_EV_PRESS_THRUST 0x2u
+#define SF_EV_PRESS_LEFT 0x4u
+#define SF_EV_PRESS_RIGHT 0x8u
+#define SF_EV_RELEASE_FIRE 0x10u
+#define SF_EV_RELEASE_THRUST 0x20u
+#define SF_EV_RELEASE_LEFT 0x40u
+#define SF_EV_RELEASE_RIGHT 0x80u
+#define SF_EV_MISSILE_FIRED 0x100u      /* "missile-fired" */
+#define SF_EV_SHIP_RESPAWN 0x200u       /* "ship-respawn" */
+#define SF_EV_EXPLODE_BIGHEX 0x400u     /* "explode-bighex" */
+#define SF_EV_EXPLODE_SMALLHEX 0x800u   /* "explode-smallhex" */
+#define SF_EV_FORTRESS_RESPAWN 0x1000u  /* "fortress-respawn" */
+#define SF_EV_FORTRESS_FIRED 0x2000u    /* "fortress-fired" */
+#define SF_EV_SHELL_HIT_SHIP 0x4000u    /* "shell-hit-ship" */
+#define SF_EV_HIT_FORTRESS 0x8000u      /* "hit-fortress" */
+#define SF_EV_VLNER_INCREASED 0x10000u  /* "vlner-increased" */
+#define SF_EV_FORTRESS_DESTROYED 0x20000u /* "fortress-destroyed" */
+#define SF_EV_VLNER_RESET 0x40000u      /* "vlner-reset" */
+#define SF_EV_HIT_DEAD_FORTRESS 0x80000u /* "hit-dead-fortress" */
+#define SF_EV_MISSILE_LEFT 0x100000u    /* a missile left the game area (Stats.missedShots; no string in the reference) */
+#define SF_EV_GAME_OVER 0x200000u       /* is_game_over() became true (the env is auto-reset unless SF_FLAG_NO_AUTO_RESET) */
+int sf_set_event_output(sf_batch* b, uint32_t* events_dev);
+
 /* Out-of-range actions are executed as NOOP and counted on the device; this reads and clears the
  * count (synchronises `stream`).  Returns SF_ERR_ACTION if any were seen since the last call. */
 int sf_check_actions(sf_batch* b, void* stream);

@@ -15,6 +15,13 @@ SF_OK = 0
 SF_ERR_PRESET, SF_ERR_ARG, SF_ERR_HIP, SF_ERR_NO_DEVICE, SF_ERR_ACTION, SF_ERR_FIELD = -1, -2, -3, -4, -5, -6
 OBS_TYPES = {"features": 0, "normalized-features": 1, "monitors": 2, "none": 3, "image": 4, "image-raw": 5}
 IMAGE_W, IMAGE_H, IMAGE_OUT = 90, 92, 84
+# SF_EV_* (include/sfmi.h): bit -> the reference's event string, in the order Game::stepOneTick can emit them
+EVENT_NAMES = {0x1: "press-fire", 0x2: "press-thrust", 0x4: "press-left", 0x8: "press-right", 0x10: "release-fire",
+               0x20: "release-thrust", 0x40: "release-left", 0x80: "release-right", 0x100: "missile-fired",
+               0x200: "ship-respawn", 0x400: "explode-bighex", 0x800: "explode-smallhex", 0x1000: "fortress-respawn",
+               0x2000: "fortress-fired", 0x4000: "shell-hit-ship", 0x8000: "hit-fortress", 0x10000: "vlner-increased",
+               0x20000: "fortress-destroyed", 0x40000: "vlner-reset", 0x80000: "hit-dead-fortress",
+               0x100000: "missile-left", 0x200000: "game-over"}
 FLAG_OBS_F64 = 1
 FLAG_REAL_SHELL_COUNT = 2
 FLAG_NO_AUTO_RESET = 4
@@ -85,6 +92,7 @@ SYMBOLS = {
     "sf_record_step": (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]),
     "sf_compute_returns": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "sf_frame_stack_clear": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    "sf_set_event_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sf_render": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sf_image_background": (C.c_int, [C.c_void_p]),
     "sf_image_static": (C.c_int, [C.c_int, C.c_void_p]),

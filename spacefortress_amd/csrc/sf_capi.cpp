@@ -396,6 +396,16 @@ extern "C" int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, in
   return SF_OK;
 }
 
+extern "C" int sf_set_event_output(sf_batch* b, uint32_t* events_dev) {
+  if (!b) return SF_ERR_ARG;
+  if (((uintptr_t)events_dev & 3) != 0) {
+    sf_set_error("sf_set_event_output: the buffer must be 4-byte aligned");
+    return SF_ERR_ARG;
+  }
+  b->args.events = events_dev;
+  return SF_OK;
+}
+
 extern "C" int sf_check_actions(sf_batch* b, void* stream) {
   if (!b) return SF_ERR_ARG;
   DeviceGuard guard(b->device);

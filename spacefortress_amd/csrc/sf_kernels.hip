@@ -612,10 +612,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   //      flag; an edge zeroes that key's timer (:227,231,235,244,250,253,257,261), a press edge
   //      counts (:228,232,236,245).
   int new_m_slot = -1;
+  unsigned key_edges;  // SF_EV_PRESS_* | SF_EV_RELEASE_*: the key STATE changes of this tick
   {
     const unsigned kmask = AUTOTURN ? 0x3u : 0xFu;  // autoturn games send two keys (ENV:221)
     const unsigned old = (L.fl >> 2) & kmask, now = keys & kmask;
     const unsigned edge = old ^ now, press = now & ~old;
+    key_edges = press | ((old & ~now) << 4);
     L.fl = (L.fl & ~(kmask << 2)) | (now << 2);
     L.fire_t = (edge & 1u) ? 0 : L.fire_t;
     L.thrust_t = (edge & 2u) ? 0 : L.thrust_t;
@@ -692,12 +694,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   // ---- updateFortress (SRC/game.cpp:194-216)
   int new_s_slot = -1;
   double new_s_vx = 0, new_s_vy = 0;
+  bool fort_respawned = false;
   {
     double ats = rad2deg(a_pos);  // stdAngle: in [-180, 180], only the sign fix applies
     if (ats < 0) ats += 360;
     if (!(L.fl & SF_FL_FORT_ALIVE) && L.fort_death_t > sfc::fort_respawn) {
       L.fort_t = 0;
       L.fl |= SF_FL_FORT_ALIVE;
+      fort_respawned = true;
     }
     if (L.fl & SF_FL_SHIP_ALIVE) {
       double q = ceil(ats / sfc::sector_size) * sfc::sector_size;  // in [0, 360]
@@ -826,6 +830,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   // ---- updateMissiles (SRC/game.cpp:353-402).  Ballistics per slot are independent; what a hit
   //      or a miss does to the fortress / score is order dependent, so the events are collected
   //      as bitmasks and replayed in slot order afterwards.
+  unsigned hit_count = 0;  // missiles that reached the fortress this tick (alive or not)
   {
     unsigned ev_hit = 0, ev_out = 0;
     auto m_move = [&](int s, double x, double y, int ang, bool isnew, double& nx, double& ny)
@@ -879,6 +884,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       }
     }
     unsigned ev = ev_hit | ev_out;
+    hit_count = __popc(ev_hit);
     L.mmask &= ~ev;
     if (__ballot(ev != 0u) != 0ull) {
       while (ev) {  // slot order (SRC/game.cpp:355)
@@ -936,6 +942,20 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     L.prev_vlner = L.vlner;
   }
   const int done = L.time >= sfc::game_time;  // Game::isGameOver (SRC/game.cpp:487-489)
+
+  // ---- optional telemetry: what happened this tick, as a bitmask (the reference's addEvent strings,
+  //      SRC/game.cpp:124-127 and its call sites; include/sfmi.h SF_EV_*).  Everything it needs is already live.
+  unsigned evmask = 0;
+  if (a.events) {
+    const int live_hits = S.vlner_incs + S.destroyed + S.resets;
+    evmask = key_edges | (new_m_slot >= 0 ? SF_EV_MISSILE_FIRED : 0u) | (will_respawn ? SF_EV_SHIP_RESPAWN : 0u) |
+             (S.big_hex_deaths ? SF_EV_EXPLODE_BIGHEX : 0u) | (S.small_hex_deaths ? SF_EV_EXPLODE_SMALLHEX : 0u) |
+             (fort_respawned ? SF_EV_FORTRESS_RESPAWN : 0u) | (new_s_slot >= 0 ? SF_EV_FORTRESS_FIRED : 0u) |
+             (S.shell_deaths ? SF_EV_SHELL_HIT_SHIP : 0u) | (live_hits ? SF_EV_HIT_FORTRESS : 0u) |
+             (S.vlner_incs ? SF_EV_VLNER_INCREASED : 0u) | (S.destroyed ? SF_EV_FORTRESS_DESTROYED : 0u) |
+             (S.resets ? SF_EV_VLNER_RESET : 0u) | ((int)hit_count > live_hits ? SF_EV_HIT_DEAD_FORTRESS : 0u) |
+             (S.missed ? SF_EV_MISSILE_LEFT : 0u) | (done ? SF_EV_GAME_OVER : 0u);
+  }
 
   // ================= statistics and the vec-env worker's auto-reset (rl/train.py:80-88) ======
   if (done && a.auto_reset) {
@@ -995,6 +1015,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     if (reward_out) SF_ST(int32_t, (unsigned char*)(reward_out + so), g.o4, r);
     if (done_out) SF_ST(uint8_t, (unsigned char*)(done_out + so), g.o1, (uint8_t)done);
     if (info_out) SF_ST(uint8_t, (unsigned char*)(info_out + so), g.o1, (uint8_t)fort_kill);
+    if (a.events) SF_ST(uint32_t, (unsigned char*)(a.events + so), g.o4, evmask);
   }
   SF_STAMP(7, false);
   if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid

@@ -204,4 +204,5 @@ struct SfKernelArgs {
   // episode accumulators / error counter (device)
   unsigned long long* acc;   // SF_EPISODE_STATS_LEN + 1 words; [8] = bad-action count
   unsigned long long* dbg;   // SF_STAMPS diagnostic builds only: [wave][16] clock stamps; else null
+  unsigned* events;          // optional per-tick event bitmask output (SF_EV_*), [n_steps][n_envs]; else null
 };

@@ -147,10 +147,17 @@ class SFVecEnv:
             rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
             done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
             info = torch.empty((K, n), dtype=torch.uint8, device=self.device)
+        ev = None
+        if getattr(self, "events", None) is not None:  # the fused launch writes one row of event masks per tick
+            ev = torch.zeros((K, n), dtype=torch.int32, device=self.device)
+            _lib.check(self._L.sf_set_event_output(self._h, C.c_void_p(ev.data_ptr())))
+        self.rollout_events = ev
         _lib.check(self._L.sf_rollout(self._h, C.c_void_p(actions.data_ptr()), at, int(K),
                                       C.c_void_p(obs.data_ptr()) if obs is not None else None,
                                       C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
                                       C.c_void_p(info.data_ptr()), self._stream()))
+        if ev is not None:
+            _lib.check(self._L.sf_set_event_output(self._h, C.c_void_p(self.events.data_ptr())))
         return obs, rew, done, info
 
     def step_async(self, actions):
@@ -204,6 +211,13 @@ class SFVecEnv:
         stride = out.stride(0) if self.num_envs > 1 else 0
         _lib.check(self._L.sf_render(self._h, _lib.OBS_TYPES[mode], C.c_void_p(out.data_ptr()), stride, self._stream()))
         return out
+
+    def enable_events(self, on=True):
+        """Per-tick event bitmasks (sfmi.h SF_EV_*; `_lib.EVENT_NAMES`): after every step `self.events` holds
+        uint32 [N] for that tick.  Off by default: it is one more 4-byte store per env and step."""
+        self.events = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device) if on else None
+        _lib.check(self._L.sf_set_event_output(self._h, C.c_void_p(self.events.data_ptr()) if on else None))
+        return self.events
 
     # ------------------------------------------------------------------ extras
     def check_actions(self):
