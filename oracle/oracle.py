@@ -343,6 +343,14 @@ class RefGame(_GameApi):
     def rollout(self, n_steps, lcg_seed):
         return self.L.sfref_rollout(self.h, n_steps, lcg_seed)
 
+    def durations(self, which):
+        """0 thrust_durations, 1 shot_durations, 2 shot_intervals_invul, 3 shot_intervals_vul (SRC/game.hh:98-101)."""
+        buf = np.zeros(8192, np.int32)
+        self.L.sfref_durations.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        n = self.L.sfref_durations(self.h, which, _ptr(buf), len(buf))
+        assert n <= len(buf)
+        return buf[:n].copy()
+
     def dump(self):
         """Game::dumpState(), the string `Game.dump()` returns (SRC/pymodule.cpp:361-370)."""
         buf = C.create_string_buffer(8192)

@@ -110,6 +110,16 @@ int sfref_step_one_tick(void* h, int ms) {
 
 int sfref_is_game_over(void* h) { return ((RefGame*)h)->game->isGameOver() ? 1 : 0; }
 
+// the telemetry vectors behind the `thrust_durations`, `shot_durations`, `shot_intervals_invul`,
+// `shot_intervals_vul` getters (SRC/pymodule.cpp:143-181; SRC/game.hh:98-101): which = 0..3
+int sfref_durations(void* h, int which, int* out, int cap) {
+  Game* g = ((RefGame*)h)->game;
+  const std::vector<int>& v = which == 0 ? g->mThrustDurations : which == 1 ? g->mShotDurations
+                              : which == 2 ? g->mShotIntervalsInvul : g->mShotIntervalsVul;
+  for (int i = 0; i < (int)v.size() && i < cap; i++) out[i] = v[i];
+  return (int)v.size();
+}
+
 // Game::dumpState() (SRC/game.cpp:519-576), what the `dump` method of the Python type returns
 int sfref_dump(void* h, char* buf, int cap) {
   std::string s = ((RefGame*)h)->game->dumpState();

@@ -10,7 +10,8 @@ It is a batch of ONE lane of libsfmi (no CPU engine behind it).  Differences fro
   * `events` / `dump()` rebuild the tick's event list on the host from the recorded key calls and the state
     change of the tick (exact on the recorded reference runs in tests/golden/telemetry; the order of two
     missile hits inside ONE tick is not recoverable and is emitted in hit-count order);
-  * `thrust_durations`, `shot_durations`, `shot_intervals_*` are not kept by the device engine: AttributeError;
+  * `thrust_durations`, `shot_durations`, `shot_intervals_*` are kept on the host by this view (they are pure
+    functions of the key edges and of the timers / vulnerability before the tick, SRC/game.cpp:237-261);
   * `vulnerability_timer` / `vulnerability_time` return the values the reference's getters intend (their
     "d"-format-with-int bug is undefined behaviour, SRC/pymodule.cpp:44-45).
 """
@@ -44,6 +45,9 @@ class Game:
         self._keys = 0
         self._calls = []       # (pressed, sym) since the last tick, in call order
         self._events = ()
+        # SRC/game.hh:98-101, cleared by the constructor (SRC/game.cpp:64-67)
+        self.thrust_durations, self.shot_durations = (), ()
+        self.shot_intervals_invul, self.shot_intervals_vul = (), ()
         self._obs = None
         self._sd = None
         self.pb_width, self.pb_height = (width, height) if width > 0 else (90, 92)
@@ -70,6 +74,7 @@ class Game:
         if ms != self._vec.tickdur:
             raise ValueError("the device engine ticks in %d ms steps (ENV:61)" % self._vec.tickdur)
         before = self._state()
+        self._telemetry_vectors(before)
         a = self._torch.tensor([self._action_of[self._keys]], dtype=self._torch.uint8, device=self._vec.device)
         obs, _, _, _ = self._vec.step_tensors(a)
         self._obs = obs[0].cpu().numpy()
@@ -78,6 +83,28 @@ class Game:
         self._events = tuple(self._derive_events(before, after))
         self._calls = []
         return int(after["last_reward"])
+
+    def _telemetry_vectors(self, b):
+        """processKeyState's pushes (SRC/game.cpp:237-261), from the key calls of this tick in call order and
+        the flags / timers / vulnerability they meet."""
+        fl = int(b["flags"])
+        fire, thrust = bool(fl & 4), bool(fl & 8)
+        fire_t, thrust_t = int(b["fire_timer"]), int(b["thrust_timer"])
+        for pressed, sym in self._calls:
+            if sym == FIRE_KEY and pressed and not fire:
+                if int(b["vlner"]) > 10:
+                    self.shot_intervals_vul += (abs(fire_t),)
+                else:
+                    self.shot_intervals_invul += (abs(fire_t),)
+                fire, fire_t = True, 0
+            elif sym == FIRE_KEY and not pressed and fire:
+                self.shot_durations += (fire_t,)
+                fire, fire_t = False, 0
+            elif sym == THRUST_KEY and pressed and not thrust:
+                thrust, thrust_t = True, 0
+            elif sym == THRUST_KEY and not pressed and thrust:
+                self.thrust_durations += (thrust_t,)
+                thrust, thrust_t = False, 0
 
     def is_game_over(self):
         return bool(self.time >= self.max_time)
@@ -202,8 +229,8 @@ class Game:
         return tuple(names)
 
     def __getattr__(self, name):
-        if name in ("thrust_durations", "shot_durations", "shot_intervals_invul", "shot_intervals_vul", "max_points"):
-            raise AttributeError("%s is not kept by the device engine (DESIGN.md, telemetry)" % name)
+        if name == "max_points":  # its getter reads a double out of an int-typed entry (SRC/pymodule.cpp:41): undefined
+            raise AttributeError("max_points is not defined by the reference either")
         raise AttributeError(name)
 
     # ------------------------------------------------------------------ telemetry

@@ -27,6 +27,9 @@ for name in ("autoturn_destroy", "youturn_deaths", "youturn_rapid_fire"):
         dumps.append(g.dump())
     assert np.array_equal(np.array(eng, np.int32), z["eng_reward"])  # same run as the golden
     out[name] = np.array([d.encode() for d in dumps])
+    for w, key in enumerate(("thrust_durations", "shot_durations", "shot_intervals_invul", "shot_intervals_vul")):
+        out[name + "__" + key] = g.durations(w)
 np.savez_compressed(os.path.join(HERE, "dumps.npz"), **out)
 print({k: (len(v), v.dtype) for k, v in out.items()})
+print({k: v[:6] for k, v in out.items() if "__" in k and k.startswith("youturn_deaths")})
 print(out["youturn_deaths"][120].decode())

@@ -26,7 +26,8 @@ def drive(g, keys, youturn):
 def test_game_shim_replays_the_reference(name):
     import spacefortress.core as sf
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    dumps = np.load(os.path.join(GOLDEN, "telemetry", "dumps.npz"))[name]
+    tele = np.load(os.path.join(GOLDEN, "telemetry", "dumps.npz"))
+    dumps = tele[name]
     meta = json.loads(str(z["meta"]))
     youturn = meta["gametype"] in ("youturn", "test-youturn")
     g = sf.Game(meta["gametype"], width=90, height=92, viewport=(130, 80, 450, 460), lw=3, grayscale=True)
@@ -60,8 +61,10 @@ def test_game_shim_replays_the_reference(name):
     assert g.config("bigHex") == 200 and g.bighex == 200 and g.smallhex == 40
     with pytest.raises(ValueError):
         g.config("nonsense")
+    for key in ("thrust_durations", "shot_durations", "shot_intervals_invul", "shot_intervals_vul"):
+        assert getattr(g, key) == tuple(int(v) for v in tele[name + "__" + key]), key
     with pytest.raises(AttributeError):
-        g.thrust_durations
+        g.max_points
     with pytest.raises(ValueError):
         g.step_one_tick(33)
     g.close()
