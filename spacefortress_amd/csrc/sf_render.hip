@@ -474,15 +474,40 @@ __device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned 
   }
   const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows;
   if (hit && fits) {
-    for (int i = lane; i < kXcFbRows * kXcRow; i += 64) {
-      const int r = i / kXcRow, c = i - r * kXcRow;
-      if (r < b.y1 - b.y0 && c < b.x1 - b.x0) F.fb[(b.y0 + r) * SF_IMG_W + b.x0 + c] = xc[kXcFb + i];
+    // every load first (3 + 4 dwords per lane), then the byte writes: one memory round trip instead of 25
+    constexpr int kRowW = kXcRow / 4;  // 7 dwords a row
+    const uint32_t* gf = reinterpret_cast<const uint32_t*>(xc + kXcFb);
+    const uint32_t* go = reinterpret_cast<const uint32_t*>(xc + kXcOut);
+    uint32_t wf[3], wo[4];
+#pragma unroll
+    for (int j = 0; j < 3; j++) wf[j] = (lane + 64 * j < kXcFbRows * kRowW) ? gf[lane + 64 * j] : 0u;
+    if (RESIZE) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) wo[j] = (lane + 64 * j < kXcOutRows * kRowW) ? go[lane + 64 * j] : 0u;
     }
-    if (RESIZE)
-      for (int i = lane; i < kXcOutRows * kXcRow; i += 64) {
-        const int r = i / kXcRow, c = i - r * kXcRow;
-        if (r < o.y1 - o.y0 && c < o.x1 - o.x0) F.obuf[(o.y0 + r) * SF_OUT + o.x0 + c] = xc[kXcOut + i];
+    const int bw = b.x1 - b.x0, bh = b.y1 - b.y0, ow = o.x1 - o.x0, oh = o.y1 - o.y0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int d = lane + 64 * j, r = d / kRowW, c4 = (d - r * kRowW) * 4;
+      if (r < bh) {
+        uint8_t* p = F.fb + (b.y0 + r) * SF_IMG_W + b.x0 + c4;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (c4 + k < bw) p[k] = (uint8_t)(wf[j] >> (8 * k));
       }
+    }
+    if (RESIZE) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int d = lane + 64 * j, r = d / kRowW, c4 = (d - r * kRowW) * 4;
+        if (r < oh) {
+          uint8_t* p = F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4;
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (c4 + k < ow) p[k] = (uint8_t)(wo[j] >> (8 * k));
+        }
+      }
+    }
     __builtin_amdgcn_wave_barrier();
     return;
   }
@@ -529,6 +554,34 @@ template <bool RESIZE>
 __device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned char* gp, bool store) {
   const Box b{kFpX0, kFpY0, kFpX1, kFpY1}, o = out_box(b);
   const int lane = F.lane;
+  if (!store) {
+    // every load first (one dword of the surface patch, two of the image patch per lane), then the byte writes
+    const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gp);
+    const int ow = o.x1 - o.x0, oh = o.y1 - o.y0;
+    const uint32_t w = g32[lane];
+    uint32_t v[2] = {0u, 0u};
+    if (RESIZE) {
+      v[0] = g32[kFpOutAt / 4 + lane];
+      if (64 + lane < (kFpOutRow / 4) * oh) v[1] = g32[kFpOutAt / 4 + 64 + lane];
+    }
+    uint8_t* p = F.fb + (kFpY0 + (lane >> 2)) * SF_IMG_W + kFpX0 + (lane & 3) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) p[k] = (uint8_t)(w >> (8 * k));
+    if (RESIZE) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int d = lane + 64 * j, r = d / (kFpOutRow / 4), c4 = (d - r * (kFpOutRow / 4)) * 4;
+        if (r < oh) {
+          uint8_t* q = F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4;
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (c4 + k < ow) q[k] = (uint8_t)(v[j] >> (8 * k));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
   for (int i = lane; i < 256; i += 64) {
     uint8_t* p = F.fb + (kFpY0 + (i >> 4)) * SF_IMG_W + kFpX0 + (i & 15);
     if (store) gp[i] = *p; else *p = gp[i];
@@ -684,7 +737,7 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
     float s, c;
     sincos_deg((float)ship_angle, &s, &c);
     const Quad q = line_quad(kShipLines[lane < 3 ? lane : 0], c, s, ship_x, ship_y);
-    F.draw_quads(q, 255, lane < 3, 64);
+    F.draw_objects(q, 255, lane < 3, 4);
   } else {
     ship_explosion(F, a.xcache ? a.xcache + (size_t)env * SF_XC_BYTES : nullptr, sp.x, sp.y);
   }
