@@ -43,7 +43,9 @@
 // Four waves per workgroup share one LDS copy of the cos/sin table (one barrier, early, while the
 // waves are still in step; a copy per wave was tried: 1024 waves pulling the same 45 cache lines
 // out of L2 at once made the load phase 3x longer).  Everything after that is wave-private.
+#ifndef SF_BLOCK
 #define SF_BLOCK 256
+#endif
 #define SF_TRIG_PIECES ((SF_LDS_DOUBLES / 2 + SF_BLOCK - 1) / SF_BLOCK)
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #define SF_MPF 12 /* missile slots prefetched into registers; higher slots take the slow loop */
