@@ -5,16 +5,19 @@
 // 3 user units = 0.6 px, SRC/draw.cpp:257-270), takes the grey channel (cv2.cvtColor, an identity
 // on R=G=B) and the trainer's wrapper shrinks the frame to 84x84 with cv2.INTER_AREA.
 //
-// Here: ONE WAVEFRONT PER ENV.  The frame lives in LDS as bytes (8.3 KB: 12+ waves per CU), starts
-// as a copy of the static hexagon background, and every stroke of the reference's draw order is a
-// convex quad (a line with butt caps, an arc chord, a filled rectangle) composited OVER it with
-// 8-bit arithmetic, like the image backend does.  The quads of one draw phase are built one per
-// lane (<= 64 per round); the wave then walks the live ones in order (ballot + readlane, no LDS
-// list) and, for each, its lanes take the pixels of its bounding box: exact area coverage from an
-// edge integral (no arrays, no scratch).  The 84x84 frame is kept in LDS too: it starts as the
-// resampled background (host-made) and after every object the wave re-evaluates INTER_AREA only for
-// the output pixels whose footprint the object's bounding box touches -- a frame is a few dozen
-// changed pixels on a static picture.  The epilogue copies 7 KB (or the raw 8 KB) out, 16 B a lane.
+// Here: ONE WAVEFRONT PER ENV.  The 90x92 frame lives in LDS as bytes (8.3 KB: 18 waves per CU), starts
+// as a copy of the static background (hexagons; score 0000000 / empty bar baked in when nothing can
+// reach them), and every stroke of the reference's draw order is a convex quad (a line with butt
+// caps, an arc chord, a filled rectangle) composited OVER it with 8-bit arithmetic, like the image
+// backend does.  Quads are built one per lane; the ship's are walked in order (ballot + readlane, no
+// LDS list) with the lanes on the pixels of the quad's bounding box -- exact area coverage from an edge
+// integral (no arrays, no scratch); missiles and shells take two phases (all coverage masks of an object
+// at once, then a lane per pixel composites them in stroke order); explosions go ring by ring, twelve
+// arcs at once, and a dead ship's explosion is cached per env; the live fortress is one of 36 pictures
+// drawn once per batch.  The 84x84 frame is built IN PLACE in the caller's buffer in HBM: it starts as
+// the resampled background (host-made) and after every object the wave re-evaluates INTER_AREA only for
+// the output pixels whose footprint the object's bounding box touches -- a frame is a few dozen changed
+// pixels on a static picture.  VALU-bound (2.2 k instructions per frame), not memory-bound.
 //
 // Pixel values: what is drawn where, in which order and grey follows the reference; the
 // anti-aliasing model is ours (cairo is not in this image).  Pixel parity with cairo + cv2 is
