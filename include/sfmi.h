@@ -245,6 +245,11 @@ int sf_normalizer_set_state(sf_normalizer* z, const double* host, const double* 
  *      sf_compute_returns: RolloutStorage.compute_returns (rl/storage.py:50-63) over rewards [T][n],
  *      value_preds [T+1][n] (row T is overwritten with next_value when use_gae, like the reference),
  *      masks [T+1][n], next_value [n] -> returns [T+1][n]; float32, bit-identical to the reference. ---- */
+/* sf_step with sf_record_step's bookkeeping in the SAME launch (the epilogue of the step kernel): one launch per
+ * trainer step.  reward_f32 is required; mask_f32, episode_rewards, final_rewards, actions_out may be NULL. */
+int sf_step_record(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
+                   uint8_t* done_dev, uint8_t* info_dev, float* reward_f32, float* mask_f32, float* episode_rewards,
+                   float* final_rewards, int64_t* actions_out, void* stream);
 int sf_record_step(int n, const int32_t* reward_dev, const uint8_t* done_dev, float* reward_out, float* mask_out,
                    float* episode_rewards, float* final_rewards, const void* actions_dev, int act_type,
                    int64_t* actions_out, void* stream);

@@ -371,6 +371,36 @@ extern "C" int sf_step(sf_batch* b, const void* actions_dev, int act_type, void*
   return SF_OK;
 }
 
+extern "C" int sf_step_record(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
+                              uint8_t* done_dev, uint8_t* info_dev, float* reward_f32, float* mask_f32, float* episode_rewards,
+                              float* final_rewards, int64_t* actions_out, void* stream) {
+  if (!b || !actions_dev || !reward_f32) {
+    sf_set_error("sf_step_record: null batch, actions or reward_f32");
+    return SF_ERR_ARG;
+  }
+  if (act_type != SF_ACT_U8 && act_type != SF_ACT_I32 && act_type != SF_ACT_I64) {
+    sf_set_error("sf_step_record: act_type must be 1, 4 or 8 (got %d)", act_type);
+    return SF_ERR_ARG;
+  }
+  if (((uintptr_t)reward_f32 | (uintptr_t)mask_f32 | (uintptr_t)episode_rewards | (uintptr_t)final_rewards) & 3 ||
+      ((uintptr_t)actions_out & 7)) {
+    sf_set_error("sf_step_record: float outputs must be 4-byte, actions_out 8-byte aligned");
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  SfKernelArgs args = b->args;
+  args.t_reward = reward_f32;
+  args.t_mask = mask_f32;
+  args.t_episode = episode_rewards;
+  args.t_final = final_rewards;
+  args.t_actions = (long long*)actions_out;
+  const bool image = is_image(b);
+  HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, image ? nullptr : obs_dev,
+                         reward_dev, done_dev, info_dev, 1, false, (hipStream_t)stream));
+  if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
+  return SF_OK;
+}
+
 extern "C" int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, void* obs_dev,
                           int32_t* reward_dev, uint8_t* done_dev, uint8_t* info_dev, void* stream) {
   if (!b || !actions_dev) {

@@ -595,6 +595,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   }
   const size_t so = (size_t)step * (size_t)a.n_envs;  // this tick's row of the output arrays
 
+  const int act_raw = act;  // what rollouts.actions[step] records
   if (act < 0 || act >= a.n_actions) {
     atomicAdd(&a.acc[8], 1ull);  // reference: IndexError; here NOOP + counted (sf_check_actions)
     act = 0;
@@ -1018,6 +1019,21 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     if (done_out) SF_ST(uint8_t, (unsigned char*)(done_out + so), g.o1, (uint8_t)done);
     if (info_out) SF_ST(uint8_t, (unsigned char*)(info_out + so), g.o1, (uint8_t)fort_kill);
     if (a.events) SF_ST(uint32_t, (unsigned char*)(a.events + so), g.o4, evmask);
+    if (a.t_reward) {  // uniform; the same float32 operations in the same order as rl/train.py:82-88
+      const float rf = (float)r, mask = done ? 0.0f : 1.0f;
+      SF_ST(float, (unsigned char*)(a.t_reward + so), g.o4, rf);
+      if (a.t_mask) SF_ST(float, (unsigned char*)(a.t_mask + so), g.o4, mask);
+      if (a.t_episode) {
+        const float ep = SF_LD(float, (const unsigned char*)a.t_episode, g.o4) + rf;  // episode_rewards += reward
+        if (a.t_final) {
+          float fin = SF_LD(float, (const unsigned char*)a.t_final, g.o4) * mask;     // final_rewards *= masks
+          fin = fin + (1.0f - mask) * ep;                                              // += (1 - masks) * episode_rewards
+          SF_ST(float, (unsigned char*)a.t_final, g.o4, fin);
+        }
+        SF_ST(float, (unsigned char*)a.t_episode, g.o4, ep * mask);                    // episode_rewards *= masks
+      }
+      if (a.t_actions) SF_ST(long long, (unsigned char*)(a.t_actions + so), g.o8, (long long)act_raw);
+    }
   }
   SF_STAMP(7, false);
   if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid

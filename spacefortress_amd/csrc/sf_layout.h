@@ -205,4 +205,12 @@ struct SfKernelArgs {
   unsigned long long* acc;   // SF_EPISODE_STATS_LEN + 1 words; [8] = bad-action count
   unsigned long long* dbg;   // SF_STAMPS diagnostic builds only: [wave][16] clock stamps; else null
   unsigned* events;          // optional per-tick event bitmask output (SF_EV_*), [n_steps][n_envs]; else null
+  // optional trainer bookkeeping of rl/train.py:82-88 + rollouts.insert (sf_step_record): reward as float and
+  // mask = 1 - done for this tick ([n_steps][n_envs]); episode / final reward accumulators and the action as
+  // int64 per env; t_reward == null switches the whole block off
+  float* t_reward;
+  float* t_mask;
+  float* t_episode;
+  float* t_final;
+  long long* t_actions;
 };

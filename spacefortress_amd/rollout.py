@@ -3,10 +3,11 @@
 
 The reference moves every step through the host: `action.cpu().numpy()` -> SubprocVecEnv pipes ->
 `torch.from_numpy(reward)`, five small tensor ops for the episode bookkeeping, `rollouts.insert(...)`.
-Here `sf_step` writes the next observation straight into `observations[step + 1]`, one helper launch
-(`sf_record_step`) produces `rewards[step]`, `masks[step + 1]` and the episode / final reward
-accumulators, and `compute_returns` is one backward-scan kernel (`sf_compute_returns`, bit-identical to
-the reference's float32 arithmetic).  Tensor names and shapes are RolloutStorage's.
+Here ONE launch per step (`sf_step_record`) writes the next observation straight into
+`observations[step + 1]` and, in the step kernel's own epilogue, `rewards[step]`, `masks[step + 1]`, the
+episode / final reward accumulators and `actions[step]`; `compute_returns` is one backward-scan kernel
+(`sf_compute_returns`, bit-identical to the reference's float32 arithmetic).  Tensor names and shapes are
+RolloutStorage's.
 """
 import ctypes as C
 
@@ -81,9 +82,9 @@ class DeviceRollout:
         P = self._ptr
         stream = self._stream()
         ap, at = C.c_void_p(a.data_ptr()), a.element_size()
-        _lib.check(self._L.sf_step(e._h, ap, at, P["obs"][step + 1], P["r"], P["d"], P["i"], stream))
-        _lib.check(self._L.sf_record_step(e.num_envs, P["r"], P["d"], P["rew"][step], P["mask"][step + 1], P["ep"], P["fin"],
-                                          ap, at, P["act"][step], stream))
+        # one launch: the step kernel's epilogue does the trainer's bookkeeping (sfmi.h: sf_step_record)
+        _lib.check(self._L.sf_step_record(e._h, ap, at, P["obs"][step + 1], P["r"], P["d"], P["i"], P["rew"][step],
+                                          P["mask"][step + 1], P["ep"], P["fin"], P["act"][step], stream))
         if value_pred is not None:
             self.value_preds[step].copy_(value_pred)
         if action_log_prob is not None:

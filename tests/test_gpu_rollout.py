@@ -98,3 +98,34 @@ def test_device_rollout_end_to_end(sfa):
     assert torch.equal(ro.observations[0], last) and torch.equal(ro.masks[0], ro.masks[-1])
     env.close()
     twin.close()
+
+
+def test_step_record_equals_step_then_record(sfa):
+    """sf_step_record (bookkeeping in the step kernel's epilogue) against sf_step followed by sf_record_step,
+    both bit-exact images of rl/train.py:82-88; also with an image observation and uint8 / int64 actions."""
+    from spacefortress_amd import _lib
+    L = _lib.lib()
+    N, T = 700, 40
+    rng = np.random.default_rng(6)
+    for obs_type, adt in (("features", torch.uint8), ("image", torch.int64)):
+        a_env = sfa.SFVecEnv(N, gametype="youturn", obs_type=obs_type, spawn_stride=2)
+        b_env = sfa.SFVecEnv(N, gametype="youturn", obs_type=obs_type, spawn_stride=2)
+        for e in (a_env, b_env):
+            e.set_field("time", np.full(N, 34 * 5270, np.int32))
+        dev = a_env.device
+        z = lambda dt=torch.float32: torch.zeros(N, dtype=dt, device=dev)
+        ep1, fin1, ep2, fin2 = z(), z(), z(), z()
+        r1, m1, r2, m2 = z(), z(), z(), z()
+        act1, act2 = z(torch.int64), z(torch.int64)
+        for t in range(T):
+            a = torch.from_numpy(rng.integers(0, 5, N)).to(dev).to(adt)
+            o1, rew, done, info = a_env.step_tensors(a)
+            _lib.check(L.sf_record_step(N, _p(rew), _p(done), _p(r1), _p(m1), _p(ep1), _p(fin1), _p(a), a.element_size(), _p(act1), None))
+            o2, rw2, dn2, in2 = b_env._alloc()
+            _lib.check(L.sf_step_record(b_env._h, _p(a), a.element_size(), _p(o2), _p(rw2), _p(dn2), _p(in2), _p(r2), _p(m2),
+                                        _p(ep2), _p(fin2), _p(act2), None))
+            for x, y in ((o1, o2), (rew, rw2), (done, dn2), (info, in2), (r1, r2), (m1, m2), (ep1, ep2), (fin1, fin2), (act1, act2)):
+                assert torch.equal(x, y), (obs_type, t)
+        assert float(m1.min()) == 0.0 or (ep1 != 0).any()
+        a_env.close()
+        b_env.close()
