@@ -231,6 +231,14 @@ int sf_normalizer_destroy(sf_normalizer* z);
  * frozen != 0: normalise with the statistics as they are (evaluation), update nothing. */
 int sf_normalize(sf_normalizer* z, const void* obs_dev, void* obs_out_dev, const int32_t* reward_dev,
                  float* reward_out_dev, int frozen, void* stream);
+/* sf_step + sf_normalize with the batch reduction riding on the step kernel (its waves sum the observation
+ * tile they have just written): step -> merge -> apply, one launch less than the two calls.  obs_dev is written
+ * raw by the step and normalised in place; reward_dev keeps the raw int32 rewards (the trainer's episode
+ * bookkeeping uses them), reward_out_dev gets the normalised ones.  The batch must have been created with a
+ * 1-D observation type and the normalizer with its n_envs / obs_dim / obs_f64. */
+int sf_step_normalize(sf_batch* b, sf_normalizer* z, const void* actions_dev, int act_type, void* obs_dev,
+                      int32_t* reward_dev, uint8_t* done_dev, uint8_t* info_dev, float* reward_out_dev, int frozen,
+                      void* stream);
 /* statistics as host doubles [2*obs_dim + 4]: ob mean[D], ob var[D], ret mean, ret var, ob count, ret
  * count; ret_host (may be NULL): the per-env discounted returns [n_envs].  Synchronise `stream`. */
 int sf_normalizer_get_state(sf_normalizer* z, double* host, double* ret_host, void* stream);

@@ -87,6 +87,7 @@ SYMBOLS = {
     "sf_normalizer_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "sf_normalizer_destroy": (C.c_int, [C.c_void_p]),
     "sf_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sf_step_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "sf_normalizer_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_normalizer_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_step_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10),

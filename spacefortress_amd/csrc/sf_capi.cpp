@@ -371,6 +371,32 @@ extern "C" int sf_step(sf_batch* b, const void* actions_dev, int act_type, void*
   return SF_OK;
 }
 
+int sf_step_with_norm_partials(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
+                               uint8_t* done_dev, uint8_t* info_dev, double* partials, double* ret, double gamma, int* rows_out,
+                               void* stream) {
+  if (!b || !actions_dev || !partials) {
+    sf_set_error("sf_step_normalize: null batch, actions or normalizer");
+    return SF_ERR_ARG;
+  }
+  if (act_type != SF_ACT_U8 && act_type != SF_ACT_I32 && act_type != SF_ACT_I64) {
+    sf_set_error("sf_step_normalize: act_type must be 1, 4 or 8 (got %d)", act_type);
+    return SF_ERR_ARG;
+  }
+  if (is_image(b) || b->args.obs_dim < 4) {
+    sf_set_error("sf_step_normalize: VecNormalize applies to 1-D observations (rl/train.py:35)");
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  SfKernelArgs args = b->args;
+  args.n_partials = partials;
+  args.n_ret = ret;
+  args.n_gamma = gamma;
+  HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev,
+                         info_dev, 1, false, (hipStream_t)stream));
+  *rows_out = (int)(b->args.lanes / 64);
+  return SF_OK;
+}
+
 extern "C" int sf_step_record(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
                               uint8_t* done_dev, uint8_t* info_dev, float* reward_f32, float* mask_f32, float* episode_rewards,
                               float* final_rewards, int64_t* actions_out, void* stream) {

@@ -36,6 +36,15 @@ hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, cons
 
 hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n, hipStream_t stream);
 
+hipError_t sf_launch_normalize_after_step(const void* obs, void* obs_out, int obs_f64, const int32_t* rew, float* rew_out, int n,
+                                          int dim, double eps, double clipob, double cliprew, int do_ob, int do_ret,
+                                          const double* partials, int rows, const double* stats, double* stats_next,
+                                          hipStream_t stream);
+// sf_capi.cpp: sf_step with the VecNormalize reduction riding on it (partials: [2 (obs_dim + 1)][lanes / 64])
+int sf_step_with_norm_partials(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
+                               uint8_t* done_dev, uint8_t* info_dev, double* partials, double* ret, double gamma, int* rows_out,
+                               void* stream);
+
 // sf_host.cpp (no HIP calls: usable and tested without a GPU)
 void sf_host_fill_consts(const sf_preset& p, double* consts /* SF_CONST_DOUBLES */);
 void sf_set_error(const char* fmt, ...);

@@ -434,6 +434,54 @@ __device__ __forceinline__ void flush_obs_wave(const SfKernelArgs& a, const T* s
   for (int t = done_elems + lane; t < total; t += 64) dst[t] = stage_w[t];
 }
 
+// VecNormalize's batch sums for this wave's rows, from the observation tile the wave has just flushed (it is
+// still in the wave's private piece of LDS): lanes [g*dim, (g+1)*dim) add every groups-th row of feature
+// lane % dim and of its square; the tile is then reused to fold the groups.  One row of the column-major
+// partial-sum array per wave (sf_normalize.hip adds the rows up); no workgroup barrier.
+template <typename T>
+__device__ __forceinline__ void norm_partials_wave(const SfKernelArgs& a, T* stage_w, unsigned wave_env0, unsigned lane,
+                                                   double my_ret, bool has_obs) {
+  const int dim = a.obs_dim, groups = 64 / dim;
+  const size_t waves = (size_t)(a.lanes / 64), w = wave_env0 >> 6;
+  long rows = (long)a.n_envs - (long)wave_env0;
+  rows = rows > 64 ? 64 : (rows < 0 ? 0 : rows);
+  double s = 0, q = 0;
+  if (has_obs && (int)lane < groups * dim)
+    for (int r = (int)lane / dim; r < rows; r += groups) {
+      const double v = (double)stage_w[r * dim + (int)lane % dim];
+      s += v;
+      q += v * v;
+    }
+  __builtin_amdgcn_wave_barrier();
+  double* fold = reinterpret_cast<double*>(stage_w);  // 2 x 64 doubles <= 64 rows x dim x sizeof(T) for dim >= 4
+  if (has_obs) {
+    fold[lane] = s;
+    fold[64 + lane] = q;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if ((int)lane < dim) {
+    double ts = 0, tq = 0;
+    if (has_obs)
+      for (int g = 0; g < groups; g++) {
+        ts += fold[g * dim + lane];
+        tq += fold[64 + g * dim + lane];
+      }
+    a.n_partials[(size_t)lane * waves + w] = ts;
+    a.n_partials[(size_t)(dim + 1 + lane) * waves + w] = tq;
+  }
+  double rs = (long)lane < rows ? my_ret : 0.0, rq = rs * rs;
+  for (int o = 32; o > 0; o >>= 1) {
+    rs += __shfl_xor(rs, o);
+    rq += __shfl_xor(rq, o);
+  }
+  if (lane == 0) {
+    a.n_partials[(size_t)dim * waves + w] = rs;
+    a.n_partials[(size_t)(2 * dim + 1) * waves + w] = rq;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1049,6 +1097,19 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       flush_obs_wave<float>(a, stage + (tid & ~63u) * a.obs_dim, (float*)obs + so * a.obs_dim, i & ~63u, lane,
                             obs_vec_ok);
     }
+  }
+  if (!FUSED && a.n_partials) {  // uniform: VecNormalize's reduction rides on the step (sf_step_normalize)
+    double my_ret = 0;
+    if (a.n_ret && real) {
+      my_ret = SF_LD(double, (const unsigned char*)a.n_ret, g.o8) * a.n_gamma + (double)r;  // ret = ret * gamma + rews
+      SF_ST(double, (unsigned char*)a.n_ret, g.o8, my_ret);
+    }
+    const bool has_obs = obs != nullptr && a.obs_type != 3;
+    if (a.obs_f64)
+      norm_partials_wave<double>(a, lds + SF_LDS_DOUBLES + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u, lane, my_ret, has_obs);
+    else
+      norm_partials_wave<float>(a, reinterpret_cast<float*>(lds + SF_LDS_DOUBLES) + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u,
+                                lane, my_ret, has_obs);
   }
   }  // tick loop
   if (FUSED) store_lane(tb, o, L);

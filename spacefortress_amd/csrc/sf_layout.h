@@ -213,4 +213,9 @@ struct SfKernelArgs {
   float* t_episode;
   float* t_final;
   long long* t_actions;
+  // optional VecNormalize reduction (sf_step_normalize): per-wave partial sums of the observations just written
+  // and of the discounted returns, column-major [2 * (obs_dim + 1)][lanes / 64]; null = off
+  double* n_partials;
+  double* n_ret;    // per-env discounted return, ret = ret * n_gamma + reward
+  double n_gamma;
 };

@@ -74,8 +74,12 @@ extern "C" int sf_normalizer_create(const sf_normalizer_params* p, sf_normalizer
   } while (0)
   TRY_FREE(hipMalloc((void**)&z->d_ret, sizeof(double) * p->n_envs));
   TRY_FREE(hipMemset(z->d_ret, 0, sizeof(double) * p->n_envs));
-  TRY_FREE(hipMalloc((void**)&z->d_partials, sizeof(double) * (n_sums(z) * SF_NORM_GROUPS + 1)));
-  TRY_FREE(hipMemset(z->d_partials, 0, sizeof(double) * (n_sums(z) * SF_NORM_GROUPS + 1)));
+  // rows of partial sums: SF_NORM_GROUPS from the stand-alone reduction, or one per wave of the step kernel
+  // (sf_step_normalize; the batch is padded to whole workgroups of 256 envs)
+  const size_t rows = (size_t)((p->n_envs + 255) / 256) * 4;
+  const size_t prow = rows > SF_NORM_GROUPS ? rows : SF_NORM_GROUPS;
+  TRY_FREE(hipMalloc((void**)&z->d_partials, sizeof(double) * n_sums(z) * prow));
+  TRY_FREE(hipMemset(z->d_partials, 0, sizeof(double) * n_sums(z) * prow));
   for (int k = 0; k < 2; k++) {
     TRY_FREE(hipMalloc((void**)&z->d_stats[k], sizeof(double) * n_stats(z)));
     TRY_FREE(hipMemcpy(z->d_stats[k], st.data(), sizeof(double) * n_stats(z), hipMemcpyHostToDevice));
@@ -135,5 +139,35 @@ extern "C" int sf_normalizer_set_state(sf_normalizer* z, const double* host, con
   if (ret_host)
     HIP_TRY(hipMemcpyAsync(z->d_ret, ret_host, sizeof(double) * z->p.n_envs, hipMemcpyHostToDevice, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_step_normalize(sf_batch* b, sf_normalizer* z, const void* actions_dev, int act_type, void* obs_dev,
+                                 int32_t* reward_dev, uint8_t* done_dev, uint8_t* info_dev, float* reward_out_dev, int frozen,
+                                 void* stream) {
+  if (!b || !z || !obs_dev || !reward_dev || !reward_out_dev) {
+    sf_set_error("sf_step_normalize: null batch, normalizer, obs, reward or reward_out");
+    return SF_ERR_ARG;
+  }
+  if (sf_n_envs(b) != z->p.n_envs || sf_obs_dim(b) != z->p.obs_dim) {
+    sf_set_error("sf_step_normalize: the normalizer was made for %d envs x %d features", z->p.n_envs, z->p.obs_dim);
+    return SF_ERR_ARG;
+  }
+  if (frozen) {
+    int rc = sf_step(b, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev, stream);
+    if (rc != SF_OK) return rc;
+    return sf_normalize(z, obs_dev, obs_dev, reward_dev, reward_out_dev, 1, stream);
+  }
+  DeviceGuard guard(z->p.device_id);
+  int rows = 0;
+  int rc = sf_step_with_norm_partials(b, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev, z->d_partials,
+                                      z->p.ret ? z->d_ret : nullptr, z->p.gamma, &rows, stream);
+  if (rc != SF_OK) return rc;
+  const int k = z->parity;
+  HIP_TRY(sf_launch_normalize_after_step(z->p.ob ? obs_dev : nullptr, z->p.ob ? obs_dev : nullptr, z->p.obs_f64,
+                                         z->p.ret ? reward_dev : nullptr, z->p.ret ? reward_out_dev : nullptr, z->p.n_envs,
+                                         z->p.obs_dim, z->p.epsilon, z->p.clipob, z->p.cliprew, z->p.ob, z->p.ret, z->d_partials,
+                                         rows, z->d_stats[k], z->d_stats[k ^ 1], (hipStream_t)stream));
+  z->parity = k ^ 1;
   return SF_OK;
 }

@@ -17,8 +17,9 @@
 //                          every third row; lane-per-env return update and its two sums; one row of
 //                          partial sums per workgroup (no atomics on the sums: 1024 waves adding into the
 //                          same 40 addresses serialise in L2 -- measured 45 us);
-//   sf_norm_merge_kernel   one workgroup adds the 256 rows up, merges them into the running statistics
-//                          (RunningMeanStd.update) and stores those for the other step parity;
+//   sf_norm_merge_kernel   one workgroup per feature (and one for the returns) adds its two columns up, merges
+//                          them into the running statistics (RunningMeanStd.update) and stores those for the
+//                          other step parity;
 //   sf_norm_apply_kernel   reads the 40 merged values, normalises and clips.
 // Statistics are double-buffered by step parity so that nothing is read while it is written; sums are
 // added in a fixed order: run-to-run deterministic.
@@ -108,36 +109,48 @@ __global__ __launch_bounds__(256) void sf_norm_reduce_kernel(const T* obs, const
   if (t < width) partials[(size_t)t * kReduceGroups + blockIdx.x] = (wsum[0][t] + wsum[1][t]) + (wsum[2][t] + wsum[3][t]);
 }
 
-// One workgroup: column c of the partial sums is 256 contiguous doubles; wave w takes the columns c = w, w + 4,
-// ...: a lane adds four of them, a butterfly the 64 lanes -- a fixed order, so the statistics are run-to-run
-// deterministic -- then RunningMeanStd.update per feature and for the returns.  (Folding this into the
-// reduction behind a "last workgroup" ticket was tried: 256 atomics on one address cost 11 us.)
-__global__ __launch_bounds__(256) void sf_norm_merge_kernel(const double* partials, int n, int dim, int do_ob, int do_ret,
-                                                            const double* stats, double* stats_next) {
-  __shared__ double total[2 * (kMaxDim + 1)];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = threadIdx.x, width = 2 * (dim + 1);
-  for (int c = wave; c < width; c += 4) {
-    const double* col = partials + (size_t)c * kReduceGroups;
-    double v = (col[lane] + col[lane + 64]) + (col[lane + 128] + col[lane + 192]);
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) total[c] = v;
+// RunningMeanStd.update per feature and for the returns.  (Tried and dropped: folding this into the reduction
+// behind a "last workgroup" ticket -- 256 atomics on one address cost 11 us; a single workgroup walking 1024 rows
+// of every column -- its 160 dependent loads per thread cost 50 us.)
+__global__ __launch_bounds__(256) void sf_norm_merge_kernel(const double* partials, int rows, int n, int dim, int do_ob,
+                                                            int do_ret, const double* stats, double* stats_next) {
+  // workgroup f < dim: feature f; workgroup dim: the returns.  Its two columns (sum, sum of squares) are `rows`
+  // contiguous doubles each (256 from sf_norm_reduce_kernel, one per wave of the step kernel otherwise): every
+  // thread adds its share with all loads in flight, a butterfly and four LDS words finish -- a fixed order
+  __shared__ double part[2][4];
+  const int f = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const bool is_ret = f == dim;
+  const double* cs = partials + (size_t)f * rows;
+  const double* cq = partials + (size_t)(dim + 1 + f) * rows;
+  double s = 0, q = 0;
+#pragma unroll 4
+  for (int r = t; r < rows; r += 256) {
+    s += cs[r];
+    q += cq[r];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane == 0) {
+    part[0][wave] = s;
+    part[1][wave] = q;
   }
   __syncthreads();
-  if (t <= dim) {
-    const bool is_ret = t == dim;
-    const bool upd = is_ret ? do_ret != 0 : do_ob != 0;
-    double mean = is_ret ? stats[2 * dim] : stats[t], var = is_ret ? stats[2 * dim + 1] : stats[dim + t];
-    double count = stats[2 * dim + 2 + (is_ret ? 1 : 0)];
-    if (upd) merge(mean, var, count, total[t], total[dim + 1 + t], (double)n, &mean, &var, &count);
-    if (is_ret) {
-      stats_next[2 * dim] = mean;
-      stats_next[2 * dim + 1] = var;
-      stats_next[2 * dim + 3] = count;
-    } else {
-      stats_next[t] = mean;
-      stats_next[dim + t] = var;
-      if (t == 0) stats_next[2 * dim + 2] = count;
-    }
+  if (t != 0) return;
+  const double sum = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+  const double sumsq = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+  double mean = is_ret ? stats[2 * dim] : stats[f], var = is_ret ? stats[2 * dim + 1] : stats[dim + f];
+  double count = stats[2 * dim + 2 + (is_ret ? 1 : 0)];
+  if (is_ret ? do_ret != 0 : do_ob != 0) merge(mean, var, count, sum, sumsq, (double)n, &mean, &var, &count);
+  if (is_ret) {
+    stats_next[2 * dim] = mean;
+    stats_next[2 * dim + 1] = var;
+    stats_next[2 * dim + 3] = count;
+  } else {
+    stats_next[f] = mean;
+    stats_next[dim + f] = var;
+    if (f == 0) stats_next[2 * dim + 2] = count;
   }
 }
 
@@ -176,6 +189,25 @@ __global__ __launch_bounds__(256) void sf_norm_apply_kernel(const T* obs, T* obs
 
 }  // namespace
 
+// the tail of sf_step_normalize: the step kernel has already left `rows` rows of partial sums (one per wave)
+hipError_t sf_launch_normalize_after_step(const void* obs, void* obs_out, int obs_f64, const int32_t* rew, float* rew_out, int n,
+                                          int dim, double eps, double clipob, double cliprew, int do_ob, int do_ret,
+                                          const double* partials, int rows, const double* stats, double* stats_next,
+                                          hipStream_t stream) {
+  if (n <= 0 || dim <= 0 || dim > kMaxDim) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_norm_merge_kernel, dim3(dim + 1), dim3(256), 0, stream, partials, rows, n, dim, do_ob, do_ret, stats, stats_next);
+  long g2 = ((long)n * dim + 255) / 256;
+  g2 = g2 > 2048 ? 2048 : g2;
+  g2 = (g2 + dim - 1) / dim * dim;
+  if (obs_f64)
+    hipLaunchKernelGGL(sf_norm_apply_kernel<double>, dim3((unsigned)g2), dim3(256), 0, stream, (const double*)obs,
+                       (double*)obs_out, rew, rew_out, n, dim, eps, clipob, cliprew, stats_next);
+  else
+    hipLaunchKernelGGL(sf_norm_apply_kernel<float>, dim3((unsigned)g2), dim3(256), 0, stream, (const float*)obs,
+                       (float*)obs_out, rew, rew_out, n, dim, eps, clipob, cliprew, stats_next);
+  return hipGetLastError();
+}
+
 hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, const int32_t* rew, float* rew_out, double* ret,
                                int n, int dim, double gamma, double eps, double clipob, double cliprew, int do_ob,
                                int do_ret, double* partials, const double* stats, double* stats_next,
@@ -191,7 +223,7 @@ hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, cons
     if (update) {
       hipLaunchKernelGGL(sf_norm_reduce_kernel<double>, dim3(kReduceGroups), dim3(256), 0, stream, (const double*)obs, rew,
                          ret, n, dim, gamma, do_ob, do_ret, partials);
-      hipLaunchKernelGGL(sf_norm_merge_kernel, dim3(1), dim3(256), 0, stream, partials, n, dim, do_ob, do_ret, stats, stats_next);
+      hipLaunchKernelGGL(sf_norm_merge_kernel, dim3(dim + 1), dim3(256), 0, stream, partials, kReduceGroups, n, dim, do_ob, do_ret, stats, stats_next);
     }
     hipLaunchKernelGGL(sf_norm_apply_kernel<double>, dim3((unsigned)g2), dim3(256), 0, stream, (const double*)obs,
                        (double*)obs_out, rew, rew_out, n, dim, eps, clipob, cliprew, use);
@@ -199,7 +231,7 @@ hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, cons
     if (update) {
       hipLaunchKernelGGL(sf_norm_reduce_kernel<float>, dim3(kReduceGroups), dim3(256), 0, stream, (const float*)obs, rew, ret,
                          n, dim, gamma, do_ob, do_ret, partials);
-      hipLaunchKernelGGL(sf_norm_merge_kernel, dim3(1), dim3(256), 0, stream, partials, n, dim, do_ob, do_ret, stats, stats_next);
+      hipLaunchKernelGGL(sf_norm_merge_kernel, dim3(dim + 1), dim3(256), 0, stream, partials, kReduceGroups, n, dim, do_ob, do_ret, stats, stats_next);
     }
     hipLaunchKernelGGL(sf_norm_apply_kernel<float>, dim3((unsigned)g2), dim3(256), 0, stream, (const float*)obs,
                        (float*)obs_out, rew, rew_out, n, dim, eps, clipob, cliprew, use);

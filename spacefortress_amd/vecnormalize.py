@@ -62,9 +62,22 @@ class SFVecNormalize:
         return obs.cpu().numpy() if numpy else obs
 
     def step_tensors(self, actions):
-        obs, rew, done, info = self.venv.step_tensors(actions)
-        obs, rew = self._filter(obs, rew)
-        return obs, rew, done, info
+        v = self.venv
+        if not (self.ob and self.ret_on) or not hasattr(v, "_alloc"):
+            obs, rew, done, info = v.step_tensors(actions)
+            obs, rew = self._filter(obs, rew)
+            return obs, rew, done, info
+        # the fused path (sfmi.h: sf_step_normalize): the reduction rides on the step kernel
+        if actions.device != v.device or not actions.is_contiguous() or actions.numel() != v.num_envs:
+            raise ValueError("actions must be a contiguous tensor of %d elements on %s" % (v.num_envs, v.device))
+        at = {torch.uint8: 1, torch.int32: 4, torch.int64: 8}.get(actions.dtype)
+        if at is None:
+            raise TypeError("actions dtype must be uint8, int32 or int64 (got %s)" % (actions.dtype,))
+        obs, rew, done, info = v._alloc()
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(self._L.sf_step_normalize(v._h, self._h, p(actions), at, p(obs), p(rew), p(done), p(info), p(self._rew),
+                                             0 if self.training else 1, self._stream()))
+        return obs, self._rew, done, info
 
     def step_async(self, actions):
         if torch.is_tensor(actions):
