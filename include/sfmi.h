@@ -143,6 +143,11 @@ int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, 
  *      DESIGN.md "image observation". ---- */
 int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, void* stream);
 
+/* One step of the trainer's frame stack in one launch (rl/train.py:51-56,92-97): the 84x84 frame of every env
+ * goes to slot `slot` of stack_dev uint8 [n_envs][num_stack][84][84] (16-byte aligned), and an env whose
+ * done_dev flag is set (may be NULL) first gets its other slots zeroed. */
+int sf_render_stack(sf_batch* b, uint8_t* stack_dev, int num_stack, int slot, const uint8_t* done_dev, void* stream);
+
 /* `current_obs *= masks` of the trainer's frame stack (rl/train.py:92-93): zero the bytes_per_env bytes of
  * every env whose done flag is set, touching nothing else.  stack_dev uint8 [n_envs][bytes_per_env]. */
 int sf_frame_stack_clear(uint8_t* stack_dev, size_t bytes_per_env, const uint8_t* done_dev, int n_envs, void* stream);

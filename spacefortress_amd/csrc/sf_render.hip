@@ -542,6 +542,10 @@ struct SfRenderArgs {
   size_t out_stride;     // bytes from one env's frame to the next (>= the frame size, multiple of 16)
   unsigned char* xcache; // SF_XC_BYTES per env (zero-initialised), or null
   const unsigned char* fpatch;  // 36 x SF_FP_BYTES: the live fortress at 0, 10, ... 350 degrees on the bare background, or null
+  // frame stack (sf_render_stack): `out` is slot stack_slot of stack_n frames per env; an env whose done flag is
+  // set gets its other slots zeroed first (`current_obs *= masks`, rl/train.py:92-93); stack_done null = plain render
+  const uint8_t* stack_done;
+  int stack_slot, stack_n;
 };
 
 // The fortress never moves and its heading is a multiple of the 10-degree sector (SRC/game.cpp:205-208):
@@ -724,6 +728,14 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
     for (int i = lane; i < kFbVec; i += 64) dst[i] = src[i];
     for (int i = 4 * kFbVec + lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bgv[i] : 0u;
   }
+  if (RESIZE && a.stack_done && a.stack_done[env]) {
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (int sl = 0; sl < a.stack_n; sl++) {
+      if (sl == a.stack_slot) continue;
+      uint4* dst = reinterpret_cast<uint4*>(frame_out + (ptrdiff_t)(sl - a.stack_slot) * kOutBytes);
+      for (int i = lane; i < kOutBytes / 16; i += 64) dst[i] = z;
+    }
+  }
   if (RESIZE) {
     const uint4* src = reinterpret_cast<const uint4*>(a.bg84 + variant * (kOutBytes / 4));
     uint4* dst = reinterpret_cast<uint4*>(frame_out);
@@ -862,9 +874,10 @@ hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uin
 
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
-                            const unsigned char* fpatch, int resize, hipStream_t stream) {
+                            const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
+                            hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
-  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch};
+  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n};
   if (resize)
     hipLaunchKernelGGL(sf_render_kernel<true>, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
   else

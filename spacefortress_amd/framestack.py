@@ -46,13 +46,12 @@ class FrameStack:
         at = {torch.uint8: 1, torch.int32: 4, torch.int64: 8}[actions.dtype]
         _lib.check(e._L.sf_step(e._h, C.c_void_p(actions.data_ptr()), at, None, C.c_void_p(self._rew.data_ptr()),
                                 C.c_void_p(self._done.data_ptr()), C.c_void_p(self._info.data_ptr()), e._stream()))
-        # current_obs *= masks (rl/train.py:92-93): only the finished envs' stacks are touched
-        _lib.check(e._L.sf_frame_stack_clear(C.c_void_p(self.ring.data_ptr()), self.ring.stride(0),
-                                             C.c_void_p(self._done.data_ptr()), e.num_envs, e._stream()))
-        done = self._done.bool()
+        # the new frame into the next slot; finished envs get their other slots zeroed by the same launch
+        # (current_obs *= masks, rl/train.py:92-93)
         self.head = (self.head + 1) % self.num_stack
-        e.render("image", out=self._slot(self.head))
-        return self._rew, done, self._info.bool()
+        _lib.check(e._L.sf_render_stack(e._h, C.c_void_p(self.ring.data_ptr()), self.num_stack, self.head,
+                                        C.c_void_p(self._done.data_ptr()), e._stream()))
+        return self._rew, self._done.bool(), self._info.bool()
 
     def stacked(self):
         """[N, num_stack, 84, 84] uint8, oldest frame first -- the reference's channel order."""
