@@ -69,3 +69,42 @@ def test_steps_can_be_captured_in_a_hip_graph():
     assert all(np.array_equal(sa[f], sb[f]) for f in sa)
     a.close()
     b.close()
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Status codes of the entry points added around the path (image, stack, normaliser, trainer helpers)."""
+    import ctypes as C
+    from spacefortress_amd import SFVecEnv, _lib
+    L = _lib.lib()
+    env = SFVecEnv(8, obs_type="features")
+    img = SFVecEnv(8, obs_type="image")
+    buf = torch.zeros(8 * 4 * 84 * 84 + 64, dtype=torch.uint8, device=env.device)
+    p = lambda t, off=0: C.c_void_p(t.data_ptr() + off)
+    assert L.sf_render(env._h, 0, p(buf), 0, None) == _lib.SF_ERR_ARG             # mode is not an image mode
+    assert L.sf_render(env._h, 4, p(buf, 4), 0, None) == _lib.SF_ERR_ARG          # misaligned frames
+    assert L.sf_render(env._h, 4, p(buf), 1000, None) == _lib.SF_ERR_ARG          # stride smaller than a frame
+    assert L.sf_render(env._h, 4, p(buf), 0, None) == 0                           # any batch can be rendered
+    assert L.sf_render_stack(img._h, p(buf), 4, 4, None, None) == _lib.SF_ERR_ARG  # slot out of range
+    assert L.sf_render_stack(img._h, p(buf), 4, 3, None, None) == 0
+    assert L.sf_set_event_output(env._h, p(buf, 2)) == _lib.SF_ERR_ARG
+    a = torch.zeros(8, dtype=torch.uint8, device=env.device)
+    assert L.sf_rollout(img._h, p(a), 1, 1, p(buf), None, None, None, None) == _lib.SF_ERR_ARG  # frames come from sf_step
+    assert L.sf_step_record(env._h, p(a), 1, None, None, None, None, None, None, None, None, None, None) == _lib.SF_ERR_ARG
+    assert L.sf_compute_returns(0, 8, None, None, None, None, None, 1, 0.99, 0.95, None) == _lib.SF_ERR_ARG
+    z = C.c_void_p()
+    from spacefortress_amd.vecnormalize import _Params
+    bad = _Params(8, 40, 0, 0, 1, 1, 10., 10., .99, 1e-8)
+    assert L.sf_normalizer_create(C.byref(bad), C.byref(z)) == _lib.SF_ERR_ARG     # obs_dim out of range
+    ok = _Params(16, 19, 0, 0, 1, 1, 10., 10., .99, 1e-8)
+    assert L.sf_normalizer_create(C.byref(ok), C.byref(z)) == 0
+    r = torch.zeros(8, dtype=torch.int32, device=env.device)
+    o = torch.zeros(8, 19, device=env.device)
+    f = torch.zeros(8, device=env.device)
+    d = torch.zeros(8, dtype=torch.uint8, device=env.device)
+    # a normaliser made for another batch size
+    assert L.sf_step_normalize(env._h, z, p(a), 1, p(o), p(r), p(d), p(d), p(f), 0, None) == _lib.SF_ERR_ARG
+    assert L.sf_normalize(z, p(o), None, None, None, 0, None) == _lib.SF_ERR_ARG   # inputs and outputs come in pairs
+    assert L.sf_normalizer_destroy(z) == 0
+    torch.cuda.synchronize()
+    env.close()
+    img.close()
