@@ -15,8 +15,9 @@ What the reference draws, where, in which order and in which grey comes from its
   WrapPyTorch           rl/envs.py:28-30       cv2.resize(.., (84, 84), INTER_AREA)
 
 PARITY UNPINNED at the pixel level: cairo, freetype and cv2 are not in this image and the
-reference ships no frame fixtures (rl/imgs/screens.png is a full-colour screenshot at another
-scale), so how a 0.6-pixel stroke turns into grey levels is a MODEL here -- exact area coverage of
+reference ships no frame fixtures.  Its documentation screenshot rl/imgs/screens.png (full colour, scale 1)
+pins the layout of the score text and the bar and the grey levels 128 / 84 / 168
+(tests/golden/telemetry/screens_layout.json); how a 0.6-pixel stroke turns into grey levels is a MODEL here -- exact area coverage of
 each stroke's rectangles, 8-bit OVER compositing, seven-segment digits for the score text, one chord
 per explosion arc and a 12-gon ring for its circle; INTER_AREA follows OpenCV's published algorithm (imgproc/resize.cpp,
 computeResizeAreaTab + resizeArea_).  This file restates that model independently of the HIP
@@ -37,7 +38,7 @@ MISSILE_LINES = [(0, 0, -25, 0), (0, 0, -5, 5), (0, 0, -5, -5)]
 SHELL_LINES = [(-8, 0, 0, -6), (0, -6, 16, 0), (16, 0, 0, 6), (0, 6, -8, 0)]
 
 # seven-segment glyph model of the score text (see sf_raster.h)
-TXT_ADV, TXT_PAD, TXT_W, TXT_H, TXT_T = 18.0, 2.0, 14.0, 22.0, 5.0
+TXT_ADV, TXT_PAD, TXT_W, TXT_H, TXT_T = 18.0, 3.0, 16.0, 22.0, 5.0
 TXT_X0 = 355.0 - 3.5 * TXT_ADV
 TXT_TOP = 97.0 - 0.5 * TXT_H
 SEGS = {"0": "ABCDEF", "1": "BC", "2": "ABDEG", "3": "ABCDG", "4": "BCFG", "5": "ACDFG", "6": "ACDEFG",

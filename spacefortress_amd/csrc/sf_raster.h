@@ -22,13 +22,15 @@
 #define SF_LINE_W 3.0 /* ls = 3 user units (ENV:50), i.e. 0.6 device pixels */
 
 // Score text (drawScore, SRC/draw.cpp:190-203): "%07d", bold monospace 30 user units, centred on
-// (355, 97), grey .5.  No font rasteriser here: seven-segment glyphs in a cell of about the same
-// metrics (advance .6 em = 18, cap height .73 em = 22, stem 5), user units.  At .2 scale a glyph is
-// 2.8 x 4.4 pixels either way.
+// (355, 97), grey .5.  No font rasteriser here: seven-segment glyphs in a cell of the same metrics,
+// user units: advance 18, ink 16 x 22 starting 3 into the cell, stem 5 -- calibrated so that the ink box of
+// the seven characters is where the reference's own screenshot has it (rl/imgs/screens.png: 295..419 x
+// 85..107; tests/test_image_host.py::test_layout_matches_the_references_own_screenshot).  At .2 scale a
+// glyph is 3.2 x 4.4 pixels either way.
 #define SF_TXT_ADV 18.0f
 #define SF_TXT_X0 (355.0f - 3.5f * SF_TXT_ADV)
-#define SF_TXT_PAD 2.0f
-#define SF_TXT_W 14.0f
+#define SF_TXT_PAD 3.0f
+#define SF_TXT_W 16.0f
 #define SF_TXT_H 22.0f
 #define SF_TXT_T 5.0f
 #define SF_TXT_TOP (97.0f - 0.5f * SF_TXT_H)

@@ -136,3 +136,36 @@ def test_static_variants_match_model():
             R.over(want, R.rect_poly(255, 522, 455, 532), 84)
         assert np.array_equal(out, want), v
     assert L.sf_image_static(4, bg.ctypes.data_as(C.c_void_p)) < 0
+
+
+def test_layout_matches_the_references_own_screenshot():
+    """Where things are and how grey they are, against measurements of the reference's documentation
+    screenshot (rl/imgs/screens.png, rendered by the reference at scale 1; numbers extracted by
+    tests/golden/telemetry/make_layout_golden.py).  Positions are compared relative to the big hexagon, in user
+    units, within 3.5 (0.7 pixel of the 0.2-scale observation; the extents are thresholded anti-aliased edges, +-1 each); grey levels exactly.  This pins the layout of
+    the score text and the bar and the three greys to real reference output; anti-aliasing stays unpinned."""
+    import json
+    from oracle import render_np as R
+    lay = json.load(open(os.path.join(GOLDEN, "telemetry", "screens_layout.json")))
+    hb, _ = _hex()
+    hx, hy = hb.reshape(6, 2)[:, 0], hb.reshape(6, 2)[:, 1]
+    half = R.LINE_W / 2
+    hex_left, hex_top, hex_bottom = hx.min() - half, hy.min() - half, hy.max() + half  # outer edge of the stroke
+    text_left = R.TXT_X0 + R.TXT_PAD
+    text_right = R.TXT_X0 + 6 * R.TXT_ADV + R.TXT_PAD + R.TXT_W
+    model = {"text_l": text_left - hex_left, "text_r": text_right - hex_left, "text_t": R.TXT_TOP - hex_top,
+             "text_b": R.TXT_TOP + R.TXT_H - hex_top, "bar_l": 255 - hex_left, "bar_r": 455 - hex_left,
+             "bar_t": 522 - hex_bottom, "bar_b": 532 - hex_bottom, "hex_w": hx.max() - hx.min() + 2 * half,
+             "hex_h": hy.max() - hy.min() + 2 * half}
+    for name, p in lay.items():
+        shot = {"text_l": p["text_x"][0] - p["hex_x"][0], "text_r": p["text_x"][1] + 1 - p["hex_x"][0],
+                "text_t": p["text_y"][0] - p["hex_y"][0], "text_b": p["text_y"][1] + 1 - p["hex_y"][0],
+                "bar_l": p["bar_x"][0] - p["hex_x"][0], "bar_r": p["bar_x"][1] + 1 - p["hex_x"][0],
+                "bar_t": p["bar_y"][0] - (p["hex_y"][1] + 1), "bar_b": p["bar_y"][1] + 1 - (p["hex_y"][1] + 1),
+                "hex_w": p["hex_x"][1] + 1 - p["hex_x"][0], "hex_h": p["hex_y"][1] + 1 - p["hex_y"][0]}
+        for k in model:
+            # the panels are not all at exactly scale 1 (the hexagon is 405..407 wide for 400 + stroke): 1 % on the
+            # two absolute sizes, 3.5 units on every position relative to the hexagon
+            assert abs(model[k] - shot[k]) <= (5.0 if k in ("hex_w", "hex_h") else 3.5), (name, k, model[k], shot[k])
+        assert p["text_grey_max"] == 128                    # .5 grey
+        assert p["bar_grey_mode"] in (84, 168)              # .33 / .66 grey
