@@ -117,13 +117,20 @@ def wireframe(fb, lines, angle, pos, grey=255):
         over(fb, line_poly(ln, int(angle), pos), grey)
 
 
-def explosion(fb, pos):
-    ofs = 0
+def explosion_arcs():
+    """(radius, start degree, end degree, grey) of the 84 arcs of drawExplosion, SRC/draw.cpp:149-166."""
+    arcs, ofs = [], 0
     for radius in range(15, 70, 8):
         ofs += 3
-        grey = 191 if radius < 60 else 128
+        grey = 191 if radius < 60 else 128  # .75 (yellow in colour mode), .5 (red)
         for angle in range(0, 360, 30):
-            _arc(fb, pos, radius, angle + ofs, angle + ofs + 10, grey)
+            arcs.append((radius, angle + ofs, angle + ofs + 10, grey))
+    return arcs
+
+
+def explosion(fb, pos):
+    for radius, a0, a1, grey in explosion_arcs():
+        _arc(fb, pos, radius, a0, a1, grey)
     # the radius-7 circle: ONE stroke (cairo_arc 0..2pi + cairo_stroke), modelled as the ring between
     # two regular 12-gons of circumradius 7 -/+ half the line width
     gons = []

@@ -169,3 +169,114 @@ def test_layout_matches_the_references_own_screenshot():
             assert abs(model[k] - shot[k]) <= (5.0 if k in ("hex_w", "hex_h") else 3.5), (name, k, model[k], shot[k])
         assert p["text_grey_max"] == 128                    # .5 grey
         assert p["bar_grey_mode"] in (84, 168)              # .33 / .66 grey
+
+
+def test_explosion_geometry_matches_the_references_own_screenshot():
+    """The right panel of rl/imgs/screens.png is a fortress explosion rendered by the reference: every yellow /
+    red pixel of it must lie on one of the model's arcs (or on the radius-7 circle) of the right colour class,
+    and every one of the model's 84 arcs must have pixels of the picture on it (radii within 2.5 user units,
+    angles within 2 units of arc length)."""
+    from oracle import render_np as R
+    z = np.load(os.path.join(GOLDEN, "telemetry", "explosion_pixels.npz"))
+    arcs = R.explosion_arcs()
+    hit = np.zeros(len(arcs), int)
+    stray = 0
+    for colour, grey in (("yellow", 191), ("red", 128)):
+        for r, th in zip(z[colour + "_r"], z[colour + "_theta"]):
+            if colour == "yellow" and abs(r - 7) <= 2.5:
+                continue  # the circle
+            slack = np.degrees(2.0 / r)
+            ok = False
+            for k, (radius, a0, a1, g) in enumerate(arcs):
+                if g != grey or abs(r - radius) > 2.5:
+                    continue
+                d = (th - a0) % 360
+                if d <= (a1 - a0) + slack or d >= 360 - slack:
+                    hit[k] += 1
+                    ok = True
+            stray += not ok
+    n = len(z["yellow_r"]) + len(z["red_r"])
+    assert stray <= 0.01 * n, (stray, n)
+    assert (hit > 0).all(), np.flatnonzero(hit == 0)
+    assert (np.abs(z["yellow_r"] - 7) <= 2.5).sum() > 20  # the circle is there too
+
+
+def test_fortress_wireframe_matches_the_references_own_screenshot():
+    """The live fortress of the left and middle panels of rl/imgs/screens.png: for one heading that is a multiple
+    of the 10-degree sector, (nearly) every yellow pixel lies within 2 user units of a segment of the model's
+    fortress wireframe, and every segment is covered along its length."""
+    from oracle import render_np as R
+    z = np.load(os.path.join(GOLDEN, "telemetry", "fortress_pixels.npz"))
+
+    def dist_to_segment(p, a, b):
+        ab, ap = b - a, p - a
+        t = np.clip((ap @ ab) / (ab @ ab), 0, 1)
+        return np.hypot(*(ap - np.outer(t, ab)).T), t
+
+    for name in ("left", "middle"):
+        pts = z[name].astype(np.float64)
+        assert len(pts) > 60
+        best = None
+        for ang in range(0, 360, 10):
+            c, s = np.cos(np.radians(ang)), np.sin(np.radians(ang))
+            d = np.full(len(pts), 1e9)
+            cover = []
+            for ax, ay, bx, by in R.FORT_LINES:
+                a = np.array([c * ax - s * ay, s * ax + c * ay])
+                b = np.array([c * bx - s * by, s * bx + c * by])
+                dk, tk = dist_to_segment(pts, a, b)
+                near = dk <= 2.0
+                cover.append((tk[near].min(), tk[near].max()) if near.any() else (1, 0))
+                d = np.minimum(d, dk)
+            frac = (d <= 2.0).mean()
+            if best is None or frac > best[0]:
+                best = (frac, ang, cover)
+        frac, ang, cover = best
+        assert frac >= 0.97, (name, frac, ang)
+        for lo, hi in cover:  # each of the four segments is drawn end to end
+            assert lo <= 0.15 and hi >= 0.85, (name, ang, cover)
+
+
+def test_ship_wireframe_matches_the_references_own_screenshot():
+    """The ship of each panel of rl/imgs/screens.png (position and heading unknown): for some integer heading and
+    a position near the pixels' centroid, (nearly) every yellow pixel lies within 2 user units of a segment of
+    the model's ship wireframe and every segment is covered end to end."""
+    from oracle import render_np as R
+    z = np.load(os.path.join(GOLDEN, "telemetry", "ship_pixels.npz"))
+    lines = np.array(R.SHIP_LINES, np.float64)
+    lens = np.hypot(lines[:, 2] - lines[:, 0], lines[:, 3] - lines[:, 1])
+    mid = np.stack([(lines[:, 0] + lines[:, 2]) / 2, (lines[:, 1] + lines[:, 3]) / 2], 1)
+    c_local = (mid * lens[:, None]).sum(0) / lens.sum()  # centroid of the strokes in wireframe coordinates
+
+    def score(pts, ang, pos):
+        c, s = np.cos(np.radians(ang)), np.sin(np.radians(ang))
+        d = np.full(len(pts), 1e9)
+        cover = []
+        for ax, ay, bx, by in lines:
+            a = pos + np.array([c * ax - s * ay, s * ax + c * ay])
+            b = pos + np.array([c * bx - s * by, s * bx + c * by])
+            ab, ap = b - a, pts - a
+            t = np.clip((ap @ ab) / (ab @ ab), 0, 1)
+            dk = np.hypot(*(ap - np.outer(t, ab)).T)
+            near = dk <= 2.0
+            cover.append((t[near].min(), t[near].max()) if near.any() else (1, 0))
+            d = np.minimum(d, dk)
+        return (d <= 2.0).mean(), cover
+
+    for name in ("left", "middle", "right"):
+        pts = z[name].astype(np.float64)
+        assert len(pts) > 60
+        cen = pts.mean(0)
+        best = (0, None, None)
+        for ang in range(360):
+            c, s = np.cos(np.radians(ang)), np.sin(np.radians(ang))
+            pos0 = cen - np.array([c * c_local[0] - s * c_local[1], s * c_local[0] + c * c_local[1]])
+            f, cover = score(pts, ang, pos0)
+            if f > best[0]:
+                best = (f, ang, pos0)
+        f, ang, pos0 = best
+        fine = max((score(pts, a2, pos0 + np.array([dx, dy])) + (a2,) for a2 in (ang - 1, ang, ang + 1)
+                    for dx in (-2, -1, 0, 1, 2) for dy in (-2, -1, 0, 1, 2)), key=lambda r: r[0])
+        assert fine[0] >= 0.97, (name, fine[0], fine[2])
+        for lo, hi in fine[1]:
+            assert lo <= 0.15 and hi >= 0.85, (name, fine)
