@@ -266,6 +266,10 @@ int sf_step_record(sf_batch* b, const void* actions_dev, int act_type, void* obs
 int sf_record_step(int n, const int32_t* reward_dev, const uint8_t* done_dev, float* reward_out, float* mask_out,
                    float* episode_rewards, float* final_rewards, const void* actions_dev, int act_type,
                    int64_t* actions_out, void* stream);
+/* ... on rewards that are already float (the trainer behind VecNormalize sees normalised rewards) */
+int sf_record_step_f32(int n, const float* reward_dev, const uint8_t* done_dev, float* reward_out, float* mask_out,
+                       float* episode_rewards, float* final_rewards, const void* actions_dev, int act_type,
+                       int64_t* actions_out, void* stream);
 int sf_compute_returns(int num_steps, int n, const float* rewards, float* value_preds, const float* masks,
                        const float* next_value, float* returns, int use_gae, double gamma, double tau, void* stream);
 

@@ -91,6 +91,7 @@ SYMBOLS = {
     "sf_normalizer_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_normalizer_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_step_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10),
+    "sf_record_step_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]),
     "sf_record_step": (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]),
     "sf_compute_returns": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "sf_render_stack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -17,7 +17,8 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sf_record_kernel(int n, const int32_t* reward, const uint8_t* done, float* reward_out,
+template <typename R>
+__global__ __launch_bounds__(256) void sf_record_kernel(int n, const R* reward, const uint8_t* done, float* reward_out,
                                                         float* mask_out, float* episode_rewards, float* final_rewards,
                                                         const void* actions, int act_type, int64_t* actions_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -86,11 +87,33 @@ extern "C" int sf_record_step(int n, const int32_t* reward_dev, const uint8_t* d
     sf_set_error("sf_record_step: actions_out needs actions_dev and act_type 1, 4 or 8");
     return SF_ERR_ARG;
   }
-  hipLaunchKernelGGL(sf_record_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, reward_dev, done_dev,
-                     reward_out, mask_out, episode_rewards, final_rewards, actions_dev, act_type, actions_out);
+  hipLaunchKernelGGL(sf_record_kernel<int32_t>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, reward_dev,
+                     done_dev, reward_out, mask_out, episode_rewards, final_rewards, actions_dev, act_type, actions_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     sf_set_error("sf_record_step: %s", hipGetErrorString(e));
+    return SF_ERR_HIP;
+  }
+  return SF_OK;
+}
+
+// the same bookkeeping on rewards that are already float: what the trainer sees behind VecNormalize
+extern "C" int sf_record_step_f32(int n, const float* reward_dev, const uint8_t* done_dev, float* reward_out, float* mask_out,
+                                  float* episode_rewards, float* final_rewards, const void* actions_dev, int act_type,
+                                  int64_t* actions_out, void* stream) {
+  if (n <= 0 || !reward_dev || !done_dev) {
+    sf_set_error("sf_record_step_f32: need n > 0, reward_dev and done_dev");
+    return SF_ERR_ARG;
+  }
+  if (actions_out && (!actions_dev || (act_type != SF_ACT_U8 && act_type != SF_ACT_I32 && act_type != SF_ACT_I64))) {
+    sf_set_error("sf_record_step_f32: actions_out needs actions_dev and act_type 1, 4 or 8");
+    return SF_ERR_ARG;
+  }
+  hipLaunchKernelGGL(sf_record_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, reward_dev, done_dev,
+                     reward_out, mask_out, episode_rewards, final_rewards, actions_dev, act_type, actions_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    sf_set_error("sf_record_step_f32: %s", hipGetErrorString(e));
     return SF_ERR_HIP;
   }
   return SF_OK;

@@ -22,6 +22,10 @@ def _p(t):
 
 class DeviceRollout:
     def __init__(self, env, num_steps, state_size=1):
+        # `env`: an SFVecEnv, or an SFVecNormalize around one (the trainer's configuration for 1-D observations,
+        # rl/train.py:35-36: observations and rewards reach the storage normalised)
+        self.norm = env if hasattr(env, "venv") else None
+        env = env.venv if self.norm is not None else env
         self.env = env
         self._L = _lib.lib()
         T, n, dev = int(num_steps), env.num_envs, env.device
@@ -50,6 +54,8 @@ class DeviceRollout:
         """obs = envs.reset(); rollouts.observations[0].copy_(obs) (rl/train.py:60-62)."""
         e = self.env
         _lib.check(e._L.sf_reset(e._h, _p(self.observations[0]), e._stream()))
+        if self.norm is not None:
+            self.norm._filter(self.observations[0], None)  # VecNormalize.reset: update + normalise in place
         return self.observations[0]
 
     def _pointers(self):
@@ -82,9 +88,16 @@ class DeviceRollout:
         P = self._ptr
         stream = self._stream()
         ap, at = C.c_void_p(a.data_ptr()), a.element_size()
-        # one launch: the step kernel's epilogue does the trainer's bookkeeping (sfmi.h: sf_step_record)
-        _lib.check(self._L.sf_step_record(e._h, ap, at, P["obs"][step + 1], P["r"], P["d"], P["i"], P["rew"][step],
-                                          P["mask"][step + 1], P["ep"], P["fin"], P["act"][step], stream))
+        if self.norm is not None:
+            z = self.norm
+            if not (z.ob and z.ret_on):
+                raise NotImplementedError("DeviceRollout drives VecNormalize(ob=True, ret=True), the trainer's configuration")
+            _lib.check(self._L.sf_step_normalize(e._h, z._h, ap, at, P["obs"][step + 1], P["r"], P["d"], P["i"],
+                                                 C.c_void_p(z._rew.data_ptr()), 0 if z.training else 1, stream))
+            _lib.check(self._L.sf_record_step_f32(e.num_envs, C.c_void_p(z._rew.data_ptr()), P["d"], P["rew"][step],
+                                                  P["mask"][step + 1], P["ep"], P["fin"], ap, at, P["act"][step], stream))
+        else:
+            self._step_record(ap, at, step, stream)
         if value_pred is not None:
             self.value_preds[step].copy_(value_pred)
         if action_log_prob is not None:
@@ -92,6 +105,12 @@ class DeviceRollout:
         if state is not None:
             self.states[step + 1].copy_(state)
         return self.observations[step + 1], self.rewards[step], self.masks[step + 1]
+
+    def _step_record(self, ap, at, step, stream):
+        e, P = self.env, self._ptr
+        # one launch: the step kernel's epilogue does the trainer's bookkeeping (sfmi.h: sf_step_record)
+        _lib.check(self._L.sf_step_record(e._h, ap, at, P["obs"][step + 1], P["r"], P["d"], P["i"], P["rew"][step],
+                                          P["mask"][step + 1], P["ep"], P["fin"], P["act"][step], stream))
 
     @property
     def num_destruction(self):

@@ -129,3 +129,37 @@ def test_step_record_equals_step_then_record(sfa):
         assert float(m1.min()) == 0.0 or (ep1 != 0).any()
         a_env.close()
         b_env.close()
+
+
+def test_device_rollout_over_vecnormalize(sfa):
+    """The trainer's configuration for 1-D observations (rl/train.py:35-36): the storage receives NORMALISED
+    observations and rewards, and the episode bookkeeping runs on the normalised rewards.  Against a twin
+    SFVecNormalize stepped one call at a time + the numpy restatement of the bookkeeping."""
+    from oracle import trainer_np as TN
+    N, T = 500, 10
+    mk = lambda: sfa.SFVecNormalize(sfa.SFVecEnv(N, gametype="youturn", spawn_stride=1))
+    env, twin = mk(), mk()
+    ro = sfa.DeviceRollout(env, T)
+    o0 = ro.reset()
+    assert torch.allclose(o0, twin.reset(), atol=1e-6)
+    for e in (env, twin):  # late in the episode, so that `done` happens inside the rollout
+        e.venv.set_field("time", np.full(N, 34 * 5288, np.int32))
+    g = torch.Generator(device=o0.device).manual_seed(1)
+    ep, fin = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    for t in range(T):
+        a = torch.randint(0, 5, (N,), device=o0.device, generator=g)
+        obs, rew, mask = ro.step(t, a)
+        o2, r2, d2, i2 = twin.step_tensors(a)
+        assert torch.allclose(obs, o2, atol=1e-6) and torch.allclose(rew[:, 0], r2, atol=1e-6)
+        r_np = rew[:, 0].cpu().numpy()
+        m = np.where(d2.cpu().numpy().astype(bool), np.float32(0), np.float32(1))
+        ep = ep + r_np
+        fin = fin * m + (np.float32(1) - m) * ep
+        ep = ep * m
+        assert np.array_equal(mask[:, 0].cpu().numpy(), m)
+    assert np.array_equal(ro.episode_rewards[:, 0].cpu().numpy(), ep) and np.array_equal(ro.final_rewards[:, 0].cpu().numpy(), fin)
+    assert (ro.masks[1:] == 0).any()
+    st1, st2 = env.state_dict()["stats"], twin.state_dict()["stats"]
+    assert np.allclose(st1, st2, rtol=1e-12)
+    env.close()
+    twin.close()
