@@ -148,6 +148,12 @@ int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, voi
  * done_dev flag is set (may be NULL) first gets its other slots zeroed. */
 int sf_render_stack(sf_batch* b, uint8_t* stack_dev, int num_stack, int slot, const uint8_t* done_dev, void* stream);
 
+/* The same update from one buffer into ANOTHER (the trainer stores the stacked observation of every step,
+ * rollouts.observations[step + 1], rl/train.py:98): frames 1 .. num_stack-1 of prev_stack_dev become frames
+ * 0 .. num_stack-2 of stack_dev (zeros for an env whose done flag is set), the new frame goes last. */
+int sf_render_shift(sf_batch* b, const uint8_t* prev_stack_dev, uint8_t* stack_dev, int num_stack, const uint8_t* done_dev,
+                    void* stream);
+
 /* `current_obs *= masks` of the trainer's frame stack (rl/train.py:92-93): zero the bytes_per_env bytes of
  * every env whose done flag is set, touching nothing else.  stack_dev uint8 [n_envs][bytes_per_env]. */
 int sf_frame_stack_clear(uint8_t* stack_dev, size_t bytes_per_env, const uint8_t* done_dev, int n_envs, void* stream);

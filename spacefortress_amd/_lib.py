@@ -95,6 +95,7 @@ SYMBOLS = {
     "sf_record_step": (C.c_int, [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]),
     "sf_compute_returns": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "sf_render_stack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sf_render_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "sf_frame_stack_clear": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "sf_set_event_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sf_render": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

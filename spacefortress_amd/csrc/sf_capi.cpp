@@ -298,7 +298,8 @@ extern "C" int sf_max_ticks(const sf_batch* b) { return b ? (int)sfc::max_ticks 
 static bool is_image(const sf_batch* b) { return b->obs_mode == SF_OBS_IMAGE || b->obs_mode == SF_OBS_IMAGE_RAW; }
 
 static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, hipStream_t stream,
-                  const uint8_t* stack_done = nullptr, int stack_slot = 0, int stack_n = 1) {
+                  const uint8_t* stack_done = nullptr, int stack_slot = 0, int stack_n = 1,
+                  const uint8_t* stack_prev = nullptr) {
   const size_t frame = mode == SF_OBS_IMAGE ? (size_t)SF_OUT * SF_OUT : (size_t)SF_IMG_W * SF_IMG_H;
   if (env_stride == 0) env_stride = frame;
   if (((uintptr_t)frames_dev & 15) != 0 || env_stride < frame || (env_stride & (mode == SF_OBS_IMAGE ? 15 : 7)) != 0) {
@@ -316,7 +317,7 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
   }
   const unsigned char* fpatch = b->d_xcache ? b->d_xcache + (size_t)b->n_envs * SF_XC_BYTES : nullptr;
   HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache, fpatch,
-                           mode == SF_OBS_IMAGE ? 1 : 0, stack_done, stack_slot, stack_n, stream));
+                           mode == SF_OBS_IMAGE ? 1 : 0, stack_done, stack_slot, stack_n, stack_prev, stream));
   return SF_OK;
 }
 
@@ -342,6 +343,19 @@ extern "C" int sf_render_stack(sf_batch* b, uint8_t* stack_dev, int num_stack, i
   const size_t frame = (size_t)SF_OUT * SF_OUT;
   return render(b, SF_OBS_IMAGE, stack_dev + (size_t)slot * frame, (size_t)num_stack * frame, (hipStream_t)stream, done_dev, slot,
                 num_stack);
+}
+
+extern "C" int sf_render_shift(sf_batch* b, const uint8_t* prev_stack_dev, uint8_t* stack_dev, int num_stack,
+                               const uint8_t* done_dev, void* stream) {
+  if (!b || !prev_stack_dev || !stack_dev || num_stack < 1 || prev_stack_dev == stack_dev ||
+      ((uintptr_t)prev_stack_dev & 15) != 0) {
+    sf_set_error("sf_render_shift: need a batch and two different 16-byte aligned stacks");
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  const size_t frame = (size_t)SF_OUT * SF_OUT;
+  return render(b, SF_OBS_IMAGE, stack_dev + (size_t)(num_stack - 1) * frame, (size_t)num_stack * frame, (hipStream_t)stream,
+                done_dev, num_stack - 1, num_stack, prev_stack_dev);
 }
 
 extern "C" int sf_frame_stack_clear(uint8_t* stack_dev, size_t bytes_per_env, const uint8_t* done_dev, int n_envs, void* stream) {

@@ -546,6 +546,10 @@ struct SfRenderArgs {
   // set gets its other slots zeroed first (`current_obs *= masks`, rl/train.py:92-93); stack_done null = plain render
   const uint8_t* stack_done;
   int stack_slot, stack_n;
+  // sf_render_shift: the stack of the PREVIOUS step (same layout); its frames 1 .. stack_n-1 become frames
+  // 0 .. stack_n-2 of this one (zeros for a finished env), the new frame is rendered into the last slot: the
+  // trainer's update_current_obs + rollouts.insert (rl/train.py:51-56,98) without a separate copy
+  const uint8_t* stack_prev;
 };
 
 // The fortress never moves and its heading is a multiple of the 10-degree sector (SRC/game.cpp:205-208):
@@ -728,7 +732,13 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
     for (int i = lane; i < kFbVec; i += 64) dst[i] = src[i];
     for (int i = 4 * kFbVec + lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bgv[i] : 0u;
   }
-  if (RESIZE && a.stack_done && a.stack_done[env]) {
+  if (RESIZE && a.stack_prev) {
+    const bool fin = a.stack_done && a.stack_done[env];
+    const uint4 z = {0u, 0u, 0u, 0u};
+    const uint4* src = reinterpret_cast<const uint4*>(a.stack_prev + (size_t)env * a.out_stride + kOutBytes);
+    uint4* dst = reinterpret_cast<uint4*>(frame_out - (ptrdiff_t)a.stack_slot * kOutBytes);
+    for (int i = lane; i < (a.stack_n - 1) * (kOutBytes / 16); i += 64) dst[i] = fin ? z : src[i];
+  } else if (RESIZE && a.stack_done && a.stack_done[env]) {
     const uint4 z = {0u, 0u, 0u, 0u};
     for (int sl = 0; sl < a.stack_n; sl++) {
       if (sl == a.stack_slot) continue;
@@ -875,9 +885,9 @@ hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uin
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
-                            hipStream_t stream) {
+                            const uint8_t* stack_prev, hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
-  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n};
+  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n, stack_prev};
   if (resize)
     hipLaunchKernelGGL(sf_render_kernel<true>, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
   else

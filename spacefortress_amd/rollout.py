@@ -21,7 +21,7 @@ def _p(t):
 
 
 class DeviceRollout:
-    def __init__(self, env, num_steps, state_size=1):
+    def __init__(self, env, num_steps, state_size=1, num_stack=1):
         # `env`: an SFVecEnv, or an SFVecNormalize around one (the trainer's configuration for 1-D observations,
         # rl/train.py:35-36: observations and rewards reach the storage normalised)
         self.norm = env if hasattr(env, "venv") else None
@@ -31,6 +31,13 @@ class DeviceRollout:
         T, n, dev = int(num_steps), env.num_envs, env.device
         self.num_steps = T
         obs_shape = tuple(env.obs_shape)
+        # image observations: obs_shape = (obs_shape[0] * num_stack, ...) as in rl/train.py:38-39; every step stores
+        # the whole stack (shifted by one frame, zeroed for finished envs, new frame last)
+        self.num_stack = int(num_stack)
+        if self.num_stack > 1:
+            if env.obs_type != "image" or self.norm is not None:
+                raise ValueError("num_stack > 1 is for obs_type='image' (rl/train.py:38-39)")
+            obs_shape = (self.num_stack,) + obs_shape[1:]
         self.observations = torch.zeros((T + 1, n) + obs_shape, dtype=env.obs_dtype, device=dev)
         self.states = torch.zeros(T + 1, n, state_size, device=dev)
         self.rewards = torch.zeros(T, n, 1, device=dev)
@@ -53,6 +60,12 @@ class DeviceRollout:
     def reset(self):
         """obs = envs.reset(); rollouts.observations[0].copy_(obs) (rl/train.py:60-62)."""
         e = self.env
+        if self.num_stack > 1:  # update_current_obs on a zeroed stack (rl/train.py:43,60-62)
+            _lib.check(e._L.sf_reset(e._h, None, e._stream()))
+            self.observations[0].zero_()
+            _lib.check(e._L.sf_render_stack(e._h, _p(self.observations[0]), self.num_stack, self.num_stack - 1, None,
+                                            e._stream()))
+            return self.observations[0]
         _lib.check(e._L.sf_reset(e._h, _p(self.observations[0]), e._stream()))
         if self.norm is not None:
             self.norm._filter(self.observations[0], None)  # VecNormalize.reset: update + normalise in place
@@ -108,6 +121,13 @@ class DeviceRollout:
 
     def _step_record(self, ap, at, step, stream):
         e, P = self.env, self._ptr
+        if self.num_stack > 1:
+            # the step without an observation, then ONE render launch builds observations[step + 1] from
+            # observations[step]: shift by a frame, zero the finished envs, new frame last
+            _lib.check(self._L.sf_step_record(e._h, ap, at, None, P["r"], P["d"], P["i"], P["rew"][step],
+                                              P["mask"][step + 1], P["ep"], P["fin"], P["act"][step], stream))
+            _lib.check(self._L.sf_render_shift(e._h, P["obs"][step], P["obs"][step + 1], self.num_stack, P["d"], stream))
+            return
         # one launch: the step kernel's epilogue does the trainer's bookkeeping (sfmi.h: sf_step_record)
         _lib.check(self._L.sf_step_record(e._h, ap, at, P["obs"][step + 1], P["r"], P["d"], P["i"], P["rew"][step],
                                           P["mask"][step + 1], P["ep"], P["fin"], P["act"][step], stream))

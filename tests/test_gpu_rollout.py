@@ -163,3 +163,34 @@ def test_device_rollout_over_vecnormalize(sfa):
     assert np.allclose(st1, st2, rtol=1e-12)
     env.close()
     twin.close()
+
+
+def test_device_rollout_with_frame_stack(sfa):
+    """Image observations with num_stack = 4 (BASELINE configs[4]; rl/train.py:38-39,51-56,92-98): every step's
+    stored observation is the previous one shifted by a frame, zeroed for finished envs, with the new frame
+    last -- against FrameStack (already checked against the trainer's own update) on a twin batch."""
+    N, T, S = 96, 14, 4
+    env = sfa.SFVecEnv(N, gametype="autoturn", obs_type="image", spawn_stride=1)
+    twin = sfa.SFVecEnv(N, gametype="autoturn", obs_type="image", spawn_stride=1)
+    ro = sfa.DeviceRollout(env, T, num_stack=S)
+    fs = sfa.FrameStack(twin, S)
+    assert ro.observations.shape == (T + 1, N, S, 84, 84) and ro.observations.dtype == torch.uint8
+    assert torch.equal(ro.reset(), fs.reset())
+    for e in (env, twin):
+        e.set_field("time", np.full(N, 34 * 5287, np.int32))
+    g = torch.Generator(device=env.device).manual_seed(2)
+    saw_done = False
+    for t in range(T):
+        a = torch.randint(0, 3, (N,), device=env.device, generator=g, dtype=torch.uint8)
+        obs, rew, mask = ro.step(t, a)
+        r2, d2, i2 = fs.step(a)
+        assert torch.equal(obs, fs.stacked()), t
+        assert torch.equal(rew[:, 0], r2.float()) and torch.equal(mask[:, 0] == 0, d2)
+        saw_done = saw_done or bool(d2.any())
+    assert saw_done
+    ro.after_update()
+    assert torch.equal(ro.observations[0], fs.stacked())
+    with pytest.raises(ValueError):
+        sfa.DeviceRollout(sfa.SFVecEnv(4), 2, num_stack=4)
+    env.close()
+    twin.close()
