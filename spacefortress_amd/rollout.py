@@ -150,3 +150,31 @@ class DeviceRollout:
         self.observations[0].copy_(self.observations[-1])
         self.states[0].copy_(self.states[-1])
         self.masks[0].copy_(self.masks[-1])
+
+    # ------------------------------------------------------------------ PPO sampling (rl/storage.py:66-122)
+    def feed_forward_generator(self, advantages, num_mini_batch):
+        """Random minibatches over the T x N transitions; same tuple and shapes as the reference's generator."""
+        T, n = self.rewards.shape[0:2]
+        batch = T * n
+        assert batch >= num_mini_batch, "ppo req batch size to be greater than number of mini batches"
+        mb = batch // num_mini_batch
+        perm = torch.randperm(batch, device=self.env.device)
+        obs = self.observations[:-1].reshape(batch, *self.observations.shape[2:])
+        flat = lambda t: t.reshape(batch, t.shape[-1])
+        states, actions, returns, masks = flat(self.states[:-1]), flat(self.actions), flat(self.returns[:-1]), flat(self.masks[:-1])
+        logp, adv = flat(self.action_log_probs), advantages.reshape(batch, 1)
+        for s in range(0, batch, mb):  # BatchSampler(..., drop_last=False)
+            idx = perm[s:s + mb]
+            yield obs[idx], states[idx], actions[idx], returns[idx], masks[idx], logp[idx], adv[idx]
+
+    def recurrent_generator(self, advantages, num_mini_batch):
+        """Whole trajectories of num_processes // num_mini_batch random envs per minibatch, concatenated env by env."""
+        n = self.rewards.shape[1]
+        per = n // num_mini_batch
+        perm = torch.randperm(n, device=self.env.device)
+        cat = lambda t, idx: t[:, idx].transpose(0, 1).reshape(-1, *t.shape[2:])
+        for s in range(0, n, per):
+            idx = perm[s:s + per]
+            yield (cat(self.observations[:-1], idx), cat(self.states[:-1], idx), cat(self.actions, idx),
+                   cat(self.returns[:-1], idx), cat(self.masks[:-1], idx), cat(self.action_log_probs, idx),
+                   cat(advantages, idx))

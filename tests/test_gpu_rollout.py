@@ -194,3 +194,34 @@ def test_device_rollout_with_frame_stack(sfa):
         sfa.DeviceRollout(sfa.SFVecEnv(4), 2, num_stack=4)
     env.close()
     twin.close()
+
+
+def test_ppo_generators_cover_the_rollout(sfa):
+    """feed_forward_generator / recurrent_generator (rl/storage.py:66-122): shapes of the reference's tuples,
+    every transition sampled exactly once, rows consistent across the tensors of a minibatch."""
+    N, T = 24, 6
+    env = sfa.SFVecEnv(N, gametype="youturn", spawn_stride=1)
+    ro = sfa.DeviceRollout(env, T)
+    ro.reset()
+    for t in range(T):
+        a = torch.randint(0, 5, (N,), device=env.device)
+        ro.step(t, a, value_pred=torch.full((N, 1), float(t), device=env.device))
+    ro.compute_returns(torch.zeros(N, 1, device=env.device), True, 0.99, 0.95)
+    ro.returns[:-1] = torch.arange(T * N, device=env.device, dtype=torch.float32).view(T, N, 1)  # a unique tag per transition
+    adv = ro.returns[:-1] * 2
+    seen = []
+    for obs, st, act, ret, msk, logp, ad in ro.feed_forward_generator(adv, 4):
+        assert obs.shape == (T * N // 4, 19) and act.shape == (T * N // 4, 1) and ret.shape == msk.shape == logp.shape == ad.shape
+        assert torch.equal(ad, ret * 2)
+        tags = ret[:, 0].long()
+        assert torch.equal(obs, ro.observations[:-1].reshape(T * N, 19)[tags])
+        seen.append(tags)
+    assert torch.equal(torch.sort(torch.cat(seen)).values, torch.arange(T * N, device=env.device))
+    seen = []
+    for obs, st, act, ret, msk, logp, ad in ro.recurrent_generator(adv, 3):
+        assert obs.shape == (T * (N // 3), 19) and torch.equal(ad, ret * 2)
+        tags = ret[:, 0].long().view(N // 3, T)
+        assert bool((tags[:, 1:] - tags[:, :-1] == N).all())  # consecutive steps of one env
+        seen.append(tags.reshape(-1))
+    assert torch.equal(torch.sort(torch.cat(seen)).values, torch.arange(T * N, device=env.device))
+    env.close()
