@@ -15,7 +15,8 @@
  *     `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *   - every *_dev pointer is DEVICE memory owned by the caller (PyTorch); the
  *     library borrows it for the duration of the stream work it enqueues and
- *     makes no allocation after sf_create.
+ *     makes no allocation after sf_create (one exception: the first image frame
+ *     of a batch allocates that batch's render caches).
  *   - calls are asynchronous and stream-ordered; nothing synchronises unless
  *     documented (sf_get_field / sf_episode_stats do).
  *   - every function returns an sf_status (0 = ok, < 0 = error);
@@ -54,7 +55,7 @@ typedef enum {
   SF_ERR_FIELD = -6      /* unknown field id / size mismatch in sf_get_field / sf_set_field */
 } sf_status;
 
-/* obs_type of SSF_Env (ENV:50-52); image observations are not built yet */
+/* obs_type of SSF_Env (ENV:50-52) */
 #define SF_OBS_FEATURES 0   /* ENV:134-157: 19 (youturn) / 17 (autoturn) values */
 #define SF_OBS_NORMALIZED 1 /* ENV:109-133 */
 #define SF_OBS_MONITORS 2   /* ENV:96-108: 10 values */
