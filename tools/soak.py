@@ -1,0 +1,43 @@
+"""Long lock-step parity run: N lanes x T steps (several episodes) on the GPU (chunks of fused rollouts and,
+alternately, single steps) against the CPU oracle; every reward / done / info, every observation (float32
+tolerance), the full state at every chunk end.  python tools/soak.py [gametype] [lanes] [steps]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from spacefortress_amd import SFVecEnv
+from oracle import oracle as O
+from sfcompare import compare_state
+
+gametype = sys.argv[1] if len(sys.argv) > 1 else "youturn"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 16500
+K = 250
+env = SFVecEnv(N, gametype=gametype, spawn_stride=3, spawn_skip=1)
+orc = O.OracleVecEnv(gametype, N, spawn_stride=3, spawn_skip=1)
+rng = np.random.default_rng(99)
+o0 = env.reset().cpu().numpy(); oo0 = orc.reset()
+assert np.allclose(o0, oo0, rtol=1e-5, atol=4e-5)
+t0 = time.time(); done_total = 0; kills = 0
+for c in range(0, T, K):
+    k = min(K, T - c)
+    acts = rng.integers(0, env.n_actions, (k, N)).astype(np.uint8)
+    a = torch.from_numpy(acts).to(env.device)
+    if (c // K) % 2 == 0:
+        obs, rew, done, info = env.rollout(a)
+    else:
+        outs = [tuple(x.clone() for x in env.step_tensors(a[j])) for j in range(k)]
+        obs, rew, done, info = (torch.stack([o[j] for o in outs]) for j in range(4))
+    obs, rew, done, info = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool), info.cpu().numpy().astype(bool)
+    for j in range(k):
+        oo, orw, od, oi = orc.step(acts[j].astype(np.int32))
+        assert np.array_equal(rew[j], orw), (c + j, np.flatnonzero(rew[j] != orw)[:5])
+        assert np.array_equal(done[j], od) and np.array_equal(info[j], oi), c + j
+        assert np.allclose(obs[j], oo, rtol=1e-5, atol=4e-5), (c + j)
+        done_total += int(od.sum()); kills += int(oi.sum())
+    bad = compare_state(env.state_dict(), orc.snapshots())
+    assert not bad, (c, bad)
+    if (c // K) % 10 == 9:
+        print("step %6d ok  (episodes finished %d, kills %d, %.0f s)" % (c + k, done_total, kills, time.time() - t0), flush=True)
+print("SOAK OK: %s, %d lanes x %d steps = %.1fM env-steps, %d episodes finished, %d fortress kills" % (
+    gametype, N, T, N * T / 1e6, done_total, kills))
