@@ -49,8 +49,50 @@
 #define SF_TRIG_PIECES ((SF_LDS_DOUBLES / 2 + SF_BLOCK - 1) / SF_BLOCK)
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #define SF_MPF 12 /* missile slots prefetched into registers; higher slots take the slow loop */
+#ifndef SF_MG_VARIANT
+#define SF_MG_VARIANT 4
+#endif
+#if SF_MG_VARIANT == 0
 #define SF_MGROUPS 4
-#define SF_SPF 6 /* shell slots prefetched (groups of 3) */
+#define SF_MG_LO {0, 2, 4, 8}
+#define SF_MG_N {2, 2, 4, 4}
+#elif SF_MG_VARIANT == 1
+#define SF_MGROUPS 6
+#define SF_MG_LO {0, 2, 4, 6, 8, 10}
+#define SF_MG_N {2, 2, 2, 2, 2, 2}
+#elif SF_MG_VARIANT == 2
+#define SF_MGROUPS 7
+#define SF_MG_LO {0, 2, 3, 4, 5, 6, 8}
+#define SF_MG_N {2, 1, 1, 1, 1, 2, 4}
+#elif SF_MG_VARIANT == 3
+#define SF_MGROUPS 5
+#define SF_MG_LO {0, 2, 4, 6, 8}
+#define SF_MG_N {2, 2, 2, 2, 4}
+#elif SF_MG_VARIANT == 4
+#define SF_MGROUPS 8
+#define SF_MG_LO {0, 2, 4, 6, 8, 9, 10, 11}
+#define SF_MG_N {2, 2, 2, 2, 1, 1, 1, 1}
+#elif SF_MG_VARIANT == 5
+#define SF_MGROUPS 9
+#define SF_MG_LO {0, 2, 4, 5, 6, 7, 8, 9, 10}
+#define SF_MG_N {2, 2, 1, 1, 1, 1, 1, 1, 2}
+#elif SF_MG_VARIANT == 7
+#define SF_MGROUPS 9
+#define SF_MG_LO {0, 2, 4, 6, 7, 8, 9, 10, 11}
+#define SF_MG_N {2, 2, 2, 1, 1, 1, 1, 1, 1}
+#elif SF_MG_VARIANT == 8
+#define SF_MGROUPS 7
+#define SF_MG_LO {0, 2, 4, 6, 8, 9, 10}
+#define SF_MG_N {2, 2, 2, 2, 1, 1, 2}
+#else
+#define SF_MGROUPS 7
+#define SF_MG_LO {0, 2, 4, 6, 8, 10, 11}
+#define SF_MG_N {2, 2, 2, 2, 2, 1, 1}
+#endif
+#define SF_SPF 6 /* shell slots prefetched (groups of SF_SGSZ) */
+#ifndef SF_SGSZ
+#define SF_SGSZ 2
+#endif
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -566,7 +608,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   // Slot groups (missiles {0,1} {2,3} {4..7} {8..11}, shells {0,1,2} {3,4,5}): a wave ballot
   // skips a group no lane uses.  The kernel lasts as long as its slowest wave, so the groups reach
   // well past the common case: the dependent-load loop behind them is for slots hardly ever used.
-  constexpr int kMgLo[SF_MGROUPS] = {0, 2, 4, 8}, kMgN[SF_MGROUPS] = {2, 2, 4, 4};
+  constexpr int kMgLo[SF_MGROUPS] = SF_MG_LO, kMgN[SF_MGROUPS] = SF_MG_N;
   double mx[SF_MPF], my[SF_MPF];
   int mang[SF_MPF];
   double shx[SF_SPF], shy[SF_SPF], shvx[SF_SPF], shvy[SF_SPF];
@@ -602,11 +644,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       }
     }
 #pragma unroll
-    for (int g = 0; g < SF_SPF / 3; g++) {
-      if (__ballot((L.smask & (0x7u << (3 * g))) != 0u) != 0ull) {
+    for (int g = 0; g < SF_SPF / SF_SGSZ; g++) {
+      if (__ballot((L.smask & (((1u << SF_SGSZ) - 1u) << (SF_SGSZ * g))) != 0u) != 0ull) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const int s = 3 * g + k;
+        for (int k = 0; k < SF_SGSZ; k++) {
+          const int s = SF_SGSZ * g + k;
           if ((L.smask >> s) & 1u) {
             const d2_t sp = SF_LD(d2_t, SF_CHUNK(shell_pos, s), o.o16);
             const d2_t sv = SF_LD(d2_t, SF_CHUNK(shell_vel, s), o.o16);
@@ -789,14 +831,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   //      straight-line code; then the (ship-alive dependent) outcome in slot order.
   {
 #pragma unroll
-    for (int g = 0; g < SF_SPF / 3; g++) {
-      const unsigned gmask = 0x7u << (3 * g);
+    for (int g = 0; g < SF_SPF / SF_SGSZ; g++) {
+      const unsigned gmask = ((1u << SF_SGSZ) - 1u) << (SF_SGSZ * g);
       if (__ballot((L.smask & gmask) != 0u) == 0ull) continue;
       unsigned col = 0, out = 0;
-      double nx[3], ny[3];
+      double nx[SF_SGSZ], ny[SF_SGSZ];
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int s = 3 * g + k;
+      for (int k = 0; k < SF_SGSZ; k++) {
+        const int s = SF_SGSZ * g + k;
         const bool isnew = (s == new_s_slot);
         const double vx = isnew ? new_s_vx : shvx[s], vy = isnew ? new_s_vy : shvy[s];
         nx[k] = (isnew ? sfc::fort_x : shx[s]) + vx;
@@ -829,8 +871,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       }
       L.smask &= ~dead;
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int s = 3 * g + k;
+      for (int k = 0; k < SF_SGSZ; k++) {
+        const int s = SF_SGSZ * g + k;
         if ((L.smask >> s) & 1u) SF_ST(d2_t, SF_CHUNK(shell_pos, s), o.o16, (d2_t{nx[k], ny[k]}));
       }
     }
