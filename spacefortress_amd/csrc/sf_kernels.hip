@@ -125,6 +125,9 @@
 // leave L2 while the kernel still runs, so the end-of-kernel write-back has less to flush.  (With
 // the earlier 1-8-byte rows `sc1` LOST 1 %: narrow write-through stores are one fabric write each.)
 // Nothing stored this way is read again inside the launch.
+#ifndef SF_OBS_NT
+#define SF_OBS_NT 0
+#endif
 #ifndef SF_STORE_MODE
 #define SF_STORE_MODE 2
 #endif
@@ -469,8 +472,13 @@ __device__ __forceinline__ void flush_obs_wave(const SfKernelArgs& a, const T* s
   if (vec_ok) {
     typedef T vec_t __attribute__((ext_vector_type(V)));
     const int nvec = total / V;
-    for (int v = lane; v < nvec; v += 64)
+    for (int v = lane; v < nvec; v += 64) {
+#if SF_OBS_NT
+      __builtin_nontemporal_store(reinterpret_cast<const vec_t*>(stage_w)[v], reinterpret_cast<vec_t*>(dst) + v);
+#else
       reinterpret_cast<vec_t*>(dst)[v] = reinterpret_cast<const vec_t*>(stage_w)[v];
+#endif
+    }
     done_elems = nvec * V;
   }
   for (int t = done_elems + lane; t < total; t += 64) dst[t] = stage_w[t];
