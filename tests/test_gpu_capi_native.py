@@ -108,3 +108,23 @@ def test_new_entry_points_reject_bad_arguments():
     torch.cuda.synchronize()
     env.close()
     img.close()
+
+
+def test_gym_namespace_builds_the_registered_ids():
+    """`import spacefortress.gym`: the four ids the reference registers, as device batches and single envs."""
+    import spacefortress.gym as sfg
+    for env_id, (n_act, dim) in {"SpaceFortress-youturn-image-v0": (5, 19), "SpaceFortress-autoturn-image-v0": (3, 17),
+                                 "SpaceFortress-testyouturn-image-v0": (5, 19), "SpaceFortress-testautoturn-image-v0": (3, 17)}.items():
+        v = sfg.make_vec_env(env_id, 6)
+        assert v.action_space.n == n_act and v.observation_space.shape == (dim,)
+        o, r, d, i = v.step(np.zeros(6, np.int64))
+        assert o.shape == (6, dim) and r.dtype == np.int64 and d.dtype == bool
+        v.close()
+    img = sfg.make_vec_env("SpaceFortress-youturn-image-v0", 4, obs_type="image")  # what rl/envs.py wraps workers into
+    assert img.observation_space.shape == (1, 84, 84) and img.reset().shape == (4, 1, 84, 84)
+    img.close()
+    e = sfg.make_env("SpaceFortress-autoturn-image-v0", 0, 0)()
+    assert e.reset().shape == (17,) and e.action_space.n == 3
+    e.close()
+    with pytest.raises(KeyError):
+        sfg.make_vec_env("SpaceFortress-nope-v0", 2)
