@@ -128,6 +128,18 @@
 #ifndef SF_OBS_NT
 #define SF_OBS_NT 0
 #endif
+// SF_ABL_TRIG (timing-only ablation, results are WRONG when set): 1 = no workgroup barrier after the
+// table staging, 2 = no table at all (hardware v_cos_f32 / v_sin_f32 instead of the exact entries).
+#ifndef SF_ABL_TRIG
+#define SF_ABL_TRIG 0
+#endif
+#if SF_ABL_TRIG == 2
+#define SF_COS(ang) ((double)__builtin_amdgcn_cosf((float)(ang) * (1.0f / 360.0f)))
+#define SF_SIN(ang) ((double)__builtin_amdgcn_sinf((float)(ang) * (1.0f / 360.0f)))
+#else
+#define SF_COS(ang) trig[2 * (ang)]
+#define SF_SIN(ang) trig[2 * (ang) + 1]
+#endif
 #ifndef SF_STORE_MODE
 #define SF_STORE_MODE 2
 #endif
@@ -674,10 +686,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   }
 
   // cos/sin table -> LDS (the loads were issued in round trip 1)
+#if SF_ABL_TRIG != 2
 #pragma unroll
   for (int k = 0; k < SF_TRIG_PIECES; k++)
     if (tid + k * SF_BLOCK < SF_LDS_DOUBLES / 2) reinterpret_cast<d2_t*>(lds)[tid + k * SF_BLOCK] = cst[k];
+#endif
+#if SF_ABL_TRIG == 0
   __syncthreads();  // the only workgroup barrier of the kernel
+#endif
   const double* trig = lds;
   SF_STAMP(3, false);
 
@@ -772,8 +788,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       }
     }
     if (L.fl & SF_FL_THRUST) {
-      L.vx += sfc::ship_accel * trig[2 * L.angle];
-      L.vy += sfc::ship_accel * trig[2 * L.angle + 1];
+      L.vx += sfc::ship_accel * SF_COS(L.angle);
+      L.vy += sfc::ship_accel * SF_SIN(L.angle);
     }
     L.sx += L.vx;
     L.sy += L.vy;
@@ -937,8 +953,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     auto m_move = [&](int s, double x, double y, int ang, bool isnew, double& nx, double& ny)
                       __attribute__((always_inline)) {
       // velocity = missileSpeed * (cos, sin)(deg2rad(angle)) with an integer angle: table
-      nx = x + sfc::missile_speed * trig[2 * ang];
-      ny = y + sfc::missile_speed * trig[2 * ang + 1];
+      nx = x + sfc::missile_speed * SF_COS(ang);
+      ny = y + sfc::missile_speed * SF_SIN(ang);
       const double dx = nx - sfc::fort_x, dy = ny - sfc::fort_y;
       const bool live = (L.mmask >> s) & 1u;
       const bool hit = live & (dx * dx + dy * dy <= sfc::missile_hit_r2);  // collided(mFortress), see shells
