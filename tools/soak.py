@@ -1,6 +1,9 @@
 """Long lock-step parity run: N lanes x T steps (several episodes) on the GPU (chunks of fused rollouts and,
 alternately, single steps) against the CPU oracle; every reward / done / info, every observation (float32
-tolerance), the full state at every chunk end.  python tools/soak.py [gametype] [lanes] [steps]"""
+tolerance), the full state at every chunk end.  python tools/soak.py [gametype] [lanes] [steps] [random|hunter]
+`hunter`: an open-loop firing pattern per lane (a shot every 8 ticks = 272 ms > the 250 ms vulnerability window
+until the fortress is kill-ready, then a double shot), random phase per lane, 10 % of the actions random: thousands
+of fortress kills, resets and misses instead of the handful random play produces."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,16 +15,22 @@ from sfcompare import compare_state
 gametype = sys.argv[1] if len(sys.argv) > 1 else "youturn"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 16500
+policy = sys.argv[4] if len(sys.argv) > 4 else "random"
 K = 250
 env = SFVecEnv(N, gametype=gametype, spawn_stride=3, spawn_skip=1)
 orc = O.OracleVecEnv(gametype, N, spawn_stride=3, spawn_skip=1)
 rng = np.random.default_rng(99)
+phase = rng.integers(0, 96, N)
 o0 = env.reset().cpu().numpy(); oo0 = orc.reset()
 assert np.allclose(o0, oo0, rtol=1e-5, atol=4e-5)
 t0 = time.time(); done_total = 0; kills = 0
 for c in range(0, T, K):
     k = min(K, T - c)
     acts = rng.integers(0, env.n_actions, (k, N)).astype(np.uint8)
+    if policy == "hunter":  # FIRE is action 1 in both action sets (ENV:211-229)
+        pat = np.array(([1] + [0] * 7) * 11 + [1, 0, 1, 0] + [0] * 4, np.uint8)
+        tt = (np.arange(c, c + k)[:, None] + phase[None, :]) % len(pat)
+        acts = np.where(rng.random((k, N)) < 0.1, acts, pat[tt]).astype(np.uint8)
     a = torch.from_numpy(acts).to(env.device)
     if (c // K) % 2 == 0:
         obs, rew, done, info = env.rollout(a)
@@ -39,5 +48,5 @@ for c in range(0, T, K):
     assert not bad, (c, bad)
     if (c // K) % 10 == 9:
         print("step %6d ok  (episodes finished %d, kills %d, %.0f s)" % (c + k, done_total, kills, time.time() - t0), flush=True)
-print("SOAK OK: %s, %d lanes x %d steps = %.1fM env-steps, %d episodes finished, %d fortress kills" % (
-    gametype, N, T, N * T / 1e6, done_total, kills))
+print("SOAK OK: %s (%s), %d lanes x %d steps = %.1fM env-steps, %d episodes finished, %d fortress kills" % (
+    gametype, policy, N, T, N * T / 1e6, done_total, kills))
