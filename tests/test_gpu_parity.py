@@ -114,6 +114,23 @@ def test_hip_replays_golden(sfa, name):
 def test_hip_vs_oracle_random(sfa, oracle_mod, gametype, action_set, obs_type, f64):
     """2048 lanes, different random actions and spawn offsets per lane, 1500 steps in lock-step
     with the CPU oracle: every output of every step, and the full state at checkpoints."""
+    lockstep(sfa, oracle_mod, gametype, action_set, obs_type, f64, hunter=False)
+
+
+@pytest.mark.parametrize("gametype,action_set,obs_type,f64", [
+    ("autoturn", 1, "features", False),
+    ("autoturn", 0, "normalized-features", True),
+    ("youturn", 1, "features", True),
+])
+def test_hip_vs_oracle_hunter(sfa, oracle_mod, gametype, action_set, obs_type, f64):
+    """Random play almost never destroys the fortress; this firing pattern (a shot per 272 ms until kill-ready,
+    then a double shot; random phase per lane, 10 % random actions) does so hundreds of times in the batch:
+    vulnerability resets, kills with info=True, fortress respawns and the reward shaping around them."""
+    kills = lockstep(sfa, oracle_mod, gametype, action_set, obs_type, f64, hunter=True)
+    assert kills > (400 if gametype == "autoturn" else 20), kills
+
+
+def lockstep(sfa, oracle_mod, gametype, action_set, obs_type, f64, hunter):
     O = oracle_mod
     N, T = 2048, 1500
     rng = np.random.default_rng(sum(map(ord, gametype)) + action_set)
@@ -121,6 +138,10 @@ def test_hip_vs_oracle_random(sfa, oracle_mod, gametype, action_set, obs_type, f
                        spawn_skip=1, obs_dtype=torch.float64 if f64 else torch.float32)
     orc = O.OracleVecEnv(gametype, N, action_set=action_set, obs_type=obs_type, spawn_stride=3, spawn_skip=1)
     acts = rng.integers(0, env.n_actions, (T, N)).astype(np.uint8)
+    if hunter:  # FIRE is action 1 in every action set (ENV:211-229)
+        pat = np.array(([1] + [0] * 7) * 11 + [1, 0, 1, 0] + [0] * 4, np.uint8)
+        tt = (np.arange(T)[:, None] + rng.integers(0, len(pat), N)[None, :]) % len(pat)
+        acts = np.where(rng.random((T, N)) < 0.1, acts, pat[tt]).astype(np.uint8)
     o0 = env.reset().cpu().numpy()
     oo0 = orc.reset()
     assert obs_close(o0, oo0, f64).all()
@@ -141,6 +162,7 @@ def test_hip_vs_oracle_random(sfa, oracle_mod, gametype, action_set, obs_type, f
             assert not bad, (t, bad)
             assert np.array_equal(checkpoints[t]["prev_vlner"], orc.prev_vlner())
     env.close()
+    return int(info.sum())
 
 
 def test_episode_rollover_and_stats(sfa, oracle_mod):
