@@ -133,6 +133,12 @@
 #ifndef SF_ABL_TRIG
 #define SF_ABL_TRIG 0
 #endif
+#ifndef SF_ABL_SPAWN
+#define SF_ABL_SPAWN 0
+#endif
+#ifndef SF_TRIG_HOIST
+#define SF_TRIG_HOIST 8 /* missile slots whose (cos, sin) lookups are batched ahead of the shells; 0 = none.  A/B at 65 536 envs: 0: 10.22 us, 4: 10.13, 6: 10.10, 8: 10.07, 12: 10.12 */
+#endif
 #if SF_ABL_TRIG == 2
 #define SF_COS(ang) ((double)__builtin_amdgcn_cosf((float)(ang) * (1.0f / 360.0f)))
 #define SF_SIN(ang) ((double)__builtin_amdgcn_sinf((float)(ang) * (1.0f / 360.0f)))
@@ -159,9 +165,22 @@ __device__ __forceinline__ void sf_store(T* p, T v) {
 }
 #define SF_ST(T, base, off, v) sf_store<T>(reinterpret_cast<T*>((base) + (off)), (T)(v))
 
+// SF_BUFOPS: the projectile slots go through `buffer_*` instructions on a per-wave descriptor of the
+// tile.  The slot's chunk offset (a compile-time constant too big for the 12-bit immediate) rides in
+// the scalar offset instead of costing two 64-bit VALU adds per access, and a lane that has nothing in
+// the slot gets an out-of-range offset: the hardware range check returns 0 for its load and drops its
+// store, so there is no exec-mask branch around each access.
+#ifndef SF_BUFOPS
+#define SF_BUFOPS 1
+#endif
+#define SF_GOFF(group, s) \
+  ((unsigned)sfl::chunk_offset(SF_G_##group, 0) + (unsigned)(s) * (unsigned)(sfl::kGroups[SF_G_##group].chunk * sfl::kTileLanes))
+#define SF_OOB 0x80000000u /* beyond any tile: the lane's access does not happen */
+
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 typedef int i2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -595,6 +614,40 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   const Off o = {lane * 16u, lane * 8u, lane * 4u, lane * 2u, lane};  // lane offsets inside the tile's rows
   const Off g = {i * 16u, i * 8u, i * 4u, i * 2u, i};     // env offsets into the caller's arrays
   const bool real = i < (unsigned)a.n_envs;  // lanes in [n_envs, lanes) are padding: they run NOOPs
+  // predicated access to one projectile slot of the lane: `goff` = SF_GOFF(group, slot), wave-uniform
+#if SF_BUFOPS
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)sfl::kTileBytes, 0x00020000);
+  constexpr int kStAux = SF_STORE_MODE == 2 ? 16 /* sc1 */ : 0;
+  auto pld16 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> d2_t {
+    return __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, p ? o.o16 : SF_OOB, goff, 0));
+  };
+  auto pld2 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> int {
+    return (int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, p ? o.o2 : SF_OOB, goff, 0);
+  };
+  auto pst16 = [&](unsigned goff, bool p, d2_t v) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, p ? o.o16 : SF_OOB, goff, kStAux);
+  };
+  auto pst2 = [&](unsigned goff, bool p, int v) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, rs, p ? o.o2 : SF_OOB, goff, 0);
+  };
+#else
+  auto pld16 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> d2_t {
+    d2_t v = {0, 0};
+    if (p) v = SF_LD(d2_t, tb + goff, o.o16);
+    return v;
+  };
+  auto pld2 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> int {
+    int v = 0;
+    if (p) v = SF_LD(int16_t, tb + goff, o.o2);
+    return v;
+  };
+  auto pst16 = [&](unsigned goff, bool p, d2_t v) __attribute__((always_inline)) {
+    if (p) SF_ST(d2_t, tb + goff, o.o16, v);
+  };
+  auto pst2 = [&](unsigned goff, bool p, int v) __attribute__((always_inline)) {
+    if (p) SF_ST(int16_t, tb + goff, o.o2, (int16_t)v);
+  };
+#endif
 #ifdef SF_STAMPS
   unsigned long long stamp_[16];
   stamp_[12] = __builtin_amdgcn_s_memrealtime();
@@ -615,14 +668,29 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   load_lane(tb, o, L);
   // cos/sin table: 720 doubles = 360 16-byte pieces, six per lane (the last one partial)
   const unsigned char* cb = (const unsigned char*)a.consts;
+  // (threads past the end re-load and re-store the last piece: straight-line code, no exec-masked
+  // branches for the compiler's wait-count insertion to be conservative about)
   d2_t cst[SF_TRIG_PIECES];
+  unsigned cpi[SF_TRIG_PIECES];
 #pragma unroll
   for (int k = 0; k < SF_TRIG_PIECES; k++) {
-    cst[k] = d2_t{0, 0};
-    if (tid + k * SF_BLOCK < SF_LDS_DOUBLES / 2) cst[k] = SF_LD(d2_t, cb, (tid + k * SF_BLOCK) * 16u);
+    cpi[k] = min(tid + k * SF_BLOCK, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
+    cst[k] = SF_LD(d2_t, cb, cpi[k] * 16u);
   }
   SF_STAMP(1, false);
   SF_STAMP(2, true);
+
+  // cos/sin table -> LDS (the loads were issued in round trip 1).  BEFORE the projectile loads are issued:
+  // memory returns in order and the number of predicated loads below is not known at compile time, so a
+  // wait for the table placed after them is a wait for all of them (`s_waitcnt vmcnt(0)`) -- round trip 2
+  // would be over before the workgroup barrier instead of running under the ship / fortress arithmetic.
+  // For the same reason EVERY load of round trip 1 is waited for here, explicitly (vmcnt(0), the other counters
+  // untouched): a first use of, say, the flags after the predicated loads would otherwise be a vmcnt(0) too.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+#if SF_ABL_TRIG != 2
+#pragma unroll
+  for (int k = 0; k < SF_TRIG_PIECES; k++) reinterpret_cast<d2_t*>(lds)[cpi[k]] = cst[k];
+#endif
 
   // ================= round trip 2: live projectile slots, predicated by the alive masks ======
   // Slot groups (missiles {0,1} {2,3} {4..7} {8..11}, shells {0,1,2} {3,4,5}): a wave ballot
@@ -653,12 +721,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         for (int k = 0; k < 4; k++) {
           if (k < kMgN[g]) {
             const int s = kMgLo[g] + k;
-            if ((L.mmask >> s) & 1u) {
-              const d2_t m = SF_LD(d2_t, SF_CHUNK(missile_pos, s), o.o16);
-              mx[s] = m.x;
-              my[s] = m.y;
-              mang[s] = SF_LD(int16_t, SF_CHUNK(missile_ang, s), o.o2);
-            }
+            const bool live = (L.mmask >> s) & 1u;
+            const d2_t m = pld16(SF_GOFF(missile_pos, s), live);
+            mx[s] = m.x;
+            my[s] = m.y;
+            mang[s] = pld2(SF_GOFF(missile_ang, s), live);
           }
         }
       }
@@ -669,28 +736,25 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
 #pragma unroll
         for (int k = 0; k < SF_SGSZ; k++) {
           const int s = SF_SGSZ * g + k;
-          if ((L.smask >> s) & 1u) {
-            const d2_t sp = SF_LD(d2_t, SF_CHUNK(shell_pos, s), o.o16);
-            const d2_t sv = SF_LD(d2_t, SF_CHUNK(shell_vel, s), o.o16);
-            shx[s] = sp.x;
-            shy[s] = sp.y;
-            shvx[s] = sv.x;
-            shvy[s] = sv.y;
-          }
+          const bool live = (L.smask >> s) & 1u;
+          const d2_t sp = pld16(SF_GOFF(shell_pos, s), live);
+          const d2_t sv = pld16(SF_GOFF(shell_vel, s), live);
+          shx[s] = sp.x;
+          shy[s] = sp.y;
+          shvx[s] = sv.x;
+          shvy[s] = sv.y;
         }
       }
     }
     if (__ballot(will_respawn) != 0ull) {
+#if SF_ABL_SPAWN  /* timing-only: no dependent spawn-entry load (WRONG results) */
+      if (will_respawn) spawn_e = 0x0000005A00C800C8ull + (L.cursor & 63u);
+#else
       if (will_respawn) spawn_e = *reinterpret_cast<const unsigned long long*>(a.spawn + 4 * (size_t)(L.cursor & a.spawn_mask));
+#endif
     }
   }
 
-  // cos/sin table -> LDS (the loads were issued in round trip 1)
-#if SF_ABL_TRIG != 2
-#pragma unroll
-  for (int k = 0; k < SF_TRIG_PIECES; k++)
-    if (tid + k * SF_BLOCK < SF_LDS_DOUBLES / 2) reinterpret_cast<d2_t*>(lds)[tid + k * SF_BLOCK] = cst[k];
-#endif
 #if SF_ABL_TRIG == 0
   __syncthreads();  // the only workgroup barrier of the kernel
 #endif
@@ -851,6 +915,23 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   SF_STAMP(4, false);
   SF_STAMP(5, true);
 
+  // keep the spawn entry's register allocated up to here: reused earlier, the compiler must first wait for the
+  // (predicated, possibly outstanding) load into it -- a vmcnt(0), i.e. the whole of round trip 2, right
+  // after the key processing
+  asm volatile("" ::"v"(spawn_e));
+#if SF_TRIG_HOIST
+  // the (cos, sin) of every prefetched missile slot in ONE batch of LDS reads, here, so that their
+  // latency hides under the shells: looked up inside the slot groups below, each active group
+  // would pay its own LDS round trip (a wave alone on its SIMD hides nothing)
+  double mcs[SF_TRIG_HOIST], msn[SF_TRIG_HOIST];
+#pragma unroll
+  for (int s = 0; s < SF_TRIG_HOIST; s++) {
+    const int ang = (s == new_m_slot) ? new_m_angle : mang[s];
+    mcs[s] = SF_COS(ang);
+    msn[s] = SF_SIN(ang);
+  }
+#endif
+
   // ---- updateShells (SRC/game.cpp:404-423).  Ballistics of the prefetched slots first, as
   //      straight-line code; then the (ship-alive dependent) outcome in slot order.
   {
@@ -873,7 +954,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
         const double dx = nx[k] - L.sx, dy = ny[k] - L.sy;
         col |= (unsigned)(dx * dx + dy * dy <= sfc::shell_hit_r2) << s;
         out |= (unsigned)outside_area(a, nx[k], ny[k]) << s;
-        if (isnew) SF_ST(d2_t, SF_CHUNK(shell_vel, s), o.o16, (d2_t{vx, vy}));
+        pst16(SF_GOFF(shell_vel, s), isnew, d2_t{vx, vy});
         if (FUSED) {  // the registers carry the shell into the next tick
           shx[s] = nx[k];
           shy[s] = ny[k];
@@ -897,7 +978,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
 #pragma unroll
       for (int k = 0; k < SF_SGSZ; k++) {
         const int s = SF_SGSZ * g + k;
-        if ((L.smask >> s) & 1u) SF_ST(d2_t, SF_CHUNK(shell_pos, s), o.o16, (d2_t{nx[k], ny[k]}));
+        pst16(SF_GOFF(shell_pos, s), (L.smask >> s) & 1u, d2_t{nx[k], ny[k]});
       }
     }
     if (__ballot((L.smask >> SF_SPF) != 0u) != 0ull) {  // rare: more than SF_SPF shells in some lane
@@ -950,25 +1031,35 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   unsigned hit_count = 0;  // missiles that reached the fortress this tick (alive or not)
   {
     unsigned ev_hit = 0, ev_out = 0;
-    auto m_move = [&](int s, double x, double y, int ang, bool isnew, double& nx, double& ny)
-                      __attribute__((always_inline)) {
+    auto m_move_cs = [&](int s, double x, double y, int ang, bool isnew, double c, double sn, double& nx, double& ny)
+                         __attribute__((always_inline)) {
       // velocity = missileSpeed * (cos, sin)(deg2rad(angle)) with an integer angle: table
-      nx = x + sfc::missile_speed * SF_COS(ang);
-      ny = y + sfc::missile_speed * SF_SIN(ang);
+      nx = x + sfc::missile_speed * c;
+      ny = y + sfc::missile_speed * sn;
       const double dx = nx - sfc::fort_x, dy = ny - sfc::fort_y;
       const bool live = (L.mmask >> s) & 1u;
       const bool hit = live & (dx * dx + dy * dy <= sfc::missile_hit_r2);  // collided(mFortress), see shells
       const bool out = live & !hit & outside_area(a, nx, ny);
       ev_hit |= (unsigned)hit << s;
       ev_out |= (unsigned)out << s;
-      if (live & !hit & !out) SF_ST(d2_t, SF_CHUNK(missile_pos, s), o.o16, (d2_t{nx, ny}));
-      if (isnew) SF_ST(int16_t, SF_CHUNK(missile_ang, s), o.o2, (int16_t)ang);
+      pst16(SF_GOFF(missile_pos, s), live & !hit & !out, d2_t{nx, ny});
+      pst2(SF_GOFF(missile_ang, s), isnew, ang);
+    };
+    auto m_move = [&](int s, double x, double y, int ang, bool isnew, double& nx, double& ny)
+                      __attribute__((always_inline)) {
+      m_move_cs(s, x, y, ang, isnew, SF_COS(ang), SF_SIN(ang), nx, ny);
     };
     auto m_pref = [&](int s) __attribute__((always_inline)) {
       const bool isnew = (s == new_m_slot);
       const int ang = isnew ? new_m_angle : mang[s];
       double nx, ny;
-      m_move(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], ang, isnew, nx, ny);
+#if SF_TRIG_HOIST
+      if (s < SF_TRIG_HOIST)
+        m_move_cs(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], ang, isnew, mcs[s < SF_TRIG_HOIST ? s : 0],
+                  msn[s < SF_TRIG_HOIST ? s : 0], nx, ny);
+      else
+#endif
+        m_move(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], ang, isnew, nx, ny);
       if (FUSED) {  // the registers carry the missile into the next tick
         mx[s] = nx;
         my[s] = ny;
