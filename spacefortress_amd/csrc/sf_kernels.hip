@@ -339,6 +339,27 @@ __device__ __forceinline__ void store_lane(unsigned char* tb, const Off& o, cons
               (int)((unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16))}));
 }
 
+#if SF_BUFOPS
+// the same through the wave's tile descriptor: the chunk offsets ride in the scalar offset, no 64-bit address per store
+__device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const Off& o, const Lane& L) {
+  constexpr int aux = SF_STORE_MODE == 2 ? 16 /* sc1 */ : 0;
+#define SF_BST16(group, v) \
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, o.o16, SF_GOFF(group, 0), aux)
+  SF_BST16(ship_pos, (d2_t{L.sx, L.sy}));
+  SF_BST16(ship_vel, (d2_t{L.vx, L.vy}));
+  SF_BST16(timers_a, (i4_t{L.death_t, L.fire_t, L.thrust_t, L.left_t}));
+  SF_BST16(timers_b, (i4_t{L.right_t, L.fort_t, L.fort_death_t, L.fort_vuln_t}));
+  SF_BST16(score, (i4_t{__float_as_int(L.points), __float_as_int(L.raw), L.vlner, L.time}));
+  SF_BST16(misc, (i4_t{L.prev_vlner, (int)L.cursor, (int)L.mmask, (int)L.smask}));
+#undef SF_BST16
+  typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(
+      u2_t{(unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16),
+           (unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16)},
+      rs, o.o8, SF_GOFF(small, 0), 0);
+}
+#endif
+
 // Agent-scope (L2-coherent, L1-bypassing) accesses for the few places where one launch may read
 // back what it wrote earlier or mixes plain stores with atomics on the same word: the counter
 // rows (atomics + the zeroing at a new game) and the dependent-load slow path of the projectile
@@ -1188,10 +1209,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     a_vel = atan2(L.vy, L.vx);
   } else {
     // no-return atomics, executed at the memory side: the counters are never loaded
-#define SF_FLUSH(idx, v)                                                                      \
-  if (__ballot((v) != 0) != 0ull) {                                                           \
-    if ((v) != 0) atomicAdd(reinterpret_cast<int*>(SF_CHUNK(stats, idx) + o.o4), (v)); \
-  }
+#if SF_BUFOPS
+#define SF_ATOMIC_ADD(goff, v) __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((v), rs, (v) != 0 ? o.o4 : SF_OOB, (goff), 0)
+#else
+#define SF_ATOMIC_ADD(goff, v) \
+  if ((v) != 0) atomicAdd(reinterpret_cast<int*>(tb + (goff) + o.o4), (v))
+#endif
+#define SF_FLUSH(idx, v) \
+  if (__ballot((v) != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(stats, idx), (v)); }
     SF_FLUSH(SF_ST_BIG_HEX_DEATHS, S.big_hex_deaths)
     SF_FLUSH(SF_ST_SMALL_HEX_DEATHS, S.small_hex_deaths)
     SF_FLUSH(SF_ST_SHELL_DEATHS, S.shell_deaths)
@@ -1209,15 +1234,17 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
       if (S.max_vlner != 0)
         atomicMax(reinterpret_cast<int*>(SF_CHUNK(stats, SF_ST_MAX_VLNER) + o.o4), S.max_vlner);
     }
-    if (__ballot(r != 0) != 0ull) {
-      if (r != 0) atomicAdd(reinterpret_cast<int*>(SF_CHUNK(ep_return, 0) + o.o4), r);
-    }
-    if (__ballot(fort_kill != 0) != 0ull) {
-      if (fort_kill) atomicAdd(reinterpret_cast<int*>(SF_CHUNK(ep_kills, 0) + o.o4), 1);
-    }
+    if (__ballot(r != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(ep_return, 0), r); }
+    const int kill1 = fort_kill ? 1 : 0;
+    if (__ballot(kill1 != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(ep_kills, 0), kill1); }
+#undef SF_ATOMIC_ADD
   }
 
+#if SF_BUFOPS
+  if (!FUSED) store_lane_buf(rs, o, L);
+#else
   if (!FUSED) store_lane(tb, o, L);
+#endif
 
   if (real) {
     if (reward_out) SF_ST(int32_t, (unsigned char*)(reward_out + so), g.o4, r);
@@ -1269,7 +1296,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
                                 lane, my_ret, has_obs);
   }
   }  // tick loop
+#if SF_BUFOPS
+  if (FUSED) store_lane_buf(rs, o, L);
+#else
   if (FUSED) store_lane(tb, o, L);
+#endif
   SF_STAMP(8, false);
   SF_STAMP(9, true);
 #ifdef SF_STAMPS
