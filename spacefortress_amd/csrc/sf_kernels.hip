@@ -133,6 +133,9 @@
 #ifndef SF_ABL_TRIG
 #define SF_ABL_TRIG 0
 #endif
+#ifndef SF_ABL_STATS
+#define SF_ABL_STATS 0
+#endif
 #ifndef SF_ABL_SPAWN
 #define SF_ABL_SPAWN 0
 #endif
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   };
 #endif
 #ifdef SF_STAMPS
-  unsigned long long stamp_[16];
+  unsigned long long stamp_[16] = {};
   stamp_[12] = __builtin_amdgcn_s_memrealtime();
 #endif
   SF_STAMP(0, false);
@@ -1186,6 +1189,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
              (S.missed ? SF_EV_MISSILE_LEFT : 0u) | (done ? SF_EV_GAME_OVER : 0u);
   }
 
+  SF_STAMP(10, false);
   // ================= statistics and the vec-env worker's auto-reset (rl/train.py:80-88) ======
   if (done && a.auto_reset) {
     // episode totals = what previous launches accumulated + this tick's share
@@ -1215,42 +1219,56 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
 #define SF_ATOMIC_ADD(goff, v) \
   if ((v) != 0) atomicAdd(reinterpret_cast<int*>(tb + (goff) + o.o4), (v))
 #endif
+#if SF_ABL_STATS == 1 /* timing-only: no key-press counters */
+#define SF_FLUSH(idx, v) \
+  if ((idx) < SF_ST_SHOTS || (idx) > SF_ST_RIGHTS) if (__ballot((v) != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(stats, idx), (v)); }
+#elif SF_ABL_STATS == 2 /* timing-only: no counters at all */
+#define SF_FLUSH(idx, v)
+#else
 #define SF_FLUSH(idx, v) \
   if (__ballot((v) != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(stats, idx), (v)); }
-    SF_FLUSH(SF_ST_BIG_HEX_DEATHS, S.big_hex_deaths)
-    SF_FLUSH(SF_ST_SMALL_HEX_DEATHS, S.small_hex_deaths)
-    SF_FLUSH(SF_ST_SHELL_DEATHS, S.shell_deaths)
-    SF_FLUSH(SF_ST_SHIP_DEATHS, S.ship_deaths)
-    SF_FLUSH(SF_ST_RESETS, S.resets)
-    SF_FLUSH(SF_ST_DESTROYED, S.destroyed)
-    SF_FLUSH(SF_ST_MISSED, S.missed)
+#endif
+    // the key presses happen in some lane of nearly every tick; everything else is rare and sits behind
+    // ONE wave-wide test (all of these deltas are >= 0, so their OR is their "any")
     SF_FLUSH(SF_ST_SHOTS, S.shots)
     SF_FLUSH(SF_ST_THRUSTS, S.thrusts)
     SF_FLUSH(SF_ST_LEFTS, S.lefts)
     SF_FLUSH(SF_ST_RIGHTS, S.rights)
-    SF_FLUSH(SF_ST_VLNER_INCS, S.vlner_incs)
-#undef SF_FLUSH
-    if (__ballot(S.max_vlner != 0) != 0ull) {
-      if (S.max_vlner != 0)
-        atomicMax(reinterpret_cast<int*>(SF_CHUNK(stats, SF_ST_MAX_VLNER) + o.o4), S.max_vlner);
+    if (__ballot((S.ship_deaths | S.resets | S.destroyed | S.missed | S.vlner_incs | S.max_vlner) != 0) != 0ull) {
+      SF_FLUSH(SF_ST_BIG_HEX_DEATHS, S.big_hex_deaths)
+      SF_FLUSH(SF_ST_SMALL_HEX_DEATHS, S.small_hex_deaths)
+      SF_FLUSH(SF_ST_SHELL_DEATHS, S.shell_deaths)
+      SF_FLUSH(SF_ST_SHIP_DEATHS, S.ship_deaths)
+      SF_FLUSH(SF_ST_RESETS, S.resets)
+      SF_FLUSH(SF_ST_DESTROYED, S.destroyed)
+      SF_FLUSH(SF_ST_MISSED, S.missed)
+      SF_FLUSH(SF_ST_VLNER_INCS, S.vlner_incs)
+      if (__ballot(S.max_vlner != 0) != 0ull) {
+        if (S.max_vlner != 0)
+          atomicMax(reinterpret_cast<int*>(SF_CHUNK(stats, SF_ST_MAX_VLNER) + o.o4), S.max_vlner);
+      }
     }
+#undef SF_FLUSH
     if (__ballot(r != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(ep_return, 0), r); }
     const int kill1 = fort_kill ? 1 : 0;
     if (__ballot(kill1 != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(ep_kills, 0), kill1); }
 #undef SF_ATOMIC_ADD
   }
 
+  SF_STAMP(11, false);
 #if SF_BUFOPS
   if (!FUSED) store_lane_buf(rs, o, L);
 #else
   if (!FUSED) store_lane(tb, o, L);
 #endif
+  SF_STAMP(14, false);
 
   if (real) {
     if (reward_out) SF_ST(int32_t, (unsigned char*)(reward_out + so), g.o4, r);
     if (done_out) SF_ST(uint8_t, (unsigned char*)(done_out + so), g.o1, (uint8_t)done);
     if (info_out) SF_ST(uint8_t, (unsigned char*)(info_out + so), g.o1, (uint8_t)fort_kill);
     if (a.events) SF_ST(uint32_t, (unsigned char*)(a.events + so), g.o4, evmask);
+    SF_STAMP(15, false);
     if (a.t_reward) {  // uniform; the same float32 operations in the same order as rl/train.py:82-88
       const float rf = (float)r, mask = done ? 0.0f : 1.0f;
       SF_ST(float, (unsigned char*)(a.t_reward + so), g.o4, rf);
@@ -1309,7 +1327,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   if (a.dbg != nullptr && (tid & 63) == 0) {
     unsigned long long* d = a.dbg + (size_t)(i >> 6) * 16;
 #pragma unroll
-    for (int k = 0; k < 14; k++) d[k] = stamp_[k];
+    for (int k = 0; k < 16; k++) d[k] = stamp_[k];
   }
 #endif
 }

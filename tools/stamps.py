@@ -81,6 +81,10 @@ def main():
     for k, nm in enumerate(names):
         print("  %-45s %7.0f %7.0f  (%4.1f%%)" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 90),
                                                 100 * np.median(d[:, k]) / np.median(tot)))
+    if buf[:, 10].any():  # sub-stamps inside "timers ... stores issue": 6 -> 10 -> 11 -> 14 -> 15 -> 7
+        seq = buf[:, [6, 10, 11, 14, 15, 7]].astype(np.int64)
+        print("  inside 'timers ... stores issue': timers+reward %d | counter atomics %d | lane stores %d | "
+              "reward/done/info stores %d | trainer epilogue %d" % tuple(np.median(np.diff(seq, axis=1), axis=0)))
     print("  %-45s %7.0f %7.0f   p99 %.0f  max %.0f" % ("wave total", np.median(tot), np.percentile(tot, 90),
                                                    np.percentile(tot, 99), tot.max()))
     slow = np.argsort(tot)[-8:]
