@@ -687,9 +687,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     if (act_type == 4) return SF_LD(int, ab, e * 4u);
     return SF_LD(unsigned char, ab, e);
   };
-  int act_next = load_action(0);
   Lane L;
-  load_lane(tb, o, L);
+  load_lane(tb, o, L);  // before the action: its address needs two more kernel arguments and a branch on the action type
   // cos/sin table: 720 doubles = 360 16-byte pieces, six per lane (the last one partial)
   const unsigned char* cb = (const unsigned char*)a.consts;
   // (threads past the end re-load and re-store the last piece: straight-line code, no exec-masked
@@ -701,6 +700,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
     cpi[k] = min(tid + k * SF_BLOCK, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
     cst[k] = SF_LD(d2_t, cb, cpi[k] * 16u);
   }
+  int act_next = load_action(0);
   SF_STAMP(1, false);
   SF_STAMP(2, true);
 
