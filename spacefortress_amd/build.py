@@ -18,6 +18,15 @@ SOURCES = ["sf_kernels.hip", "sf_render.hip", "sf_normalize.hip", "sf_rollout_op
 HEADERS = ["sf_layout.h", "sf_internal.h", "sf_raster.h", "sf_render_tables.h", os.path.join(ROOT, "include", "sfmi.h")]
 
 
+# -amdgpu-kernarg-preload-count: the first five kernel parameters arrive in SGPRs at wave launch (gfx950 command
+# processor) instead of through a scalar-load round trip to the kernel-argument segment; sf_step_kernel's leading
+# parameters are ordered for it (9.43 -> 9.18 us per launch at 65 536 envs).  A firmware without the feature runs
+# the compiler's compatibility preamble, which loads them the old way.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-mllvm", "-amdgpu-kernarg-preload-count=5",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -31,11 +40,7 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [
-        hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-ffp-contract=off", "-fno-fast-math",
-        "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-    ] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

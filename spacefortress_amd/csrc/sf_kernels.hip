@@ -626,18 +626,23 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 // (sf_rollout): the wave keeps its state in registers between ticks, so a tick costs neither the
 // two memory round trips nor a kernel boundary.  Same body, bit-identical results.
 template <bool AUTOTURN, bool SHAPED, bool FUSED>
-__global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const void* actions, int act_type,
-                                                          void* obs, int obs_vec_ok, int32_t* reward_out,
+__global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
+                                                          const void* actions, int n_envs_p, int act_type,
+                                                          SfKernelArgs a, void* obs, int obs_vec_ok, int32_t* reward_out,
                                                           uint8_t* done_out, uint8_t* info_out, int n_steps) {
+  // The five leading parameters (= a.state, a.consts, the actions, a.n_envs, the action type) are what round trip 1
+  // needs; the library is built with -amdgpu-kernarg-preload-count=5, so the command processor hands them over in
+  // SGPRs at wave launch and the state loads issue without a scalar-load round trip to the kernel-argument
+  // segment first (on a firmware without the feature the compiler's compatibility preamble loads them).
   extern __shared__ double lds[];  // [SF_LDS_DOUBLES] cos/sin table, then the obs staging rows
   const unsigned tid = threadIdx.x;
   const unsigned i = blockIdx.x * SF_BLOCK + tid;  // env index: actions and outputs
   const unsigned lane = tid & 63u;
   // this wave's tile: wave-uniform by construction, made scalar for the compiler
-  unsigned char* const tb = a.state + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * sfl::kTileBytes;
+  unsigned char* const tb = state_p + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * sfl::kTileBytes;
   const Off o = {lane * 16u, lane * 8u, lane * 4u, lane * 2u, lane};  // lane offsets inside the tile's rows
   const Off g = {i * 16u, i * 8u, i * 4u, i * 2u, i};     // env offsets into the caller's arrays
-  const bool real = i < (unsigned)a.n_envs;  // lanes in [n_envs, lanes) are padding: they run NOOPs
+  const bool real = i < (unsigned)n_envs_p;  // lanes in [n_envs, lanes) are padding: they run NOOPs
   // predicated access to one projectile slot of the lane: `goff` = SF_GOFF(group, slot), wave-uniform
 #if SF_BUFOPS
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)sfl::kTileBytes, 0x00020000);
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   auto load_action = [&](int step) __attribute__((always_inline)) -> int {  // ENV:211-212
     if (!real) return 0;
     const unsigned char* ab = (const unsigned char*)actions;
-    const unsigned e = (unsigned)step * (unsigned)a.n_envs + i;
+    const unsigned e = (unsigned)step * (unsigned)n_envs_p + i;
     if (act_type == 8) return (int)SF_LD(long long, ab, e * 8u);
     if (act_type == 4) return SF_LD(int, ab, e * 4u);
     return SF_LD(unsigned char, ab, e);
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(SfKernelArgs a, const
   Lane L;
   load_lane(tb, o, L);  // before the action: its address needs two more kernel arguments and a branch on the action type
   // cos/sin table: 720 doubles = 360 16-byte pieces, six per lane (the last one partial)
-  const unsigned char* cb = (const unsigned char*)a.consts;
+  const unsigned char* cb = (const unsigned char*)consts_p;
   // (threads past the end re-load and re-store the last piece: straight-line code, no exec-masked
   // branches for the compiler's wait-count insertion to be conservative about)
   d2_t cst[SF_TRIG_PIECES];
@@ -1416,8 +1421,8 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
   // 16-byte obs stores need every tick's row of the output to start 16-byte aligned
   const int vec_ok = ((uintptr_t)obs & 15u) == 0 && (!fused || ((size_t)a.n_envs * a.obs_dim * elem) % 16 == 0);
 #define SF_GO(AT, SH, FU)                                                                                   \
-  hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a, actions, \
-                     act_type, obs, vec_ok, reward, done, info, n_steps)
+  hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state, a.consts, \
+                     actions, a.n_envs, act_type, a, obs, vec_ok, reward, done, info, n_steps)
   // the four presets of SRC/configs.cpp:51-89 are exactly (autoTurn) x (shaped scoring)
   const int sel = (autoturn ? 4 : 0) | (shaped ? 2 : 0) | (fused ? 1 : 0);
   switch (sel) {

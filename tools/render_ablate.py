@@ -10,8 +10,7 @@ if "--build" in sys.argv:
     os.makedirs(os.path.join(ROOT, "build/abl"), exist_ok=True)
     for name, bits in VARIANTS.items():
         out = os.path.join(ROOT, "build/abl/libsfmi_render_%s.so" % name)
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-fno-fast-math", "-I" + os.path.join(ROOT, "include"), "-I" + B.CSRC, "-DSF_RENDER_SKIP=%d" % bits] + \
+        cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DSF_RENDER_SKIP=%d" % bits] + \
               [os.path.join(B.CSRC, s) for s in B.SOURCES] + ["-o", out]
         subprocess.check_call(cmd)
         print("built", out)

@@ -25,9 +25,9 @@ def build(lite=False):
         DIAG = DIAG.replace("_stamps.so", "_stamps_lite.so")
     os.makedirs(os.path.dirname(DIAG), exist_ok=True)
     csrc = os.path.join(ROOT, "spacefortress_amd", "csrc")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-DSF_STAMPS"] + (["-DSF_STAMPS_LITE"] if lite else []) + ["-I" + os.path.join(ROOT, "include"), "-I" + csrc,
-           ] + [os.path.join(csrc, f) for f in __import__("spacefortress_amd.build", fromlist=["SOURCES"]).SOURCES] + ["-o", DIAG]
+    B = __import__("spacefortress_amd.build", fromlist=["SOURCES"])
+    cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DSF_STAMPS"] + (["-DSF_STAMPS_LITE"] if lite else []) + [
+        os.path.join(csrc, f) for f in B.SOURCES] + ["-o", DIAG]
     subprocess.check_call(cmd)
 
 
