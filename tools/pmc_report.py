@@ -27,7 +27,7 @@ def load(d):
     rows = list(csv.DictReader(open(f)))
     by = collections.defaultdict(list)
     for r in rows:
-        by[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        by[r["Kernel_Name"], int(r.get("Grid_Size", 0) or 0)].append(float(r["Counter_Value"]))
     return by
 
 
@@ -44,7 +44,7 @@ def main():
 
     def calib(by):
         out = []
-        for k, v in by.items():
+        for (k, _grid), v in by.items():
             if "sf_group_copy_kernel" in k:
                 out += [("16B chunk rows", CALIB_BYTES_PER_ENV * a.envs, x * 1024) for x in v]
         return out
@@ -52,8 +52,9 @@ def main():
     cf, cw = calib(fe), calib(wr)
     read_factor = sum(b for _, b, m in cf) / sum(m for _, b, m in cf)
     write_factor = sum(b for _, b, m in cw) / sum(m for _, b, m in cw)
-    step_f = [v for k, v in fe.items() if "sf_step_kernel" in k][0]
-    step_w = [v for k, v in wr.items() if "sf_step_kernel" in k][0]
+    lanes = (a.envs + 255) // 256 * 256  # only the launches of THIS workload (bench.py has legs at other sizes), one tick each
+    pick = lambda by: [v for (k, grid), v in by.items() if "sf_step_kernel" in k and ", false>" in k and grid == lanes][0]
+    step_f, step_w = pick(fe), pick(wr)
     fetch_kib = sum(step_f) / len(step_f)
     write_kib = sum(step_w) / len(step_w)
     read_b = fetch_kib * 1024 * read_factor
