@@ -213,8 +213,21 @@ struct Off {  // 32-bit byte offsets of this lane into rows of 16-, 8-, 4-, 2- a
   unsigned o16, o8, o4, o2, o1;
 };
 
-__device__ __forceinline__ double rad2deg(double a) { return a / M_PI * 180; }  // SRC/vector.cpp:38-40
-__device__ __forceinline__ double deg2rad(double a) { return a * M_PI / 180; }  // SRC/vector.cpp:34-36
+// a / C for a compile-time constant C, bit-identical to the IEEE division it replaces, in three dependent
+// operations instead of the eleven of the general v_div_* sequence (v_rcp_f64 included): with rc = RN(1/C),
+// q = RN(a * rc) is within an ulp of a / C, rem = a - C * q is exact in an FMA, and RN(q + rem * rc) is the
+// correctly rounded quotient (Markstein's theorem).  Checked exhaustively enough on the host for every C used
+// here -- pi, 10, 20, 80, 90, 92, 180, 360, 5294: 4e8 operands each, none differ (tests/test_div_const.py keeps a
+// smaller run of the same check).  Only the sign of a zero quotient can differ (-0.0 / C gives +0.0 here); nothing
+// downstream looks at it.  The operands are angles, pixels and tick counts: no overflow, underflow or NaN.
+__device__ __forceinline__ double sf_div_const(double a, double c, double rc) {
+  const double q = a * rc;
+  const double rem = __builtin_fma(-c, q, a);
+  return __builtin_fma(rem, rc, q);
+}
+#define SF_DIV(a, C) sf_div_const((a), (double)(C), 1.0 / (double)(C))
+__device__ __forceinline__ double rad2deg(double a) { return SF_DIV(a, M_PI) * 180; }  // SRC/vector.cpp:38-40
+__device__ __forceinline__ double deg2rad(double a) { return SF_DIV(a * M_PI, 180); }  // SRC/vector.cpp:34-36
 
 // Game::reward (SRC/game.cpp:97-102): three float32 adds in this order, points clamped at 0.
 __device__ __forceinline__ void score(float amount, float& rew, Lane& L) {
@@ -423,7 +436,7 @@ __device__ __forceinline__ Extras compute_extras(const SfKernelArgs& a, const La
   // fdist, ndist (SRC/game.cpp:310-311): the y term of the reference subtracts the ship from
   // itself, so fdist = sqrt(dx^2 + 0) = |dx|.
   const double fdist = fabs(L.sx - sfc::fort_x);
-  e.ndist = -1 + (fdist - sfc::ndist_a) / sfc::ndist_b;
+  e.ndist = -1 + SF_DIV(fdist - sfc::ndist_a, sfc::ndist_b);
   return e;
 }
 
@@ -452,12 +465,12 @@ __device__ __forceinline__ void write_obs(const SfKernelArgs& a, T* o, const Lan
   } else if (a.obs_type == 1) {  // normalized-features, ENV:109-133
     double f[19];
     f[0] = ship_alive ? 1 : 0;
-    f[1] = L.sx / sfc::pb_width;
-    f[2] = L.sy / sfc::pb_height;
-    f[3] = L.vx / 10;
-    f[4] = L.vy / 10;
-    f[5] = (double)L.angle / 360;
-    f[6] = e.aim / 180;
+    f[1] = SF_DIV(L.sx, sfc::pb_width);
+    f[2] = SF_DIV(L.sy, sfc::pb_height);
+    f[3] = SF_DIV(L.vx, 10);
+    f[4] = SF_DIV(L.vy, 10);
+    f[5] = SF_DIV((double)L.angle, 360);
+    f[6] = SF_DIV(e.aim, 180);
     {
       double m = fmod(e.vdir, 360.0);  // Python float %: result takes the divisor's sign
       if (m != 0) {
@@ -465,17 +478,17 @@ __device__ __forceinline__ void write_obs(const SfKernelArgs& a, T* o, const Lan
       } else {
         m = 0.0;
       }
-      f[7] = m / 360;
+      f[7] = SF_DIV(m, 360);
     }
     f[8] = e.ndist;
     f[9] = fort_alive ? 1 : 0;
-    f[10] = (double)L.fort_angle / 360;
-    f[11] = (double)(L.vlner > 10 ? L.vlner : 10) / 10;  // ENV:122 max(), as written
+    f[10] = SF_DIV((double)L.fort_angle, 360);
+    f[11] = SF_DIV((double)(L.vlner > 10 ? L.vlner : 10), 10);  // ENV:122 max(), as written
     f[12] = kill_ready;
-    f[13] = (double)n_missiles / SF_MAX_MISSILES_D;
-    f[14] = (double)n_shells / SF_MAX_MISSILES_D;
+    f[13] = SF_DIV((double)n_missiles, SF_MAX_MISSILES_D);
+    f[14] = SF_DIV((double)n_shells, SF_MAX_MISSILES_D);
 #pragma unroll
-    for (int k = 0; k < 4; k++) f[15 + k] = (double)timers[k] / sfc::max_ticks;
+    for (int k = 0; k < 4; k++) f[15 + k] = SF_DIV((double)timers[k], sfc::max_ticks);
 #pragma unroll
     for (int k = 0; k < 19; k++) {
       if (k < 15 + n_keys_t) {
@@ -914,7 +927,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       fort_respawned = true;
     }
     if (L.fl & SF_FL_SHIP_ALIVE) {
-      double q = ceil(ats / sfc::sector_size) * sfc::sector_size;  // in [0, 360]
+      double q = ceil(SF_DIV(ats, sfc::sector_size)) * sfc::sector_size;  // in [0, 360]
       int fa = (int)q;
       if (fa >= 360) fa -= 360;
       L.fort_angle = fa;
