@@ -519,6 +519,50 @@ __device__ __forceinline__ void write_obs(const SfKernelArgs& a, T* o, const Lan
   }
 }
 
+// The default observation -- obs_type 'features', float32, full waves, 16-byte aligned output -- with everything
+// the generic path decides at run time fixed at compile time (OBSK = 1 instantiations of the step kernel): DIM
+// stores into the wave's staging rows at constant offsets, then the wave's 64 rows (one contiguous span of
+// 64 * DIM floats, in LDS and in global memory alike) leave as 16-byte pieces: all LDS reads issued, then all stores.
+template <int DIM>
+__device__ __forceinline__ void write_features_f32(float* o, const Lane& L, const Extras& e, int real_shell_count) {
+  const int n_missiles = __popc(L.mmask);
+  const int n_shells = real_shell_count ? __popc(L.smask) : n_missiles;  // SRC/pymodule.cpp:131-134
+  const int kill_ready = (L.vlner > 10 && L.fort_vuln_t < sfc::vuln_time) ? 1 : 0;
+  const int timers[4] = {L.fire_t, L.thrust_t, L.left_t, L.right_t};
+  o[0] = (L.fl & SF_FL_SHIP_ALIVE) ? 1.0f : 0.0f;  // ENV:134-157, as in write_obs
+  o[1] = (float)L.sx;
+  o[2] = (float)L.sy;
+  o[3] = (float)L.vx;
+  o[4] = (float)L.vy;
+  o[5] = (float)L.angle;
+  o[6] = (float)e.aim;
+  o[7] = (float)e.vdir;
+  o[8] = (float)e.ndist;
+  o[9] = (L.fl & SF_FL_FORT_ALIVE) ? 1.0f : 0.0f;
+  o[10] = (float)L.fort_angle;
+  o[11] = (float)L.vlner;
+  o[12] = (float)kill_ready;
+  o[13] = (float)n_missiles;
+  o[14] = (float)n_shells;
+#pragma unroll
+  for (int k = 0; k < DIM - 15; k++) o[15 + k] = (float)timers[k];
+}
+template <int DIM>
+__device__ __forceinline__ void flush_features_f32(const float* stage_w, float* dst_w, unsigned lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  constexpr int NV = 64 * DIM / 4, IT = (NV + 63) / 64;  // 304 pieces of 16 bytes (DIM 19), 272 (DIM 17)
+  f4_t v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; k++)
+    if (k * 64 + 63 < NV || (int)lane + k * 64 < NV) v[k] = reinterpret_cast<const f4_t*>(stage_w)[lane + k * 64];
+#pragma unroll
+  for (int k = 0; k < IT; k++)
+    if (k * 64 + 63 < NV || (int)lane + k * 64 < NV) reinterpret_cast<f4_t*>(dst_w)[lane + k * 64] = v[k];
+}
+
 // A wave's 64 observation rows sit in ITS OWN piece of LDS as [lane][obs_dim]; global memory wants
 // exactly the same order ([N, obs_dim] row-major), so the wave's rows form one contiguous span:
 // copy it with 16-byte lanes-consecutive stores instead of obs_dim strided 4-byte stores per lane.
@@ -638,7 +682,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 // FUSED = true:  n_steps ticks per launch with the actions of all of them given up front
 // (sf_rollout): the wave keeps its state in registers between ticks, so a tick costs neither the
 // two memory round trips nor a kernel boundary.  Same body, bit-identical results.
-template <bool AUTOTURN, bool SHAPED, bool FUSED>
+template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK>
 __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
                                                           const void* actions, int n_envs_p, int act_type,
                                                           SfKernelArgs a, void* obs, int obs_vec_ok, int32_t* reward_out,
@@ -1304,7 +1348,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
   }
   SF_STAMP(7, false);
-  if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid
+  if constexpr (OBSK == 1) {  // the host guarantees: features, float32, n_envs % 64 == 0, aligned output (sf_launch_step)
+    constexpr int DIM = AUTOTURN ? 17 : 19;
+    const Extras e = compute_extras(a, L, a_pos, a_vel);
+    float* stage = reinterpret_cast<float*>(lds + SF_LDS_DOUBLES);
+    write_features_f32<DIM>(stage + tid * DIM, L, e, a.real_shell_count);
+    if ((i & ~63u) < (unsigned)n_envs_p)  // the padding waves behind the batch write nothing
+      flush_features_f32<DIM>(stage + (tid & ~63u) * DIM, (float*)obs + (so + (i & ~63u)) * DIM, lane);
+  } else if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid
     const Extras e = compute_extras(a, L, a_pos, a_vel);
     if (a.obs_f64) {
       double* stage = lds + SF_LDS_DOUBLES;
@@ -1433,9 +1484,16 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
   const size_t lds_bytes = SF_LDS_DOUBLES * sizeof(double) + (size_t)SF_BLOCK * a.obs_dim * elem;
   // 16-byte obs stores need every tick's row of the output to start 16-byte aligned
   const int vec_ok = ((uintptr_t)obs & 15u) == 0 && (!fused || ((size_t)a.n_envs * a.obs_dim * elem) % 16 == 0);
-#define SF_GO(AT, SH, FU)                                                                                   \
-  hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state, a.consts, \
-                     actions, a.n_envs, act_type, a, obs, vec_ok, reward, done, info, n_steps)
+#define SF_GO(AT, SH, FU)                                                                                          \
+  if (fast_obs)                                                                                                    \
+    hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, 1>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state,    \
+                       a.consts, actions, a.n_envs, act_type, a, obs, vec_ok, reward, done, info, n_steps);       \
+  else                                                                                                             \
+    hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, 0>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state,    \
+                       a.consts, actions, a.n_envs, act_type, a, obs, vec_ok, reward, done, info, n_steps)
+  // the default observation has its own instantiations (OBSK = 1): see write_features_f32
+  const bool fast_obs = obs != nullptr && a.obs_type == 0 && !a.obs_f64 && vec_ok && a.n_envs % 64 == 0 &&
+                        a.obs_dim == (autoturn ? 17 : 19);
   // the four presets of SRC/configs.cpp:51-89 are exactly (autoTurn) x (shaped scoring)
   const int sel = (autoturn ? 4 : 0) | (shaped ? 2 : 0) | (fused ? 1 : 0);
   switch (sel) {
