@@ -18,12 +18,13 @@ SOURCES = ["sf_kernels.hip", "sf_render.hip", "sf_normalize.hip", "sf_rollout_op
 HEADERS = ["sf_layout.h", "sf_internal.h", "sf_raster.h", "sf_render_tables.h", os.path.join(ROOT, "include", "sfmi.h")]
 
 
-# -amdgpu-kernarg-preload-count: the first five kernel parameters arrive in SGPRs at wave launch (gfx950 command
-# processor) instead of through a scalar-load round trip to the kernel-argument segment; sf_step_kernel's leading
-# parameters are ordered for it (9.43 -> 9.18 us per launch at 65 536 envs).  A firmware without the feature runs
-# the compiler's compatibility preamble, which loads them the old way.
+# -amdgpu-kernarg-preload-count: the first eight kernel parameters (as many as fit the 14 free user SGPRs) arrive in
+# SGPRs at wave launch (gfx950 command processor) instead of through a scalar-load round trip to the
+# kernel-argument segment; sf_step_kernel's leading parameters are ordered for it: what round trip 1 needs first
+# (9.43 -> 9.18 us per launch at 65 536 envs), then the reward / done / info pointers of the epilogue (8.76 -> 8.69).
+# A firmware without the feature runs the compiler's compatibility preamble, which loads them the old way.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-         "-mllvm", "-amdgpu-kernarg-preload-count=5",
+         "-mllvm", "-amdgpu-kernarg-preload-count=8",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

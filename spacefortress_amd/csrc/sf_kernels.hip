@@ -685,12 +685,13 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK>
 __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
                                                           const void* actions, int n_envs_p, int act_type,
-                                                          SfKernelArgs a, void* obs, int obs_vec_ok, int32_t* reward_out,
-                                                          uint8_t* done_out, uint8_t* info_out, int n_steps) {
+                                                          int32_t* reward_out, uint8_t* done_out, uint8_t* info_out,
+                                                          SfKernelArgs a, void* obs, int obs_vec_ok, int n_steps) {
   // The five leading parameters (= a.state, a.consts, the actions, a.n_envs, the action type) are what round trip 1
-  // needs; the library is built with -amdgpu-kernarg-preload-count=5, so the command processor hands them over in
+  // needs; the library is built with -amdgpu-kernarg-preload-count=8, so the command processor hands them over in
   // SGPRs at wave launch and the state loads issue without a scalar-load round trip to the kernel-argument
-  // segment first (on a firmware without the feature the compiler's compatibility preamble loads them).
+  // segment first (on a firmware without the feature the compiler's compatibility preamble loads them).  The
+  // three output pointers ride along: the epilogue then stores without a scalar load and its wait.
   extern __shared__ double lds[];  // [SF_LDS_DOUBLES] cos/sin table, then the obs staging rows
   const unsigned tid = threadIdx.x;
   const unsigned i = blockIdx.x * SF_BLOCK + tid;  // env index: actions and outputs
@@ -1487,10 +1488,10 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
 #define SF_GO(AT, SH, FU)                                                                                          \
   if (fast_obs)                                                                                                    \
     hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, 1>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state,    \
-                       a.consts, actions, a.n_envs, act_type, a, obs, vec_ok, reward, done, info, n_steps);       \
+                       a.consts, actions, a.n_envs, act_type, reward, done, info, a, obs, vec_ok, n_steps);       \
   else                                                                                                             \
     hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, 0>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state,    \
-                       a.consts, actions, a.n_envs, act_type, a, obs, vec_ok, reward, done, info, n_steps)
+                       a.consts, actions, a.n_envs, act_type, reward, done, info, a, obs, vec_ok, n_steps)
   // the default observation has its own instantiations (OBSK = 1): see write_features_f32
   const bool fast_obs = obs != nullptr && a.obs_type == 0 && !a.obs_f64 && vec_ok && a.n_envs % 64 == 0 &&
                         a.obs_dim == (autoturn ? 17 : 19);
