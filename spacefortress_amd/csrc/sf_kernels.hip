@@ -717,6 +717,13 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   auto pst2 = [&](unsigned goff, bool p, int v) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, rs, p ? o.o2 : SF_OOB, goff, 0);
   };
+  // the same with a per-lane slot offset (`extra` = slot * row bytes)
+  auto pst16_at = [&](unsigned goff, bool p, unsigned extra, d2_t v) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, p ? o.o16 + extra : SF_OOB, goff, kStAux);
+  };
+  auto pst2_at = [&](unsigned goff, bool p, unsigned extra, int v) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, rs, p ? o.o2 + extra : SF_OOB, goff, 0);
+  };
 #else
   auto pld16 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> d2_t {
     d2_t v = {0, 0};
@@ -733,6 +740,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   };
   auto pst2 = [&](unsigned goff, bool p, int v) __attribute__((always_inline)) {
     if (p) SF_ST(int16_t, tb + goff, o.o2, (int16_t)v);
+  };
+  auto pst16_at = [&](unsigned goff, bool p, unsigned extra, d2_t v) __attribute__((always_inline)) {
+    if (p) SF_ST(d2_t, tb + goff, o.o16 + extra, v);
+  };
+  auto pst2_at = [&](unsigned goff, bool p, unsigned extra, int v) __attribute__((always_inline)) {
+    if (p) SF_ST(int16_t, tb + goff, o.o2 + extra, (int16_t)v);
   };
 #endif
 #ifdef SF_STAMPS
@@ -1021,6 +1034,15 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 
   // ---- updateShells (SRC/game.cpp:404-423).  Ballistics of the prefetched slots first, as
   //      straight-line code; then the (ship-alive dependent) outcome in slot order.
+  // What is written ONCE per projectile -- a new shell's velocity, a new missile's heading -- is one store for the
+  // wave with the slot in the lane's offset, not a predicated store per slot: every memory instruction of the four
+  // waves of a CU goes through the one address unit they share, idle lanes or not.
+  static_assert(sfl::kGroups[SF_G_shell_vel].chunk * sfl::kTileLanes == 1024 && sfl::kGroups[SF_G_missile_ang].chunk * sfl::kTileLanes == 128,
+                "slot strides of the two rows below");
+  if (__ballot(new_s_slot >= 0) != 0ull)
+    pst16_at(SF_GOFF(shell_vel, 0), new_s_slot >= 0, (unsigned)new_s_slot * 1024u, d2_t{new_s_vx, new_s_vy});
+  if (__ballot(new_m_slot >= 0) != 0ull)
+    pst2_at(SF_GOFF(missile_ang, 0), new_m_slot >= 0, (unsigned)new_m_slot * 128u, new_m_angle);
   {
 #pragma unroll
     for (int g = 0; g < SF_SPF / SF_SGSZ; g++) {
@@ -1041,7 +1063,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         const double dx = nx[k] - L.sx, dy = ny[k] - L.sy;
         col |= (unsigned)(dx * dx + dy * dy <= sfc::shell_hit_r2) << s;
         out |= (unsigned)outside_area(a, nx[k], ny[k]) << s;
-        pst16(SF_GOFF(shell_vel, s), isnew, d2_t{vx, vy});
         if (FUSED) {  // the registers carry the shell into the next tick
           shx[s] = nx[k];
           shy[s] = ny[k];
@@ -1080,7 +1101,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
             y = sfc::fort_y;
             vx = new_s_vx;
             vy = new_s_vy;
-            SF_ST(d2_t, SF_CHUNK(shell_vel, s), o.o16, (d2_t{vx, vy}));
           } else {
             const d2_t sp = ld_coherent_d2(SF_CHUNK(shell_pos, s) + o.o16);
             const d2_t sv = ld_coherent_d2(SF_CHUNK(shell_vel, s) + o.o16);
@@ -1130,7 +1150,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       ev_hit |= (unsigned)hit << s;
       ev_out |= (unsigned)out << s;
       pst16(SF_GOFF(missile_pos, s), live & !hit & !out, d2_t{nx, ny});
-      pst2(SF_GOFF(missile_ang, s), isnew, ang);
     };
     auto m_move = [&](int s, double x, double y, int ang, bool isnew, double& nx, double& ny)
                       __attribute__((always_inline)) {
