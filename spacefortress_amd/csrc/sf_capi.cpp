@@ -141,6 +141,7 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   } while (0)
 
   HIP_TRY_FREE(hipMalloc((void**)&b->d_state, b->state_bytes));
+  HIP_TRY_FREE(hipMemset(b->d_state, 0, b->state_bytes));  // dead projectile slots are read (and ignored): keep them defined
   HIP_TRY_FREE(hipMalloc((void**)&b->d_consts, consts.size() * sizeof(double)));
   HIP_TRY_FREE(hipMalloc((void**)&b->d_spawn, spawn.size() * sizeof(int16_t)));
   HIP_TRY_FREE(hipMalloc((void**)&b->d_acc, sizeof(kAccInit)));
