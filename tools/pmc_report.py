@@ -18,6 +18,7 @@ import csv
 import glob
 import json
 import os
+import re
 
 CALIB_BYTES_PER_ENV = 20 * 16  # sf_group_copy_kernel: 20 slots x one 16-byte chunk
 
@@ -53,7 +54,8 @@ def main():
     read_factor = sum(b for _, b, m in cf) / sum(m for _, b, m in cf)
     write_factor = sum(b for _, b, m in cw) / sum(m for _, b, m in cw)
     lanes = (a.envs + 255) // 256 * 256  # only the launches of THIS workload (bench.py has legs at other sizes), one tick each
-    pick = lambda by: [v for (k, grid), v in by.items() if "sf_step_kernel" in k and ", false>" in k and grid == lanes][0]
+    one_tick = re.compile(r"sf_step_kernel<\w+, \w+, false\b")  # <AUTOTURN, SHAPED, FUSED = false, ...>
+    pick = lambda by: [v for (k, grid), v in by.items() if one_tick.search(k) and grid == lanes][0]
     step_f, step_w = pick(fe), pick(wr)
     fetch_kib = sum(step_f) / len(step_f)
     write_kib = sum(step_w) / len(step_w)
