@@ -133,6 +133,9 @@
 #ifndef SF_ABL_TRIG
 #define SF_ABL_TRIG 0
 #endif
+#ifndef SF_VCONST
+#define SF_VCONST 1
+#endif
 #ifndef SF_ABL_STATS
 #define SF_ABL_STATS 0
 #endif
@@ -1032,6 +1035,22 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   }
 #endif
 
+  // The constants of the projectile arithmetic, parked in VGPRs: none of them is an inline constant, SGPRs are
+  // scarce (101 of 102 in use), and the compiler re-materialises each as an `s_mov_b32` pair in front of every slot
+  // group -- about a hundred scalar moves per tick that a lone wave pays in full.  Opaque to the optimiser on
+  // purpose; the values are the same doubles.
+#if SF_VCONST
+  double kv_speed = sfc::missile_speed, kv_fx = sfc::fort_x, kv_fy = sfc::fort_y, kv_w = sfc::width_d, kv_h = sfc::height_d,
+         kv_mr2 = sfc::missile_hit_r2, kv_sr2 = sfc::shell_hit_r2;
+  asm volatile("" : "+v"(kv_speed), "+v"(kv_fx), "+v"(kv_fy), "+v"(kv_w), "+v"(kv_h), "+v"(kv_mr2), "+v"(kv_sr2));
+#else
+  constexpr double kv_speed = sfc::missile_speed, kv_fx = sfc::fort_x, kv_fy = sfc::fort_y, kv_w = sfc::width_d,
+                   kv_h = sfc::height_d, kv_mr2 = sfc::missile_hit_r2, kv_sr2 = sfc::shell_hit_r2;
+#endif
+  auto outside = [&](double x, double y) __attribute__((always_inline)) -> bool {  // Game::isOutsideGameArea, as outside_area
+    return (x < 0) | (x > kv_w) | (y > kv_h) | (y < 0);
+  };
+
   // ---- updateShells (SRC/game.cpp:404-423).  Ballistics of the prefetched slots first, as
   //      straight-line code; then the (ship-alive dependent) outcome in slot order.
   // What is written ONCE per projectile -- a new shell's velocity, a new missile's heading -- is one store for the
@@ -1055,14 +1074,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         const int s = SF_SGSZ * g + k;
         const bool isnew = (s == new_s_slot);
         const double vx = isnew ? new_s_vx : shvx[s], vy = isnew ? new_s_vy : shvy[s];
-        nx[k] = (isnew ? sfc::fort_x : shx[s]) + vx;
-        ny[k] = (isnew ? sfc::fort_y : shy[s]) + vy;
+        nx[k] = (isnew ? kv_fx : shx[s]) + vx;
+        ny[k] = (isnew ? kv_fy : shy[s]) + vy;
         // Object::collided (SRC/object.cpp:12-15): sqrt(dx^2+dy^2) <= r.  With a correctly
         // rounded sqrt and r an integer, RN(sqrt(s)) <= r  <=>  s <= r^2 (r^2 is exactly
         // representable and the next double above r^2 has a root that rounds above r).
         const double dx = nx[k] - L.sx, dy = ny[k] - L.sy;
-        col |= (unsigned)(dx * dx + dy * dy <= sfc::shell_hit_r2) << s;
-        out |= (unsigned)outside_area(a, nx[k], ny[k]) << s;
+        col |= (unsigned)(dx * dx + dy * dy <= kv_sr2) << s;
+        out |= (unsigned)outside(nx[k], ny[k]) << s;
         if (FUSED) {  // the registers carry the shell into the next tick
           shx[s] = nx[k];
           shy[s] = ny[k];
@@ -1141,12 +1160,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     auto m_move_cs = [&](int s, double x, double y, int ang, bool isnew, double c, double sn, double& nx, double& ny)
                          __attribute__((always_inline)) {
       // velocity = missileSpeed * (cos, sin)(deg2rad(angle)) with an integer angle: table
-      nx = x + sfc::missile_speed * c;
-      ny = y + sfc::missile_speed * sn;
-      const double dx = nx - sfc::fort_x, dy = ny - sfc::fort_y;
+      nx = x + kv_speed * c;
+      ny = y + kv_speed * sn;
+      const double dx = nx - kv_fx, dy = ny - kv_fy;
       const bool live = (L.mmask >> s) & 1u;
-      const bool hit = live & (dx * dx + dy * dy <= sfc::missile_hit_r2);  // collided(mFortress), see shells
-      const bool out = live & !hit & outside_area(a, nx, ny);
+      const bool hit = live & (dx * dx + dy * dy <= kv_mr2);  // collided(mFortress), see shells
+      const bool out = live & !hit & outside(nx, ny);
       ev_hit |= (unsigned)hit << s;
       ev_out |= (unsigned)out << s;
       pst16(SF_GOFF(missile_pos, s), live & !hit & !out, d2_t{nx, ny});
