@@ -133,6 +133,9 @@
 #ifndef SF_ABL_TRIG
 #define SF_ABL_TRIG 0
 #endif
+#ifndef SF_VMASK
+#define SF_VMASK 1
+#endif
 #ifndef SF_VCONST
 #define SF_VCONST 1
 #endif
@@ -1047,9 +1050,19 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   constexpr double kv_speed = sfc::missile_speed, kv_fx = sfc::fort_x, kv_fy = sfc::fort_y, kv_w = sfc::width_d,
                    kv_h = sfc::height_d, kv_mr2 = sfc::missile_hit_r2, kv_sr2 = sfc::shell_hit_r2;
 #endif
-  auto outside = [&](double x, double y) __attribute__((always_inline)) -> bool {  // Game::isOutsideGameArea, as outside_area
+  // Game::isOutsideGameArea (SRC/game.cpp:129-131), (x < 0) | (x > W) | (y > H) | (y < 0), as ONE comparison:
+  // the largest of -x, x - W, -y, y - H is positive exactly when one of the four holds (a difference of two
+  // doubles has the exact sign; no NaN on this path).  Four compares OR-ed through scalar registers are a chain of
+  // VALU -> SALU -> VALU hand-offs per slot, which a wave alone on its SIMD waits out every time.
+#if SF_VMASK
+  auto outside = [&](double x, double y) __attribute__((always_inline)) -> bool {
+    return __builtin_fmax(__builtin_fmax(-x, x - kv_w), __builtin_fmax(-y, y - kv_h)) > 0;
+  };
+#else
+  auto outside = [&](double x, double y) __attribute__((always_inline)) -> bool {
     return (x < 0) | (x > kv_w) | (y > kv_h) | (y < 0);
   };
+#endif
 
   // ---- updateShells (SRC/game.cpp:404-423).  Ballistics of the prefetched slots first, as
   //      straight-line code; then the (ship-alive dependent) outcome in slot order.
@@ -1163,12 +1176,23 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       nx = x + kv_speed * c;
       ny = y + kv_speed * sn;
       const double dx = nx - kv_fx, dy = ny - kv_fy;
+#if SF_VMASK
+      // the same truth values as below, kept as bits of integer masks (vector ALU only); `live` and `!hit` are
+      // applied to the collected masks once, after the last slot
+      const unsigned bit = 1u << s;
+      const unsigned hb = (dx * dx + dy * dy <= kv_mr2) ? bit : 0u;  // collided(mFortress), see shells
+      const unsigned ob = outside(nx, ny) ? bit : 0u;
+      ev_hit |= hb;
+      ev_out |= ob;
+      pst16(SF_GOFF(missile_pos, s), (L.mmask & bit & ~(hb | ob)) != 0u, d2_t{nx, ny});
+#else
       const bool live = (L.mmask >> s) & 1u;
       const bool hit = live & (dx * dx + dy * dy <= kv_mr2);  // collided(mFortress), see shells
       const bool out = live & !hit & outside(nx, ny);
       ev_hit |= (unsigned)hit << s;
       ev_out |= (unsigned)out << s;
       pst16(SF_GOFF(missile_pos, s), live & !hit & !out, d2_t{nx, ny});
+#endif
     };
     auto m_move = [&](int s, double x, double y, int ang, bool isnew, double& nx, double& ny)
                       __attribute__((always_inline)) {
@@ -1216,6 +1240,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         }
       }
     }
+#if SF_VMASK
+    ev_hit &= L.mmask;             // hit = live & collided
+    ev_out &= L.mmask & ~ev_hit;   // out = live & !hit & outside
+#endif
     unsigned ev = ev_hit | ev_out;
     hit_count = __popc(ev_hit);
     L.mmask &= ~ev;
