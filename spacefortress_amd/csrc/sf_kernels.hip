@@ -46,6 +46,9 @@
 #ifndef SF_BLOCK
 #define SF_BLOCK 256
 #endif
+#ifndef SF_VMASK
+#define SF_VMASK 1 /* 0: the truth values of the hexagon / hit / outside tests meet in scalar registers, as first written */
+#endif
 #define SF_TRIG_PIECES ((SF_LDS_DOUBLES / 2 + SF_BLOCK - 1) / SF_BLOCK)
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #define SF_MPF 12 /* missile slots prefetched into registers; higher slots take the slow loop */
@@ -132,9 +135,6 @@
 // table staging, 2 = no table at all (hardware v_cos_f32 / v_sin_f32 instead of the exact entries).
 #ifndef SF_ABL_TRIG
 #define SF_ABL_TRIG 0
-#endif
-#ifndef SF_VMASK
-#define SF_VMASK 1
 #endif
 #ifndef SF_VCONST
 #define SF_VCONST 1
@@ -250,11 +250,30 @@ __device__ __forceinline__ void score(float amount, float& rew, Lane& L) {
 // of y against the edge: y < py for ny > 0, y > py for ny < 0 (the sign of a difference of two
 // doubles is exact, and scaling by |ny| >= 1 cannot flush it to zero).  Eight multiplies, eight
 // subtractions and four additions less per ship and tick, same truth value for every finite y.
+// The six truth values are folded arithmetically: "no edge value is < 0" is "the smallest edge value is not < 0"
+// (for the horizontal edges the value is the difference y - py or py - y; -0.0 is not < 0 either way; no NaN
+// here), one comparison per hexagon instead of six whose results meet in scalar registers.
+#if SF_VMASK
+#define SF_EDGE_TEST(nx, ny, px, py)                                                                  \
+  m = __builtin_fmin(m, (nx) == 0.0 ? ((ny) > 0 ? y - (py) : (py) - y) : (nx) * (x - (px)) + (ny) * (y - (py)));
+__device__ __forceinline__ bool inside_big_hex(double x, double y) {
+  double m = 1.0;
+  SF_BIG_HEX_EDGES(SF_EDGE_TEST)
+  return !(m < 0);
+}
+__device__ __forceinline__ bool inside_small_hex(double x, double y) {
+  double m = 1.0;
+  SF_SMALL_HEX_EDGES(SF_EDGE_TEST)
+  return !(m < 0);
+}
+#undef SF_EDGE_TEST
+#endif
 #define SF_EDGE_TEST(nx, ny, px, py)                                     \
   if ((nx) == 0.0)                                                       \
     in = in & !((ny) > 0 ? (y < (py)) : (y > (py)));                     \
   else                                                                   \
     in = in & !((nx) * (x - (px)) + (ny) * (y - (py)) < 0);
+#if !SF_VMASK
 __device__ __forceinline__ bool inside_big_hex(double x, double y) {
   bool in = true;
   SF_BIG_HEX_EDGES(SF_EDGE_TEST)
@@ -265,6 +284,7 @@ __device__ __forceinline__ bool inside_small_hex(double x, double y) {
   SF_SMALL_HEX_EDGES(SF_EDGE_TEST)
   return in;
 }
+#endif
 #undef SF_EDGE_TEST
 
 // Game::isOutsideGameArea (SRC/game.cpp:129-131)
