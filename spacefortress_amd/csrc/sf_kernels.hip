@@ -46,6 +46,9 @@
 #ifndef SF_BLOCK
 #define SF_BLOCK 256
 #endif
+#ifndef SF_BRANCHFREE
+#define SF_BRANCHFREE 1 /* 0: the small conditionals of the ship / fortress update as exec-mask branches, as first written */
+#endif
 #ifndef SF_VMASK
 #define SF_VMASK 1 /* 0: the truth values of the hexagon / hit / outside tests meet in scalar registers, as first written */
 #endif
@@ -938,6 +941,18 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
     // FIRE press edge: fireMissile (SRC/game.cpp:175-192,237-238) before this tick's turn and
     // move; the shot is counted and the timer zeroed even if nothing could be created
+#if SF_BRANCHFREE
+    // as selects: an exec-mask branch around a three-line body costs a lone wave more than the body (the
+    // compare travels VALU -> SALU -> EXEC -> VALU).  score(+0.0f) changes nothing: x + 0.0f == x bit for bit for
+    // every x these sums can hold (none of them is ever -0.0f), and the clamp does not move a non-negative total.
+    {
+      const int slot = __ffs(~L.mmask) - 1;
+      const bool can = (press & 1u) && (L.fl & SF_FL_SHIP_ALIVE) && slot >= 0 && slot < SF_NSLOT;
+      new_m_slot = can ? slot : -1;
+      L.mmask |= can ? (1u << (slot & 31)) : 0u;
+      score(can ? -sfc::Score<SHAPED>::missile_penalty : 0.0f, rew, L);
+    }
+#else
     if ((press & 1u) && (L.fl & SF_FL_SHIP_ALIVE)) {
       const int slot = __ffs(~L.mmask) - 1;
       if (slot < SF_NSLOT) {
@@ -946,6 +961,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         score(-sfc::Score<SHAPED>::missile_penalty, rew, L);
       }
     }
+#endif
   }
   // the missile created above starts at the ship's pre-move position and heading
   const double new_m_x = L.sx, new_m_y = L.sy;
@@ -968,6 +984,13 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       if (ia >= 360) ia -= 360;  // fmod(360, 360)
       L.angle = ia;
     } else {
+#if SF_BRANCHFREE
+      // TURN_LEFT / TURN_RIGHT / both or none (:317-325): right - left steps of turnSpeed, then stdAngle's wrap
+      // (one of the two corrections can apply, and only on the side that was stepped towards)
+      L.angle += sfc::turn_speed * ((int)((L.fl / SF_FL_RIGHT) & 1u) - (int)((L.fl / SF_FL_LEFT) & 1u));
+      L.angle += L.angle < 0 ? 360 : 0;
+      L.angle -= L.angle >= 360 ? 360 : 0;
+#else
       const bool left = L.fl & SF_FL_LEFT, right = L.fl & SF_FL_RIGHT;
       if (left && !right) {  // TURN_LEFT: stdAngle(angle - turnSpeed)
         L.angle -= sfc::turn_speed;
@@ -976,20 +999,40 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         L.angle += sfc::turn_speed;
         if (L.angle >= 360) L.angle -= 360;
       }
+#endif
     }
+#if SF_BRANCHFREE
+    {
+      const bool th = L.fl & SF_FL_THRUST;
+      const double tvx = L.vx + sfc::ship_accel * SF_COS(L.angle), tvy = L.vy + sfc::ship_accel * SF_SIN(L.angle);
+      L.vx = th ? tvx : L.vx;
+      L.vy = th ? tvy : L.vy;
+    }
+#else
     if (L.fl & SF_FL_THRUST) {
       L.vx += sfc::ship_accel * SF_COS(L.angle);
       L.vy += sfc::ship_accel * SF_SIN(L.angle);
     }
+#endif
     L.sx += L.vx;
     L.sy += L.vy;
     // `if (!big.isInside) ... else if (small.isInside) ...` (:337-349), counters branch-free
     const int out_big = !inside_big_hex(L.sx, L.sy);
     const int in_small = !out_big & inside_small_hex(L.sx, L.sy);
+#if SF_BRANCHFREE
+    {
+      const int dead_now = out_big | in_small;  // killShip (:274-280) on a live ship, as selects
+      L.fl &= dead_now ? ~SF_FL_SHIP_ALIVE : ~0u;
+      L.death_t = dead_now ? 0 : L.death_t;
+      S.ship_deaths += dead_now;
+      score(dead_now ? -sfc::Score<SHAPED>::death_penalty : 0.0f, rew, L);
+    }
+#else
     if (out_big | in_small) {
       kill_ship(L, S);
       score(-sfc::Score<SHAPED>::death_penalty, rew, L);
     }
+#endif
     S.big_hex_deaths += out_big;
     S.small_hex_deaths += in_small;
   }
@@ -1005,6 +1048,23 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   {
     double ats = rad2deg(a_pos);  // stdAngle: in [-180, 180], only the sign fix applies
     if (ats < 0) ats += 360;
+#if SF_BRANCHFREE
+    fort_respawned = !(L.fl & SF_FL_FORT_ALIVE) && L.fort_death_t > sfc::fort_respawn;
+    L.fort_t = fort_respawned ? 0 : L.fort_t;
+    L.fl |= fort_respawned ? SF_FL_FORT_ALIVE : 0u;
+    const bool ship_up = L.fl & SF_FL_SHIP_ALIVE;
+    {
+      double q = ceil(SF_DIV(ats, sfc::sector_size)) * sfc::sector_size;  // in [0, 360]
+      int fa = (int)q;
+      fa -= fa >= 360 ? 360 : 0;
+      L.fort_angle = ship_up ? fa : L.fort_angle;
+      const bool moved = ship_up && fa != L.fort_last;
+      L.fort_last = moved ? fa : L.fort_last;
+      L.fort_t = moved ? 0 : L.fort_t;
+    }
+    if (ship_up) {
+      if (L.fort_t >= sfc::lock_time && (L.fl & SF_FL_FORT_ALIVE)) {
+#else
     if (!(L.fl & SF_FL_FORT_ALIVE) && L.fort_death_t > sfc::fort_respawn) {
       L.fort_t = 0;
       L.fl |= SF_FL_FORT_ALIVE;
@@ -1020,6 +1080,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         L.fort_t = 0;
       }
       if (L.fort_t >= sfc::lock_time && (L.fl & SF_FL_FORT_ALIVE)) {
+#endif
         // fireShell (SRC/game.cpp:159-173): vel = shellSpeed * (cos, sin)(deg2rad(angle_to_ship)).
         // angle_to_ship is the bearing of d = ship - fortress, so (cos, sin) = d / |d|: one sqrt
         // and two divisions instead of a device sincos with argument reduction.  Shell velocity
