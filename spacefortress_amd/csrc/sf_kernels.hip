@@ -1188,6 +1188,17 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       // slot order: the first colliding shell kills a live ship; every other shell only
       // leaves by flying out (`if (alive && collided) ... else if (outside)`, :410-420)
       unsigned dead = out & live;
+#if SF_BRANCHFREE
+      {
+        const int hitship = (L.fl & SF_FL_SHIP_ALIVE) && col;
+        dead |= hitship ? (col & (0u - col)) : 0u;  // lowest colliding slot
+        L.fl &= hitship ? ~SF_FL_SHIP_ALIVE : ~0u;  // killShip on a live ship, as selects
+        L.death_t = hitship ? 0 : L.death_t;
+        S.ship_deaths += hitship;
+        S.shell_deaths += hitship;
+        score(hitship ? -sfc::Score<SHAPED>::death_penalty : 0.0f, rew, L);
+      }
+#else
       if ((L.fl & SF_FL_SHIP_ALIVE) && col) {
         const unsigned kbit = col & (0u - col);  // lowest colliding slot
         dead |= kbit;
@@ -1195,6 +1206,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         score(-sfc::Score<SHAPED>::death_penalty, rew, L);
         S.shell_deaths += 1;
       }
+#endif
       L.smask &= ~dead;
 #pragma unroll
       for (int k = 0; k < SF_SGSZ; k++) {
@@ -1328,6 +1340,31 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     unsigned ev = ev_hit | ev_out;
     hit_count = __popc(ev_hit);
     L.mmask &= ~ev;
+#if SF_BRANCHFREE
+    // slot order (SRC/game.cpp:355): one event per lane and round, rounds while any lane has one left; the
+    // fortress state machine of :357-399 as selects (a lane without an event in this round has bit == 0)
+    while (__ballot(ev != 0u) != 0ull) {
+      const unsigned bit = ev & (0u - ev);
+      ev &= ~bit;
+      const bool on = bit != 0u, h = (ev_hit & bit) != 0u;
+      const bool hv = h && (L.fl & SF_FL_FORT_ALIVE);        // a hit on a live fortress (:358)
+      const int inc = hv && L.fort_vuln_t >= sfc::vuln_time;  // :359-363
+      const int low = hv && !inc;                             // inside the vulnerability window (:364-384)
+      const int destroy = low && L.vlner >= sfc::vuln_threshold + 1;
+      L.vlner = inc ? L.vlner + 1 : (low ? 0 : L.vlner);
+      S.vlner_incs += inc;
+      S.max_vlner = (inc && L.vlner > S.max_vlner) ? L.vlner : S.max_vlner;
+      L.fl &= destroy ? ~SF_FL_FORT_ALIVE : ~0u;
+      L.fort_death_t = destroy ? 0 : L.fort_death_t;
+      score(destroy ? sfc::Score<SHAPED>::destroy_reward : 0.0f, rew, L);
+      S.destroyed += destroy;
+      S.resets += low && !destroy;
+      L.fort_vuln_t = hv ? 0 : L.fort_vuln_t;
+      const int miss = on && !h;                              // left the game area (:394-398); miss_penalty is 0
+      score(miss ? -sfc::Score<SHAPED>::miss_penalty : 0.0f, rew, L);
+      S.missed += miss;
+    }
+#else
     if (__ballot(ev != 0u) != 0ull) {
       while (ev) {  // slot order (SRC/game.cpp:355)
         const unsigned bit = ev & (0u - ev);
@@ -1357,6 +1394,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         }
       }
     }
+#endif
   }
   SF_STAMP(6, false);
 
