@@ -167,7 +167,10 @@ __device__ __forceinline__ void sf_store(T* p, T v) {
   __builtin_nontemporal_store(v, p);
 #elif SF_STORE_MODE == 2
   if constexpr (sizeof(T) == 16) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // the s_nop belongs to the store: a store of more than 64 bits reads its data registers over several cycles and
+    // the next VALU write of one of them needs a wait state in between, which the compiler cannot insert for an
+    // instruction it does not see (found as misc.prev_vlner of lanes 12-15 of every 16 holding the NEXT store's word)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   } else {
     *p = v;
   }
@@ -207,6 +210,7 @@ struct Lane {
   int vlner, time;
   int prev_vlner;
   unsigned cursor, mmask, smask;
+  unsigned kc0, kc1;  // key-press counters: shots | thrusts << 16, lefts | rights << 16 (sf_layout.h: SF_KEYCOUNT_BYTE)
 };
 
 // What one tick adds to the statistics (SRC/game.hh:29-43); flushed with atomics.
@@ -327,6 +331,7 @@ __device__ __forceinline__ void new_game(const SfKernelArgs& a, Lane& L) {
   L.fort_t = L.fort_death_t = 0;
   L.fort_vuln_t = sfc::vuln_time;  // :78 adds to a never-initialised member; defined as 0 + 250
   L.mmask = L.smask = 0;
+  L.kc0 = L.kc1 = 0;  // statistics start over with the game (SRC/game.cpp:18-82)
 }
 
 __device__ __forceinline__ void kill_ship(Lane& L, StatDelta& S) {  // SRC/game.cpp:274-280
@@ -345,7 +350,7 @@ __device__ __forceinline__ void load_lane(const unsigned char* tb, const Off& o,
   const i4_t ta = SF_LD(i4_t, SF_CHUNK(timers_a, 0), o.o16);
   const i4_t tc = SF_LD(i4_t, SF_CHUNK(timers_b, 0), o.o16);
   const i4_t sc = SF_LD(i4_t, SF_CHUNK(score, 0), o.o16);
-  const i2_t sm = SF_LD(i2_t, SF_CHUNK(small, 0), o.o8);
+  const i4_t sm = SF_LD(i4_t, SF_CHUNK(small, 0), o.o16);
   L.prev_vlner = mi.x;
   L.cursor = (unsigned)mi.y;
   L.mmask = (unsigned)mi.z;
@@ -370,18 +375,20 @@ __device__ __forceinline__ void load_lane(const unsigned char* tb, const Off& o,
   L.fort_angle = (int16_t)((unsigned)sm.x >> 16);
   L.fort_last = (int16_t)(sm.y & 0xFFFF);
   L.fl = ((unsigned)sm.y >> 16) & 0xFFu;
+  L.kc0 = (unsigned)sm.z;
+  L.kc1 = (unsigned)sm.w;
 }
 
-__device__ __forceinline__ void store_lane(unsigned char* tb, const Off& o, const Lane& L) {
+__device__ __forceinline__ void store_lane_plain(unsigned char* tb, const Off& o, const Lane& L) {
   SF_ST(d2_t, SF_CHUNK(ship_pos, 0), o.o16, (d2_t{L.sx, L.sy}));
   SF_ST(d2_t, SF_CHUNK(ship_vel, 0), o.o16, (d2_t{L.vx, L.vy}));
   SF_ST(i4_t, SF_CHUNK(timers_a, 0), o.o16, (i4_t{L.death_t, L.fire_t, L.thrust_t, L.left_t}));
   SF_ST(i4_t, SF_CHUNK(timers_b, 0), o.o16, (i4_t{L.right_t, L.fort_t, L.fort_death_t, L.fort_vuln_t}));
   SF_ST(i4_t, SF_CHUNK(score, 0), o.o16, (i4_t{__float_as_int(L.points), __float_as_int(L.raw), L.vlner, L.time}));
   SF_ST(i4_t, SF_CHUNK(misc, 0), o.o16, (i4_t{L.prev_vlner, (int)L.cursor, (int)L.mmask, (int)L.smask}));
-  SF_ST(i2_t, SF_CHUNK(small, 0), o.o8,
-        (i2_t{(int)((unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16)),
-              (int)((unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16))}));
+  SF_ST(i4_t, SF_CHUNK(small, 0), o.o16,
+        (i4_t{(int)((unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16)),
+              (int)((unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16)), (int)L.kc0, (int)L.kc1}));
 }
 
 #if SF_BUFOPS
@@ -397,13 +404,20 @@ __device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const 
   SF_BST16(score, (i4_t{__float_as_int(L.points), __float_as_int(L.raw), L.vlner, L.time}));
   SF_BST16(misc, (i4_t{L.prev_vlner, (int)L.cursor, (int)L.mmask, (int)L.smask}));
 #undef SF_BST16
-  typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
-  __builtin_amdgcn_raw_buffer_store_b64(
-      u2_t{(unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16),
-           (unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16)},
-      rs, o.o8, SF_GOFF(small, 0), 0);
+  __builtin_amdgcn_raw_buffer_store_b128(
+      u4_t{(unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16),
+           (unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16), L.kc0, L.kc1},
+      rs, o.o16, SF_GOFF(small, 0), aux);
 }
 #endif
+
+__device__ __forceinline__ void store_lane(unsigned char* tb, const Off& o, const Lane& L) {
+#if SF_BUFOPS
+  store_lane_buf(__builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)sfl::kTileBytes, 0x00020000), o, L);
+#else
+  store_lane_plain(tb, o, L);
+#endif
+}
 
 // Agent-scope (L2-coherent, L1-bypassing) accesses for the few places where one launch may read
 // back what it wrote earlier or mixes plain stores with atomics on the same word: the counter
@@ -933,6 +947,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     L.thrust_t = (edge & 2u) ? 0 : L.thrust_t;
     S.shots += (int)(press & 1u);
     S.thrusts += (int)((press >> 1) & 1u);
+    L.kc0 += (press & 1u) | ((press & 2u) << 15);  // shots in the low half, thrusts in the high half
+    if (!AUTOTURN) L.kc1 += ((press >> 2) & 1u) | ((press & 8u) << 13);  // lefts, rights
     if (!AUTOTURN) {
       L.left_t = (edge & 4u) ? 0 : L.left_t;
       L.right_t = (edge & 8u) ? 0 : L.right_t;
@@ -1444,7 +1460,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     const int ep_ret = ld_coherent_i32(SF_CHUNK(ep_return, 0) + o.o4) + r;
     const int ep_kil = ld_coherent_i32(SF_CHUNK(ep_kills, 0) + o.o4) + fort_kill;
     const int deaths = ld_coherent_i32(SF_CHUNK(stats, SF_ST_SHIP_DEATHS) + o.o4) + S.ship_deaths;
-    const int shots = ld_coherent_i32(SF_CHUNK(stats, SF_ST_SHOTS) + o.o4) + S.shots;
+    const int shots = (int)(L.kc0 & 0xFFFFu);  // this tick's press included
     if (real) {
       atomicAdd(&a.acc[0], 1ull);
       atomicAdd(&a.acc[1], (unsigned long long)(long long)ep_ret);
@@ -1478,10 +1494,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 #endif
     // the key presses happen in some lane of nearly every tick; everything else is rare and sits behind
     // ONE wave-wide test (all of these deltas are >= 0, so their OR is their "any")
-    SF_FLUSH(SF_ST_SHOTS, S.shots)
-    SF_FLUSH(SF_ST_THRUSTS, S.thrusts)
-    SF_FLUSH(SF_ST_LEFTS, S.lefts)
-    SF_FLUSH(SF_ST_RIGHTS, S.rights)
+    // (shots, thrusts, lefts, rights: in the lane's own chunk, L.kc0 / L.kc1 -- no atomics)
     if (__ballot((S.ship_deaths | S.resets | S.destroyed | S.missed | S.vlner_incs | S.max_vlner) != 0) != 0ull) {
       SF_FLUSH(SF_ST_BIG_HEX_DEATHS, S.big_hex_deaths)
       SF_FLUSH(SF_ST_SMALL_HEX_DEATHS, S.small_hex_deaths)
@@ -1606,6 +1619,23 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_field_copy_kernel(unsigned char* 
   }
 }
 
+// sf_get_field / sf_set_field("stats"): rows SF_ST_KEY_FIRST .. +3 of the linear [13][n_envs] int32 buffer come from
+// (go to) the four uint16 key-press counters in the lane's `small` chunk (sf_layout.h: SF_KEYCOUNT_BYTE).
+__global__ __launch_bounds__(SF_BLOCK) void sf_keycount_copy_kernel(unsigned char* state, int n_envs, int32_t* linear,
+                                                                   int to_linear) {
+  const long e = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
+  if (e >= n_envs) return;
+  uint16_t* kc = reinterpret_cast<uint16_t*>(state + (e >> 6) * sfl::kTileBytes + sfl::chunk_offset(SF_G_small, 0) +
+                                             (e & 63) * sfl::kGroups[SF_G_small].chunk + SF_KEYCOUNT_BYTE);
+  for (int c = 0; c < SF_ST_KEY_COUNT; c++) {
+    int32_t* p = linear + (long)(SF_ST_KEY_FIRST + c) * n_envs + e;
+    if (to_linear)
+      *p = kc[c];
+    else
+      kc[c] = (uint16_t)*p;
+  }
+}
+
 // PMC calibration (sf_calibration_copy): copy whole 16-byte chunks of one group to the linear
 // buffer -- 16 B per lane, 1 KiB per wave-instruction, exactly the step kernel's access pattern.
 __global__ __launch_bounds__(SF_BLOCK) void sf_group_copy_kernel(const unsigned char* state, int n_envs, long tile_off,
@@ -1650,6 +1680,9 @@ hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, uns
                          lane_stride, slot_stride, count, (uint64_t*)linear, to_linear);
       break;
   }
+  if (field == SF_F_stats)  // four of the 13 counters live in the `small` chunk (stream order: after the generic copy)
+    hipLaunchKernelGGL(sf_keycount_copy_kernel, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, (int32_t*)linear,
+                       to_linear);
   return hipGetLastError();
 }
 

@@ -32,7 +32,7 @@
   G(timers_b, 16, 1)              /* right, fort, fort_death, fort_vuln timers */               \
   G(score, 16, 1)                 /* points, raw_points, vlner, time */                         \
   G(misc, 16, 1)                  /* prev_vlner, spawn_cursor, missile_mask, shell_mask */      \
-  G(small, 8, 1)                  /* ship_angle, fort_angle, fort_last_angle (i16), flags (u8), last_reward (i8) */ \
+  G(small, 16, 1)                 /* ship_angle, fort_angle, fort_last_angle (i16), flags (u8), last_reward (i8); then the four key-press counters of `stats` as u16 (see SF_KEYCOUNT_BYTE) */ \
   G(missile_pos, 16, SF_NSLOT)    /* missile_x, missile_y */                                    \
   G(missile_ang, 2, SF_NSLOT)     /* missile_angle */                                           \
   G(shell_pos, 16, SF_NSLOT)      /* shell_x, shell_y */                                        \
@@ -94,6 +94,15 @@ enum SfFieldId {
       SF_F_COUNT
 };
 
+// The four counters that move on nearly every tick -- shots, thrusts, lefts, rights (stats[7..10]) -- live as four
+// uint16 at bytes 8..15 of the lane's `small` chunk, which every step loads and stores anyway: no atomic, no extra
+// memory instruction.  (An episode has 5 295 ticks and a key can be pressed once per two ticks, so 16 bits hold
+// them; they are zeroed with a new game.)  The other nine counters stay in the `stats` rows and move by atomics.
+// sf_get_field / sf_set_field("stats") put the two sources together, so the field is the reference's 13 ints.
+#define SF_KEYCOUNT_BYTE 8
+#define SF_ST_KEY_FIRST 7 /* SF_ST_SHOTS */
+#define SF_ST_KEY_COUNT 4
+
 // flags bits
 #define SF_FL_SHIP_ALIVE 1u
 #define SF_FL_FORT_ALIVE 2u
@@ -126,8 +135,8 @@ constexpr long group_offset(int g) {
   for (int i = 0; i < g; i++) o += (long)kGroups[i].chunk * kGroups[i].slots * kTileLanes;
   return o;
 }
-constexpr long kTileBytes = group_offset(SF_G_COUNT);          // 74 496 B
-constexpr long kBytesPerLane = kTileBytes / kTileLanes;        // 1164 B
+constexpr long kTileBytes = group_offset(SF_G_COUNT);          // 75 008 B
+constexpr long kBytesPerLane = kTileBytes / kTileLanes;        // 1172 B
 // byte offset, inside a tile, of lane 0's chunk of (group g, slot s)
 constexpr long chunk_offset(int g, int s = 0) { return group_offset(g) + (long)s * kGroups[g].chunk * kTileLanes; }
 

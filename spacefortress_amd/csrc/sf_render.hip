@@ -641,9 +641,9 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   const i4_t tb = R_LD(i4_t, R_CHUNK(timers_b, 0), o16);
   const i4_t sc = R_LD(i4_t, R_CHUNK(score, 0), o16);
   const i4_t mi = R_LD(i4_t, R_CHUNK(misc, 0), o16);
-  const int ship_angle = R_LD(int16_t, R_CHUNK(small, 0), o8);
-  const int fort_angle = R_LD(int16_t, R_CHUNK(small, 0), o8 + 2);
-  const unsigned flags = R_LD(uint8_t, R_CHUNK(small, 0), o8 + 6);
+  const int ship_angle = R_LD(int16_t, R_CHUNK(small, 0), o16);  // `small` is a 16-byte chunk (sf_layout.h)
+  const int fort_angle = R_LD(int16_t, R_CHUNK(small, 0), o16 + 2);
+  const unsigned flags = R_LD(uint8_t, R_CHUNK(small, 0), o16 + 6);
   const unsigned mmask = (SF_RENDER_SKIP & 2) ? 0u : (unsigned)mi.z, smask = (SF_RENDER_SKIP & 2) ? 0u : (unsigned)mi.w;
   const int pnts = (int)__int_as_float(sc.x);  // drawScore takes mScore.mPoints as an int (SRC/draw.cpp:190,266)
   const int vlner = sc.z;

@@ -508,6 +508,32 @@ def test_autoturn_heading_on_the_spawn_lattice(sfa, oracle_mod):
     env.close()
 
 
+@pytest.mark.parametrize("n", [256, 4096])
+def test_a_fresh_batch_is_the_oracles_initial_state(sfa, oracle_mod, n):
+    """Right after sf_create, and again right after sf_reset, every field of every lane is what the oracle holds
+    (the kernels that write the state from scratch; a store-data hazard in them once left prev_vlner of four lanes
+    in sixteen holding a neighbouring chunk's word until the first step rewrote it)."""
+    O = oracle_mod
+    for gametype in ("youturn", "autoturn"):
+        env = sfa.SFVecEnv(n, gametype=gametype, spawn_stride=3, spawn_skip=1)
+        orc = O.OracleVecEnv(gametype, n, spawn_stride=3, spawn_skip=1)
+        sd = env.state_dict()
+        assert not compare_state(sd, orc.snapshots())
+        assert not np.asarray(sd["prev_vlner"]).any() and not np.asarray(sd["stats"]).any()
+        assert not np.asarray(sd["ep_return"]).any() and not np.asarray(sd["last_reward"]).any()
+        acts = np.random.default_rng(n).integers(0, env.n_actions, (40, n)).astype(np.uint8)
+        run_device(env, acts)
+        for t in range(40):
+            orc.step(acts[t].astype(np.int32))
+        env.reset()
+        orc.reset()
+        sd = env.state_dict()
+        assert not compare_state(sd, orc.snapshots())
+        assert np.array_equal(np.asarray(sd["prev_vlner"]).ravel(), orc.prev_vlner())
+        assert not np.asarray(sd["stats"]).any()
+        env.close()
+
+
 def test_no_auto_reset_and_reset_keeps_prev_vlner(sfa, oracle_mod):
     """auto_reset=False is the bare SSF_Env: a finished game keeps ticking (ENV:246 only reports);
     sf_reset starts new games and keeps prev_vlner (ENV:92,163-178)."""
