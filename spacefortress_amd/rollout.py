@@ -55,7 +55,7 @@ class DeviceRollout:
         self._ptr = None
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.env.device).cuda_stream)
+        return _lib.raw_stream(self.env.device)
 
     def reset(self):
         """obs = envs.reset(); rollouts.observations[0].copy_(obs) (rl/train.py:60-62)."""

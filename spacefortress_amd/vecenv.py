@@ -85,12 +85,13 @@ class SFVecEnv:
                                          np.float32 if obs_dtype == torch.float32 else np.float64)
         self.reuse_buffers = reuse_buffers
         self._bufs = None
+        self._buf_ptrs = None
         self._pending = None
         self._fields = None
 
     # ------------------------------------------------------------------ buffers
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return _lib.raw_stream(self.device)
 
     def _alloc(self):
         if self.reuse_buffers and self._bufs is not None:
@@ -102,6 +103,7 @@ class SFVecEnv:
                 torch.empty(n, dtype=torch.uint8, device=self.device))
         if self.reuse_buffers:
             self._bufs = bufs
+            self._buf_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in bufs)
         return bufs
 
     # ------------------------------------------------------------------ VecEnv API
@@ -119,11 +121,14 @@ class SFVecEnv:
         at = _ACT_TYPES.get(actions.dtype)
         if at is None:
             raise TypeError("actions dtype must be uint8, int32 or int64 (got %s)" % (actions.dtype,))
-        obs, rew, done, info = out if out is not None else self._alloc()
-        _lib.check(self._L.sf_step(self._h, C.c_void_p(actions.data_ptr()), at, C.c_void_p(obs.data_ptr()),
-                                   C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
-                                   C.c_void_p(info.data_ptr()), self._stream()))
-        return obs, rew, done, info
+        if out is None and self._bufs is not None and self.reuse_buffers:  # the addresses of the reused outputs, made once
+            bufs, ptrs = self._bufs, self._buf_ptrs
+        else:
+            bufs = out if out is not None else self._alloc()
+            ptrs = tuple(C.c_void_p(t.data_ptr()) for t in bufs)
+        _lib.check(self._L.sf_step(self._h, C.c_void_p(actions.data_ptr()), at, ptrs[0], ptrs[1], ptrs[2], ptrs[3],
+                                   self._stream()))
+        return bufs
 
     def rollout(self, actions, out=None, want_obs=True):
         """K steps whose actions are all known up front, fused into one launch (sfmi.h: sf_rollout).

@@ -43,7 +43,7 @@ class SFVecNormalize:
         self._pending = None
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return _lib.raw_stream(self.device)
 
     def _filter(self, obs, rew):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
