@@ -84,6 +84,8 @@ class DeviceRollout:
             "r": vp(self._rew.data_ptr()), "d": vp(self._done.data_ptr()), "i": vp(self._info.data_ptr()),
             "ep": vp(self.episode_rewards.data_ptr()), "fin": vp(self.final_rewards.data_ptr()),
         }
+        # what step() returns, as views made once
+        self._views = [(self.observations[t + 1], self.rewards[t], self.masks[t + 1]) for t in range(T)]
 
     def step(self, step, action, value_pred=None, action_log_prob=None, state=None):
         """envs.step(action) + the bookkeeping + rollouts.insert(...) of rl/train.py:79-98.
@@ -117,7 +119,7 @@ class DeviceRollout:
             self.action_log_probs[step].copy_(action_log_prob)
         if state is not None:
             self.states[step + 1].copy_(state)
-        return self.observations[step + 1], self.rewards[step], self.masks[step + 1]
+        return self._views[step]
 
     def _step_record(self, ap, at, step, stream):
         e, P = self.env, self._ptr
