@@ -122,6 +122,10 @@ __global__ __launch_bounds__(256) void sf_norm_merge_kernel(const double* partia
   const bool is_ret = f == dim;
   const double* cs = partials + (size_t)f * rows;
   const double* cq = partials + (size_t)(dim + 1 + f) * rows;
+  // the running statistics this workgroup merges into: fetched now, with the column loads, not after the
+  // reduction (thread 0 would wait a memory round trip of its own for them)
+  const double mean0 = is_ret ? stats[2 * dim] : stats[f], var0 = is_ret ? stats[2 * dim + 1] : stats[dim + f];
+  const double count0 = stats[2 * dim + 2 + (is_ret ? 1 : 0)];
   double s = 0, q = 0;
 #pragma unroll 4
   for (int r = t; r < rows; r += 256) {
@@ -140,8 +144,7 @@ __global__ __launch_bounds__(256) void sf_norm_merge_kernel(const double* partia
   if (t != 0) return;
   const double sum = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
   const double sumsq = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
-  double mean = is_ret ? stats[2 * dim] : stats[f], var = is_ret ? stats[2 * dim + 1] : stats[dim + f];
-  double count = stats[2 * dim + 2 + (is_ret ? 1 : 0)];
+  double mean = mean0, var = var0, count = count0;
   if (is_ret ? do_ret != 0 : do_ob != 0) merge(mean, var, count, sum, sumsq, (double)n, &mean, &var, &count);
   if (is_ret) {
     stats_next[2 * dim] = mean;
