@@ -1495,10 +1495,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 #define SF_ATOMIC_ADD(goff, v) \
   if ((v) != 0) atomicAdd(reinterpret_cast<int*>(tb + (goff) + o.o4), (v))
 #endif
-#if SF_ABL_STATS == 1 /* timing-only: no key-press counters */
-#define SF_FLUSH(idx, v) \
-  if ((idx) < SF_ST_SHOTS || (idx) > SF_ST_RIGHTS) if (__ballot((v) != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(stats, idx), (v)); }
-#elif SF_ABL_STATS == 2 /* timing-only: no counters at all */
+#if SF_ABL_STATS == 2 /* timing-only: no counter atomics at all (WRONG results) */
 #define SF_FLUSH(idx, v)
 #else
 #define SF_FLUSH(idx, v) \
