@@ -165,6 +165,11 @@
 #ifndef SF_STORE_MODE
 #define SF_STORE_MODE 2
 #endif
+// the cache bits of the write-through stores: inline-asm text and the builtins' aux value (1 = sc0, 2 = nt, 16 = sc1)
+#ifndef SF_SC_AUX
+#define SF_SC_AUX 16
+#define SF_SC_ASM "sc1"
+#endif
 template <typename T>
 __device__ __forceinline__ void sf_store(T* p, T v) {
 #if SF_STORE_MODE == 1
@@ -174,7 +179,7 @@ __device__ __forceinline__ void sf_store(T* p, T v) {
     // the s_nop belongs to the store: a store of more than 64 bits reads its data registers over several cycles and
     // the next VALU write of one of them needs a wait state in between, which the compiler cannot insert for an
     // instruction it does not see (found as misc.prev_vlner of lanes 12-15 of every 16 holding the NEXT store's word)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off " SF_SC_ASM "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   } else {
     *p = v;
   }
@@ -398,7 +403,7 @@ __device__ __forceinline__ void store_lane_plain(unsigned char* tb, const Off& o
 #if SF_BUFOPS
 // the same through the wave's tile descriptor: the chunk offsets ride in the scalar offset, no 64-bit address per store
 __device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const Off& o, const Lane& L) {
-  constexpr int aux = SF_STORE_MODE == 2 ? 16 /* sc1 */ : 0;
+  constexpr int aux = SF_STORE_MODE == 2 ? SF_SC_AUX : 0;
 #define SF_BST16(group, v) \
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, o.o16, SF_GOFF(group, 0), aux)
   SF_BST16(ship_pos, (d2_t{L.sx, L.sy}));
@@ -759,7 +764,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // predicated access to one projectile slot of the lane: `goff` = SF_GOFF(group, slot), wave-uniform
 #if SF_BUFOPS
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)sfl::kTileBytes, 0x00020000);
-  constexpr int kStAux = SF_STORE_MODE == 2 ? 16 /* sc1 */ : 0;
+  constexpr int kStAux = SF_STORE_MODE == 2 ? SF_SC_AUX : 0;
   auto pld16 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> d2_t {
     return __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, p ? o.o16 : SF_OOB, goff, 0));
   };
