@@ -40,8 +40,9 @@ class FrameStack:
         return self.stacked()
 
     def step(self, actions):
-        """One VecEnv step; returns (reward int32 [N], done bool [N], info bool [N]); the stack is
-        updated in place: finished envs keep only the first frame of their next episode."""
+        """One VecEnv step; returns (reward int32 [N], done bool [N], info bool [N]) -- views of buffers the
+        next step overwrites; the stack is updated in place: finished envs keep only the first frame of their next
+        episode."""
         e = self.env
         at = {torch.uint8: 1, torch.int32: 4, torch.int64: 8}[actions.dtype]
         _lib.check(e._L.sf_step(e._h, C.c_void_p(actions.data_ptr()), at, None, C.c_void_p(self._rew.data_ptr()),
@@ -51,7 +52,7 @@ class FrameStack:
         self.head = (self.head + 1) % self.num_stack
         _lib.check(e._L.sf_render_stack(e._h, C.c_void_p(self.ring.data_ptr()), self.num_stack, self.head,
                                         C.c_void_p(self._done.data_ptr()), e._stream()))
-        return self._rew, self._done.bool(), self._info.bool()
+        return self._rew, self._done.view(torch.bool), self._info.view(torch.bool)  # 0 / 1 bytes: a view, not a kernel
 
     def stacked(self):
         """[N, num_stack, 84, 84] uint8, oldest frame first -- the reference's channel order."""

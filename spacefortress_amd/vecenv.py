@@ -182,7 +182,7 @@ class SFVecEnv:
         (obs, rew, done, info), as_numpy = self._pending
         self._pending = None
         if not as_numpy:
-            return obs, rew, done.bool(), info.bool()
+            return obs, rew, done.view(torch.bool), info.view(torch.bool)  # 0 / 1 bytes: views, not kernels
         # np.stack of per-env python ints / bools, as the subprocess vec-env returns them
         return (obs.cpu().numpy(), rew.cpu().numpy().astype(np.int64), done.cpu().numpy().astype(bool),
                 info.cpu().numpy().astype(bool))

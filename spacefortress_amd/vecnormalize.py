@@ -82,7 +82,7 @@ class SFVecNormalize:
     def step_async(self, actions):
         if torch.is_tensor(actions):
             o, r, d, i = self.step_tensors(actions)
-            self._pending = ((o, r, d.bool(), i.bool()), False)
+            self._pending = ((o, r, d.view(torch.bool), i.view(torch.bool)), False)
             return
         self.venv.step_async(actions)
         (obs, rew, done, info), _ = self.venv._pending
