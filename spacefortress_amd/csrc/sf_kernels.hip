@@ -46,12 +46,6 @@
 #ifndef SF_BLOCK
 #define SF_BLOCK 256
 #endif
-#ifndef SF_BRANCHFREE
-#define SF_BRANCHFREE 1 /* 0: the small conditionals of the ship / fortress update as exec-mask branches, as first written */
-#endif
-#ifndef SF_VMASK
-#define SF_VMASK 1 /* 0: the truth values of the hexagon / hit / outside tests meet in scalar registers, as first written */
-#endif
 #define SF_TRIG_PIECES ((SF_LDS_DOUBLES / 2 + SF_BLOCK - 1) / SF_BLOCK)
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #define SF_MPF 12 /* missile slots prefetched into registers; higher slots take the slow loop */
@@ -143,9 +137,6 @@
 #define SF_OBS_SC1 1 /* the observation rows leave write-through (`sc1`) like the state chunks: 5 MB less for the
                         end-of-kernel write-back, 8.19 -> 7.94 us per launch; the 4- and 1-byte outputs gain nothing */
 #endif
-#ifndef SF_VCONST
-#define SF_VCONST 1
-#endif
 #ifndef SF_ABL_STATS
 #define SF_ABL_STATS 0
 #endif
@@ -189,14 +180,11 @@ __device__ __forceinline__ void sf_store(T* p, T v) {
 }
 #define SF_ST(T, base, off, v) sf_store<T>(reinterpret_cast<T*>((base) + (off)), (T)(v))
 
-// SF_BUFOPS: the projectile slots go through `buffer_*` instructions on a per-wave descriptor of the
+// The projectile slots, the lane's chunks and the counters go through `buffer_*` instructions on a per-wave descriptor of the
 // tile.  The slot's chunk offset (a compile-time constant too big for the 12-bit immediate) rides in
 // the scalar offset instead of costing two 64-bit VALU adds per access, and a lane that has nothing in
 // the slot gets an out-of-range offset: the hardware range check returns 0 for its load and drops its
 // store, so there is no exec-mask branch around each access.
-#ifndef SF_BUFOPS
-#define SF_BUFOPS 1
-#endif
 #define SF_GOFF(group, s) \
   ((unsigned)sfl::chunk_offset(SF_G_##group, 0) + (unsigned)(s) * (unsigned)(sfl::kGroups[SF_G_##group].chunk * sfl::kTileLanes))
 #define SF_OOB 0x80000000u /* beyond any tile: the lane's access does not happen */
@@ -269,7 +257,6 @@ __device__ __forceinline__ void score(float amount, float& rew, Lane& L) {
 // The six truth values are folded arithmetically: "no edge value is < 0" is "the smallest edge value is not < 0"
 // (for the horizontal edges the value is the difference y - py or py - y; -0.0 is not < 0 either way; no NaN
 // here), one comparison per hexagon instead of six whose results meet in scalar registers.
-#if SF_VMASK
 #define SF_EDGE_TEST(nx, ny, px, py)                                                                  \
   m = __builtin_fmin(m, (nx) == 0.0 ? ((ny) > 0 ? y - (py) : (py) - y) : (nx) * (x - (px)) + (ny) * (y - (py)));
 __device__ __forceinline__ bool inside_big_hex(double x, double y) {
@@ -283,24 +270,11 @@ __device__ __forceinline__ bool inside_small_hex(double x, double y) {
   return !(m < 0);
 }
 #undef SF_EDGE_TEST
-#endif
 #define SF_EDGE_TEST(nx, ny, px, py)                                     \
   if ((nx) == 0.0)                                                       \
     in = in & !((ny) > 0 ? (y < (py)) : (y > (py)));                     \
   else                                                                   \
     in = in & !((nx) * (x - (px)) + (ny) * (y - (py)) < 0);
-#if !SF_VMASK
-__device__ __forceinline__ bool inside_big_hex(double x, double y) {
-  bool in = true;
-  SF_BIG_HEX_EDGES(SF_EDGE_TEST)
-  return in;
-}
-__device__ __forceinline__ bool inside_small_hex(double x, double y) {
-  bool in = true;
-  SF_SMALL_HEX_EDGES(SF_EDGE_TEST)
-  return in;
-}
-#endif
 #undef SF_EDGE_TEST
 
 // Game::isOutsideGameArea (SRC/game.cpp:129-131)
@@ -388,20 +362,8 @@ __device__ __forceinline__ void load_lane(const unsigned char* tb, const Off& o,
   L.kc1 = (unsigned)sm.w;
 }
 
-__device__ __forceinline__ void store_lane_plain(unsigned char* tb, const Off& o, const Lane& L) {
-  SF_ST(d2_t, SF_CHUNK(ship_pos, 0), o.o16, (d2_t{L.sx, L.sy}));
-  SF_ST(d2_t, SF_CHUNK(ship_vel, 0), o.o16, (d2_t{L.vx, L.vy}));
-  SF_ST(i4_t, SF_CHUNK(timers_a, 0), o.o16, (i4_t{L.death_t, L.fire_t, L.thrust_t, L.left_t}));
-  SF_ST(i4_t, SF_CHUNK(timers_b, 0), o.o16, (i4_t{L.right_t, L.fort_t, L.fort_death_t, L.fort_vuln_t}));
-  SF_ST(i4_t, SF_CHUNK(score, 0), o.o16, (i4_t{__float_as_int(L.points), __float_as_int(L.raw), L.vlner, L.time}));
-  SF_ST(i4_t, SF_CHUNK(misc, 0), o.o16, (i4_t{L.prev_vlner, (int)L.cursor, (int)L.mmask, (int)L.smask}));
-  SF_ST(i4_t, SF_CHUNK(small, 0), o.o16,
-        (i4_t{(int)((unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16)),
-              (int)((unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16)), (int)L.kc0, (int)L.kc1}));
-}
-
-#if SF_BUFOPS
-// the same through the wave's tile descriptor: the chunk offsets ride in the scalar offset, no 64-bit address per store
+// The lane's seven chunks back to the tile, through the wave's descriptor: the chunk offsets ride in the scalar
+// offset, no 64-bit address per store; write-through (SF_SC_AUX).
 __device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const Off& o, const Lane& L) {
   constexpr int aux = SF_STORE_MODE == 2 ? SF_SC_AUX : 0;
 #define SF_BST16(group, v) \
@@ -418,14 +380,9 @@ __device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const 
            (unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16), L.kc0, L.kc1},
       rs, o.o16, SF_GOFF(small, 0), aux);
 }
-#endif
 
 __device__ __forceinline__ void store_lane(unsigned char* tb, const Off& o, const Lane& L) {
-#if SF_BUFOPS
   store_lane_buf(__builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)sfl::kTileBytes, 0x00020000), o, L);
-#else
-  store_lane_plain(tb, o, L);
-#endif
 }
 
 // Agent-scope (L2-coherent, L1-bypassing) accesses for the few places where one launch may read
@@ -762,7 +719,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   const Off g = {i * 16u, i * 8u, i * 4u, i * 2u, i};     // env offsets into the caller's arrays
   const bool real = i < (unsigned)n_envs_p;  // lanes in [n_envs, lanes) are padding: they run NOOPs
   // predicated access to one projectile slot of the lane: `goff` = SF_GOFF(group, slot), wave-uniform
-#if SF_BUFOPS
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)sfl::kTileBytes, 0x00020000);
   constexpr int kStAux = SF_STORE_MODE == 2 ? SF_SC_AUX : 0;
   auto pld16 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> d2_t {
@@ -784,30 +740,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   auto pst2_at = [&](unsigned goff, bool p, unsigned extra, int v) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, rs, p ? o.o2 + extra : SF_OOB, goff, 0);
   };
-#else
-  auto pld16 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> d2_t {
-    d2_t v = {0, 0};
-    if (p) v = SF_LD(d2_t, tb + goff, o.o16);
-    return v;
-  };
-  auto pld2 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> int {
-    int v = 0;
-    if (p) v = SF_LD(int16_t, tb + goff, o.o2);
-    return v;
-  };
-  auto pst16 = [&](unsigned goff, bool p, d2_t v) __attribute__((always_inline)) {
-    if (p) SF_ST(d2_t, tb + goff, o.o16, v);
-  };
-  auto pst2 = [&](unsigned goff, bool p, int v) __attribute__((always_inline)) {
-    if (p) SF_ST(int16_t, tb + goff, o.o2, (int16_t)v);
-  };
-  auto pst16_at = [&](unsigned goff, bool p, unsigned extra, d2_t v) __attribute__((always_inline)) {
-    if (p) SF_ST(d2_t, tb + goff, o.o16 + extra, v);
-  };
-  auto pst2_at = [&](unsigned goff, bool p, unsigned extra, int v) __attribute__((always_inline)) {
-    if (p) SF_ST(int16_t, tb + goff, o.o2 + extra, (int16_t)v);
-  };
-#endif
 #ifdef SF_STAMPS
   unsigned long long stamp_[16] = {};
   stamp_[12] = __builtin_amdgcn_s_memrealtime();
@@ -974,7 +906,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
     // FIRE press edge: fireMissile (SRC/game.cpp:175-192,237-238) before this tick's turn and
     // move; the shot is counted and the timer zeroed even if nothing could be created
-#if SF_BRANCHFREE
     // as selects: an exec-mask branch around a three-line body costs a lone wave more than the body (the
     // compare travels VALU -> SALU -> EXEC -> VALU).  score(+0.0f) changes nothing: x + 0.0f == x bit for bit for
     // every x these sums can hold (none of them is ever -0.0f), and the clamp does not move a non-negative total.
@@ -985,16 +916,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       L.mmask |= can ? (1u << (slot & 31)) : 0u;
       score(can ? -sfc::Score<SHAPED>::missile_penalty : 0.0f, rew, L);
     }
-#else
-    if ((press & 1u) && (L.fl & SF_FL_SHIP_ALIVE)) {
-      const int slot = __ffs(~L.mmask) - 1;
-      if (slot < SF_NSLOT) {
-        new_m_slot = slot;
-        L.mmask |= 1u << slot;
-        score(-sfc::Score<SHAPED>::missile_penalty, rew, L);
-      }
-    }
-#endif
   }
   // the missile created above starts at the ship's pre-move position and heading
   const double new_m_x = L.sx, new_m_y = L.sy;
@@ -1017,42 +938,23 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       if (ia >= 360) ia -= 360;  // fmod(360, 360)
       L.angle = ia;
     } else {
-#if SF_BRANCHFREE
       // TURN_LEFT / TURN_RIGHT / both or none (:317-325): right - left steps of turnSpeed, then stdAngle's wrap
       // (one of the two corrections can apply, and only on the side that was stepped towards)
       L.angle += sfc::turn_speed * ((int)((L.fl / SF_FL_RIGHT) & 1u) - (int)((L.fl / SF_FL_LEFT) & 1u));
       L.angle += L.angle < 0 ? 360 : 0;
       L.angle -= L.angle >= 360 ? 360 : 0;
-#else
-      const bool left = L.fl & SF_FL_LEFT, right = L.fl & SF_FL_RIGHT;
-      if (left && !right) {  // TURN_LEFT: stdAngle(angle - turnSpeed)
-        L.angle -= sfc::turn_speed;
-        if (L.angle < 0) L.angle += 360;
-      } else if (right && !left) {  // TURN_RIGHT
-        L.angle += sfc::turn_speed;
-        if (L.angle >= 360) L.angle -= 360;
-      }
-#endif
     }
-#if SF_BRANCHFREE
     {
       const bool th = L.fl & SF_FL_THRUST;
       const double tvx = L.vx + sfc::ship_accel * SF_COS(L.angle), tvy = L.vy + sfc::ship_accel * SF_SIN(L.angle);
       L.vx = th ? tvx : L.vx;
       L.vy = th ? tvy : L.vy;
     }
-#else
-    if (L.fl & SF_FL_THRUST) {
-      L.vx += sfc::ship_accel * SF_COS(L.angle);
-      L.vy += sfc::ship_accel * SF_SIN(L.angle);
-    }
-#endif
     L.sx += L.vx;
     L.sy += L.vy;
     // `if (!big.isInside) ... else if (small.isInside) ...` (:337-349), counters branch-free
     const int out_big = !inside_big_hex(L.sx, L.sy);
     const int in_small = !out_big & inside_small_hex(L.sx, L.sy);
-#if SF_BRANCHFREE
     {
       const int dead_now = out_big | in_small;  // killShip (:274-280) on a live ship, as selects
       L.fl &= dead_now ? ~SF_FL_SHIP_ALIVE : ~0u;
@@ -1060,12 +962,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       S.ship_deaths += dead_now;
       score(dead_now ? -sfc::Score<SHAPED>::death_penalty : 0.0f, rew, L);
     }
-#else
-    if (out_big | in_small) {
-      kill_ship(L, S);
-      score(-sfc::Score<SHAPED>::death_penalty, rew, L);
-    }
-#endif
     S.big_hex_deaths += out_big;
     S.small_hex_deaths += in_small;
   }
@@ -1081,7 +977,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   {
     double ats = rad2deg(a_pos);  // stdAngle: in [-180, 180], only the sign fix applies
     if (ats < 0) ats += 360;
-#if SF_BRANCHFREE
     fort_respawned = !(L.fl & SF_FL_FORT_ALIVE) && L.fort_death_t > sfc::fort_respawn;
     L.fort_t = fort_respawned ? 0 : L.fort_t;
     L.fl |= fort_respawned ? SF_FL_FORT_ALIVE : 0u;
@@ -1097,23 +992,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
     if (ship_up) {
       if (L.fort_t >= sfc::lock_time && (L.fl & SF_FL_FORT_ALIVE)) {
-#else
-    if (!(L.fl & SF_FL_FORT_ALIVE) && L.fort_death_t > sfc::fort_respawn) {
-      L.fort_t = 0;
-      L.fl |= SF_FL_FORT_ALIVE;
-      fort_respawned = true;
-    }
-    if (L.fl & SF_FL_SHIP_ALIVE) {
-      double q = ceil(SF_DIV(ats, sfc::sector_size)) * sfc::sector_size;  // in [0, 360]
-      int fa = (int)q;
-      if (fa >= 360) fa -= 360;
-      L.fort_angle = fa;
-      if (fa != L.fort_last) {
-        L.fort_last = fa;
-        L.fort_t = 0;
-      }
-      if (L.fort_t >= sfc::lock_time && (L.fl & SF_FL_FORT_ALIVE)) {
-#endif
         // fireShell (SRC/game.cpp:159-173): vel = shellSpeed * (cos, sin)(deg2rad(angle_to_ship)).
         // angle_to_ship is the bearing of d = ship - fortress, so (cos, sin) = d / |d|: one sqrt
         // and two divisions instead of a device sincos with argument reduction.  Shell velocity
@@ -1156,27 +1034,16 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // scarce (101 of 102 in use), and the compiler re-materialises each as an `s_mov_b32` pair in front of every slot
   // group -- about a hundred scalar moves per tick that a lone wave pays in full.  Opaque to the optimiser on
   // purpose; the values are the same doubles.
-#if SF_VCONST
   double kv_speed = sfc::missile_speed, kv_fx = sfc::fort_x, kv_fy = sfc::fort_y, kv_w = sfc::width_d, kv_h = sfc::height_d,
          kv_mr2 = sfc::missile_hit_r2, kv_sr2 = sfc::shell_hit_r2;
   asm volatile("" : "+v"(kv_speed), "+v"(kv_fx), "+v"(kv_fy), "+v"(kv_w), "+v"(kv_h), "+v"(kv_mr2), "+v"(kv_sr2));
-#else
-  constexpr double kv_speed = sfc::missile_speed, kv_fx = sfc::fort_x, kv_fy = sfc::fort_y, kv_w = sfc::width_d,
-                   kv_h = sfc::height_d, kv_mr2 = sfc::missile_hit_r2, kv_sr2 = sfc::shell_hit_r2;
-#endif
   // Game::isOutsideGameArea (SRC/game.cpp:129-131), (x < 0) | (x > W) | (y > H) | (y < 0), as ONE comparison:
   // the largest of -x, x - W, -y, y - H is positive exactly when one of the four holds (a difference of two
   // doubles has the exact sign; no NaN on this path).  Four compares OR-ed through scalar registers are a chain of
   // VALU -> SALU -> VALU hand-offs per slot, which a wave alone on its SIMD waits out every time.
-#if SF_VMASK
   auto outside = [&](double x, double y) __attribute__((always_inline)) -> bool {
     return __builtin_fmax(__builtin_fmax(-x, x - kv_w), __builtin_fmax(-y, y - kv_h)) > 0;
   };
-#else
-  auto outside = [&](double x, double y) __attribute__((always_inline)) -> bool {
-    return (x < 0) | (x > kv_w) | (y > kv_h) | (y < 0);
-  };
-#endif
 
   // ---- updateShells (SRC/game.cpp:404-423).  Ballistics of the prefetched slots first, as
   //      straight-line code; then the (ship-alive dependent) outcome in slot order.
@@ -1221,7 +1088,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       // slot order: the first colliding shell kills a live ship; every other shell only
       // leaves by flying out (`if (alive && collided) ... else if (outside)`, :410-420)
       unsigned dead = out & live;
-#if SF_BRANCHFREE
       {
         const int hitship = (L.fl & SF_FL_SHIP_ALIVE) && col;
         dead |= hitship ? (col & (0u - col)) : 0u;  // lowest colliding slot
@@ -1231,15 +1097,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         S.shell_deaths += hitship;
         score(hitship ? -sfc::Score<SHAPED>::death_penalty : 0.0f, rew, L);
       }
-#else
-      if ((L.fl & SF_FL_SHIP_ALIVE) && col) {
-        const unsigned kbit = col & (0u - col);  // lowest colliding slot
-        dead |= kbit;
-        kill_ship(L, S);
-        score(-sfc::Score<SHAPED>::death_penalty, rew, L);
-        S.shell_deaths += 1;
-      }
-#endif
       L.smask &= ~dead;
 #pragma unroll
       for (int k = 0; k < SF_SGSZ; k++) {
@@ -1302,7 +1159,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       nx = x + kv_speed * c;
       ny = y + kv_speed * sn;
       const double dx = nx - kv_fx, dy = ny - kv_fy;
-#if SF_VMASK
       // the same truth values as below, kept as bits of integer masks (vector ALU only); `live` and `!hit` are
       // applied to the collected masks once, after the last slot
       const unsigned bit = 1u << s;
@@ -1311,14 +1167,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       ev_hit |= hb;
       ev_out |= ob;
       pst16(SF_GOFF(missile_pos, s), (L.mmask & bit & ~(hb | ob)) != 0u, d2_t{nx, ny});
-#else
-      const bool live = (L.mmask >> s) & 1u;
-      const bool hit = live & (dx * dx + dy * dy <= kv_mr2);  // collided(mFortress), see shells
-      const bool out = live & !hit & outside(nx, ny);
-      ev_hit |= (unsigned)hit << s;
-      ev_out |= (unsigned)out << s;
-      pst16(SF_GOFF(missile_pos, s), live & !hit & !out, d2_t{nx, ny});
-#endif
     };
     auto m_move = [&](int s, double x, double y, int ang, bool isnew, double& nx, double& ny)
                       __attribute__((always_inline)) {
@@ -1366,14 +1214,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         }
       }
     }
-#if SF_VMASK
     ev_hit &= L.mmask;             // hit = live & collided
     ev_out &= L.mmask & ~ev_hit;   // out = live & !hit & outside
-#endif
     unsigned ev = ev_hit | ev_out;
     hit_count = __popc(ev_hit);
     L.mmask &= ~ev;
-#if SF_BRANCHFREE
     // slot order (SRC/game.cpp:355): one event per lane and round, rounds while any lane has one left; the
     // fortress state machine of :357-399 as selects (a lane without an event in this round has bit == 0)
     while (__ballot(ev != 0u) != 0ull) {
@@ -1397,37 +1242,6 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       score(miss ? -sfc::Score<SHAPED>::miss_penalty : 0.0f, rew, L);
       S.missed += miss;
     }
-#else
-    if (__ballot(ev != 0u) != 0ull) {
-      while (ev) {  // slot order (SRC/game.cpp:355)
-        const unsigned bit = ev & (0u - ev);
-        ev &= ~bit;
-        if (ev_hit & bit) {
-          if (L.fl & SF_FL_FORT_ALIVE) {
-            if (L.fort_vuln_t >= sfc::vuln_time) {
-              L.vlner += 1;
-              S.vlner_incs += 1;
-              if (L.vlner > S.max_vlner) S.max_vlner = L.vlner;
-            } else {
-              const int destroy = L.vlner >= sfc::vuln_threshold + 1;
-              if (destroy) {
-                L.fl &= ~SF_FL_FORT_ALIVE;
-                L.fort_death_t = 0;
-                score(sfc::Score<SHAPED>::destroy_reward, rew, L);
-              }
-              S.destroyed += destroy;
-              S.resets += 1 - destroy;
-              L.vlner = 0;
-            }
-            L.fort_vuln_t = 0;
-          }
-        } else {
-          score(-sfc::Score<SHAPED>::miss_penalty, rew, L);
-          S.missed += 1;
-        }
-      }
-    }
-#endif
   }
   SF_STAMP(6, false);
 
@@ -1494,12 +1308,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     a_vel = atan2(L.vy, L.vx);
   } else {
     // no-return atomics, executed at the memory side: the counters are never loaded
-#if SF_BUFOPS
 #define SF_ATOMIC_ADD(goff, v) __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((v), rs, (v) != 0 ? o.o4 : SF_OOB, (goff), 0)
-#else
-#define SF_ATOMIC_ADD(goff, v) \
-  if ((v) != 0) atomicAdd(reinterpret_cast<int*>(tb + (goff) + o.o4), (v))
-#endif
 #if SF_ABL_STATS == 2 /* timing-only: no counter atomics at all (WRONG results) */
 #define SF_FLUSH(idx, v)
 #else
@@ -1531,11 +1340,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   }
 
   SF_STAMP(11, false);
-#if SF_BUFOPS
   if (!FUSED) store_lane_buf(rs, o, L);
-#else
-  if (!FUSED) store_lane(tb, o, L);
-#endif
   SF_STAMP(14, false);
 
   if (real) {
@@ -1596,11 +1401,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
                                 lane, my_ret, has_obs);
   }
   }  // tick loop
-#if SF_BUFOPS
   if (FUSED) store_lane_buf(rs, o, L);
-#else
-  if (FUSED) store_lane(tb, o, L);
-#endif
   SF_STAMP(8, false);
   SF_STAMP(9, true);
 #ifdef SF_STAMPS
