@@ -27,12 +27,22 @@
 //  * projectile ballistics run as straight-line code over the prefetched slots (the
 //    slots are independent until a hit), so their f64 chains interleave; only the
 //    rare hit / miss events walk the fortress state machine, in slot order;
-//  * the fixed game constants that are tables -- the 360-entry cos/sin table (indexed per
-//    lane) and the 12 hexagon edges -- are staged into LDS once per workgroup (6 KB);
-//    scalar presets are kernel arguments (SGPRs);
-//  * the 13 statistics counters are never loaded: events add to them with no-return
-//    atomics (executed at the memory side), so a step reads and dirties less;
-//  * observations are transposed through LDS and leave as 16-byte coalesced stores;
+//  * the 360-entry cos/sin table (indexed per lane) is staged into LDS once per workgroup (6 KB),
+//    BEFORE the predicated loads are issued (any wait behind them is a vmcnt(0)); the hexagon
+//    edges and the scalar presets are immediates, what round trip 1 needs of the kernel arguments
+//    is preloaded into SGPRs by the command processor;
+//  * a lone wave waits out every hand-off between units, so truth values stay in the vector ALU
+//    (integer masks, min / max folds, selects instead of small exec-mask branches), constants
+//    used per slot live in VGPRs, divisions by constants are three operations;
+//  * the four waves of a CU share one address unit: projectile slots, lane chunks and counters go
+//    through buffer instructions on a per-wave descriptor (constant part of the address in the
+//    scalar offset, idle lanes out of range instead of branched around), what is written once
+//    per projectile is one store with the slot in the lane offset;
+//  * the nine rare statistics counters are never loaded: events add to them with no-return
+//    atomics (executed at the memory side); the four key-press counters ride in a chunk the
+//    lane loads and stores anyway;
+//  * observations are transposed through LDS and leave as 16-byte coalesced stores; every 16-byte
+//    store is write-through (sc1), so the end-of-kernel write-back has little left to flush;
 //  * no dense contraction anywhere on this path: no MFMA.  The bound is HBM traffic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
