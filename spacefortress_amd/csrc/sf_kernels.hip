@@ -143,6 +143,11 @@
 #ifndef SF_ABL_TRIG
 #define SF_ABL_TRIG 0
 #endif
+#ifndef SF_AXIS_VEL
+#define SF_AXIS_VEL 0 /* 1: the near-axis form of sf_atan2 for the velocity bearing as well.  It only feeds the `vdir`
+                         observation, a velocity component within 2^-27 of zero takes an exact cancellation of thrusts that
+                         the 0.3 * cos / sin(6k degrees) steps do not produce, and the test costs 0.1 us per launch */
+#endif
 #ifndef SF_OBS_SC1
 #define SF_OBS_SC1 1 /* the observation rows leave write-through (`sc1`) like the state chunks: 5 MB less for the
                         end-of-kernel write-back, 8.19 -> 7.94 us per launch; the 4- and 1-byte outputs gain nothing */
@@ -248,6 +253,32 @@ __device__ __forceinline__ double sf_div_const(double a, double c, double rc) {
 #define SF_DIV(a, C) sf_div_const((a), (double)(C), 1.0 / (double)(C))
 __device__ __forceinline__ double rad2deg(double a) { return SF_DIV(a, M_PI) * 180; }  // SRC/vector.cpp:38-40
 __device__ __forceinline__ double deg2rad(double a) { return SF_DIV(a * M_PI, 180); }  // SRC/vector.cpp:34-36
+
+// atan2 as the reference's libm rounds it where it matters.  The device libm (ocml) is faithful, glibc is correctly
+// rounded, and for nearly every argument the last-bit difference is invisible: the results only feed ceil-to-10
+// degrees (fortress sector), ceil-to-1 degree (autoturn heading) and observations.  Ships move on near-lattices,
+// though (integer spawns, velocities that are sums of 0.3 * cos(6k degrees)), and do cross x = 355 or y = 315 within
+// 1e-13: the bearing is then a whisker off +-90 or +-180 degrees -- multiples of 10 -- and which side of the
+// boundary the ROUNDED value falls on is decided by that last bit (found by a 3e8-step soak: sector 280 against the
+// reference's 270).  Next to the y axis and to the negative x axis the result is therefore formed as
+// +-pi/2 - x/y and +-pi + y/x with pi in two doubles: one rounding, the correctly rounded value, bit for bit what
+// glibc returns there (4e7 such arguments checked on the host, tests/native/atan2_axis.c).  A wave-wide test skips
+// the block on all but a handful of ticks.
+__device__ __forceinline__ double sf_atan2(double y, double x) {
+  double r = atan2(y, x);
+  const double ax = fabs(x), ay = fabs(y);
+  const bool ny = ax * 0x1p27 < ay;              // next to the y axis (x == 0 included)
+  const bool nx = (x < 0) & (ay * 0x1p27 < ax);  // next to the negative x axis (y == 0 included)
+  if (__ballot(ny | nx) != 0ull) {
+    if (ny | nx) {
+      const double t = ny ? x / y : y / x;
+      const double hi = ny ? 1.5707963267948966 : 3.141592653589793;          // pi/2, pi
+      const double lo = ny ? 6.123233995736766e-17 : 1.2246467991473532e-16;  // their low parts
+      r = copysign(hi, y) + (ny ? copysign(lo, y) - t : copysign(lo, y) + t);
+    }
+  }
+  return r;
+}
 
 // Game::reward (SRC/game.cpp:97-102): three float32 adds in this order, points clamped at 0.
 __device__ __forceinline__ void score(float amount, float& rew, Lane& L) {
@@ -444,7 +475,7 @@ __device__ __forceinline__ Extras compute_extras(const SfKernelArgs& a, const La
     const double dy = L.sy - sfc::fort_y;
     double ov;
     if (dy == 0)  // on the fortress row the two calls sit on different branch cuts: call it
-      ov = atan2(-(sfc::fort_y - L.sy), sfc::fort_x - L.sx);
+      ov = sf_atan2(-(sfc::fort_y - L.sy), sfc::fort_x - L.sx);
     else
       ov = dy < 0 ? (-M_PI - a_pos) : (M_PI - a_pos);
     double diff = a_vel - ov;
@@ -696,7 +727,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
   zero_counters(tb, o);
   if (obs != nullptr && i < (unsigned)a.n_envs && a.obs_type != 3) {
     // the reference's extras are stale heap until the first tick; defined as computeExtra(spawn)
-    Extras e = compute_extras(a, L, atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x), atan2(L.vy, L.vx));
+    Extras e = compute_extras(a, L, sf_atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x), sf_atan2(L.vy, L.vx));
     if (a.obs_f64)
       write_obs<double>(a, (double*)obs + (size_t)i * a.obs_dim, L, e);
     else
@@ -941,7 +972,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   if (L.fl & SF_FL_SHIP_ALIVE) {
     if (AUTOTURN) {
       // stdAngle(ceil(angleTo(ship, fortress)))  (SRC/vector.cpp:42-52)
-      double t = atan2(sfc::fort_y - L.sy, sfc::fort_x - L.sx);
+      double t = sf_atan2(sfc::fort_y - L.sy, sfc::fort_x - L.sx);
       if (t < 0) t += M_PI * 2;
       double c = ceil(rad2deg(t));  // in [0, 360]
       int ia = (int)c;
@@ -977,8 +1008,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   }
 
   // the two bearings the rest of the tick and the observation need, side by side (ILP)
-  double a_pos = atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
+  double a_pos = sf_atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
+#if SF_AXIS_VEL
+  double a_vel = sf_atan2(L.vy, L.vx);
+#else
   double a_vel = atan2(L.vy, L.vx);
+#endif
 
   // ---- updateFortress (SRC/game.cpp:194-216)
   int new_s_slot = -1;
@@ -1314,8 +1349,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
     new_game(a, L);
     zero_counters(tb, o);
-    a_pos = atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
-    a_vel = atan2(L.vy, L.vx);
+    a_pos = sf_atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
+    a_vel = sf_atan2(L.vy, L.vx);
   } else {
     // no-return atomics, executed at the memory side: the counters are never loaded
 #define SF_ATOMIC_ADD(goff, v) __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((v), rs, (v) != 0 ? o.o4 : SF_OOB, (goff), 0)

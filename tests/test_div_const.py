@@ -41,3 +41,12 @@ def test_every_divisor_of_the_kernel_is_covered():
     assert divisors and divisors <= set(known), divisors - set(known)
     assert "ndist_b = (200 - 40) / 2.0" in lay and "pb_width = 90, pb_height = 92, max_ticks = 5294" in lay
     assert "sector_size = 10" in lay and "#define SF_MAX_MISSILES_D 20.0" in src
+
+
+def test_near_axis_atan2_is_glibcs(tmp_path):
+    """sf_atan2's near-axis form (sf_kernels.hip) against the host libm the reference engine runs on."""
+    exe = str(tmp_path / "atan2_axis")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tests", "native", "atan2_axis.c"),
+                           "-o", exe, "-lm"])
+    out = subprocess.run([exe, "4000000"], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout

@@ -42,7 +42,13 @@ for c in range(0, T, K):
         oo, orw, od, oi = orc.step(acts[j].astype(np.int32))
         assert np.array_equal(rew[j], orw), (c + j, np.flatnonzero(rew[j] != orw)[:5])
         assert np.array_equal(done[j], od) and np.array_equal(info[j], oi), c + j
-        assert np.allclose(obs[j], oo, rtol=1e-5, atol=4e-5), (c + j)
+        ok = np.isclose(obs[j], oo, rtol=1e-5, atol=4e-5)
+        if not ok.all():
+            bad = np.argwhere(~ok)
+            for lane, feat in bad[:8]:
+                print("OBS MISMATCH step %d lane %d feature %d: device %r oracle %r   (device row %s)" % (
+                    c + j, lane, feat, obs[j][lane, feat], oo[lane, feat], np.array2string(obs[j][lane], precision=6)), flush=True)
+            raise AssertionError(c + j)
         done_total += int(od.sum()); kills += int(oi.sum())
     bad = compare_state(env.state_dict(), orc.snapshots())
     assert not bad, (c, bad)
