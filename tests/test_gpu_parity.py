@@ -508,6 +508,42 @@ def test_autoturn_heading_on_the_spawn_lattice(sfa, oracle_mod):
     env.close()
 
 
+@pytest.mark.parametrize("gametype", ["youturn", "autoturn"])
+def test_bearings_a_whisker_off_the_axes(sfa, oracle_mod, gametype):
+    """Ships a few ulps to 1e-9 off the fortress column / row: the bearing is a hair off +-90 or +-180 degrees --
+    sector boundaries -- and the side the ROUNDED atan2 falls on decides the fortress sector (and the autoturn
+    heading).  The device forms atan2 there as glibc rounds it (sf_kernels.hip: sf_atan2); a soak once found sector
+    280 against the reference's 270 for a ship at x = 355 + 2^-44."""
+    O = oracle_mod
+    rng = np.random.default_rng(5)
+    offs = np.concatenate([[0.0], 2.0 ** -np.arange(20, 46), -(2.0 ** -np.arange(20, 46)),
+                           np.ldexp(rng.integers(1, 4096, 200).astype(np.float64), -rng.integers(30, 52, 200)) *
+                           rng.choice([-1.0, 1.0], 200)])
+    far = np.concatenate([rng.uniform(45, 190, 64), [101.72240646055117, 60.0, 150.5]])
+    pts = []
+    for o in offs:
+        for f in far[rng.integers(0, len(far), 6)]:
+            pts += [(355.0 + o, 315.0 + f), (355.0 + o, 315.0 - f), (355.0 - f, 315.0 + o), (355.0 + f, 315.0 + o)]
+    pts = np.array(pts)
+    n = len(pts)
+    base = O.OracleVecEnv(gametype, n).snapshots()
+    base["ship_x"] = pts[:, 0]
+    base["ship_y"] = pts[:, 1]
+    base["ship_vx"] = 0.0  # stay where they are
+    base["ship_vy"] = 0.0
+    env, orc = _load_both(sfa, O, gametype, base)
+    acts = np.zeros((1, n), np.uint8)
+    obs, rew, done, info = run_device(env, acts)
+    oo, orw, od, oi = orc.step(acts[0].astype(np.int32))
+    sd, sn = env.state_dict(), orc.snapshots()
+    bad = np.flatnonzero(sd["fort_angle"].astype(np.float64) != sn["fort_angle"])
+    assert bad.size == 0, (pts[bad][:5], sd["fort_angle"][bad][:5], sn["fort_angle"][bad][:5])
+    assert np.array_equal(sd["ship_angle"].astype(np.float64), sn["ship_angle"])
+    assert not compare_state(sd, sn)
+    assert obs_close(obs[0], oo, True).all()
+    env.close()
+
+
 @pytest.mark.parametrize("n", [256, 4096])
 def test_a_fresh_batch_is_the_oracles_initial_state(sfa, oracle_mod, n):
     """Right after sf_create, and again right after sf_reset, every field of every lane is what the oracle holds
