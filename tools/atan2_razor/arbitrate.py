@@ -1,7 +1,7 @@
 from decimal import Decimal, getcontext
 getcontext().prec=70
 import math
-exec(open('gen.py').read().split("rows=[]")[0])
+exec(open(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'gen_tables.py')).read().split("rows=[]")[0])
 cases=[(8,"-0x1.dce6f693f96d7p+3","0x1.a82abc3494767p+6","-0x1.1df46a2529d38p-3","-0x1.1df46a2529d39p-3"),
 (49,"0x1.383559c6c888ap+6","0x1.0f660c206abeep+6","0x1.b5de4288e80cp-1","0x1.b5de4288e80bfp-1"),
 (17,"-0x1.a0181acb41b5ap+6","0x1.543ee40c79b39p+8","-0x1.2fd3b0c77be9ap-2","-0x1.2fd3b0c77be99p-2"),
