@@ -49,6 +49,7 @@
 
 #include "sf_internal.h"
 #include "sf_layout.h"
+#include "sf_deg_dd.h"
 
 // Four waves per workgroup share one LDS copy of the cos/sin table (one barrier, early, while the
 // waves are still in step; a copy per wave was tried: 1024 waves pulling the same 45 cache lines
@@ -264,6 +265,14 @@ __device__ __forceinline__ double deg2rad(double a) { return SF_DIV(a * M_PI, 18
 // +-pi/2 - x/y and +-pi + y/x with pi in two doubles: one rounding, the correctly rounded value, bit for bit what
 // glibc returns there (4e7 such arguments checked on the host, tests/native/atan2_axis.c).  A wave-wide test skips
 // the block on all but a handful of ticks.
+//
+// The same last bit decides whenever the bearing is within rounding noise of ANY integer degree, and in autoturn games
+// that is a regime, not an accident: a ship that thrusts at the fortress flies along an exact-degree ray.  RAZOR = 1:
+// within 1e-9 degrees of k degrees the result is formed as phi_k + N / D, N = |y| cos k - x sin k in double-double
+// (products exact by FMA; phi, cos, sin of k = 0..180 as (hi, lo) pairs, sf_deg_dd.h), D = x cos k + |y| sin k: the
+// correctly rounded value.  glibc's own atan2 is not correctly rounded in 0.08 % of such arguments (0.503-ulp errors,
+// tools/atan2_razor), so agreement there is 99.9 %, not 100 % -- against a coin toss per tick for the plain device libm.
+template <bool RAZOR>
 __device__ __forceinline__ double sf_atan2(double y, double x) {
   double r = atan2(y, x);
   const double ax = fabs(x), ay = fabs(y);
@@ -275,6 +284,23 @@ __device__ __forceinline__ double sf_atan2(double y, double x) {
       const double hi = ny ? 1.5707963267948966 : 3.141592653589793;          // pi/2, pi
       const double lo = ny ? 6.123233995736766e-17 : 1.2246467991473532e-16;  // their low parts
       r = copysign(hi, y) + (ny ? copysign(lo, y) - t : copysign(lo, y) + t);
+    }
+  }
+  if (RAZOR) {
+    const double deg = SF_DIV(fabs(r), M_PI) * 180, kd = rint(deg);
+    const bool rz = !(ny | nx) & (fabs(deg - kd) < 1e-9) & (y != 0.0);
+    if (__ballot(rz) != 0ull) {
+      if (rz) {
+        const double* e = kDegDD[(int)kd];  // (phi_hi, phi_lo, cos_hi, cos_lo, sin_hi, sin_lo) of kd degrees
+        const double ph = e[0], pl = e[1], ch = e[2], cl = e[3], sh = e[4], sl = e[5];
+        const double p1 = ay * ch, e1 = __builtin_fma(ay, ch, -p1);
+        const double p2 = x * sh, e2 = __builtin_fma(x, sh, -p2);
+        const double d = p1 - p2;  // nearly cancels
+        const double bb = d - p1, err = (p1 - (d - bb)) + (-p2 - bb);  // two-sum error term of p1 + (-p2)
+        const double lo = err + (e1 - e2) + (ay * cl - x * sl);
+        const double N = d + lo, D = x * ch + ay * sh;
+        r = copysign(ph + (pl + N / D), y);
+      }
     }
   }
   return r;
@@ -475,7 +501,7 @@ __device__ __forceinline__ Extras compute_extras(const SfKernelArgs& a, const La
     const double dy = L.sy - sfc::fort_y;
     double ov;
     if (dy == 0)  // on the fortress row the two calls sit on different branch cuts: call it
-      ov = sf_atan2(-(sfc::fort_y - L.sy), sfc::fort_x - L.sx);
+      ov = sf_atan2<false>(-(sfc::fort_y - L.sy), sfc::fort_x - L.sx);
     else
       ov = dy < 0 ? (-M_PI - a_pos) : (M_PI - a_pos);
     double diff = a_vel - ov;
@@ -727,7 +753,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
   zero_counters(tb, o);
   if (obs != nullptr && i < (unsigned)a.n_envs && a.obs_type != 3) {
     // the reference's extras are stale heap until the first tick; defined as computeExtra(spawn)
-    Extras e = compute_extras(a, L, sf_atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x), sf_atan2(L.vy, L.vx));
+    Extras e = compute_extras(a, L, sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x), sf_atan2<false>(L.vy, L.vx));
     if (a.obs_f64)
       write_obs<double>(a, (double*)obs + (size_t)i * a.obs_dim, L, e);
     else
@@ -972,7 +998,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   if (L.fl & SF_FL_SHIP_ALIVE) {
     if (AUTOTURN) {
       // stdAngle(ceil(angleTo(ship, fortress)))  (SRC/vector.cpp:42-52)
-      double t = sf_atan2(sfc::fort_y - L.sy, sfc::fort_x - L.sx);
+      double t = sf_atan2<true>(sfc::fort_y - L.sy, sfc::fort_x - L.sx);
       if (t < 0) t += M_PI * 2;
       double c = ceil(rad2deg(t));  // in [0, 360]
       int ia = (int)c;
@@ -1008,9 +1034,9 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   }
 
   // the two bearings the rest of the tick and the observation need, side by side (ILP)
-  double a_pos = sf_atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
+  double a_pos = sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
 #if SF_AXIS_VEL
-  double a_vel = sf_atan2(L.vy, L.vx);
+  double a_vel = sf_atan2<false>(L.vy, L.vx);
 #else
   double a_vel = atan2(L.vy, L.vx);
 #endif
@@ -1349,8 +1375,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
     new_game(a, L);
     zero_counters(tb, o);
-    a_pos = sf_atan2(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
-    a_vel = sf_atan2(L.vy, L.vx);
+    a_pos = sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
+    a_vel = sf_atan2<false>(L.vy, L.vx);
   } else {
     // no-return atomics, executed at the memory side: the counters are never loaded
 #define SF_ATOMIC_ADD(goff, v) __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((v), rs, (v) != 0 ? o.o4 : SF_OOB, (goff), 0)

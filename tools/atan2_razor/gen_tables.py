@@ -29,7 +29,9 @@ rows=[]
 for k in range(181):
     s,c=sincos_deg(k); phi=Decimal(k)*PI/180
     rows.append(split(phi)+split(c)+split(s))
-with open("tab.h","w") as f:
+import os,sys
+OUT=sys.argv[1] if len(sys.argv)>1 else "tab.h"
+with open(OUT,"w") as f:
     f.write("/* k degrees, k = 0..180: (phi_hi, phi_lo, cos_hi, cos_lo, sin_hi, sin_lo), double-double, generated with 60-digit decimals */\n")
     f.write("static const double kDegDD[181][6] = {\n")
     for r in rows: f.write("  {"+", ".join(float.hex(x) for x in r)+"},\n")
