@@ -544,6 +544,38 @@ def test_bearings_a_whisker_off_the_axes(sfa, oracle_mod, gametype):
     env.close()
 
 
+@pytest.mark.parametrize("gametype", ["autoturn", "youturn"])
+def test_bearings_on_exact_degree_rays(sfa, oracle_mod, gametype):
+    """Ships on (and an ulp or two off) the rays of integer degrees from the fortress -- where an autoturn ship that
+    thrusts at the fortress flies.  ceil() of the bearing follows the last bit of atan2 there; the device forms it
+    correctly rounded (sf_atan2, RAZOR), glibc mis-rounds about 0.08 % of such arguments itself (tools/atan2_razor),
+    so a handful of differences in a few thousand are the reference's; the plain device libm differs in a large
+    fraction of them."""
+    O = oracle_mod
+    rng = np.random.default_rng(11)
+    pts = []
+    for k in range(0, 360):
+        th = np.deg2rad(float(k))
+        for r in (47.0, 86.5, 120.25, 173.0 + rng.uniform(0, 10)):
+            x, y = 355.0 + r * np.cos(th), 315.0 + r * np.sin(th)
+            pts += [(x, y), (np.nextafter(x, 1e9), y), (np.nextafter(x, -1e9), y), (x, np.nextafter(y, 1e9))]
+    pts = np.array([p for p in pts if 40 < p[0] < 670 and 40 < p[1] < 590])
+    n = len(pts)
+    base = O.OracleVecEnv(gametype, n).snapshots()
+    base["ship_x"] = pts[:, 0]
+    base["ship_y"] = pts[:, 1]
+    base["ship_vx"] = 0.0
+    base["ship_vy"] = 0.0
+    env, orc = _load_both(sfa, O, gametype, base)
+    acts = np.zeros((1, n), np.uint8)
+    run_device(env, acts)
+    orc.step(acts[0].astype(np.int32))
+    sd, sn = env.state_dict(), orc.snapshots()
+    diff = (sd["fort_angle"].astype(np.float64) != sn["fort_angle"]) | (sd["ship_angle"].astype(np.float64) != sn["ship_angle"])
+    assert diff.mean() <= 0.005, (int(diff.sum()), n, pts[diff][:5])
+    env.close()
+
+
 @pytest.mark.parametrize("n", [256, 4096])
 def test_a_fresh_batch_is_the_oracles_initial_state(sfa, oracle_mod, n):
     """Right after sf_create, and again right after sf_reset, every field of every lane is what the oracle holds
