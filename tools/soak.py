@@ -1,6 +1,6 @@
 """Long lock-step parity run: N lanes x T steps (several episodes) on the GPU (chunks of fused rollouts and,
 alternately, single steps) against the CPU oracle; every reward / done / info, every observation (float32
-tolerance), the full state at every chunk end.  python tools/soak.py [gametype] [lanes] [steps] [random|hunter]
+tolerance), the full state at every chunk end.  python tools/soak.py [gametype] [lanes] [steps] [random|hunter|charger]
 `hunter`: an open-loop firing pattern per lane (a shot every 8 ticks = 272 ms > the 250 ms vulnerability window
 until the fortress is kill-ready, then a double shot), random phase per lane, 10 % of the actions random: thousands
 of fortress kills, resets and misses instead of the handful random play produces."""
@@ -27,6 +27,9 @@ t0 = time.time(); done_total = 0; kills = 0
 for c in range(0, T, K):
     k = min(K, T - c)
     acts = rng.integers(0, env.n_actions, (k, N)).astype(np.uint8)
+    if policy == "charger":  # THRUST (action 2 in both action sets) half of the time: in autoturn games the ship flies at
+        # the fortress along an exact-degree ray, the regime where ceil(bearing) follows atan2's last bit
+        acts = np.where(rng.random((k, N)) < 0.5, np.uint8(2), acts).astype(np.uint8)
     if policy == "hunter":  # FIRE is action 1 in both action sets (ENV:211-229)
         pat = np.array(([1] + [0] * 7) * 11 + [1, 0, 1, 0] + [0] * 4, np.uint8)
         tt = (np.arange(c, c + k)[:, None] + phase[None, :]) % len(pat)
