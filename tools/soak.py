@@ -1,6 +1,6 @@
 """Long lock-step parity run: N lanes x T steps (several episodes) on the GPU (chunks of fused rollouts and,
 alternately, single steps) against the CPU oracle; every reward / done / info, every observation (float32
-tolerance), the full state at every chunk end.  python tools/soak.py [gametype] [lanes] [steps] [random|hunter|charger]
+tolerance), the full state at every chunk end.  python tools/soak.py [gametype] [lanes] [steps] [random|hunter|charger] [obs_type] [f64]
 `hunter`: an open-loop firing pattern per lane (a shot every 8 ticks = 272 ms > the 250 ms vulnerability window
 until the fortress is kill-ready, then a double shot), random phase per lane, 10 % of the actions random: thousands
 of fortress kills, resets and misses instead of the handful random play produces."""
@@ -16,13 +16,17 @@ gametype = sys.argv[1] if len(sys.argv) > 1 else "youturn"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 16500
 policy = sys.argv[4] if len(sys.argv) > 4 else "random"
+obs_type = sys.argv[5] if len(sys.argv) > 5 else "features"  # features | normalized-features | monitors
+f64 = len(sys.argv) > 6 and sys.argv[6] == "f64"             # float64 observations, compared to 1e-9
 K = 250
-env = SFVecEnv(N, gametype=gametype, spawn_stride=3, spawn_skip=1)
-orc = O.OracleVecEnv(gametype, N, spawn_stride=3, spawn_skip=1)
+env = SFVecEnv(N, gametype=gametype, obs_type=obs_type, spawn_stride=3, spawn_skip=1,
+               obs_dtype=torch.float64 if f64 else torch.float32)
+orc = O.OracleVecEnv(gametype, N, obs_type=obs_type, spawn_stride=3, spawn_skip=1)
+RT, AT = (1e-9, 1e-9) if f64 else (1e-5, 4e-5)
 rng = np.random.default_rng(99)
 phase = rng.integers(0, 96, N)
 o0 = env.reset().cpu().numpy(); oo0 = orc.reset()
-assert np.allclose(o0, oo0, rtol=1e-5, atol=4e-5)
+assert np.allclose(o0, oo0, rtol=RT, atol=AT)
 t0 = time.time(); done_total = 0; kills = 0
 for c in range(0, T, K):
     k = min(K, T - c)
@@ -45,7 +49,7 @@ for c in range(0, T, K):
         oo, orw, od, oi = orc.step(acts[j].astype(np.int32))
         assert np.array_equal(rew[j], orw), (c + j, np.flatnonzero(rew[j] != orw)[:5])
         assert np.array_equal(done[j], od) and np.array_equal(info[j], oi), c + j
-        ok = np.isclose(obs[j], oo, rtol=1e-5, atol=4e-5)
+        ok = np.isclose(obs[j], oo, rtol=RT, atol=AT)
         if not ok.all():
             bad = np.argwhere(~ok)
             for lane, feat in bad[:8]:
