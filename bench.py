@@ -2,6 +2,9 @@
 """bench.py -- env-steps/s of the batched Space Fortress env.step() on MI355X.
 
     python bench.py --gpus 1 --steps 2000 --warmup 100
+    python bench.py --gpus N ...          N > 1 without WORLD_SIZE: bench.py starts the N ranks itself (fresh child
+                                          processes, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; rl/train.py:30-32 starts
+                                          its N workers from one command too)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one sf_step launch: one 34 ms game tick for every env of the batch, fused
@@ -70,25 +73,59 @@ def cpu_baseline(gametype, seconds, cores):
     return out
 
 
-def pmc_traffic(gametype, envs, obs_type):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic_latest.json,
-    written by tools/pmc_report.py): a profiler measurement of this same command, not something
-    bench.py can observe itself.  None when no profile matches the workload."""
+def committed_profile(gametype, envs, obs_type):
+    """What the committed rocprofv3 runs of this same command measured (profiles/step_kernel_latest.json,
+    written by tools/pmc_report.py + tools/trace_report.py): HBM bytes per launch from the two --pmc passes
+    and the kernel-trace mean duration.  bench.py cannot observe either itself: these two numbers are
+    REPLAYED from the profile of the named kernel version, and labelled so.  {} when no profile matches."""
     try:
-        rep = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+        rep = json.load(open(os.path.join(ROOT, "profiles", "step_kernel_latest.json")))
     except Exception:
-        return None
+        return {}
     w = rep.get("workload", {})
     if (w.get("gametype"), w.get("envs_per_gpu"), w.get("obs_type")) != (gametype, envs, obs_type):
-        return None
-    return rep["traffic_bytes_per_launch"]
+        return {}
+    return rep
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` on its own: start the N ranks as FRESH child processes (nothing here has touched
+    the GPU, and nothing is re-exec'ed), one per GPU, with the torch.distributed environment set; rank 0 prints the
+    JSON line.  The reference starts its N workers from one command as well (rl/train.py:30-32)."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:  # one rank failed: do not leave the others waiting in a collective
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12000, help="timed launches (default spans two episode rollovers: 5295 steps each)")
+    ap.add_argument("--steps", type=int, default=12000, help="timed launches per block (default spans two episode rollovers: 5295 steps each)")
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed blocks of --steps launches each, every one bracketed by barrier + synchronize; the line "
+                         "reports the MEDIAN block (0 = enough blocks for about 2000 launches in all, at most 101)")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--gametype", default="youturn")
     ap.add_argument("--obs-type", default="features")
@@ -107,12 +144,22 @@ def main():
                          "uint8 [N,1,84,84] per step); reported as image_obs, never as value; 0 = skip")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not os.environ.get("SF_BENCH_NO_SPAWN"):
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or drop WORLD_SIZE and let "
+                 "bench.py start the ranks)" % (args.gpus, world))
+    # SF_BENCH_FORCE_DIST=gloo: the multi-rank control flow on CPU tensors (no GPU: nothing is timed, the line
+    # carries "dry_run": true); =1 / nccl: the RCCL path, also for a single rank
+    force = os.environ.get("SF_BENCH_FORCE_DIST", "")
+    dry = force == "gloo"
 
     base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         # before anything initialises the GPU in this process (children are plain CPU processes)
         try:
             share = len(os.sched_getaffinity(0))
@@ -125,58 +172,104 @@ def main():
     import numpy as np
     import torch
 
-    from spacefortress_amd import SFVecEnv
-    from spacefortress_amd.stats import reduce_episode_stats, summarize
+    from spacefortress_amd.stats import reduce_episode_stats, shard_lanes, summarize
 
-    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("SF_BENCH_FORCE_DIST"):  # SF_BENCH_FORCE_DIST: rehearse the RCCL path on one rank
+    if world > 1 or force:
         import torch.distributed as dist
 
+    n = args.envs
+    # the job is ONE batch of world * n lanes cut into contiguous shards: rank r's lane i is lane r*n + i of the whole
+    # batch and takes that stretch of the spawn stream (spawn_stride 1), so N ranks equal one N*n-lane batch
+    lane0, lane1 = shard_lanes(n * world, world, rank)
+    repeats = args.repeats or max(1, min(101, -(-2000 // max(1, args.steps))))
+
+    if dry:
+        dist.init_process_group("gloo")
+        local = torch.tensor([rank + 1, 10 * (rank + 1), 100, rank, 2, 3, -5 - rank, 7 + rank], dtype=torch.int64)
+        stats = reduce_episode_stats(local)
+        tt = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "env-steps/sec (whole node), youturn random-action rollout @65536 envs/GPU",
+                              "dry_run": True, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "repeats": repeats, "lanes_rank0": [lane0, lane1], "max_over_ranks": float(tt.item()),
+                              "episode_stats": summarize(stats)}))
+        dist.destroy_process_group()
+        return
+
+    from spacefortress_amd import SFVecEnv
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
+    assert local_rank < torch.cuda.device_count(), "rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist is not None:
         dist.init_process_group("nccl", device_id=dev)
 
-    n = args.envs
-    # lanes of different ranks take different stretches of the spawn stream
     env = SFVecEnv(n, gametype=args.gametype, obs_type=args.obs_type, device=dev, spawn_stride=1,
-                   spawn_skip=rank * 7919, reuse_buffers=True)
+                   spawn_skip=lane0, reuse_buffers=True)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     ring = 64
     actions = torch.randint(0, env.n_actions, (ring, n), device=dev, dtype=torch.uint8, generator=g)
     env.reset()
 
-    def barrier():
+    def sync():
         torch.cuda.synchronize()
+
+    def barrier():
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     act_rows = [actions[k] for k in range(ring)]  # the views made once: the launch loop must not be what is measured
+    step = env.step_tensors
     for t in range(args.warmup):
-        env.step_tensors(act_rows[t % ring])
-    barrier()
+        step(act_rows[t % ring])
+    K = args.steps
+    blocks, periods = [], []
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()  # HIP events on the launch stream, bracketing exactly the K launches
-    for t in range(args.steps):
-        env.step_tensors(act_rows[t % ring])
-    ev1.record()
-    stats = torch.from_numpy(env.episode_stats()).to(dev)  # syncs this rank's stream
-    stats = reduce_episode_stats(stats)  # RCCL over xGMI: the only collective of the path (64 bytes)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    tpos = args.warmup
+    for rep in range(repeats):
+        # ---- one timed block: EXACTLY K launches, barrier + synchronize on both sides, nothing else inside
+        barrier()
+        ev0.record()  # HIP events on the launch stream, bracketing exactly the K launches
+        t0 = time.perf_counter()
+        for t in range(tpos, tpos + K):
+            step(act_rows[t % ring])
+        ev1.record()
+        while not ev1.query():  # busy-wait for the last launch (a sleeping wait adds its wake-up time to a 160 us block) ...
+            pass
+        if dist is not None:    # ... then the contract's synchronize (+ barrier + synchronize when there are other ranks)
+            barrier()
+        else:
+            sync()
+        elapsed = time.perf_counter() - t0
+        tpos += K
+        if dist is not None:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        blocks.append(elapsed)
+        periods.append(ev0.elapsed_time(ev1) / K)
+    order = sorted(range(repeats), key=lambda r: blocks[r])
+    med = order[repeats // 2]
+    elapsed = blocks[med]
+    # mean launch-to-launch time of sf_step_kernel over the median block (HIP events): the launches are back to
+    # back on one stream, so this is the kernel duration plus the dependent-launch gap -- a launch PERIOD
+    region_ms = periods[med]
 
-    # mean launch-to-launch time of sf_step_kernel over the timed region (HIP events): the launches
-    # are back to back on one stream, so this is the kernel duration plus the dependent-launch gap
-    region_ms = ev0.elapsed_time(ev1) / args.steps
-    # ---- and each launch bracketed by its own event pair (outside the timed region; the events
-    #      themselves add about 2 us, so this reads high)
+    # ---- the only collective of the path, outside the timed blocks and timed on its own: 64 bytes over RCCL
+    sync()
+    ts = time.perf_counter()
+    stats = torch.from_numpy(env.episode_stats()).to(dev)  # D2H of 8 numbers: syncs this rank's stream
+    stats = reduce_episode_stats(stats, force=bool(force))
+    sync()
+    stats_reduce_us = (time.perf_counter() - ts) * 1e6
+
+    # ---- each launch bracketed by its own event pair (the events themselves add about 2 us, so this reads high)
     k = min(args.kernel_timing_launches, max(1, args.steps))
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(k)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(k)]
@@ -191,12 +284,12 @@ def main():
     env.check_actions()
     fused = None
     if args.rollout_k > 0:
-        K = min(args.rollout_k, ring)
-        ro_acts = actions[:K].contiguous()
-        ro_out = (torch.empty((K, n, env.obs_dim), dtype=env.obs_dtype, device=dev),
-                  torch.empty((K, n), dtype=torch.int32, device=dev),
-                  torch.empty((K, n), dtype=torch.uint8, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev))
-        launches = max(2, args.steps // K)
+        KF = min(args.rollout_k, ring)
+        ro_acts = actions[:KF].contiguous()
+        ro_out = (torch.empty((KF, n, env.obs_dim), dtype=env.obs_dtype, device=dev),
+                  torch.empty((KF, n), dtype=torch.int32, device=dev),
+                  torch.empty((KF, n), dtype=torch.uint8, device=dev), torch.empty((KF, n), dtype=torch.uint8, device=dev))
+        launches = max(8, args.steps // KF)
         for _ in range(2):
             env.rollout(ro_acts, out=ro_out)
         barrier()
@@ -209,8 +302,8 @@ def main():
             tt = torch.tensor([dtf], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dtf = float(tt.item())
-        fused = {"value": float(n) * K * launches * world / dtf, "unit": "env-steps/s", "ticks_per_launch": K,
-                 "launches": launches, "us_per_tick": dtf / (K * launches) * 1e6,
+        fused = {"value": float(n) * KF * launches * world / dtf, "unit": "env-steps/s", "ticks_per_launch": KF,
+                 "launches": launches, "us_per_tick": dtf / (KF * launches) * 1e6,
                  "note": "sf_rollout: K ticks fused into one launch (state stays in registers), actions of all K "
                          "ticks resident up front, obs/reward/done/info written for every tick; bit-identical to K "
                          "sf_step launches (tests/test_gpu_parity.py::test_fused_rollout_equals_single_steps)"}
@@ -249,7 +342,7 @@ def main():
         stack.reset()
         iacts = actions[:, :ni].contiguous() if ni <= n else torch.randint(0, ienv.n_actions, (ring, ni), device=dev,
                                                                            dtype=torch.uint8, generator=g)
-        isteps = max(50, min(1000, args.steps // 4))
+        isteps = max(200, min(1000, args.steps // 4))
         for t in range(400):  # into mid-episode states: missiles, shells, explosions on screen
             stack.step(iacts[t % ring])
         torch.cuda.synchronize()
@@ -260,8 +353,10 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ims = e0.elapsed_time(e1) / isteps
+        floor_us = (ni * (84 * 84 + 1200)) / 6.3e12 * 1e6  # 7 056 B written + about 1.2 KB of state read per env at 6.3 TB/s
         image_obs = {"value": ni / ims * 1e3, "unit": "env-steps/s", "envs": ni, "steps": isteps, "us_per_step": ims * 1e3,
                      "frame_bytes_per_step": ni * 84 * 84, "frames_GBps": ni * 84 * 84 / ims / 1e6,
+                     "output_floor_us": floor_us, "frac_of_output_floor": floor_us / (ims * 1e3),
                      "note": "BASELINE configs[4]: youturn image obs, 84x84 grey raster + 4-frame stack (device ring "
                              "[N,4,84,84], one new frame per env and step), sf_step + sf_frame_stack_clear + sf_render "
                              "per step; one wave per env rasterises the 90x92 frame in LDS (INTER_AREA to 84x84); HIP "
@@ -278,35 +373,51 @@ def main():
             _lib.check(_lib.lib().sf_calibration_copy(env._h, which, ctypes.byref(nb)))
 
     if rank == 0:
-        total_steps = float(n) * args.steps * world
+        total_steps = float(n) * K * world
         value = total_steps / elapsed
         algo = ALGO_BYTES[args.gametype] * n
         achieved = algo / (region_ms * 1e-3) / 1e9
+        prof = committed_profile(args.gametype, n, args.obs_type)
         out = {
             "metric": "env-steps/sec (whole node), youturn random-action rollout @65536 envs/GPU",
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": K,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "repeats": repeats,
+            "block_ms": {"median": elapsed * 1e3, "min": blocks[order[0]] * 1e3, "max": blocks[order[-1]] * 1e3,
+                         "first": blocks[0] * 1e3,
+                         "note": "each block = exactly `steps` launches between barrier + synchronize brackets (max over "
+                                 "ranks); value and ms_per_step come from the median block"},
+            "stats_reduce_us": stats_reduce_us,
             "config": {"workload": "%s, %d envs/GPU, %s obs (f32), uniform random discrete actions resident in HBM, "
                                    "per-lane auto-reset" % (args.gametype, n, args.obs_type),
                        "envs_per_gpu": n, "gametype": args.gametype, "obs_type": args.obs_type,
-                       "parallelism": "%d independent shard(s), one process per GPU" % world},
+                       "parallelism": "%d contiguous lane shard(s) of one %d-lane batch, one process per GPU, no data-path "
+                                      "collective" % (world, n * world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "frac_note": "of the 8 TB/s HBM spec peak; the 77 MB state of this workload is Infinity-Cache "
+                                      "resident (256 MB), so the bytes mostly move between L2 and the Infinity Cache",
                          "measured_copy_ceiling_GBps": copy_gbs,
                          "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
-                         "traffic": pmc_traffic(args.gametype, n, args.obs_type),
-                         "kernel": "sf_step_kernel", "kernel_ms_mean": region_ms,
+                         "traffic": prof.get("traffic_bytes_per_launch"),
+                         "traffic_source": ("replayed from the committed rocprofv3 --pmc passes of kernel version %s "
+                                            "(profiles/%s), not measured by this run" % (prof.get("version"), prof.get("pmc_file")))
+                                           if prof else None,
+                         "kernel": "sf_step_kernel", "launch_period_ms": region_ms,
+                         "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
+                         "kernel_ms_rocprof_source": ("rocprofv3 --kernel-trace mean of kernel version %s (profiles/%s)"
+                                                      % (prof.get("version"), prof.get("trace_file"))) if prof else None,
                          "kernel_ms_event_pair_mean": kern_ms, "kernel_ms_event_pair_median": kern_ms_med,
-                         "algorithmic_bytes_per_launch": algo, "launches_timed": k},
+                         "algorithmic_bytes_per_launch": algo, "launches_timed": K},
             "cpu_baseline": base,
             "rollout_fused": fused,
             "host_api": host_api,

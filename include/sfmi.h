@@ -91,8 +91,12 @@ typedef struct {
   int32_t spawn_skip;      /* spawns already drawn from the stream before lane 0's first Game
                               (rl/train.py:17 draws one in the parent before forking) */
   int32_t spawn_stride;    /* extra skip per lane; 0 = every lane sees the same stream, as in the reference */
-  int32_t spawn_table_len; /* entries of the precomputed spawn sequence (power of two; 0 = 65536);
-                              a lane wraps around after this many respawns */
+  int32_t spawn_table_len; /* entries of the precomputed spawn sequence (power of two <= 2^24).  0 = the smallest power
+                              of two >= 65536 that reaches SF_SPAWN_MARGIN entries past the LAST lane's start
+                              (spawn_skip + spawn_stride * (n_envs - 1)), so that every lane continues the libc stream
+                              from its own offset for at least that many respawns (about 370 episodes); a lane whose
+                              cursor passes the end wraps to entry 0.  A table that ends before the last lane's start
+                              is SF_ERR_ARG. */
 } sf_create_params;
 
 typedef struct sf_batch sf_batch; /* opaque: device state + constant tables */
@@ -215,6 +219,7 @@ int sf_set_field(sf_batch* b, int field_id, const void* host, size_t bytes);
  *      the wrapper (sum of info), [4]=ship deaths, [5]=shots, [6]=min return, [7]=max return
  *      ([6],[7] are INT64_MAX / INT64_MIN while no episode has ended). ---- */
 #define SF_EPISODE_STATS_LEN 8
+#define SF_SPAWN_MARGIN 65536 /* default spawn table: entries past the last lane's start (sf_create_params.spawn_table_len) */
 int sf_episode_stats(sf_batch* b, int64_t* out, int clear, void* stream);
 
 /* ---- diagnostics: reads (and writes linearly) *bytes_moved bytes of state with the step kernel's
@@ -330,6 +335,8 @@ int sf_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, 
 
 const char* sf_last_error(void);
 int sf_version(void);
+/* hash of the sources and compiler flags this binary was built from (spacefortress_amd/build.py: source_hash) */
+const char* sf_build_id(void);
 
 #ifdef __cplusplus
 }

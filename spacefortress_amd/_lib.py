@@ -105,6 +105,7 @@ SYMBOLS = {
     "sf_resize_area_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "sf_last_error": (C.c_char_p, []),
     "sf_version": (C.c_int, []),
+    "sf_build_id": (C.c_char_p, []),
 }
 
 _lib = None

@@ -28,23 +28,53 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+def source_hash(extra_flags=()):
+    """sha256 (16 hex digits) over every source, header and compiler flag that goes into libsfmi.so.  It is compiled
+    into the library (-DSFMI_BUILD_ID, returned by sf_build_id()), so a test on the GPU box can assert that the binary
+    which travelled there was built from the sources which travelled with it."""
+    import hashlib
+
+    h = hashlib.sha256()
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [x if os.path.isabs(x) else os.path.join(CSRC, x) for x in HEADERS]
+    for d in deps:
+        h.update(os.path.basename(d).encode() + b"\0")
+        h.update(open(d, "rb").read())
+    h.update(" ".join(f for f in FLAGS + list(extra_flags) if not f.startswith("-I")).encode())
+    return h.hexdigest()[:16]
+
+
+def built_id(path=None):
+    """The build id compiled into an existing libsfmi.so (None if it has none / does not load)."""
+    import ctypes
+
+    path = path or LIB
+    try:
+        L = ctypes.CDLL(path)
+        L.sf_build_id.restype = ctypes.c_char_p
+        return L.sf_build_id().decode()
+    except Exception:
+        return None
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    deps.append(os.path.abspath(__file__))
-    return any(os.path.getmtime(d) > t for d in deps)
+    idf = LIB + ".id"  # sidecar written by build(): spares loading the library just to ask
+    have = open(idf).read().strip() if os.path.exists(idf) and os.path.getmtime(idf) >= os.path.getmtime(LIB) else built_id()
+    return have != source_hash()
 
 
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    bid = source_hash(extra_flags)
+    cmd = [hipcc] + FLAGS + list(extra_flags) + ['-DSFMI_BUILD_ID="%s"' % bid] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(LIB + ".id", "w") as f:
+        f.write(bid + "\n")
     return LIB
 
 

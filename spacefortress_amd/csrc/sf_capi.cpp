@@ -84,13 +84,27 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   uint8_t keys[16];
   int n_actions = sf_action_table(p->gametype, p->action_set, keys);
   if (n_actions < 0) return n_actions;
-  long spawn_len = p->spawn_table_len ? p->spawn_table_len : 65536;
+  if (p->spawn_skip < 0 || p->spawn_stride < 0) {
+    sf_set_error("sf_create: spawn_skip / spawn_stride must be >= 0");
+    return SF_ERR_ARG;
+  }
+  // Lane i starts at entry spawn_skip + spawn_stride * i of the accepted-spawn sequence and must be able to walk on
+  // from there as the libc stream does (SRC/game.cpp:133-149), not wrap into somebody else's stretch: the default
+  // table reaches SF_SPAWN_MARGIN entries (about 370 episodes of respawns) past the LAST lane's start.
+  const long last_start = (long)p->spawn_skip + (long)p->spawn_stride * ((long)p->n_envs - 1);
+  long spawn_len = p->spawn_table_len;
+  if (spawn_len == 0) {
+    spawn_len = 65536;
+    while (spawn_len < last_start + SF_SPAWN_MARGIN && spawn_len < (1l << 24)) spawn_len <<= 1;
+  }
   if (!is_pow2(spawn_len) || spawn_len > (1l << 24)) {
     sf_set_error("sf_create: spawn_table_len must be a power of two <= 2^24 (got %ld)", spawn_len);
     return SF_ERR_ARG;
   }
-  if (p->spawn_skip < 0 || p->spawn_stride < 0) {
-    sf_set_error("sf_create: spawn_skip / spawn_stride must be >= 0");
+  if (last_start >= spawn_len) {
+    sf_set_error("sf_create: lane %d would start at entry %ld of a %ld-entry spawn table (spawn_skip %d, spawn_stride %d): "
+                 "pass a larger spawn_table_len (<= 2^24) or smaller offsets", p->n_envs - 1, last_start, spawn_len,
+                 p->spawn_skip, p->spawn_stride);
     return SF_ERR_ARG;
   }
 

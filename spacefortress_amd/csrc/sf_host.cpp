@@ -96,6 +96,10 @@ void sf_set_error(const char* fmt, ...) {
 
 extern "C" const char* sf_last_error(void) { return g_err; }
 extern "C" int sf_version(void) { return SFMI_VERSION; }
+#ifndef SFMI_BUILD_ID
+#define SFMI_BUILD_ID "unstamped"
+#endif
+extern "C" const char* sf_build_id(void) { return SFMI_BUILD_ID; }
 
 extern "C" int sf_preset_get(const char* gametype, sf_preset* c) {
   if (!gametype || !c) {

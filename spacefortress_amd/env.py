@@ -21,9 +21,12 @@ class SSF_Env(_Base):
     def __init__(self, gametype="youturn", scale=.2, viewport=(130, 80, 450, 460), ls=3, action_set=1,
                  obs_type="image", device=None, seed=1):
         assert obs_type in ("image", "features", "normalized-features", "monitors")  # ENV:51
-        if (scale, tuple(viewport), ls) != (.2, (130, 80, 450, 460), 3):
-            # the renderer's geometry (90x92 surface, 0.6-pixel strokes) is compiled into the kernel
-            raise ValueError("only the default scale=.2, viewport=(130,80,450,460), ls=3 are built")
+        # scale / viewport / ls only shape the picture (ENV:56-60 -> sf.Game(width, height, viewport, lw)); the
+        # renderer's geometry (90x92 surface, 0.6-pixel strokes) is compiled into the kernel, so any other geometry is
+        # accepted for the symbolic observations and refused where a frame would have to be drawn with it
+        self._default_geometry = (float(scale), tuple(viewport), float(ls)) == (.2, (130, 80, 450, 460), 3.0)
+        if obs_type == "image" and not self._default_geometry:
+            raise ValueError("image observations are built for the default scale=.2, viewport=(130,80,450,460), ls=3 only")
         self.obs_type = obs_type
         self.gametype = gametype
         self.viewport = viewport
@@ -63,6 +66,8 @@ class SSF_Env(_Base):
         the pyglet window of mode 'human' is not part of this library."""
         if close:
             return None
+        if not self._default_geometry:
+            raise ValueError("render() draws the default scale=.2, viewport=(130,80,450,460), ls=3 only")
         if mode != "rgb_array":
             raise NotImplementedError("render(mode='human') opens a pyglet window in the reference; "
                                       "use mode='rgb_array'")

@@ -3,7 +3,7 @@
 The batch shards over GPUs as independent lane ranges (no state is shared between envs), so the
 only cross-rank traffic of the whole path is this: the 8-element episode-statistics vector each
 batch accumulates on its device (sfmi.h: sf_episode_stats), reduced with RCCL over xGMI
-(`torch.distributed` backend "nccl") -- or gloo on CPU tensors in the tests.  It stands in for the
+(`torch.distributed` backend "nccl", one all-gather) -- or gloo on CPU tensors in the tests.  It stands in for the
 trainer's host-side `final_rewards.mean()/median()/min()/max()` and `num_destruction += sum(info)`
 (rl/train.py:81,161-164).  One call per log interval; the message is 64 bytes, latency-bound.
 """
@@ -26,20 +26,19 @@ def shard_lanes(total_envs, world_size, rank):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def reduce_episode_stats(local, group=None):
-    """All-reduce one rank's statistics vector (int64[8], any device).  Sums for the counters,
-    min / max for the two extremes.  Returns the reduced tensor on the same device."""
+def reduce_episode_stats(local, group=None, force=False):
+    """Reduce one rank's statistics vector (int64[8], any device) over all ranks: sums for the six counters,
+    min / max for the two extremes.  ONE collective -- an all-gather of the 64-byte vectors -- and the fold is
+    done locally in rank order (deterministic).  Returns the reduced tensor on the same device."""
     import torch.distributed as dist
 
     v = torch.as_tensor(local, dtype=torch.int64).clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        sums = v[:6].contiguous()
-        lo = v[6:7].contiguous()
-        hi = v[7:8].contiguous()
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-        v = torch.cat([sums, lo, hi])
+    # force: run the collective for a single rank too (rehearsing the RCCL path on a one-GPU box)
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
+        rows = [torch.empty_like(v) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(rows, v.contiguous(), group=group)
+        m = torch.stack(rows)
+        v = torch.cat([m[:, :6].sum(0), m[:, 6:7].min(0).values, m[:, 7:8].max(0).values])
     return v
 
 

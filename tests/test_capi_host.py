@@ -5,6 +5,7 @@ instead of falling back to anything."""
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -32,6 +33,16 @@ def test_exports_every_declared_symbol(L):
     for name in declared:
         assert hasattr(L, name), name
     assert L.sf_version() == 1
+
+
+def test_binary_is_stamped_with_the_hash_of_its_sources(L):
+    """sf_build_id() = sha256 over csrc/*, include/sfmi.h and the compiler flags (build.py: source_hash): the library
+    that is loaded was built from the sources that lie next to it (tests/test_gpu_capi_native.py asserts the same on
+    the GPU box, where the binary arrives prebuilt)."""
+    from spacefortress_amd import build as sfbuild
+
+    assert L.sf_build_id().decode() == sfbuild.source_hash() and len(sfbuild.source_hash()) == 16
+    assert not sfbuild.needs_build()
 
 
 def test_no_cpu_fallback_symbols(L):
@@ -149,3 +160,63 @@ def test_namespace_shim():
     assert callable(g.make_env("SpaceFortress-youturn-image-v0", 0, 0))
     with pytest.raises(KeyError):
         g.make_env("Pong-v0", 0, 0)()
+
+
+def test_gym_registration_is_the_references(monkeypatch):
+    """With gym importable, `import spacefortress.gym` makes the reference's four register() calls with the reference's
+    kwargs -- obs_type 'image' on every id (python/spacefortress.gym/spacefortress/gym/__init__.py:3-29) -- so that
+    rl/envs.py:10-16 (gym.make -> WrapPyTorch -> cv2.resize) receives a frame.  gym is not in this image: a stand-in
+    `gym.envs.registration` records the calls."""
+    import importlib
+    import sys
+    import types
+
+    calls = []
+    gym = types.ModuleType("gym")
+    envs = types.ModuleType("gym.envs")
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda **kw: calls.append(kw)
+    gym.envs, envs.registration = envs, reg
+    for name, mod in (("gym", gym), ("gym.envs", envs), ("gym.envs.registration", reg)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    import spacefortress.gym as g
+
+    importlib.reload(g)
+    want = {"SpaceFortress-youturn-image-v0": "youturn", "SpaceFortress-autoturn-image-v0": "autoturn",
+            "SpaceFortress-testyouturn-image-v0": "test-youturn", "SpaceFortress-testautoturn-image-v0": "test-autoturn"}
+    assert len(calls) == 4 and {c["id"] for c in calls} == set(want)
+    for c in calls:
+        assert c["entry_point"] == "spacefortress.gym.envs:SSF_Env" and c["nondeterministic"] is False
+        assert c["kwargs"] == {"gametype": want[c["id"]], "obs_type": "image"}
+    # the entry point resolves to the class the thunk builds
+    mod, cls = calls[0]["entry_point"].split(":")
+    assert getattr(importlib.import_module(mod), cls) is g.SSF_Env
+    monkeypatch.undo()
+    importlib.reload(g)
+
+
+def test_wrap_pytorch_is_inter_area_to_1x84x84():
+    """rl/envs.py:19-30 on the host: [92, 90] grey frame -> [1, 84, 84] uint8, the library's INTER_AREA."""
+    import spacefortress.gym as g
+    sys.path.insert(0, ROOT)
+    from oracle import render_np
+
+    class Fake:
+        action_space = "A"
+        metadata = {"k": 1}
+
+        def reset(self):
+            return np.arange(92 * 90, dtype=np.uint32).reshape(92, 90).astype(np.uint8)
+
+        def step(self, a):
+            return self.reset()[::-1].copy(), 1, False, True
+
+    w = g.WrapPyTorch(Fake())
+    assert tuple(w.observation_space.shape) == (1, 84, 84) and w.observation_space.dtype == np.uint8
+    o = w.reset()
+    assert o.shape == (1, 84, 84) and o.dtype == np.uint8
+    assert np.array_equal(o[0], render_np.resize_area(Fake().reset()))
+    o2, r, d, i = w.step(0)
+    assert o2.shape == (1, 84, 84) and (r, d, i) == (1, False, True) and w.action_space == "A"
+    with pytest.raises(ValueError):
+        w.observation(np.zeros(19))

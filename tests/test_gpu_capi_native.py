@@ -110,21 +110,55 @@ def test_new_entry_points_reject_bad_arguments():
     img.close()
 
 
+def test_the_shipped_binary_was_built_from_the_shipped_sources():
+    """The GPU box runs a prebuilt libsfmi.so (git-ignored, it travels with the snapshot): its compiled-in build id must
+    be the hash of the sources and flags that travelled with it."""
+    from spacefortress_amd import _lib
+    from spacefortress_amd import build as sfbuild
+
+    assert _lib.lib().sf_build_id().decode() == sfbuild.source_hash()
+
+
 def test_gym_namespace_builds_the_registered_ids():
-    """`import spacefortress.gym`: the four ids the reference registers, as device batches and single envs."""
+    """`import spacefortress.gym`: the four ids the reference registers (obs_type 'image'), as device batches and as
+    rl/envs.py:10-16's thunks; the symbolic observations as the explicit kwarg they are in the reference."""
     import spacefortress.gym as sfg
     for env_id, (n_act, dim) in {"SpaceFortress-youturn-image-v0": (5, 19), "SpaceFortress-autoturn-image-v0": (3, 17),
                                  "SpaceFortress-testyouturn-image-v0": (5, 19), "SpaceFortress-testautoturn-image-v0": (3, 17)}.items():
-        v = sfg.make_vec_env(env_id, 6)
+        v = sfg.make_vec_env(env_id, 6, obs_type="features")
         assert v.action_space.n == n_act and v.observation_space.shape == (dim,)
         o, r, d, i = v.step(np.zeros(6, np.int64))
         assert o.shape == (6, dim) and r.dtype == np.int64 and d.dtype == bool
         v.close()
-    img = sfg.make_vec_env("SpaceFortress-youturn-image-v0", 4, obs_type="image")  # what rl/envs.py wraps workers into
-    assert img.observation_space.shape == (1, 84, 84) and img.reset().shape == (4, 1, 84, 84)
+        # the thunk of rl/envs.py:10-16: gym.make(id) -> seed -> WrapPyTorch: [1, 84, 84] uint8 frames
+        e = sfg.make_env(env_id, 0, 0)()
+        assert tuple(e.observation_space.shape) == (1, 84, 84) and e.action_space.n == n_act
+        o = e.reset()
+        assert o.shape == (1, 84, 84) and o.dtype == np.uint8 and o.max() > 100
+        o, r, d, i = e.step(1)
+        assert o.shape == (1, 84, 84) and isinstance(r, int) and d is False and i is False
+        e.close()
+    img = sfg.make_vec_env("SpaceFortress-youturn-image-v0", 4)  # default = the registered obs_type: what rl/envs.py wraps workers into
+    assert img.observation_space.shape == (1, 84, 84)
+    frames = img.reset()
+    assert frames.shape == (4, 1, 84, 84)
+    # the single-env thunk's frame is the batch's: same game, same INTER_AREA (host arithmetic == device arithmetic)
+    e = sfg.make_env("SpaceFortress-youturn-image-v0", 0, 0)()
+    one = sfg.make_vec_env("SpaceFortress-youturn-image-v0", 1, spawn_skip=0)
+    assert np.array_equal(e.reset(), one.reset()[0].cpu().numpy())
+    one.close()
     img.close()
-    e = sfg.make_env("SpaceFortress-autoturn-image-v0", 0, 0)()
+    e.close()
+    e = sfg.make_env("SpaceFortress-autoturn-image-v0", 0, 0, obs_type="features")()
     assert e.reset().shape == (17,) and e.action_space.n == 3
     e.close()
+    # ENV:50-60: scale / viewport / ls are accepted (they only shape the picture); a picture in another geometry is not built
+    e = sfg.SSF_Env(gametype="youturn", scale=1.0, viewport=(0, 0, 710, 626), ls=2, obs_type="features")
+    assert (e.w, e.h) == (710, 626) and e.reset().shape == (19,)
+    with pytest.raises(ValueError):
+        e.render("rgb_array")
+    e.close()
+    with pytest.raises(ValueError):
+        sfg.SSF_Env(gametype="youturn", scale=1.0, obs_type="image")
     with pytest.raises(KeyError):
         sfg.make_vec_env("SpaceFortress-nope-v0", 2)

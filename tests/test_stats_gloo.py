@@ -101,3 +101,31 @@ def test_single_process_reduce_is_identity():
     s = summarize(v)
     assert s["mean_return"] == -10 and abs(s["std_return"] ** 2 - (400 / 3 - 100)) < 1e-9
     assert summarize(torch.tensor([0, 0, 0, 0, 0, 0, (1 << 63) - 1, -(1 << 63)]))["episodes"] == 0
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start two ranks on its own (rl/train.py:30-32: N workers from
+    one command).  SF_BENCH_FORCE_DIST=gloo runs the multi-rank control flow on CPU tensors: nothing is timed, the
+    line says "dry_run", but n_gpus, the shard cut and the one-collective reduction are the real code."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, SF_BENCH_FORCE_DIST="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j["dry_run"] is True and j["n_gpus"] == 2 and j["steps"] == 20 and j["repeats"] == 100
+    assert j["lanes_rank0"] == [0, 65536]
+    assert j["max_over_ranks"] == 2.0  # MAX over ranks of (1 + rank)
+    es = j["episode_stats"]  # sums of (rank + 1, 10 (rank + 1), ...), min of -5 - rank, max of 7 + rank
+    assert es["episodes"] == 3 and es["fortress_kills"] == 1 and es["min_return"] == -6 and es["max_return"] == 8
+    # a WORLD_SIZE that disagrees with --gpus is an error, not a silent single shard
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r2.returncode != 0 and "WORLD_SIZE" in r2.stderr
