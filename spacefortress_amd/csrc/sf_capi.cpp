@@ -31,6 +31,13 @@ struct sf_batch {
   uint32_t* d_bg84;          // ... resampled to 84x84
   uint32_t* d_tabs;          // INTER_AREA taps (sf_raster.h)
   unsigned char* d_xcache;   // explosion cache, SF_XC_BYTES per env; allocated by the first render
+  // The missile fields as the reference has them (per env and slot), kept only while a caller looks at or edits them
+  // through sf_get_field / sf_set_field: [SF_NSLOT][n_envs] (x, y) pairs and int32 headings.  The kernels keep a tile's
+  // live missiles as one dense pool (sf_layout.h); `mslots_dirty` = the view was edited and the pools are rebuilt from it
+  // (and from the alive masks) before the next launch that reads the state.
+  unsigned char* d_ms_pos;
+  int32_t* d_ms_ang;
+  bool mslots_dirty;
 };
 
 namespace {
@@ -55,6 +62,19 @@ struct DeviceGuard {
     if (changed) (void)hipSetDevice(prev);
   }
 };
+
+// rebuild the tiles' missile pools from the edited slot view, in stream order ahead of whatever reads the state next
+int flush_missile_view(sf_batch* b, hipStream_t stream) {
+  if (!b->mslots_dirty) return SF_OK;
+  HIP_TRY(sf_launch_slots_to_mpool(b->d_state, b->args.lanes, b->n_envs, b->d_ms_pos, b->d_ms_ang, stream));
+  b->mslots_dirty = false;
+  return SF_OK;
+}
+#define SF_FLUSH_VIEW(b, stream)                                   \
+  do {                                                             \
+    int rc_ = flush_missile_view((b), (hipStream_t)(stream));      \
+    if (rc_ != SF_OK) return rc_;                                  \
+  } while (0)
 
 const unsigned long long kAccInit[SF_EPISODE_STATS_LEN + 1] = {
     0, 0, 0, 0, 0, 0, (unsigned long long)LLONG_MAX, (unsigned long long)LLONG_MIN, 0};
@@ -280,6 +300,8 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_spawn) (void)hipFree(b->d_spawn);
   if (b->d_acc) (void)hipFree(b->d_acc);
   if (b->d_scratch) (void)hipFree(b->d_scratch);
+  if (b->d_ms_pos) (void)hipFree(b->d_ms_pos);
+  if (b->d_ms_ang) (void)hipFree(b->d_ms_ang);
   if (b->d_bg) (void)hipFree(b->d_bg);
   if (b->d_tabs) (void)hipFree(b->d_tabs);
   if (b->d_xcache) (void)hipFree(b->d_xcache);
@@ -322,6 +344,7 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
                  mode == SF_OBS_IMAGE ? 16 : 8);
     return SF_ERR_ARG;
   }
+  SF_FLUSH_VIEW(b, stream);
   if (!b->d_xcache && !getenv("SFMI_NO_EXPLOSION_CACHE")) {
     // first frame of this batch: the per-env explosion cache (feature-only batches never pay for it)
     // ... followed by the 36 fortress pictures, drawn here once
@@ -389,6 +412,7 @@ extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
   }
   DeviceGuard guard(b->device);
   const bool image = is_image(b);
+  b->mslots_dirty = false;  // new games everywhere: no missiles, whatever a caller wrote into the slot view
   HIP_TRY(sf_launch_reset(b->args, 0, 0, 0, image ? nullptr : obs_dev, (hipStream_t)stream));
   if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
   return SF_OK;
@@ -406,6 +430,7 @@ extern "C" int sf_step(sf_batch* b, const void* actions_dev, int act_type, void*
   }
   DeviceGuard guard(b->device);
   const bool image = is_image(b);
+  SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, image ? nullptr : obs_dev,
                          reward_dev, done_dev, info_dev, 1, false, (hipStream_t)stream));
   if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
@@ -432,6 +457,7 @@ int sf_step_with_norm_partials(sf_batch* b, const void* actions_dev, int act_typ
   args.n_partials = partials;
   args.n_ret = ret;
   args.n_gamma = gamma;
+  SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev,
                          info_dev, 1, false, (hipStream_t)stream));
   *rows_out = (int)(b->args.lanes / 64);
@@ -462,6 +488,7 @@ extern "C" int sf_step_record(sf_batch* b, const void* actions_dev, int act_type
   args.t_final = final_rewards;
   args.t_actions = (long long*)actions_out;
   const bool image = is_image(b);
+  SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, image ? nullptr : obs_dev,
                          reward_dev, done_dev, info_dev, 1, false, (hipStream_t)stream));
   if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
@@ -488,6 +515,7 @@ extern "C" int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, in
     return SF_ERR_ARG;
   }
   DeviceGuard guard(b->device);
+  SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev,
                          n_steps, true, (hipStream_t)stream));
   return SF_OK;
@@ -570,8 +598,27 @@ static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host
   }
   DeviceGuard guard(b->device);
   HIP_TRY(hipDeviceSynchronize());
+  const bool mview = m.kind == SF_FK_MPOOL;                      // missile_x / missile_y / missile_angle
+  const bool mmask_write = f == SF_F_missile_mask && !to_host;   // which slots hold a missile
+  if (mview || mmask_write) {
+    // the per-slot view of the missiles: made on first use, refreshed from the pools unless it already holds edits
+    const size_t cells = (size_t)b->n_envs * SF_NSLOT;
+    if (!b->d_ms_pos) {
+      HIP_TRY(hipMalloc((void**)&b->d_ms_pos, cells * 16));
+      HIP_TRY(hipMalloc((void**)&b->d_ms_ang, cells * sizeof(int32_t)));
+    }
+    if (!b->mslots_dirty) HIP_TRY(sf_launch_mpool_to_slots(b->d_state, b->n_envs, b->d_ms_pos, b->d_ms_ang, nullptr));
+  }
   if (!to_host) HIP_TRY(hipMemcpy(b->d_scratch, host, total, hipMemcpyHostToDevice));
-  HIP_TRY(sf_launch_field_copy(b->d_state, b->n_envs, f, b->d_scratch, to_host ? 1 : 0, nullptr));
+  if (mview) {
+    const int which = f == SF_F_missile_x ? 0 : (f == SF_F_missile_y ? 1 : 2);
+    HIP_TRY(sf_launch_mslot_component(b->d_ms_pos, b->d_ms_ang, (long)b->n_envs * SF_NSLOT, which, b->d_scratch,
+                                      to_host ? 1 : 0, nullptr));
+    if (!to_host) b->mslots_dirty = true;
+  } else {
+    HIP_TRY(sf_launch_field_copy(b->d_state, b->n_envs, f, b->d_scratch, to_host ? 1 : 0, nullptr));
+    if (mmask_write) b->mslots_dirty = true;  // the pools follow the masks
+  }
   HIP_TRY(hipDeviceSynchronize());
   if (to_host) HIP_TRY(hipMemcpy(host, b->d_scratch, total, hipMemcpyDeviceToHost));
   return SF_OK;

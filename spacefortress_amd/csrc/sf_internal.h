@@ -16,6 +16,14 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
 hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, unsigned char* linear, int to_linear,
                                 hipStream_t stream);
 
+// the missile fields as the reference has them, [SF_NSLOT][n_envs] slot-major ((x, y) pairs and int32 headings), from /
+// to the tiles' pools; and one component of that view from / to a linear buffer (which: 0 x, 1 y, 2 heading as int16)
+hipError_t sf_launch_mpool_to_slots(const unsigned char* state, int n_envs, void* sl_pos, int32_t* sl_ang, hipStream_t stream);
+hipError_t sf_launch_slots_to_mpool(unsigned char* state, long lanes, int n_envs, const void* sl_pos, const int32_t* sl_ang,
+                                    hipStream_t stream);
+hipError_t sf_launch_mslot_component(void* sl_pos, int32_t* sl_ang, long total, int which, void* linear, int to_linear,
+                                     hipStream_t stream);
+
 hipError_t sf_launch_group_copy(const unsigned char* state, int n_envs, int group, unsigned char* linear,
                                 hipStream_t stream);
 

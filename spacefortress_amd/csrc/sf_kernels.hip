@@ -58,47 +58,14 @@
 #define SF_BLOCK 256
 #endif
 #define SF_TRIG_PIECES ((SF_LDS_DOUBLES / 2 + SF_BLOCK - 1) / SF_BLOCK)
+// LDS map (doubles): [0, SF_LDS_DOUBLES) the cos/sin table; then one (hit, out) pair of 32-bit event words per lane,
+// through which the missile pool's entries tell their owner lanes what happened to them; then the observation staging
+#define SF_LDS_EV SF_LDS_DOUBLES
+#define SF_LDS_STAGE (SF_LDS_DOUBLES + SF_BLOCK)
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
-#define SF_MPF 12 /* missile slots prefetched into registers; higher slots take the slow loop */
-#ifndef SF_MG_VARIANT
-#define SF_MG_VARIANT 4
-#endif
-#if SF_MG_VARIANT == 0
-#define SF_MGROUPS 4
-#define SF_MG_LO {0, 2, 4, 8}
-#define SF_MG_N {2, 2, 4, 4}
-#elif SF_MG_VARIANT == 1
-#define SF_MGROUPS 6
-#define SF_MG_LO {0, 2, 4, 6, 8, 10}
-#define SF_MG_N {2, 2, 2, 2, 2, 2}
-#elif SF_MG_VARIANT == 2
-#define SF_MGROUPS 7
-#define SF_MG_LO {0, 2, 3, 4, 5, 6, 8}
-#define SF_MG_N {2, 1, 1, 1, 1, 2, 4}
-#elif SF_MG_VARIANT == 3
-#define SF_MGROUPS 5
-#define SF_MG_LO {0, 2, 4, 6, 8}
-#define SF_MG_N {2, 2, 2, 2, 4}
-#elif SF_MG_VARIANT == 4
-#define SF_MGROUPS 8
-#define SF_MG_LO {0, 2, 4, 6, 8, 9, 10, 11}
-#define SF_MG_N {2, 2, 2, 2, 1, 1, 1, 1}
-#elif SF_MG_VARIANT == 5
-#define SF_MGROUPS 9
-#define SF_MG_LO {0, 2, 4, 5, 6, 7, 8, 9, 10}
-#define SF_MG_N {2, 2, 1, 1, 1, 1, 1, 1, 2}
-#elif SF_MG_VARIANT == 7
-#define SF_MGROUPS 9
-#define SF_MG_LO {0, 2, 4, 6, 7, 8, 9, 10, 11}
-#define SF_MG_N {2, 2, 2, 1, 1, 1, 1, 1, 1}
-#elif SF_MG_VARIANT == 8
-#define SF_MGROUPS 7
-#define SF_MG_LO {0, 2, 4, 6, 8, 9, 10}
-#define SF_MG_N {2, 2, 2, 2, 1, 1, 2}
-#else
-#define SF_MGROUPS 7
-#define SF_MG_LO {0, 2, 4, 6, 8, 10, 11}
-#define SF_MG_N {2, 2, 2, 2, 2, 1, 1}
+#ifndef SF_MROWS
+#define SF_MROWS 3 /* rows of the tile's missile pool (64 entries each) loaded up front with the lane's chunks; more live
+                      missiles than that (> 192 in 64 envs; random play averages 104) take the dependent-load loop */
 #endif
 #define SF_SPF 6 /* shell slots prefetched (groups of SF_SGSZ) */
 #ifndef SF_SGSZ
@@ -159,8 +126,17 @@
 #ifndef SF_ABL_SPAWN
 #define SF_ABL_SPAWN 0
 #endif
-#ifndef SF_TRIG_HOIST
-#define SF_TRIG_HOIST 8 /* missile slots whose (cos, sin) lookups are batched ahead of the shells; 0 = none.  A/B at 65 536 envs: 0: 10.22 us, 4: 10.13, 6: 10.10, 8: 10.07, 12: 10.12 */
+// SF_ABL_PROJ (timing-only ablation, results are WRONG when set): 1 = no missile prefetch / ballistics, 2 = no shells
+// either, 3 = only the shells removed.  SF_ABL_OBS: 1 = no observation epilogue.  SF_ABL_ATAN: 1 = no velocity bearing,
+// 2 = neither bearing (cheap stand-ins).
+#ifndef SF_ABL_PROJ
+#define SF_ABL_PROJ 0
+#endif
+#ifndef SF_ABL_OBS
+#define SF_ABL_OBS 0
+#endif
+#ifndef SF_ABL_ATAN
+#define SF_ABL_ATAN 0
 #endif
 #if SF_ABL_TRIG == 2
 #define SF_COS(ang) ((double)__builtin_amdgcn_cosf((float)(ang) * (1.0f / 360.0f)))
@@ -224,6 +200,12 @@ struct Lane {
   int prev_vlner;
   unsigned cursor, mmask, smask;
   unsigned kc0, kc1;  // key-press counters: shots | thrusts << 16, lefts | rights << 16 (sf_layout.h: SF_KEYCOUNT_BYTE)
+  // the `counts` chunk (sf_layout.h: SF_CNT_*): episode return; resets | missed << 16; vlner_incs | max_vlner << 16;
+  // big-hex | small-hex << 8 | shell deaths << 16 | destroyed << 24
+  int ep_return;
+  unsigned cnt_a, cnt_b, cnt_c;
+  unsigned mpool;     // live entries of the tile's missile pool (wave-uniform; rides above the missile mask)
+  unsigned ep_kills;  // sum of info over the episode (rides above the shell mask)
 };
 
 // What one tick adds to the statistics (SRC/game.hh:29-43); flushed with atomics.
@@ -382,6 +364,10 @@ __device__ __forceinline__ void new_game(const SfKernelArgs& a, Lane& L) {
   L.fort_vuln_t = sfc::vuln_time;  // :78 adds to a never-initialised member; defined as 0 + 250
   L.mmask = L.smask = 0;
   L.kc0 = L.kc1 = 0;  // statistics start over with the game (SRC/game.cpp:18-82)
+  L.ep_return = 0;
+  L.cnt_a = L.cnt_b = L.cnt_c = 0;
+  L.ep_kills = 0;
+  // (L.mpool belongs to the tile, not to the game: the caller maintains it)
 }
 
 __device__ __forceinline__ void kill_ship(Lane& L, StatDelta& S) {  // SRC/game.cpp:274-280
@@ -392,19 +378,32 @@ __device__ __forceinline__ void kill_ship(Lane& L, StatDelta& S) {  // SRC/game.
   }
 }
 
-// The fixed part of a lane: six 16-byte chunks and one 8-byte chunk (sf_layout.h).
-__device__ __forceinline__ void load_lane(const unsigned char* tb, const Off& o, Lane& L) {
+// The fixed part of a lane: eight 16-byte chunks (sf_layout.h), in two sets.  The start of a launch is a chip-wide burst --
+// every wave of every CU pulls its state at once and the fabric delivers about 12 bytes per cycle and CU -- so what the
+// first phases of the tick need (keys, respawn, ship, fortress: flags and angles, masks, the timers, position and
+// velocity) is issued FIRST and waited for alone; the two chunks that are first read at the shells or later (score,
+// counts) and the missile pool rows are issued behind the dependent loads of round trip 2 and arrive under the
+// key / ship / fortress arithmetic.
+struct LaneLate {
+  i4_t sc, cn;
+};
+__device__ __forceinline__ void load_lane_early(const unsigned char* tb, const Off& o, Lane& L) {
   const i4_t mi = SF_LD(i4_t, SF_CHUNK(misc, 0), o.o16);  // first: the projectile prefetch waits on the masks
+  const i4_t sm = SF_LD(i4_t, SF_CHUNK(small, 0), o.o16);
+  const i4_t ta = SF_LD(i4_t, SF_CHUNK(timers_a, 0), o.o16);
   const d2_t p = SF_LD(d2_t, SF_CHUNK(ship_pos, 0), o.o16);
   const d2_t v = SF_LD(d2_t, SF_CHUNK(ship_vel, 0), o.o16);
-  const i4_t ta = SF_LD(i4_t, SF_CHUNK(timers_a, 0), o.o16);
   const i4_t tc = SF_LD(i4_t, SF_CHUNK(timers_b, 0), o.o16);
-  const i4_t sc = SF_LD(i4_t, SF_CHUNK(score, 0), o.o16);
-  const i4_t sm = SF_LD(i4_t, SF_CHUNK(small, 0), o.o16);
+  L.right_t = tc.x;
+  L.fort_t = tc.y;
+  L.fort_death_t = tc.z;
+  L.fort_vuln_t = tc.w;
   L.prev_vlner = mi.x;
   L.cursor = (unsigned)mi.y;
-  L.mmask = (unsigned)mi.z;
-  L.smask = (unsigned)mi.w;
+  L.mmask = (unsigned)mi.z & SF_MASK_LOW;
+  L.mpool = (unsigned)mi.z >> SF_MPOOL_SHIFT;
+  L.smask = (unsigned)mi.w & SF_MASK_LOW;
+  L.ep_kills = (unsigned)mi.w >> SF_KILLS_SHIFT;
   L.sx = p.x;
   L.sy = p.y;
   L.vx = v.x;
@@ -413,20 +412,28 @@ __device__ __forceinline__ void load_lane(const unsigned char* tb, const Off& o,
   L.fire_t = ta.y;
   L.thrust_t = ta.z;
   L.left_t = ta.w;
-  L.right_t = tc.x;
-  L.fort_t = tc.y;
-  L.fort_death_t = tc.z;
-  L.fort_vuln_t = tc.w;
-  L.points = __int_as_float(sc.x);
-  L.raw = __int_as_float(sc.y);
-  L.vlner = sc.z;
-  L.time = sc.w;
   L.angle = (int16_t)(sm.x & 0xFFFF);
   L.fort_angle = (int16_t)((unsigned)sm.x >> 16);
   L.fort_last = (int16_t)(sm.y & 0xFFFF);
   L.fl = ((unsigned)sm.y >> 16) & 0xFFu;
   L.kc0 = (unsigned)sm.z;
   L.kc1 = (unsigned)sm.w;
+}
+__device__ __forceinline__ LaneLate load_lane_late(const unsigned char* tb, const Off& o) {
+  LaneLate t;
+  t.sc = SF_LD(i4_t, SF_CHUNK(score, 0), o.o16);
+  t.cn = SF_LD(i4_t, SF_CHUNK(counts, 0), o.o16);
+  return t;
+}
+__device__ __forceinline__ void unpack_lane_late(const LaneLate& t, Lane& L) {
+  L.points = __int_as_float(t.sc.x);
+  L.raw = __int_as_float(t.sc.y);
+  L.vlner = t.sc.z;
+  L.time = t.sc.w;
+  L.ep_return = t.cn.x;
+  L.cnt_a = (unsigned)t.cn.y;
+  L.cnt_b = (unsigned)t.cn.z;
+  L.cnt_c = (unsigned)t.cn.w;
 }
 
 // The lane's seven chunks back to the tile, through the wave's descriptor: the chunk offsets ride in the scalar
@@ -440,7 +447,9 @@ __device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const 
   SF_BST16(timers_a, (i4_t{L.death_t, L.fire_t, L.thrust_t, L.left_t}));
   SF_BST16(timers_b, (i4_t{L.right_t, L.fort_t, L.fort_death_t, L.fort_vuln_t}));
   SF_BST16(score, (i4_t{__float_as_int(L.points), __float_as_int(L.raw), L.vlner, L.time}));
-  SF_BST16(misc, (i4_t{L.prev_vlner, (int)L.cursor, (int)L.mmask, (int)L.smask}));
+  SF_BST16(misc, (i4_t{L.prev_vlner, (int)L.cursor, (int)(L.mmask | (L.mpool << SF_MPOOL_SHIFT)),
+                       (int)(L.smask | (L.ep_kills << SF_KILLS_SHIFT))}));
+  SF_BST16(counts, (i4_t{L.ep_return, (int)L.cnt_a, (int)L.cnt_b, (int)L.cnt_c}));
 #undef SF_BST16
   __builtin_amdgcn_raw_buffer_store_b128(
       u4_t{(unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16),
@@ -471,13 +480,6 @@ __device__ __forceinline__ d2_t ld_coherent_d2(const unsigned char* p) {
 }
 __device__ __forceinline__ void st_coherent_i32(unsigned char* p, int v) {
   __hip_atomic_store(reinterpret_cast<int*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ void zero_counters(unsigned char* tb, const Off& o) {
-#pragma unroll
-  for (int k = 0; k < SF_NSTAT; k++) st_coherent_i32(SF_CHUNK(stats, k) + o.o4, 0);
-  st_coherent_i32(SF_CHUNK(ep_return, 0) + o.o4, 0);
-  st_coherent_i32(SF_CHUNK(ep_kills, 0) + o.o4, 0);
 }
 
 // ExtraGameValues of Game::computeExtra (SRC/game.cpp:282-312).  They are a pure function of the
@@ -749,8 +751,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
     L.cursor = (unsigned)mi.y;
   }
   new_game(a, L);
+  L.mpool = 0;  // every env of the tile starts over: the tile's missile pool is empty
   store_lane(tb, o, L);
-  zero_counters(tb, o);
   if (obs != nullptr && i < (unsigned)a.n_envs && a.obs_type != 3) {
     // the reference's extras are stale heap until the first tick; defined as computeExtra(spawn)
     Extras e = compute_extras(a, L, sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x), sf_atan2<false>(L.vy, L.vx));
@@ -776,7 +778,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // SGPRs at wave launch and the state loads issue without a scalar-load round trip to the kernel-argument
   // segment first (on a firmware without the feature the compiler's compatibility preamble loads them).  The
   // three output pointers ride along: the epilogue then stores without a scalar load and its wait.
-  extern __shared__ double lds[];  // [SF_LDS_DOUBLES] cos/sin table, then the obs staging rows
+  extern __shared__ double lds[];  // [SF_LDS_DOUBLES] cos/sin table, the event words, then the obs staging rows (SF_LDS_*)
   const unsigned tid = threadIdx.x;
   const unsigned i = blockIdx.x * SF_BLOCK + tid;  // env index: actions and outputs
   const unsigned lane = tid & 63u;
@@ -791,21 +793,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   auto pld16 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> d2_t {
     return __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, p ? o.o16 : SF_OOB, goff, 0));
   };
-  auto pld2 = [&](unsigned goff, bool p) __attribute__((always_inline)) -> int {
-    return (int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, p ? o.o2 : SF_OOB, goff, 0);
-  };
   auto pst16 = [&](unsigned goff, bool p, d2_t v) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, p ? o.o16 : SF_OOB, goff, kStAux);
-  };
-  auto pst2 = [&](unsigned goff, bool p, int v) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, rs, p ? o.o2 : SF_OOB, goff, 0);
   };
   // the same with a per-lane slot offset (`extra` = slot * row bytes)
   auto pst16_at = [&](unsigned goff, bool p, unsigned extra, d2_t v) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, p ? o.o16 + extra : SF_OOB, goff, kStAux);
-  };
-  auto pst2_at = [&](unsigned goff, bool p, unsigned extra, int v) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, rs, p ? o.o2 + extra : SF_OOB, goff, 0);
   };
 #ifdef SF_STAMPS
   unsigned long long stamp_[16] = {};
@@ -822,8 +815,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     if (act_type == 4) return SF_LD(int, ab, e * 4u);
     return SF_LD(unsigned char, ab, e);
   };
+  // ---- the early set: what keys, respawn and ship need (load_lane_early), the action, the cos/sin table pieces
   Lane L;
-  load_lane(tb, o, L);  // before the action: its address needs two more kernel arguments and a branch on the action type
+  load_lane_early(tb, o, L);  // before the action: its address needs two more kernel arguments and a branch on the action type
+  int act_next = load_action(0);
   // cos/sin table: 720 doubles = 360 16-byte pieces, six per lane (the last one partial)
   const unsigned char* cb = (const unsigned char*)consts_p;
   // (threads past the end re-load and re-store the last piece: straight-line code, no exec-masked
@@ -835,7 +830,22 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     cpi[k] = min(tid + k * SF_BLOCK, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
     cst[k] = SF_LD(d2_t, cb, cpi[k] * 16u);
   }
-  int act_next = load_action(0);
+#define SF_LOAD_POOL_ROWS(aux)                                                                                                \
+  _Pragma("unroll") for (int r = 0; r < SF_MROWS; r++) {                                                                      \
+    prow[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, o.o16, SF_GOFF(missile_pos, r), (aux)));   \
+    pmeta[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, o.o4, SF_GOFF(missile_meta, r), (aux));                             \
+  }
+  constexpr bool kPoolLoads = SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3;
+  d2_t prow[SF_MROWS];
+  unsigned pmeta[SF_MROWS];
+  LaneLate late;
+#ifndef SF_LATE
+#define SF_LATE 1 /* 0: the late set rides with the early one (A/B) */
+#endif
+#if !SF_LATE
+  late = load_lane_late(tb, o);
+  if (kPoolLoads) { SF_LOAD_POOL_ROWS(0) }
+#endif
   SF_STAMP(1, false);
   SF_STAMP(2, true);
 
@@ -843,55 +853,46 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // memory returns in order and the number of predicated loads below is not known at compile time, so a
   // wait for the table placed after them is a wait for all of them (`s_waitcnt vmcnt(0)`) -- round trip 2
   // would be over before the workgroup barrier instead of running under the ship / fortress arithmetic.
-  // For the same reason EVERY load of round trip 1 is waited for here, explicitly (vmcnt(0), the other counters
+  // For the same reason EVERY load issued so far is waited for here, explicitly (vmcnt(0), the other counters
   // untouched): a first use of, say, the flags after the predicated loads would otherwise be a vmcnt(0) too.
   __builtin_amdgcn_s_waitcnt(0x0F70);
 #if SF_ABL_TRIG != 2
 #pragma unroll
   for (int k = 0; k < SF_TRIG_PIECES; k++) reinterpret_cast<d2_t*>(lds)[cpi[k]] = cst[k];
 #endif
+  // this lane's (hit, out) event words start at zero; the missile pool's entries OR their slot bit into their
+  // OWNER's words (wave-private: only lanes of this wave own entries of this tile; LDS is in order per wave)
+  unsigned long long* const evw = reinterpret_cast<unsigned long long*>(lds + SF_LDS_EV) + (tid & ~63u);
+  evw[lane] = 0ull;
 
-  // ================= round trip 2: live projectile slots, predicated by the alive masks ======
-  // Slot groups (missiles {0,1} {2,3} {4..7} {8..11}, shells {0,1,2} {3,4,5}): a wave ballot
-  // skips a group no lane uses.  The kernel lasts as long as its slowest wave, so the groups reach
-  // well past the common case: the dependent-load loop behind them is for slots hardly ever used.
-  constexpr int kMgLo[SF_MGROUPS] = SF_MG_LO, kMgN[SF_MGROUPS] = SF_MG_N;
-  double mx[SF_MPF], my[SF_MPF];
-  int mang[SF_MPF];
+  // ================= round trip 2: live shell slots, predicated by the alive mask ======
+  // Slot groups (pairs): a wave ballot skips a group no lane uses.  The kernel lasts as long as its slowest wave, so
+  // the groups reach well past the common case: the dependent-load loop behind them is for slots hardly ever used.
+  // (Missiles need no second round trip: the tile's pool rows came with the first.)
   double shx[SF_SPF], shy[SF_SPF], shvx[SF_SPF], shvy[SF_SPF];
-#pragma unroll
-  for (int s = 0; s < SF_MPF; s++) {
-    mx[s] = 0;
-    my[s] = 0;
-    mang[s] = 0;
-  }
 #pragma unroll
   for (int s = 0; s < SF_SPF; s++) shx[s] = shy[s] = shvx[s] = shvy[s] = 0;
   // a dead ship whose explosion is over respawns this tick (SRC/game.cpp:151-157): fetch its
   // entry of the spawn sequence now, not in the middle of the arithmetic
   bool will_respawn = !(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration;
   unsigned long long spawn_e = 0;
+  // The spawn entry FIRST and without a branch (a lane that does not respawn gets an out-of-range offset): memory
+  // returns in order, so what is issued behind it -- shells, the late set -- is not waited for when the respawn reads it
+  const __amdgpu_buffer_rsrc_t rs_spawn =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(a.spawn), 0, (int)((a.spawn_mask + 1u) * 8u), 0x00020000);
+  auto load_spawn = [&]() __attribute__((always_inline)) {
+#if SF_ABL_SPAWN  /* timing-only: no dependent spawn-entry load (WRONG results) */
+    spawn_e = 0x0000005A00C800C8ull + (L.cursor & 63u);
+#else
+    const i2_t e = __builtin_bit_cast(i2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_spawn, will_respawn ? (L.cursor & a.spawn_mask) * 8u : SF_OOB, 0, 0));
+    spawn_e = (unsigned long long)(unsigned)e.x | ((unsigned long long)(unsigned)e.y << 32);
+#endif
+  };
+  load_spawn();
   {
 #pragma unroll
-    for (int g = 0; g < SF_MGROUPS; g++) {
-      const unsigned gm = ((1u << kMgN[g]) - 1u) << kMgLo[g];
-      if (__ballot((L.mmask & gm) != 0u) != 0ull) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (k < kMgN[g]) {
-            const int s = kMgLo[g] + k;
-            const bool live = (L.mmask >> s) & 1u;
-            const d2_t m = pld16(SF_GOFF(missile_pos, s), live);
-            mx[s] = m.x;
-            my[s] = m.y;
-            mang[s] = pld2(SF_GOFF(missile_ang, s), live);
-          }
-        }
-      }
-    }
-#pragma unroll
     for (int g = 0; g < SF_SPF / SF_SGSZ; g++) {
-      if (__ballot((L.smask & (((1u << SF_SGSZ) - 1u) << (SF_SGSZ * g))) != 0u) != 0ull) {
+      if (SF_ABL_PROJ < 2 && __ballot((L.smask & (((1u << SF_SGSZ) - 1u) << (SF_SGSZ * g))) != 0u) != 0ull) {
 #pragma unroll
         for (int k = 0; k < SF_SGSZ; k++) {
           const int s = SF_SGSZ * g + k;
@@ -905,14 +906,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         }
       }
     }
-    if (__ballot(will_respawn) != 0ull) {
-#if SF_ABL_SPAWN  /* timing-only: no dependent spawn-entry load (WRONG results) */
-      if (will_respawn) spawn_e = 0x0000005A00C800C8ull + (L.cursor & 63u);
-#else
-      if (will_respawn) spawn_e = *reinterpret_cast<const unsigned long long*>(a.spawn + 4 * (size_t)(L.cursor & a.spawn_mask));
-#endif
-    }
   }
+#if SF_LATE
+  // ---- the late set, 2 + 2 SF_MROWS unconditional memory instructions behind everything the first phases wait for: the
+  //      score and counts chunks, then the first SF_MROWS rows of the tile's missile pool -- lane l takes entry 64 r + l,
+  //      (x, y) and the meta word, whether or not that many entries are live (the count came with the early set)
+  late = load_lane_late(tb, o);
+  if (kPoolLoads) { SF_LOAD_POOL_ROWS(0) }
+#endif
 
 #if SF_ABL_TRIG == 0
   __syncthreads();  // the only workgroup barrier of the kernel
@@ -920,14 +921,18 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   const double* trig = lds;
   SF_STAMP(3, false);
 
+  unpack_lane_late(late, L);  // names only: the wait for the late set sits at the first real use
   const int n_iter = FUSED ? n_steps : 1;
   for (int step = 0; step < n_iter; step++) {
   int act = act_next;
   if (FUSED) {
     if (step + 1 < n_iter) act_next = load_action(step + 1);  // in flight while this tick computes
     if (step > 0) {
+      // the pool rows the previous tick compacted in place: agent-scope loads (they bypass the wave's L1, where the rows
+      // read a tick ago may still sit), in flight under the key / ship / fortress / shell arithmetic
+      if (SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3) { SF_LOAD_POOL_ROWS(16) }
       will_respawn = !(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration;
-      if (will_respawn) spawn_e = *reinterpret_cast<const unsigned long long*>(a.spawn + 4 * (size_t)(L.cursor & a.spawn_mask));
+      load_spawn();
     }
   }
   const size_t so = (size_t)step * (size_t)a.n_envs;  // this tick's row of the output arrays
@@ -942,8 +947,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   StatDelta S;
 
   // ================= Game::stepOneTick (SRC/game.cpp:473-485) =================
-  float rew = 0;        // mReward = 0
-  L.time += sfc::tick_ms;  // updateTime
+  float rew = 0;        // mReward = 0 (updateTime: with the game-over test below, `time` is in a late chunk)
 
   // ---- processKeyState (SRC/game.cpp:218-272); the wrapper sends FIRE, THRUST, (LEFT, RIGHT)
   //      press-or-release every step (ENV:213-229), so each key is one edge test.  Branch-free:
@@ -952,6 +956,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   //      flag; an edge zeroes that key's timer (:227,231,235,244,250,253,257,261), a press edge
   //      counts (:228,232,236,245).
   int new_m_slot = -1;
+  bool right_edge = false;
+  float amt_fire = 0.0f, amt_hex = 0.0f;  // this tick's first two score() amounts, applied in order once `points` is needed
   unsigned key_edges;  // SF_EV_PRESS_* | SF_EV_RELEASE_*: the key STATE changes of this tick
   {
     const unsigned kmask = AUTOTURN ? 0x3u : 0xFu;  // autoturn games send two keys (ENV:221)
@@ -967,7 +973,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     if (!AUTOTURN) L.kc1 += ((press >> 2) & 1u) | ((press & 8u) << 13);  // lefts, rights
     if (!AUTOTURN) {
       L.left_t = (edge & 4u) ? 0 : L.left_t;
-      L.right_t = (edge & 8u) ? 0 : L.right_t;
+      right_edge = (edge & 8u) != 0u;  // the right-key timer lives in a late chunk: zeroed at stepTimers below
       S.lefts += (int)((press >> 2) & 1u);
       S.rights += (int)((press >> 3) & 1u);
     }
@@ -981,7 +987,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       const bool can = (press & 1u) && (L.fl & SF_FL_SHIP_ALIVE) && slot >= 0 && slot < SF_NSLOT;
       new_m_slot = can ? slot : -1;
       L.mmask |= can ? (1u << (slot & 31)) : 0u;
-      score(can ? -sfc::Score<SHAPED>::missile_penalty : 0.0f, rew, L);
+      amt_fire = can ? -sfc::Score<SHAPED>::missile_penalty : 0.0f;  // reward(-penalty), :187
     }
   }
   // the missile created above starts at the ship's pre-move position and heading
@@ -990,8 +996,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 
   // ---- monitorShipRespawn (SRC/game.cpp:151-157)
   if (will_respawn) {  // !alive && deathTimer >= shipExplodeDuration, evaluated (and fetched) above
-    spawn_ship_from(a, L, spawn_e);
-    L.fort_t = 0;
+    spawn_ship_from(a, L, spawn_e);  // (mFortress.mTimer = 0, :155: at the fortress update below, a late chunk)
   }
 
   // ---- updateShip (SRC/game.cpp:314-351)
@@ -1027,15 +1032,21 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       L.fl &= dead_now ? ~SF_FL_SHIP_ALIVE : ~0u;
       L.death_t = dead_now ? 0 : L.death_t;
       S.ship_deaths += dead_now;
-      score(dead_now ? -sfc::Score<SHAPED>::death_penalty : 0.0f, rew, L);
+      amt_hex = dead_now ? -sfc::Score<SHAPED>::death_penalty : 0.0f;  // penalize(shipDeathPenalty), :339,345
     }
     S.big_hex_deaths += out_big;
     S.small_hex_deaths += in_small;
   }
 
   // the two bearings the rest of the tick and the observation need, side by side (ILP)
+#if SF_ABL_ATAN == 2
+  double a_pos = (L.sy - sfc::fort_y) * 0.001 + (L.sx - sfc::fort_x) * 0.002;
+#else
   double a_pos = sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
-#if SF_AXIS_VEL
+#endif
+#if SF_ABL_ATAN
+  double a_vel = L.vy * 0.5 + L.vx;
+#elif SF_AXIS_VEL
   double a_vel = sf_atan2<false>(L.vy, L.vx);
 #else
   double a_vel = atan2(L.vy, L.vx);
@@ -1048,6 +1059,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   {
     double ats = rad2deg(a_pos);  // stdAngle: in [-180, 180], only the sign fix applies
     if (ats < 0) ats += 360;
+    L.fort_t = will_respawn ? 0 : L.fort_t;  // monitorShipRespawn's mFortress.mTimer = 0 (SRC/game.cpp:155)
     fort_respawned = !(L.fl & SF_FL_FORT_ALIVE) && L.fort_death_t > sfc::fort_respawn;
     L.fort_t = fort_respawned ? 0 : L.fort_t;
     L.fl |= fort_respawned ? SF_FL_FORT_ALIVE : 0u;
@@ -1088,18 +1100,18 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // (predicated, possibly outstanding) load into it -- a vmcnt(0), i.e. the whole of round trip 2, right
   // after the key processing
   asm volatile("" ::"v"(spawn_e));
-#if SF_TRIG_HOIST
-  // the (cos, sin) of every prefetched missile slot in ONE batch of LDS reads, here, so that their
-  // latency hides under the shells: looked up inside the slot groups below, each active group
-  // would pay its own LDS round trip (a wave alone on its SIMD hides nothing)
-  double mcs[SF_TRIG_HOIST], msn[SF_TRIG_HOIST];
+  // the (cos, sin) of the pool rows' headings in ONE batch of LDS reads, here, so that their latency hides under the
+  // shells (a wave alone on its SIMD hides nothing: looked up row by row below, each would pay its own LDS round trip)
+  const unsigned m_live = (unsigned)__builtin_amdgcn_readfirstlane((int)L.mpool);  // entries in the pool before this tick
+  d2_t pcs[SF_MROWS];
 #pragma unroll
-  for (int s = 0; s < SF_TRIG_HOIST; s++) {
-    const int ang = (s == new_m_slot) ? new_m_angle : mang[s];
-    mcs[s] = SF_COS(ang);
-    msn[s] = SF_SIN(ang);
-  }
-#endif
+  for (int r = 0; r < SF_MROWS; r++)
+    pcs[r] = (SF_ABL_PROJ == 1 || SF_ABL_PROJ == 2) ? d2_t{0, 0} : *reinterpret_cast<const d2_t*>(&trig[2 * SF_MM_ANGLE(pmeta[r])]);
+
+  // the tick's first two score() calls (fireMissile's penalty, then a hexagon death), in their order, now that the
+  // score chunk is needed anyway (shell kills and missile events follow)
+  score(amt_fire, rew, L);
+  score(amt_hex, rew, L);
 
   // The constants of the projectile arithmetic, parked in VGPRs: none of them is an inline constant, SGPRs are
   // scarce (101 of 102 in use), and the compiler re-materialises each as an `s_mov_b32` pair in front of every slot
@@ -1118,20 +1130,17 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 
   // ---- updateShells (SRC/game.cpp:404-423).  Ballistics of the prefetched slots first, as
   //      straight-line code; then the (ship-alive dependent) outcome in slot order.
-  // What is written ONCE per projectile -- a new shell's velocity, a new missile's heading -- is one store for the
+  // What is written ONCE per projectile -- a new shell's velocity -- is one store for the
   // wave with the slot in the lane's offset, not a predicated store per slot: every memory instruction of the four
   // waves of a CU goes through the one address unit they share, idle lanes or not.
-  static_assert(sfl::kGroups[SF_G_shell_vel].chunk * sfl::kTileLanes == 1024 && sfl::kGroups[SF_G_missile_ang].chunk * sfl::kTileLanes == 128,
-                "slot strides of the two rows below");
+  static_assert(sfl::kGroups[SF_G_shell_vel].chunk * sfl::kTileLanes == 1024, "slot stride of the row below");
   if (__ballot(new_s_slot >= 0) != 0ull)
     pst16_at(SF_GOFF(shell_vel, 0), new_s_slot >= 0, (unsigned)new_s_slot * 1024u, d2_t{new_s_vx, new_s_vy});
-  if (__ballot(new_m_slot >= 0) != 0ull)
-    pst2_at(SF_GOFF(missile_ang, 0), new_m_slot >= 0, (unsigned)new_m_slot * 128u, new_m_angle);
   {
 #pragma unroll
     for (int g = 0; g < SF_SPF / SF_SGSZ; g++) {
       const unsigned gmask = ((1u << SF_SGSZ) - 1u) << (SF_SGSZ * g);
-      if (__ballot((L.smask & gmask) != 0u) == 0ull) continue;
+      if (SF_ABL_PROJ >= 2 || __ballot((L.smask & gmask) != 0u) == 0ull) continue;
       unsigned col = 0, out = 0;
       double nx[SF_SGSZ], ny[SF_SGSZ];
 #pragma unroll
@@ -1175,7 +1184,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
         pst16(SF_GOFF(shell_pos, s), (L.smask >> s) & 1u, d2_t{nx[k], ny[k]});
       }
     }
-    if (__ballot((L.smask >> SF_SPF) != 0u) != 0ull) {  // rare: more than SF_SPF shells in some lane
+    if (SF_ABL_PROJ < 2 && __ballot((L.smask >> SF_SPF) != 0u) != 0ull) {  // rare: more than SF_SPF shells in some lane
 #pragma unroll 1
       for (int s = SF_SPF; s < SF_NSLOT; s++) {
         const bool live = (L.smask >> s) & 1u;
@@ -1218,73 +1227,64 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
   }
 
-  // ---- updateMissiles (SRC/game.cpp:353-402).  Ballistics per slot are independent; what a hit
-  //      or a miss does to the fortress / score is order dependent, so the events are collected
-  //      as bitmasks and replayed in slot order afterwards.
+  // ---- updateMissiles (SRC/game.cpp:353-402) over the tile's missile POOL.  The reference walks 20 slots per env; with
+  //      one lane per env a wave would walk every slot ANY of its 64 envs uses with a couple of lanes busy.  The tile's
+  //      live missiles are kept as one dense list instead: a row is 64 entries, one per lane, whoever owns them, every
+  //      lane busy (random play: 104 missiles per tile = 2 rows instead of 8-9 slot passes).  An entry that hits the
+  //      fortress or leaves the area ORs its slot bit into its OWNER lane's event words in LDS; the survivors are
+  //      compacted IN PLACE (ballot + prefix count) as the rows go by -- a row is in registers before anything is
+  //      written, and entries only move down.  What a hit or a miss does to the fortress / score is order dependent
+  //      (slot order within an env), so the owners replay their events from the collected masks afterwards.
+  //      New missiles (fired this tick, SRC/game.cpp:237-238: before the move) are one more row, lane = owner.
   unsigned hit_count = 0;  // missiles that reached the fortress this tick (alive or not)
   {
-    unsigned ev_hit = 0, ev_out = 0;
-    auto m_move_cs = [&](int s, double x, double y, int ang, bool isnew, double c, double sn, double& nx, double& ny)
-                         __attribute__((always_inline)) {
+    unsigned wp = 0;  // write pointer of the compaction = entries kept so far (wave-uniform)
+    unsigned* const evw32 = reinterpret_cast<unsigned*>(evw);
+    auto m_row = [&](double x, double y, unsigned meta, d2_t cs, bool valid) __attribute__((always_inline)) {
       // velocity = missileSpeed * (cos, sin)(deg2rad(angle)) with an integer angle: table
-      nx = x + kv_speed * c;
-      ny = y + kv_speed * sn;
+      const double nx = x + kv_speed * cs.x, ny = y + kv_speed * cs.y;
       const double dx = nx - kv_fx, dy = ny - kv_fy;
-      // the same truth values as below, kept as bits of integer masks (vector ALU only); `live` and `!hit` are
-      // applied to the collected masks once, after the last slot
-      const unsigned bit = 1u << s;
-      const unsigned hb = (dx * dx + dy * dy <= kv_mr2) ? bit : 0u;  // collided(mFortress), see shells
-      const unsigned ob = outside(nx, ny) ? bit : 0u;
-      ev_hit |= hb;
-      ev_out |= ob;
-      pst16(SF_GOFF(missile_pos, s), (L.mmask & bit & ~(hb | ob)) != 0u, d2_t{nx, ny});
-    };
-    auto m_move = [&](int s, double x, double y, int ang, bool isnew, double& nx, double& ny)
-                      __attribute__((always_inline)) {
-      m_move_cs(s, x, y, ang, isnew, SF_COS(ang), SF_SIN(ang), nx, ny);
-    };
-    auto m_pref = [&](int s) __attribute__((always_inline)) {
-      const bool isnew = (s == new_m_slot);
-      const int ang = isnew ? new_m_angle : mang[s];
-      double nx, ny;
-#if SF_TRIG_HOIST
-      if (s < SF_TRIG_HOIST)
-        m_move_cs(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], ang, isnew, mcs[s < SF_TRIG_HOIST ? s : 0],
-                  msn[s < SF_TRIG_HOIST ? s : 0], nx, ny);
-      else
-#endif
-        m_move(s, isnew ? new_m_x : mx[s], isnew ? new_m_y : my[s], ang, isnew, nx, ny);
-      if (FUSED) {  // the registers carry the missile into the next tick
-        mx[s] = nx;
-        my[s] = ny;
-        mang[s] = ang;
-      }
-    };
-#pragma unroll
-    for (int g = 0; g < SF_MGROUPS; g++) {
-      const unsigned gm = ((1u << kMgN[g]) - 1u) << kMgLo[g];
-      if (__ballot((L.mmask & gm) != 0u) != 0ull) {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (k < kMgN[g]) m_pref(kMgLo[g] + k);
-      }
-    }
-    if (__ballot((L.mmask >> SF_MPF) != 0u) != 0ull) {  // rare: a lane with more than SF_MPF missiles
-#pragma unroll 1
-      for (int s = SF_MPF; s < SF_NSLOT; s++) {
-        const bool live = (L.mmask >> s) & 1u;
-        if (__ballot(live) == 0ull) continue;
-        if (live) {
-          double nx, ny;
-          if (s == new_m_slot)
-            m_move(s, new_m_x, new_m_y, new_m_angle, true, nx, ny);
-          else {
-            const d2_t m = ld_coherent_d2(SF_CHUNK(missile_pos, s) + o.o16);
-            m_move(s, m.x, m.y, ld_coherent_i16(SF_CHUNK(missile_ang, s) + o.o2), false, nx, ny);
-          }
+      const bool hit = valid & (dx * dx + dy * dy <= kv_mr2);  // collided(mFortress), see shells
+      const bool gone = valid & (hit | outside(nx, ny));       // `else if (isOutsideGameArea)`: hit wins
+      if (__ballot(gone) != 0ull) {
+        if (gone) {  // (slot bit) -> the owner's hit word or, for a missile that left the area, its out word
+          __hip_atomic_fetch_or(evw32 + 2 * SF_MM_OWNER(meta) + (hit ? 0 : 1), 1u << SF_MM_SLOT(meta), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
+      const bool keep = valid & !gone;
+      const unsigned long long kb = __ballot(keep);
+      const unsigned idx = wp + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u));
+      wp += (unsigned)__popcll(kb);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, (d2_t{nx, ny})), rs, keep ? idx * 16u : SF_OOB,
+                                             SF_GOFF(missile_pos, 0), kStAux);
+      __builtin_amdgcn_raw_buffer_store_b32(meta, rs, keep ? idx * 4u : SF_OOB, SF_GOFF(missile_meta, 0), kStAux);
+    };
+    if (SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3) {
+#pragma unroll
+      for (int r = 0; r < SF_MROWS; r++)
+        if (m_live > 64u * r) m_row(prow[r].x, prow[r].y, pmeta[r], pcs[r], 64u * r + lane < m_live);
+      if (m_live > 64u * SF_MROWS) {  // rare: more than SF_MROWS rows of live missiles in this tile
+#pragma unroll 1
+        for (unsigned r = SF_MROWS; 64u * r < m_live; r++) {
+          // agent-scope loads: in a fused launch the previous tick of this wave wrote these rows
+          const d2_t pr = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, o.o16 + r * 1024u, SF_GOFF(missile_pos, 0), 16));
+          const unsigned pm = __builtin_amdgcn_raw_buffer_load_b32(rs, o.o4 + r * 256u, SF_GOFF(missile_meta, 0), 16);
+          m_row(pr.x, pr.y, pm, *reinterpret_cast<const d2_t*>(&trig[2 * SF_MM_ANGLE(pm)]), 64u * r + lane < m_live);
+        }
+      }
+      if (__ballot(new_m_slot >= 0) != 0ull)
+        m_row(new_m_x, new_m_y, SF_MM_PACK(new_m_angle, lane, new_m_slot & 31),
+              *reinterpret_cast<const d2_t*>(&trig[2 * new_m_angle]), new_m_slot >= 0);
     }
+    L.mpool = wp;
+    // the owners collect what happened to their missiles (LDS is in order per wave; the fences pin the compiler)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long evp = evw[lane];
+    if (FUSED) evw[lane] = 0ull;  // ready for the next tick
+    unsigned ev_hit = (unsigned)evp, ev_out = (unsigned)(evp >> 32);
     ev_hit &= L.mmask;             // hit = live & collided
     ev_out &= L.mmask & ~ev_hit;   // out = live & !hit & outside
     unsigned ev = ev_hit | ev_out;
@@ -1324,6 +1324,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   L.fire_t += (L.fl & SF_FL_FIRE) ? 1 : -1;
   L.thrust_t += (L.fl & SF_FL_THRUST) ? 1 : -1;
   L.left_t += (L.fl & SF_FL_LEFT) ? 1 : -1;
+  L.right_t = right_edge ? 0 : L.right_t;  // the key edge of processKeyState (:253,261), deferred
   L.right_t += (L.fl & SF_FL_RIGHT) ? 1 : -1;
 
   int r = (int)rew;  // `return mReward` through `int stepOneTick` (SRC/game.hh:138): truncation
@@ -1339,6 +1340,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     r = r + 2 * fort_kill;
     L.prev_vlner = L.vlner;
   }
+  L.time += sfc::tick_ms;                     // updateTime (SRC/game.cpp:475); nothing in between reads it
   const int done = L.time >= sfc::game_time;  // Game::isGameOver (SRC/game.cpp:487-489)
 
   // ---- optional telemetry: what happened this tick, as a bitmask (the reference's addEvent strings,
@@ -1357,11 +1359,21 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 
   SF_STAMP(10, false);
   // ================= statistics and the vec-env worker's auto-reset (rl/train.py:80-88) ======
+  // The tick's share of the per-episode counters, added to the packed fields of the lane's `counts` chunk
+  // (sf_layout.h: SF_CNT_*; every delta is 0 or small, the fields cannot carry into each other within an episode)
+  L.ep_return += r;
+  L.ep_kills += (unsigned)fort_kill;
+  L.cnt_a += (unsigned)S.resets | ((unsigned)S.missed << 16);
+  {
+    const unsigned mv = L.cnt_b >> 16, nv = (unsigned)S.max_vlner > mv ? (unsigned)S.max_vlner : mv;  // counter 12: a running maximum
+    L.cnt_b = ((L.cnt_b + (unsigned)S.vlner_incs) & 0xFFFFu) | (nv << 16);
+  }
+  L.cnt_c += (unsigned)S.big_hex_deaths | ((unsigned)S.small_hex_deaths << 8) | ((unsigned)S.shell_deaths << 16) |
+             ((unsigned)S.destroyed << 24);
   if (done && a.auto_reset) {
-    // episode totals = what previous launches accumulated + this tick's share
-    const int ep_ret = ld_coherent_i32(SF_CHUNK(ep_return, 0) + o.o4) + r;
-    const int ep_kil = ld_coherent_i32(SF_CHUNK(ep_kills, 0) + o.o4) + fort_kill;
-    const int deaths = ld_coherent_i32(SF_CHUNK(stats, SF_ST_SHIP_DEATHS) + o.o4) + S.ship_deaths;
+    // episode totals (rl/train.py:81-88,161-164), this tick's share included
+    const int ep_ret = L.ep_return, ep_kil = (int)L.ep_kills;
+    const int deaths = (int)((L.cnt_c & 0xFFu) + ((L.cnt_c >> 8) & 0xFFu) + ((L.cnt_c >> 16) & 0xFFu));  // killShip's three call sites
     const int shots = (int)(L.kc0 & 0xFFFFu);  // this tick's press included
     if (real) {
       atomicAdd(&a.acc[0], 1ull);
@@ -1373,41 +1385,36 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       atomicMin((long long*)&a.acc[6], (long long)ep_ret);
       atomicMax((long long*)&a.acc[7], (long long)ep_ret);
     }
+    // a new Game (ENV:163-178).  Its missiles are gone with it: the pool entries this lane still owns leave below
     new_game(a, L);
-    zero_counters(tb, o);
     a_pos = sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
     a_vel = sf_atan2<false>(L.vy, L.vx);
-  } else {
-    // no-return atomics, executed at the memory side: the counters are never loaded
-#define SF_ATOMIC_ADD(goff, v) __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((v), rs, (v) != 0 ? o.o4 : SF_OOB, (goff), 0)
-#if SF_ABL_STATS == 2 /* timing-only: no counter atomics at all (WRONG results) */
-#define SF_FLUSH(idx, v)
-#else
-#define SF_FLUSH(idx, v) \
-  if (__ballot((v) != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(stats, idx), (v)); }
-#endif
-    // the key presses happen in some lane of nearly every tick; everything else is rare and sits behind
-    // ONE wave-wide test (all of these deltas are >= 0, so their OR is their "any")
-    // (shots, thrusts, lefts, rights: in the lane's own chunk, L.kc0 / L.kc1 -- no atomics)
-    if (__ballot((S.ship_deaths | S.resets | S.destroyed | S.missed | S.vlner_incs | S.max_vlner) != 0) != 0ull) {
-      SF_FLUSH(SF_ST_BIG_HEX_DEATHS, S.big_hex_deaths)
-      SF_FLUSH(SF_ST_SMALL_HEX_DEATHS, S.small_hex_deaths)
-      SF_FLUSH(SF_ST_SHELL_DEATHS, S.shell_deaths)
-      SF_FLUSH(SF_ST_SHIP_DEATHS, S.ship_deaths)
-      SF_FLUSH(SF_ST_RESETS, S.resets)
-      SF_FLUSH(SF_ST_DESTROYED, S.destroyed)
-      SF_FLUSH(SF_ST_MISSED, S.missed)
-      SF_FLUSH(SF_ST_VLNER_INCS, S.vlner_incs)
-      if (__ballot(S.max_vlner != 0) != 0ull) {
-        if (S.max_vlner != 0)
-          atomicMax(reinterpret_cast<int*>(SF_CHUNK(stats, SF_ST_MAX_VLNER) + o.o4), S.max_vlner);
+  }
+  // A lane that started a new game while others of its tile play on (only possible when episodes are out of step:
+  // sf_set_field, a reset of part of a tile) must take its entries out of the shared pool.  With every lane of the
+  // tile done in the same tick -- the regular case -- the pool is simply emptied.
+  {
+    const unsigned long long dn = __ballot(done && a.auto_reset);
+    if (dn != 0ull) {
+      if (dn == ~0ull) {
+        L.mpool = 0;
+      } else {
+        const unsigned n_before = (unsigned)__builtin_amdgcn_readfirstlane((int)L.mpool);
+        unsigned wp = 0;
+#pragma unroll 1
+        for (unsigned r = 0; 64u * r < n_before; r++) {
+          const u4_t pr = __builtin_amdgcn_raw_buffer_load_b128(rs, o.o16 + r * 1024u, SF_GOFF(missile_pos, 0), 16);
+          const unsigned pm = __builtin_amdgcn_raw_buffer_load_b32(rs, o.o4 + r * 256u, SF_GOFF(missile_meta, 0), 16);
+          const bool keep = (64u * r + lane < n_before) && !((dn >> SF_MM_OWNER(pm)) & 1ull);
+          const unsigned long long kb = __ballot(keep);
+          const unsigned idx = wp + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u));
+          wp += (unsigned)__popcll(kb);
+          __builtin_amdgcn_raw_buffer_store_b128(pr, rs, keep ? idx * 16u : SF_OOB, SF_GOFF(missile_pos, 0), kStAux);
+          __builtin_amdgcn_raw_buffer_store_b32(pm, rs, keep ? idx * 4u : SF_OOB, SF_GOFF(missile_meta, 0), kStAux);
+        }
+        L.mpool = wp;
       }
     }
-#undef SF_FLUSH
-    if (__ballot(r != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(ep_return, 0), r); }
-    const int kill1 = fort_kill ? 1 : 0;
-    if (__ballot(kill1 != 0) != 0ull) { SF_ATOMIC_ADD(SF_GOFF(ep_kills, 0), kill1); }
-#undef SF_ATOMIC_ADD
   }
 
   SF_STAMP(11, false);
@@ -1437,22 +1444,23 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
   }
   SF_STAMP(7, false);
-  if constexpr (OBSK == 1) {  // the host guarantees: features, float32, n_envs % 64 == 0, aligned output (sf_launch_step)
+  if constexpr (SF_ABL_OBS != 0) {
+  } else if constexpr (OBSK == 1) {  // the host guarantees: features, float32, n_envs % 64 == 0, aligned output (sf_launch_step)
     constexpr int DIM = AUTOTURN ? 17 : 19;
     const Extras e = compute_extras(a, L, a_pos, a_vel);
-    float* stage = reinterpret_cast<float*>(lds + SF_LDS_DOUBLES);
+    float* stage = reinterpret_cast<float*>(lds + SF_LDS_STAGE);
     write_features_f32<DIM>(stage + tid * DIM, L, e, a.real_shell_count);
     if ((i & ~63u) < (unsigned)n_envs_p)  // the padding waves behind the batch write nothing
       flush_features_f32<DIM>(stage + (tid & ~63u) * DIM, (float*)obs + (so + (i & ~63u)) * DIM, lane);
   } else if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid
     const Extras e = compute_extras(a, L, a_pos, a_vel);
     if (a.obs_f64) {
-      double* stage = lds + SF_LDS_DOUBLES;
+      double* stage = lds + SF_LDS_STAGE;
       write_obs<double>(a, stage + tid * a.obs_dim, L, e);
       flush_obs_wave<double>(a, stage + (tid & ~63u) * a.obs_dim, (double*)obs + so * a.obs_dim, i & ~63u, lane,
                              obs_vec_ok);
     } else {
-      float* stage = reinterpret_cast<float*>(lds + SF_LDS_DOUBLES);
+      float* stage = reinterpret_cast<float*>(lds + SF_LDS_STAGE);
       write_obs<float>(a, stage + tid * a.obs_dim, L, e);
       flush_obs_wave<float>(a, stage + (tid & ~63u) * a.obs_dim, (float*)obs + so * a.obs_dim, i & ~63u, lane,
                             obs_vec_ok);
@@ -1466,9 +1474,9 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
     const bool has_obs = obs != nullptr && a.obs_type != 3;
     if (a.obs_f64)
-      norm_partials_wave<double>(a, lds + SF_LDS_DOUBLES + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u, lane, my_ret, has_obs);
+      norm_partials_wave<double>(a, lds + SF_LDS_STAGE + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u, lane, my_ret, has_obs);
     else
-      norm_partials_wave<float>(a, reinterpret_cast<float*>(lds + SF_LDS_DOUBLES) + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u,
+      norm_partials_wave<float>(a, reinterpret_cast<float*>(lds + SF_LDS_STAGE) + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u,
                                 lane, my_ret, has_obs);
   }
   }  // tick loop
@@ -1505,21 +1513,141 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_field_copy_kernel(unsigned char* 
   }
 }
 
-// sf_get_field / sf_set_field("stats"): rows SF_ST_KEY_FIRST .. +3 of the linear [13][n_envs] int32 buffer come from
-// (go to) the four uint16 key-press counters in the lane's `small` chunk (sf_layout.h: SF_KEYCOUNT_BYTE).
-__global__ __launch_bounds__(SF_BLOCK) void sf_keycount_copy_kernel(unsigned char* state, int n_envs, int32_t* linear,
-                                                                   int to_linear) {
+// sf_get_field / sf_set_field for the fields that are not one element at a fixed place of a chunk (sf_layout.h: SF_FK_*).
+
+// "stats": the reference's 13 ints (SRC/game.hh:29-43) from / to the narrow counters of the `counts` and `small` chunks;
+// ship deaths (row 3) is the sum of rows 0-2 and is not stored (a value written to it is ignored).
+__global__ __launch_bounds__(SF_BLOCK) void sf_stats_copy_kernel(unsigned char* state, int n_envs, int32_t* linear,
+                                                                int to_linear) {
   const long e = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
   if (e >= n_envs) return;
-  uint16_t* kc = reinterpret_cast<uint16_t*>(state + (e >> 6) * sfl::kTileBytes + sfl::chunk_offset(SF_G_small, 0) +
-                                             (e & 63) * sfl::kGroups[SF_G_small].chunk + SF_KEYCOUNT_BYTE);
-  for (int c = 0; c < SF_ST_KEY_COUNT; c++) {
-    int32_t* p = linear + (long)(SF_ST_KEY_FIRST + c) * n_envs + e;
-    if (to_linear)
-      *p = kc[c];
-    else
-      kc[c] = (uint16_t)*p;
+  unsigned char* tile = state + (e >> 6) * sfl::kTileBytes;
+  uint16_t* kc = reinterpret_cast<uint16_t*>(tile + sfl::chunk_offset(SF_G_small, 0) + (e & 63) * 16 + SF_KEYCOUNT_BYTE);
+  unsigned char* cn = tile + sfl::chunk_offset(SF_G_counts, 0) + (e & 63) * 16;
+  uint16_t* c16 = reinterpret_cast<uint16_t*>(cn + SF_CNT_U16_BYTE);  // resets, missed, vlner_incs, max_vlner
+  uint8_t* c8 = cn + SF_CNT_U8_BYTE;                                   // big-hex, small-hex, shell deaths, destroyed
+#define SF_ROW(k) linear[(long)(k) * n_envs + e]
+  if (to_linear) {
+    SF_ROW(SF_ST_BIG_HEX_DEATHS) = c8[0];
+    SF_ROW(SF_ST_SMALL_HEX_DEATHS) = c8[1];
+    SF_ROW(SF_ST_SHELL_DEATHS) = c8[2];
+    SF_ROW(SF_ST_SHIP_DEATHS) = (int)c8[0] + c8[1] + c8[2];
+    SF_ROW(SF_ST_RESETS) = c16[0];
+    SF_ROW(SF_ST_DESTROYED) = c8[3];
+    SF_ROW(SF_ST_MISSED) = c16[1];
+    for (int c = 0; c < SF_ST_KEY_COUNT; c++) SF_ROW(SF_ST_KEY_FIRST + c) = kc[c];
+    SF_ROW(SF_ST_VLNER_INCS) = c16[2];
+    SF_ROW(SF_ST_MAX_VLNER) = c16[3];
+  } else {
+    c8[0] = (uint8_t)SF_ROW(SF_ST_BIG_HEX_DEATHS);
+    c8[1] = (uint8_t)SF_ROW(SF_ST_SMALL_HEX_DEATHS);
+    c8[2] = (uint8_t)SF_ROW(SF_ST_SHELL_DEATHS);
+    c16[0] = (uint16_t)SF_ROW(SF_ST_RESETS);
+    c8[3] = (uint8_t)SF_ROW(SF_ST_DESTROYED);
+    c16[1] = (uint16_t)SF_ROW(SF_ST_MISSED);
+    for (int c = 0; c < SF_ST_KEY_COUNT; c++) kc[c] = (uint16_t)SF_ROW(SF_ST_KEY_FIRST + c);
+    c16[2] = (uint16_t)SF_ROW(SF_ST_VLNER_INCS);
+    c16[3] = (uint16_t)SF_ROW(SF_ST_MAX_VLNER);
   }
+#undef SF_ROW
+}
+
+// "missile_mask" / "shell_mask" (the low SF_MASK_BITS bits of a misc word) and "ep_kills" (the top byte of the shell word)
+__global__ __launch_bounds__(SF_BLOCK) void sf_bits_copy_kernel(unsigned char* state, int n_envs, int byte_in_chunk,
+                                                               int shift, unsigned mask, uint32_t* linear, int to_linear) {
+  const long e = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
+  if (e >= n_envs) return;
+  uint32_t* w = reinterpret_cast<uint32_t*>(state + (e >> 6) * sfl::kTileBytes + sfl::chunk_offset(SF_G_misc, 0) +
+                                            (e & 63) * 16 + byte_in_chunk);
+  if (to_linear)
+    linear[e] = (*w >> shift) & mask;
+  else
+    *w = (*w & ~(mask << shift)) | ((linear[e] & mask) << shift);
+}
+
+// The missile fields, per env and slot as the reference has them (mMissiles[i], SRC/game.hh:90), from / to the tile's pool.
+// `slots` is the batch's slot-major view [SF_NSLOT][n_envs] of (x, y) as d2_t and of the heading as int32.
+// Pool -> slots: every live entry goes to (slot, owner); slots without a missile read 0.
+__global__ __launch_bounds__(64) void sf_mpool_to_slots_kernel(const unsigned char* state, int n_envs, d2_t* sl_pos,
+                                                              int32_t* sl_ang) {
+  const long tile_i = blockIdx.x;
+  const unsigned lane = threadIdx.x;
+  const unsigned char* tile = state + tile_i * sfl::kTileBytes;
+  const long e = tile_i * 64 + lane;
+  if (e < n_envs)
+    for (int s = 0; s < SF_NSLOT; s++) {
+      sl_pos[(long)s * n_envs + e] = d2_t{0, 0};
+      sl_ang[(long)s * n_envs + e] = 0;
+    }
+  __syncthreads();
+  const unsigned n = *reinterpret_cast<const uint32_t*>(tile + sfl::chunk_offset(SF_G_misc, 0) + 8) >> SF_MPOOL_SHIFT;
+  for (unsigned k = lane; k < n; k += 64) {
+    const d2_t p = *reinterpret_cast<const d2_t*>(tile + sfl::chunk_offset(SF_G_missile_pos, 0) + (size_t)k * 16);
+    const unsigned m = *reinterpret_cast<const uint32_t*>(tile + sfl::chunk_offset(SF_G_missile_meta, 0) + (size_t)k * 4);
+    const long oe = tile_i * 64 + SF_MM_OWNER(m);
+    if (oe < n_envs) {
+      sl_pos[(long)SF_MM_SLOT(m) * n_envs + oe] = p;
+      sl_ang[(long)SF_MM_SLOT(m) * n_envs + oe] = (int)SF_MM_ANGLE(m);
+    }
+  }
+}
+// Slots -> pool: the tile's pool is rebuilt from the alive masks, slot by slot (ballot + prefix count, the step
+// kernel's compaction), and the count written into every lane's missile word.
+__global__ __launch_bounds__(64) void sf_slots_to_mpool_kernel(unsigned char* state, int n_envs, const d2_t* sl_pos,
+                                                              const int32_t* sl_ang) {
+  const long tile_i = blockIdx.x;
+  const unsigned lane = threadIdx.x;
+  unsigned char* tile = state + tile_i * sfl::kTileBytes;
+  const long e = tile_i * 64 + lane;
+  uint32_t* mw = reinterpret_cast<uint32_t*>(tile + sfl::chunk_offset(SF_G_misc, 0) + lane * 16 + 8);
+  const unsigned mask = e < n_envs ? (*mw & SF_MASK_LOW) : 0u;
+  unsigned wp = 0;
+  for (int s = 0; s < SF_NSLOT; s++) {
+    const bool live = (mask >> s) & 1u;
+    const unsigned long long b = __ballot(live);
+    const unsigned idx = wp + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+    wp += (unsigned)__popcll(b);
+    if (live) {
+      *reinterpret_cast<d2_t*>(tile + sfl::chunk_offset(SF_G_missile_pos, 0) + (size_t)idx * 16) = sl_pos[(long)s * n_envs + e];
+      *reinterpret_cast<uint32_t*>(tile + sfl::chunk_offset(SF_G_missile_meta, 0) + (size_t)idx * 4) =
+          SF_MM_PACK((unsigned)sl_ang[(long)s * n_envs + e] & 511u, lane, s);
+    }
+  }
+  *mw = mask | (wp << SF_MPOOL_SHIFT);
+}
+
+hipError_t sf_launch_mpool_to_slots(const unsigned char* state, int n_envs, void* sl_pos, int32_t* sl_ang, hipStream_t stream) {
+  hipLaunchKernelGGL(sf_mpool_to_slots_kernel, dim3((unsigned)((n_envs + 63) / 64)), dim3(64), 0, stream, state, n_envs,
+                     (d2_t*)sl_pos, sl_ang);
+  return hipGetLastError();
+}
+hipError_t sf_launch_slots_to_mpool(unsigned char* state, long lanes, int n_envs, const void* sl_pos, const int32_t* sl_ang,
+                                    hipStream_t stream) {
+  hipLaunchKernelGGL(sf_slots_to_mpool_kernel, dim3((unsigned)(lanes / 64)), dim3(64), 0, stream, state, n_envs,
+                     (const d2_t*)sl_pos, sl_ang);
+  return hipGetLastError();
+}
+
+// one component of the slot-major missile view <-> the caller's linear [SF_NSLOT][n_envs] buffer
+// which: 0 = x, 1 = y (double), 2 = heading (int16)
+__global__ __launch_bounds__(SF_BLOCK) void sf_mslot_component_kernel(d2_t* sl_pos, int32_t* sl_ang, long total, int which,
+                                                                     void* linear, int to_linear) {
+  const long k = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
+  if (k >= total) return;
+  if (which == 2) {
+    if (to_linear) ((int16_t*)linear)[k] = (int16_t)sl_ang[k];
+    else sl_ang[k] = ((const int16_t*)linear)[k];
+  } else {
+    double* comp = reinterpret_cast<double*>(sl_pos + k) + which;
+    if (to_linear) ((double*)linear)[k] = *comp;
+    else *comp = ((const double*)linear)[k];
+  }
+}
+hipError_t sf_launch_mslot_component(void* sl_pos, int32_t* sl_ang, long total, int which, void* linear, int to_linear,
+                                     hipStream_t stream) {
+  hipLaunchKernelGGL(sf_mslot_component_kernel, dim3((unsigned)((total + SF_BLOCK - 1) / SF_BLOCK)), dim3(SF_BLOCK), 0, stream,
+                     (d2_t*)sl_pos, sl_ang, total, which, linear, to_linear);
+  return hipGetLastError();
 }
 
 // PMC calibration (sf_calibration_copy): copy whole 16-byte chunks of one group to the linear
@@ -1544,10 +1672,21 @@ hipError_t sf_launch_group_copy(const unsigned char* state, int n_envs, int grou
 hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, unsigned char* linear, int to_linear,
                                 hipStream_t stream) {
   const sfl::FieldMeta& m = sfl::kFields[field];
+  const unsigned grid = (unsigned)((n_envs + SF_BLOCK - 1) / SF_BLOCK);
+  if (m.kind == SF_FK_STATS) {
+    hipLaunchKernelGGL(sf_stats_copy_kernel, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, (int32_t*)linear, to_linear);
+    return hipGetLastError();
+  }
+  if (m.kind == SF_FK_MASK || m.kind == SF_FK_KILLS) {
+    const bool kills = m.kind == SF_FK_KILLS;
+    hipLaunchKernelGGL(sf_bits_copy_kernel, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, kills ? 12 : m.byte_in_chunk,
+                       kills ? SF_KILLS_SHIFT : 0, kills ? 0xFFu : SF_MASK_LOW, (uint32_t*)linear, to_linear);
+    return hipGetLastError();
+  }
+  if (m.kind == SF_FK_MPOOL) return hipErrorInvalidValue;  // sf_capi.cpp goes through the slot view (sf_launch_mslot_component)
   const int lane_stride = sfl::kGroups[m.group].chunk, slot_stride = lane_stride * sfl::kTileLanes;
   const long off = sfl::group_offset(m.group) + m.byte_in_chunk;
   const int elem_size = m.elem_size, count = m.count;
-  const unsigned grid = (unsigned)((n_envs + SF_BLOCK - 1) / SF_BLOCK);
   switch (elem_size) {
     case 1:
       hipLaunchKernelGGL(sf_field_copy_kernel<uint8_t>, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, off,
@@ -1566,9 +1705,6 @@ hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, uns
                          lane_stride, slot_stride, count, (uint64_t*)linear, to_linear);
       break;
   }
-  if (field == SF_F_stats)  // four of the 13 counters live in the `small` chunk (stream order: after the generic copy)
-    hipLaunchKernelGGL(sf_keycount_copy_kernel, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, (int32_t*)linear,
-                       to_linear);
   return hipGetLastError();
 }
 
@@ -1586,7 +1722,7 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
                           int32_t* reward, uint8_t* done, uint8_t* info, int n_steps, bool fused, hipStream_t stream) {
   const unsigned grid = (unsigned)(a.lanes / SF_BLOCK);
   const size_t elem = a.obs_f64 ? sizeof(double) : sizeof(float);
-  const size_t lds_bytes = SF_LDS_DOUBLES * sizeof(double) + (size_t)SF_BLOCK * a.obs_dim * elem;
+  const size_t lds_bytes = SF_LDS_STAGE * sizeof(double) + (size_t)SF_BLOCK * a.obs_dim * elem;
   // 16-byte obs stores need every tick's row of the output to start 16-byte aligned
   const int vec_ok = ((uintptr_t)obs & 15u) == 0 && (!fused || ((size_t)a.n_envs * a.obs_dim * elem) % 16 == 0);
 #define SF_GO(AT, SH, FU)                                                                                          \

@@ -9,9 +9,13 @@
 //     widest, fully coalesced access the hardware has (the guide's 16 B/lane rule);
 //   * C(group, slot) is a COMPILE-TIME constant: the whole state of a wave hangs off one
 //     scalar base (an SGPR pair) plus one per-lane offset per chunk size;
-//   * counters touched only by rare events (statistics, episode sums) stay 4-byte rows: they
-//     are never loaded on the hot path, events add to them with atomics;
-//   * a wave's working set is one 74 KB block: page- and channel-local.
+//   * the per-episode counters (statistics, episode sums) ride in the lane's own chunks as narrow integers -- an
+//     episode is 5 295 ticks, so 8 / 16 bits hold them (see `counts` below): no atomics, no extra round trips;
+//   * live missiles are NOT stored per env and slot: a tile keeps them as one dense POOL of entries
+//     (x, y | heading, owner lane, slot), `missile_pos` / `missile_meta` rows of 64 entries, which the wave moves a
+//     row at a time, every lane busy, and compacts in place with a ballot + prefix count as entries leave
+//     (per env and slot, two lanes in ten had a missile in a slot the wave had to walk anyway);
+//   * a wave's working set is one 73 KB block: page- and channel-local.
 // History: batch-wide [field][N] arrays -> a quarter of the instructions
 // were per-field 64-bit address math and SGPR spills; per-tile [field][64] rows -> 24 loads and
 // 23 stores of 1-8 bytes per lane and step; this layout -> 7 + 7.
@@ -31,15 +35,13 @@
   G(timers_a, 16, 1)              /* ship_death, fire, thrust, left timers */                   \
   G(timers_b, 16, 1)              /* right, fort, fort_death, fort_vuln timers */               \
   G(score, 16, 1)                 /* points, raw_points, vlner, time */                         \
-  G(misc, 16, 1)                  /* prev_vlner, spawn_cursor, missile_mask, shell_mask */      \
+  G(misc, 16, 1)                  /* prev_vlner, spawn_cursor, missile word, shell word (SF_MASK_BITS) */ \
   G(small, 16, 1)                 /* ship_angle, fort_angle, fort_last_angle (i16), flags (u8), last_reward (i8); then the four key-press counters of `stats` as u16 (see SF_KEYCOUNT_BYTE) */ \
-  G(missile_pos, 16, SF_NSLOT)    /* missile_x, missile_y */                                    \
-  G(missile_ang, 2, SF_NSLOT)     /* missile_angle */                                           \
+  G(counts, 16, 1)                /* ep_return (i32); resets, missed, vlner_incs, max_vlner (u16); big-hex, small-hex, shell deaths, destroyed (u8): SF_CNT_* */ \
+  G(missile_pos, 16, SF_NSLOT)    /* the tile's missile pool: entry e = row e / 64, lane e % 64: (x, y) */ \
+  G(missile_meta, 4, SF_NSLOT)    /* ... and its (heading | owner lane << 9 | slot << 15): SF_MM_* */      \
   G(shell_pos, 16, SF_NSLOT)      /* shell_x, shell_y */                                        \
-  G(shell_vel, 16, SF_NSLOT)      /* shell_vx, shell_vy */                                      \
-  G(stats, 4, SF_NSTAT)           /* the 13 counters: atomics only */                           \
-  G(ep_return, 4, 1)                                                                            \
-  G(ep_kills, 4, 1)
+  G(shell_vel, 16, SF_NSLOT)      /* shell_vx, shell_vy */
 
 enum SfGroupId {
 #define G(name, chunk, slots) SF_G_##name,
@@ -48,60 +50,89 @@ enum SfGroupId {
       SF_G_COUNT
 };
 
-// X(name, ctype, count, is_float, group, byte offset inside the lane's chunk)
-// `count` = elements per env (= the group's slot count).  Reference members in the comments.
+// X(name, ctype, count, is_float, group, byte offset inside the lane's chunk, kind)
+// `count` = elements per env.  Reference members in the comments.  kind: SF_FK_PLAIN = `count` slots of `group`, one
+// element at `byte offset` of the lane's chunk; the other kinds are assembled by sf_launch_field_copy:
+//   SF_FK_MASK    the low SF_MASK_BITS bits of a misc word (the upper bits carry the pool count / ep_kills)
+//   SF_FK_STATS   the 13 counters of SRC/game.hh:29-43 from `counts`, `small` and (ship deaths) their sum
+//   SF_FK_KILLS   ep_kills, the top byte of the shell word
+//   SF_FK_MPOOL   per-slot missile values, gathered from / scattered into the tile's pool by owner and slot
+#define SF_FK_PLAIN 0
+#define SF_FK_MASK 1
+#define SF_FK_STATS 2
+#define SF_FK_KILLS 3
+#define SF_FK_MPOOL 4
 #define SF_FIELDS(X)                                                                                        \
-  X(ship_x, double, 1, 1, ship_pos, 0)           /* mShip.mPos.mX            SRC/object.hh:5 */            \
-  X(ship_y, double, 1, 1, ship_pos, 8)           /* mShip.mPos.mY */                                       \
-  X(ship_vx, double, 1, 1, ship_vel, 0)          /* mShip.mVel.mX */                                       \
-  X(ship_vy, double, 1, 1, ship_vel, 8)          /* mShip.mVel.mY */                                       \
-  X(missile_x, double, SF_NSLOT, 1, missile_pos, 0) /* mMissiles[i].mPos      SRC/game.hh:90 */            \
-  X(missile_y, double, SF_NSLOT, 1, missile_pos, 8)                                                        \
-  X(shell_x, double, SF_NSLOT, 1, shell_pos, 0)  /* mShells[i].mPos, mVel    SRC/game.hh:91 */             \
-  X(shell_y, double, SF_NSLOT, 1, shell_pos, 8)                                                            \
-  X(shell_vx, double, SF_NSLOT, 1, shell_vel, 0)                                                           \
-  X(shell_vy, double, SF_NSLOT, 1, shell_vel, 8)                                                           \
-  X(ship_death_timer, int32_t, 1, 0, timers_a, 0) /* mShip.mDeathTimer       SRC/game.hh:60-64 */          \
-  X(fire_timer, int32_t, 1, 0, timers_a, 4)                                                                \
-  X(thrust_timer, int32_t, 1, 0, timers_a, 8)                                                              \
-  X(left_timer, int32_t, 1, 0, timers_a, 12)                                                               \
-  X(right_timer, int32_t, 1, 0, timers_b, 0)                                                               \
-  X(fort_timer, int32_t, 1, 0, timers_b, 4)      /* mFortress.mTimer         SRC/game.hh:77 */             \
-  X(fort_death_timer, int32_t, 1, 0, timers_b, 8)                                                          \
-  X(fort_vuln_timer, int32_t, 1, 0, timers_b, 12)                                                          \
-  X(points, float, 1, 1, score, 0)               /* mScore                   SRC/game.hh:49-52 */          \
-  X(raw_points, float, 1, 1, score, 4)                                                                     \
-  X(vlner, int32_t, 1, 0, score, 8)                                                                        \
-  X(time, int32_t, 1, 0, score, 12)              /* mTime (mTick = mTime / tick_ms) SRC/game.hh:93 */      \
-  X(stats, int32_t, SF_NSTAT, 0, stats, 0)       /* mStats                   SRC/game.hh:29-43 */          \
-  X(prev_vlner, int32_t, 1, 0, misc, 0)          /* SSF_Env.prev_vlner       ENV:92,244 */                 \
-  X(spawn_cursor, uint32_t, 1, 0, misc, 4)       /* position in the process's rand() spawn sequence */     \
-  X(missile_mask, uint32_t, 1, 0, misc, 8)       /* bit i = mMissiles[i].mAlive */                         \
-  X(shell_mask, uint32_t, 1, 0, misc, 12)        /* bit i = mShells[i].mAlive */                           \
-  X(ep_return, int32_t, 1, 0, ep_return, 0)      /* running sum of wrapper rewards (rl/train.py:84) */     \
-  X(ep_kills, int32_t, 1, 0, ep_kills, 0)        /* running sum of info (rl/train.py:81) */                \
-  X(ship_angle, int16_t, 1, 0, small, 0)         /* mShip.mAngle: always an integer in [0,360) */          \
-  X(fort_angle, int16_t, 1, 0, small, 2)         /* mFortress.mAngle: multiple of the sector size */       \
-  X(fort_last_angle, int16_t, 1, 0, small, 4)    /* mFortress.mLastAngle */                                \
-  X(missile_angle, int16_t, SF_NSLOT, 0, missile_ang, 0) /* mMissiles[i].mAngle (vel = 20*(cos,sin)) */    \
-  X(flags, uint8_t, 1, 0, small, 6)              /* SF_FL_* bits */                                        \
-  X(last_reward, int8_t, 1, 0, small, 7)         /* (int)mReward of the last tick = what step_one_tick returned (SRC/game.cpp:484) */
+  X(ship_x, double, 1, 1, ship_pos, 0, SF_FK_PLAIN)           /* mShip.mPos.mX            SRC/object.hh:5 */            \
+  X(ship_y, double, 1, 1, ship_pos, 8, SF_FK_PLAIN)           /* mShip.mPos.mY */                                       \
+  X(ship_vx, double, 1, 1, ship_vel, 0, SF_FK_PLAIN)          /* mShip.mVel.mX */                                       \
+  X(ship_vy, double, 1, 1, ship_vel, 8, SF_FK_PLAIN)          /* mShip.mVel.mY */                                       \
+  X(missile_x, double, SF_NSLOT, 1, missile_pos, 0, SF_FK_MPOOL) /* mMissiles[i].mPos      SRC/game.hh:90 */            \
+  X(missile_y, double, SF_NSLOT, 1, missile_pos, 8, SF_FK_MPOOL)                                                        \
+  X(shell_x, double, SF_NSLOT, 1, shell_pos, 0, SF_FK_PLAIN)  /* mShells[i].mPos, mVel    SRC/game.hh:91 */             \
+  X(shell_y, double, SF_NSLOT, 1, shell_pos, 8, SF_FK_PLAIN)                                                            \
+  X(shell_vx, double, SF_NSLOT, 1, shell_vel, 0, SF_FK_PLAIN)                                                           \
+  X(shell_vy, double, SF_NSLOT, 1, shell_vel, 8, SF_FK_PLAIN)                                                           \
+  X(ship_death_timer, int32_t, 1, 0, timers_a, 0, SF_FK_PLAIN) /* mShip.mDeathTimer       SRC/game.hh:60-64 */          \
+  X(fire_timer, int32_t, 1, 0, timers_a, 4, SF_FK_PLAIN)                                                                \
+  X(thrust_timer, int32_t, 1, 0, timers_a, 8, SF_FK_PLAIN)                                                              \
+  X(left_timer, int32_t, 1, 0, timers_a, 12, SF_FK_PLAIN)                                                               \
+  X(right_timer, int32_t, 1, 0, timers_b, 0, SF_FK_PLAIN)                                                               \
+  X(fort_timer, int32_t, 1, 0, timers_b, 4, SF_FK_PLAIN)      /* mFortress.mTimer         SRC/game.hh:77 */             \
+  X(fort_death_timer, int32_t, 1, 0, timers_b, 8, SF_FK_PLAIN)                                                          \
+  X(fort_vuln_timer, int32_t, 1, 0, timers_b, 12, SF_FK_PLAIN)                                                          \
+  X(points, float, 1, 1, score, 0, SF_FK_PLAIN)               /* mScore                   SRC/game.hh:49-52 */          \
+  X(raw_points, float, 1, 1, score, 4, SF_FK_PLAIN)                                                                     \
+  X(vlner, int32_t, 1, 0, score, 8, SF_FK_PLAIN)                                                                        \
+  X(time, int32_t, 1, 0, score, 12, SF_FK_PLAIN)              /* mTime (mTick = mTime / tick_ms) SRC/game.hh:93 */      \
+  X(stats, int32_t, SF_NSTAT, 0, counts, 0, SF_FK_STATS)      /* mStats                   SRC/game.hh:29-43 */          \
+  X(prev_vlner, int32_t, 1, 0, misc, 0, SF_FK_PLAIN)          /* SSF_Env.prev_vlner       ENV:92,244 */                 \
+  X(spawn_cursor, uint32_t, 1, 0, misc, 4, SF_FK_PLAIN)       /* position in the process's rand() spawn sequence */     \
+  X(missile_mask, uint32_t, 1, 0, misc, 8, SF_FK_MASK)        /* bit i = mMissiles[i].mAlive */                         \
+  X(shell_mask, uint32_t, 1, 0, misc, 12, SF_FK_MASK)         /* bit i = mShells[i].mAlive */                           \
+  X(ep_return, int32_t, 1, 0, counts, 0, SF_FK_PLAIN)         /* running sum of wrapper rewards (rl/train.py:84) */     \
+  X(ep_kills, int32_t, 1, 0, misc, 15, SF_FK_KILLS)           /* running sum of info (rl/train.py:81) */                \
+  X(ship_angle, int16_t, 1, 0, small, 0, SF_FK_PLAIN)         /* mShip.mAngle: always an integer in [0,360) */          \
+  X(fort_angle, int16_t, 1, 0, small, 2, SF_FK_PLAIN)         /* mFortress.mAngle: multiple of the sector size */       \
+  X(fort_last_angle, int16_t, 1, 0, small, 4, SF_FK_PLAIN)    /* mFortress.mLastAngle */                                \
+  X(missile_angle, int16_t, SF_NSLOT, 0, missile_meta, 0, SF_FK_MPOOL) /* mMissiles[i].mAngle (vel = 20*(cos,sin)) */   \
+  X(flags, uint8_t, 1, 0, small, 6, SF_FK_PLAIN)              /* SF_FL_* bits */                                        \
+  X(last_reward, int8_t, 1, 0, small, 7, SF_FK_PLAIN)         /* (int)mReward of the last tick = what step_one_tick returned (SRC/game.cpp:484) */
 
 enum SfFieldId {
-#define X(name, ctype, count, isf, group, off) SF_F_##name,
+#define X(name, ctype, count, isf, group, off, kind) SF_F_##name,
   SF_FIELDS(X)
 #undef X
       SF_F_COUNT
 };
 
-// The four counters that move on nearly every tick -- shots, thrusts, lefts, rights (stats[7..10]) -- live as four
-// uint16 at bytes 8..15 of the lane's `small` chunk, which every step loads and stores anyway: no atomic, no extra
-// memory instruction.  (An episode has 5 295 ticks and a key can be pressed once per two ticks, so 16 bits hold
-// them; they are zeroed with a new game.)  The other nine counters stay in the `stats` rows and move by atomics.
-// sf_get_field / sf_set_field("stats") put the two sources together, so the field is the reference's 13 ints.
+// The 13 statistics of SRC/game.hh:29-43 are per-episode counts (zeroed with a new game); an episode has 5 295 ticks,
+// a key can be pressed once per two ticks, a ship dies at most once per 31 ticks and a fortress once per ~90, so they
+// fit narrow integers inside chunks every step loads and stores anyway -- no atomics, no counter rows:
+//   * shots, thrusts, lefts, rights (stats[7..10]): four uint16 at bytes 8..15 of the lane's `small` chunk;
+//   * `counts` chunk: ep_return int32 | resets, missed, vlner_incs, max_vlner uint16 | big-hex, small-hex, shell
+//     deaths, destroyed uint8 (<= 171 / 58 per episode);
+//   * ship deaths (stats[3]) = big-hex + small-hex + shell deaths: killShip has exactly those three call sites
+//     (SRC/game.cpp:339,345,413), so the sum is not stored;
+//   * ep_kills (sum of info, <= 58) is the top byte of the shell word.
+// sf_get_field / sf_set_field("stats") put the sources together, so the field is the reference's 13 ints.
 #define SF_KEYCOUNT_BYTE 8
 #define SF_ST_KEY_FIRST 7 /* SF_ST_SHOTS */
 #define SF_ST_KEY_COUNT 4
+#define SF_CNT_RETURN_BYTE 0 /* int32 */
+#define SF_CNT_U16_BYTE 4    /* resets, missed, vlner_incs, max_vlner */
+#define SF_CNT_U8_BYTE 12    /* big-hex, small-hex, shell deaths, destroyed */
+// misc words: the two alive masks use SF_MASK_BITS bits; above them ride the tile's pool count (the same value in
+// every lane of the tile, so that any lane's chunk tells how many pool entries are live) and ep_kills
+#define SF_MASK_BITS 20
+#define SF_MASK_LOW 0xFFFFFu
+#define SF_MPOOL_SHIFT 20 /* missile word >> 20 = live entries of the tile's missile pool, <= 64 * SF_NSLOT = 1280 */
+#define SF_KILLS_SHIFT 24 /* shell word >> 24 = ep_kills */
+// missile pool entry meta: heading (integer degrees, 9 bits) | owner lane (6) | slot (5)
+#define SF_MM_ANGLE(m) ((m) & 511u)
+#define SF_MM_OWNER(m) (((m) >> 9) & 63u)
+#define SF_MM_SLOT(m) (((m) >> 15) & 31u)
+#define SF_MM_PACK(angle, owner, slot) ((unsigned)(angle) | ((unsigned)(owner) << 9) | ((unsigned)(slot) << 15))
 
 // flags bits
 #define SF_FL_SHIP_ALIVE 1u
@@ -135,17 +166,17 @@ constexpr long group_offset(int g) {
   for (int i = 0; i < g; i++) o += (long)kGroups[i].chunk * kGroups[i].slots * kTileLanes;
   return o;
 }
-constexpr long kTileBytes = group_offset(SF_G_COUNT);          // 75 008 B
-constexpr long kBytesPerLane = kTileBytes / kTileLanes;        // 1172 B
+constexpr long kTileBytes = group_offset(SF_G_COUNT);          // 74 752 B
+constexpr long kBytesPerLane = kTileBytes / kTileLanes;        // 1168 B
 // byte offset, inside a tile, of lane 0's chunk of (group g, slot s)
 constexpr long chunk_offset(int g, int s = 0) { return group_offset(g) + (long)s * kGroups[g].chunk * kTileLanes; }
 
 struct FieldMeta {
   const char* name;
-  int elem_size, count, is_float, group, byte_in_chunk;
+  int elem_size, count, is_float, group, byte_in_chunk, kind;
 };
 constexpr FieldMeta kFields[SF_F_COUNT] = {
-#define X(name, ctype, count, isf, group, off) {#name, (int)sizeof(ctype), count, isf, SF_G_##group, off},
+#define X(name, ctype, count, isf, group, off, kind) {#name, (int)sizeof(ctype), count, isf, SF_G_##group, off, kind},
     SF_FIELDS(X)
 #undef X
 };

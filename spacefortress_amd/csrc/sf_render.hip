@@ -644,7 +644,8 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   const int ship_angle = R_LD(int16_t, R_CHUNK(small, 0), o16);  // `small` is a 16-byte chunk (sf_layout.h)
   const int fort_angle = R_LD(int16_t, R_CHUNK(small, 0), o16 + 2);
   const unsigned flags = R_LD(uint8_t, R_CHUNK(small, 0), o16 + 6);
-  const unsigned mmask = (SF_RENDER_SKIP & 2) ? 0u : (unsigned)mi.z, smask = (SF_RENDER_SKIP & 2) ? 0u : (unsigned)mi.w;
+  const unsigned mmask = (SF_RENDER_SKIP & 2) ? 0u : ((unsigned)mi.z & SF_MASK_LOW),
+                 smask = (SF_RENDER_SKIP & 2) ? 0u : ((unsigned)mi.w & SF_MASK_LOW);
   const int pnts = (int)__int_as_float(sc.x);  // drawScore takes mScore.mPoints as an int (SRC/draw.cpp:190,266)
   const int vlner = sc.z;
   const int fort_vuln_timer = tb.w;
@@ -657,15 +658,36 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   Quad mq = {}, sq[2] = {{}, {}};
   bool mvalid = false, svalid[2] = {false, false};
   if (mmask) {
+    // The tile keeps its live missiles as one dense pool (sf_layout.h); this env's are the entries whose owner is its
+    // lane.  The wave scans the pool's meta words, 64 entries at a time, and files what it finds by slot -- the
+    // reference draws in slot order (SRC/draw.cpp:243-247) -- in the (still unused) mask scratch.
+    const unsigned n_pool = (unsigned)mi.z >> SF_MPOOL_SHIFT;
+    float* const mtab = reinterpret_cast<float*>(mscr);  // [slot] (x, y, heading)
+    static_assert(SF_NSLOT * 3 * sizeof(float) <= kMaskScratch, "slot table fits the scratch");
+    for (unsigned e = lane; e < n_pool; e += 64) {
+      const unsigned meta = R_LD(uint32_t, R_CHUNK(missile_meta, 0), e * 4u);
+      if (SF_MM_OWNER(meta) == (unsigned)l) {
+        const d2_t m = R_LD(d2_t, R_CHUNK(missile_pos, 0), e * 16u);
+        float* t = mtab + 3 * SF_MM_SLOT(meta);
+        t[0] = (float)m.x;
+        t[1] = (float)m.y;
+        t[2] = (float)SF_MM_ANGLE(meta);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int slot = lane / 3, k = lane - slot * 3;
     mvalid = lane < 3 * SF_NSLOT && ((mmask >> slot) & 1u);
     if (mvalid) {
-      const d2_t m = R_LD(d2_t, R_CHUNK(missile_pos, slot), o16);
-      const int ang = R_LD(int16_t, R_CHUNK(missile_ang, slot), o2);
+      const float* t = mtab + 3 * slot;
       float s, c;
-      sincos_deg((float)ang, &s, &c);
-      mq = line_quad(kMissileLines[k], c, s, (float)m.x, (float)m.y);
+      sincos_deg(t[2], &s, &c);
+      mq = line_quad(kMissileLines[k], c, s, t[0], t[1]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the scratch goes back to the coverage masks
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   if (smask) {
 #pragma unroll

@@ -314,6 +314,7 @@ def test_fuzzed_states(sfa, oracle_mod, gametype):
     base["time"] = rng.integers(0, 5000, n) * 34
     base["tick"] = base["time"] // 34
     base["stats"] = rng.integers(0, 50, (n, 13))
+    base["stats"][:, 3] = base["stats"][:, :3].sum(1)  # shipDeaths = bigHex + smallHex + shell deaths (killShip's three call sites); it is not stored
     nm = rng.integers(0, 21, n)
     ns = rng.integers(0, 21, n)
     for i in range(n):

@@ -31,7 +31,8 @@ def main():
             env = dict(os.environ, SFMI_LIB_PATH=os.path.abspath(l))
             out = subprocess.check_output(
                 [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "300",
-                 "--no-cpu-baseline", "--envs", str(a.envs), "--gametype", a.gametype, "--obs-type", a.obs_type],
+                 "--no-cpu-baseline", "--envs", str(a.envs), "--gametype", a.gametype, "--obs-type", a.obs_type,
+                 "--rollout-k", "0", "--image-envs", "0", "--kernel-timing-launches", "1", "--repeats", "1"],
                 env=env, stderr=subprocess.DEVNULL, text=True)
             res[l].append(json.loads(out.strip().splitlines()[-1])["ms_per_step"] * 1e3)
     for l, v in res.items():
