@@ -806,6 +806,15 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 #endif
   SF_STAMP(0, false);
 
+#ifndef SF_STAGGER
+#define SF_STAGGER 12 /* x 64 cycles; A/B at 65 536 envs: 0: 7.02 us per launch, 8: 6.84, 16: 6.84, 24: 6.89, 40: 7.36 */
+#endif
+#if SF_STAGGER
+  // Half of the workgroups (every other one of an XCD's: workgroup i runs on XCD i % 8) start a third of a microsecond
+  // late: a launch is a chip-wide load burst, then arithmetic with the fabric idle, then a store burst; staggered, one
+  // half's bursts meet the other half's arithmetic.
+  if ((blockIdx.x >> 3) & 1u) __builtin_amdgcn_s_sleep(SF_STAGGER);
+#endif
   // ================= round trip 1: every unconditional load =================
   auto load_action = [&](int step) __attribute__((always_inline)) -> int {  // ENV:211-212
     if (!real) return 0;
@@ -830,10 +839,13 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     cpi[k] = min(tid + k * SF_BLOCK, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
     cst[k] = SF_LD(d2_t, cb, cpi[k] * 16u);
   }
-#define SF_LOAD_POOL_ROWS(aux)                                                                                                \
+  // lane l takes entry 64 r + l if the pool has that many (`n_pool`: the tile's count, known once the early set is in;
+  // ~0u = not known yet, take everything): the instructions are unconditional, the bytes are not
+#define SF_LOAD_POOL_ROWS(aux, n_pool)                                                                                        \
   _Pragma("unroll") for (int r = 0; r < SF_MROWS; r++) {                                                                      \
-    prow[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, o.o16, SF_GOFF(missile_pos, r), (aux)));   \
-    pmeta[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, o.o4, SF_GOFF(missile_meta, r), (aux));                             \
+    const bool in_ = 64u * r + lane < (n_pool);                                                                               \
+    prow[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, in_ ? o.o16 : SF_OOB, SF_GOFF(missile_pos, r), (aux)));   \
+    pmeta[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_ ? o.o4 : SF_OOB, SF_GOFF(missile_meta, r), (aux));               \
   }
   constexpr bool kPoolLoads = SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3;
   d2_t prow[SF_MROWS];
@@ -844,7 +856,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 #endif
 #if !SF_LATE
   late = load_lane_late(tb, o);
-  if (kPoolLoads) { SF_LOAD_POOL_ROWS(0) }
+  if (kPoolLoads) { SF_LOAD_POOL_ROWS(0, ~0u) }
 #endif
   SF_STAMP(1, false);
   SF_STAMP(2, true);
@@ -910,9 +922,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 #if SF_LATE
   // ---- the late set, 2 + 2 SF_MROWS unconditional memory instructions behind everything the first phases wait for: the
   //      score and counts chunks, then the first SF_MROWS rows of the tile's missile pool -- lane l takes entry 64 r + l,
-  //      (x, y) and the meta word, whether or not that many entries are live (the count came with the early set)
+  //      (x, y) and the meta word, if the pool has that many (the count came with the early set): unconditional
+  //      instructions, so the compiler can count them when it waits for the spawn entry issued ahead of them
   late = load_lane_late(tb, o);
-  if (kPoolLoads) { SF_LOAD_POOL_ROWS(0) }
+  if (kPoolLoads) { SF_LOAD_POOL_ROWS(0, L.mpool) }
 #endif
 
 #if SF_ABL_TRIG == 0
@@ -930,7 +943,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     if (step > 0) {
       // the pool rows the previous tick compacted in place: agent-scope loads (they bypass the wave's L1, where the rows
       // read a tick ago may still sit), in flight under the key / ship / fortress / shell arithmetic
-      if (SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3) { SF_LOAD_POOL_ROWS(16) }
+      if (SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3) { SF_LOAD_POOL_ROWS(16, L.mpool) }
       will_respawn = !(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration;
       load_spawn();
     }
