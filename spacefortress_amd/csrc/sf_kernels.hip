@@ -69,7 +69,7 @@
 #endif
 #define SF_SPF 6 /* shell slots prefetched (groups of SF_SGSZ) */
 #ifndef SF_SGSZ
-#define SF_SGSZ 2
+#define SF_SGSZ 1 /* A/B at 65 536 envs with the missile pool: pairs 6.82 us per launch, singles 6.75 */
 #endif
 
 #ifndef M_PI
@@ -385,12 +385,11 @@ __device__ __forceinline__ void kill_ship(Lane& L, StatDelta& S) {  // SRC/game.
 // counts) and the missile pool rows are issued behind the dependent loads of round trip 2 and arrive under the
 // key / ship / fortress arithmetic.
 struct LaneLate {
-  i4_t sc, cn;
+  i4_t ta, sc, cn;
 };
 __device__ __forceinline__ void load_lane_early(const unsigned char* tb, const Off& o, Lane& L) {
   const i4_t mi = SF_LD(i4_t, SF_CHUNK(misc, 0), o.o16);  // first: the projectile prefetch waits on the masks
   const i4_t sm = SF_LD(i4_t, SF_CHUNK(small, 0), o.o16);
-  const i4_t ta = SF_LD(i4_t, SF_CHUNK(timers_a, 0), o.o16);
   const d2_t p = SF_LD(d2_t, SF_CHUNK(ship_pos, 0), o.o16);
   const d2_t v = SF_LD(d2_t, SF_CHUNK(ship_vel, 0), o.o16);
   const i4_t tc = SF_LD(i4_t, SF_CHUNK(timers_b, 0), o.o16);
@@ -398,7 +397,7 @@ __device__ __forceinline__ void load_lane_early(const unsigned char* tb, const O
   L.fort_t = tc.y;
   L.fort_death_t = tc.z;
   L.fort_vuln_t = tc.w;
-  L.prev_vlner = mi.x;
+  L.death_t = mi.x;
   L.cursor = (unsigned)mi.y;
   L.mmask = (unsigned)mi.z & SF_MASK_LOW;
   L.mpool = (unsigned)mi.z >> SF_MPOOL_SHIFT;
@@ -408,10 +407,6 @@ __device__ __forceinline__ void load_lane_early(const unsigned char* tb, const O
   L.sy = p.y;
   L.vx = v.x;
   L.vy = v.y;
-  L.death_t = ta.x;
-  L.fire_t = ta.y;
-  L.thrust_t = ta.z;
-  L.left_t = ta.w;
   L.angle = (int16_t)(sm.x & 0xFFFF);
   L.fort_angle = (int16_t)((unsigned)sm.x >> 16);
   L.fort_last = (int16_t)(sm.y & 0xFFFF);
@@ -421,11 +416,16 @@ __device__ __forceinline__ void load_lane_early(const unsigned char* tb, const O
 }
 __device__ __forceinline__ LaneLate load_lane_late(const unsigned char* tb, const Off& o) {
   LaneLate t;
+  t.ta = SF_LD(i4_t, SF_CHUNK(timers_a, 0), o.o16);
   t.sc = SF_LD(i4_t, SF_CHUNK(score, 0), o.o16);
   t.cn = SF_LD(i4_t, SF_CHUNK(counts, 0), o.o16);
   return t;
 }
 __device__ __forceinline__ void unpack_lane_late(const LaneLate& t, Lane& L) {
+  L.prev_vlner = t.ta.x;
+  L.fire_t = t.ta.y;
+  L.thrust_t = t.ta.z;
+  L.left_t = t.ta.w;
   L.points = __int_as_float(t.sc.x);
   L.raw = __int_as_float(t.sc.y);
   L.vlner = t.sc.z;
@@ -444,10 +444,10 @@ __device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const 
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, o.o16, SF_GOFF(group, 0), aux)
   SF_BST16(ship_pos, (d2_t{L.sx, L.sy}));
   SF_BST16(ship_vel, (d2_t{L.vx, L.vy}));
-  SF_BST16(timers_a, (i4_t{L.death_t, L.fire_t, L.thrust_t, L.left_t}));
+  SF_BST16(timers_a, (i4_t{L.prev_vlner, L.fire_t, L.thrust_t, L.left_t}));
   SF_BST16(timers_b, (i4_t{L.right_t, L.fort_t, L.fort_death_t, L.fort_vuln_t}));
   SF_BST16(score, (i4_t{__float_as_int(L.points), __float_as_int(L.raw), L.vlner, L.time}));
-  SF_BST16(misc, (i4_t{L.prev_vlner, (int)L.cursor, (int)(L.mmask | (L.mpool << SF_MPOOL_SHIFT)),
+  SF_BST16(misc, (i4_t{L.death_t, (int)L.cursor, (int)(L.mmask | (L.mpool << SF_MPOOL_SHIFT)),
                        (int)(L.smask | (L.ep_kills << SF_KILLS_SHIFT))}));
   SF_BST16(counts, (i4_t{L.ep_return, (int)L.cnt_a, (int)L.cnt_b, (int)L.cnt_c}));
 #undef SF_BST16
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
     L.cursor = cursor0 + cursor_stride * i;
   } else {
     const i4_t mi = SF_LD(i4_t, SF_CHUNK(misc, 0), o.o16);
-    L.prev_vlner = mi.x;
+    L.prev_vlner = SF_LD(int, SF_CHUNK(timers_a, 0), o.o16);
     L.cursor = (unsigned)mi.y;
   }
   new_game(a, L);
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   //      flag; an edge zeroes that key's timer (:227,231,235,244,250,253,257,261), a press edge
   //      counts (:228,232,236,245).
   int new_m_slot = -1;
-  bool right_edge = false;
+  unsigned key_edge_bits = 0;
   float amt_fire = 0.0f, amt_hex = 0.0f;  // this tick's first two score() amounts, applied in order once `points` is needed
   unsigned key_edges;  // SF_EV_PRESS_* | SF_EV_RELEASE_*: the key STATE changes of this tick
   {
@@ -978,15 +978,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     const unsigned edge = old ^ now, press = now & ~old;
     key_edges = press | ((old & ~now) << 4);
     L.fl = (L.fl & ~(kmask << 2)) | (now << 2);
-    L.fire_t = (edge & 1u) ? 0 : L.fire_t;
-    L.thrust_t = (edge & 2u) ? 0 : L.thrust_t;
+    key_edge_bits = edge;  // the key timers live in late chunks: an edge zeroes its timer at stepTimers below
     S.shots += (int)(press & 1u);
     S.thrusts += (int)((press >> 1) & 1u);
     L.kc0 += (press & 1u) | ((press & 2u) << 15);  // shots in the low half, thrusts in the high half
     if (!AUTOTURN) L.kc1 += ((press >> 2) & 1u) | ((press & 8u) << 13);  // lefts, rights
     if (!AUTOTURN) {
-      L.left_t = (edge & 4u) ? 0 : L.left_t;
-      right_edge = (edge & 8u) != 0u;  // the right-key timer lives in a late chunk: zeroed at stepTimers below
       S.lefts += (int)((press >> 2) & 1u);
       S.rights += (int)((press >> 3) & 1u);
     }
@@ -1334,11 +1331,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   L.fort_death_t += sfc::tick_ms;
   L.fort_vuln_t += sfc::tick_ms;
   L.death_t += sfc::tick_ms;
-  L.fire_t += (L.fl & SF_FL_FIRE) ? 1 : -1;
-  L.thrust_t += (L.fl & SF_FL_THRUST) ? 1 : -1;
-  L.left_t += (L.fl & SF_FL_LEFT) ? 1 : -1;
-  L.right_t = right_edge ? 0 : L.right_t;  // the key edge of processKeyState (:253,261), deferred
-  L.right_t += (L.fl & SF_FL_RIGHT) ? 1 : -1;
+  // (a key edge of processKeyState zeroes its timer, :227,231,235,244,250,253,257,261: applied here, nothing in between reads them)
+  L.fire_t = ((key_edge_bits & 1u) ? 0 : L.fire_t) + ((L.fl & SF_FL_FIRE) ? 1 : -1);
+  L.thrust_t = ((key_edge_bits & 2u) ? 0 : L.thrust_t) + ((L.fl & SF_FL_THRUST) ? 1 : -1);
+  L.left_t = ((key_edge_bits & 4u) ? 0 : L.left_t) + ((L.fl & SF_FL_LEFT) ? 1 : -1);
+  L.right_t = ((key_edge_bits & 8u) ? 0 : L.right_t) + ((L.fl & SF_FL_RIGHT) ? 1 : -1);
 
   int r = (int)rew;  // `return mReward` through `int stepOneTick` (SRC/game.hh:138): truncation
   // kept for `Game.step_one_tick`'s return value (field last_reward): the spare byte next to the flags

@@ -32,10 +32,10 @@
 #define SF_GROUPS(G)                                                                            \
   G(ship_pos, 16, 1)              /* ship_x, ship_y */                                          \
   G(ship_vel, 16, 1)              /* ship_vx, ship_vy */                                        \
-  G(timers_a, 16, 1)              /* ship_death, fire, thrust, left timers */                   \
+  G(timers_a, 16, 1)              /* prev_vlner; fire, thrust, left timers (all first read late in the tick) */                   \
   G(timers_b, 16, 1)              /* right, fort, fort_death, fort_vuln timers */               \
   G(score, 16, 1)                 /* points, raw_points, vlner, time */                         \
-  G(misc, 16, 1)                  /* prev_vlner, spawn_cursor, missile word, shell word (SF_MASK_BITS) */ \
+  G(misc, 16, 1)                  /* ship_death timer, spawn_cursor, missile word, shell word (SF_MASK_BITS): what the respawn and the slot allocation need first */ \
   G(small, 16, 1)                 /* ship_angle, fort_angle, fort_last_angle (i16), flags (u8), last_reward (i8); then the four key-press counters of `stats` as u16 (see SF_KEYCOUNT_BYTE) */ \
   G(counts, 16, 1)                /* ep_return (i32); resets, missed, vlner_incs, max_vlner (u16); big-hex, small-hex, shell deaths, destroyed (u8): SF_CNT_* */ \
   G(missile_pos, 16, SF_NSLOT)    /* the tile's missile pool: entry e = row e / 64, lane e % 64: (x, y) */ \
@@ -73,7 +73,7 @@ enum SfGroupId {
   X(shell_y, double, SF_NSLOT, 1, shell_pos, 8, SF_FK_PLAIN)                                                            \
   X(shell_vx, double, SF_NSLOT, 1, shell_vel, 0, SF_FK_PLAIN)                                                           \
   X(shell_vy, double, SF_NSLOT, 1, shell_vel, 8, SF_FK_PLAIN)                                                           \
-  X(ship_death_timer, int32_t, 1, 0, timers_a, 0, SF_FK_PLAIN) /* mShip.mDeathTimer       SRC/game.hh:60-64 */          \
+  X(ship_death_timer, int32_t, 1, 0, misc, 0, SF_FK_PLAIN) /* mShip.mDeathTimer       SRC/game.hh:60-64 */          \
   X(fire_timer, int32_t, 1, 0, timers_a, 4, SF_FK_PLAIN)                                                                \
   X(thrust_timer, int32_t, 1, 0, timers_a, 8, SF_FK_PLAIN)                                                              \
   X(left_timer, int32_t, 1, 0, timers_a, 12, SF_FK_PLAIN)                                                               \
@@ -86,7 +86,7 @@ enum SfGroupId {
   X(vlner, int32_t, 1, 0, score, 8, SF_FK_PLAIN)                                                                        \
   X(time, int32_t, 1, 0, score, 12, SF_FK_PLAIN)              /* mTime (mTick = mTime / tick_ms) SRC/game.hh:93 */      \
   X(stats, int32_t, SF_NSTAT, 0, counts, 0, SF_FK_STATS)      /* mStats                   SRC/game.hh:29-43 */          \
-  X(prev_vlner, int32_t, 1, 0, misc, 0, SF_FK_PLAIN)          /* SSF_Env.prev_vlner       ENV:92,244 */                 \
+  X(prev_vlner, int32_t, 1, 0, timers_a, 0, SF_FK_PLAIN)       /* SSF_Env.prev_vlner       ENV:92,244 */                 \
   X(spawn_cursor, uint32_t, 1, 0, misc, 4, SF_FK_PLAIN)       /* position in the process's rand() spawn sequence */     \
   X(missile_mask, uint32_t, 1, 0, misc, 8, SF_FK_MASK)        /* bit i = mMissiles[i].mAlive */                         \
   X(shell_mask, uint32_t, 1, 0, misc, 12, SF_FK_MASK)         /* bit i = mShells[i].mAlive */                           \
