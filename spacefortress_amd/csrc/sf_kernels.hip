@@ -200,10 +200,9 @@ struct Lane {
   int prev_vlner;
   unsigned cursor, mmask, smask;
   unsigned kc0, kc1;  // key-press counters: shots | thrusts << 16, lefts | rights << 16 (sf_layout.h: SF_KEYCOUNT_BYTE)
-  // the `counts` chunk (sf_layout.h: SF_CNT_*): episode return; resets | missed << 16; vlner_incs | max_vlner << 16;
-  // big-hex | small-hex << 8 | shell deaths << 16 | destroyed << 24
+  // the per-episode counters that ride above the timers, vlner, time and the cursor (sf_layout.h: SF_W_*)
   int ep_return;
-  unsigned cnt_a, cnt_b, cnt_c;
+  unsigned c_resets, c_missed, c_incs, c_maxv, c_big, c_small, c_shell, c_destroyed;
   unsigned mpool;     // live entries of the tile's missile pool (wave-uniform; rides above the missile mask)
   unsigned ep_kills;  // sum of info over the episode (rides above the shell mask)
 };
@@ -365,7 +364,7 @@ __device__ __forceinline__ void new_game(const SfKernelArgs& a, Lane& L) {
   L.mmask = L.smask = 0;
   L.kc0 = L.kc1 = 0;  // statistics start over with the game (SRC/game.cpp:18-82)
   L.ep_return = 0;
-  L.cnt_a = L.cnt_b = L.cnt_c = 0;
+  L.c_resets = L.c_missed = L.c_incs = L.c_maxv = L.c_big = L.c_small = L.c_shell = L.c_destroyed = 0;
   L.ep_kills = 0;
   // (L.mpool belongs to the tile, not to the game: the caller maintains it)
 }
@@ -385,7 +384,7 @@ __device__ __forceinline__ void kill_ship(Lane& L, StatDelta& S) {  // SRC/game.
 // counts) and the missile pool rows are issued behind the dependent loads of round trip 2 and arrive under the
 // key / ship / fortress arithmetic.
 struct LaneLate {
-  i4_t ta, sc, cn;
+  i4_t ta, sc;
 };
 __device__ __forceinline__ void load_lane_early(const unsigned char* tb, const Off& o, Lane& L) {
   const i4_t mi = SF_LD(i4_t, SF_CHUNK(misc, 0), o.o16);  // first: the projectile prefetch waits on the masks
@@ -393,12 +392,14 @@ __device__ __forceinline__ void load_lane_early(const unsigned char* tb, const O
   const d2_t p = SF_LD(d2_t, SF_CHUNK(ship_pos, 0), o.o16);
   const d2_t v = SF_LD(d2_t, SF_CHUNK(ship_vel, 0), o.o16);
   const i4_t tc = SF_LD(i4_t, SF_CHUNK(timers_b, 0), o.o16);
-  L.right_t = tc.x;
+  L.right_t = (int)(int16_t)(tc.x & 0xFFFF);
+  L.ep_return = (int)((unsigned)tc.x & 0xFFFF0000u);  // bits 16..31; the low half comes with the late set
   L.fort_t = tc.y;
   L.fort_death_t = tc.z;
   L.fort_vuln_t = tc.w;
   L.death_t = mi.x;
-  L.cursor = (unsigned)mi.y;
+  L.cursor = (unsigned)mi.y & 0xFFFFFFu;
+  L.c_destroyed = (unsigned)mi.y >> 24;
   L.mmask = (unsigned)mi.z & SF_MASK_LOW;
   L.mpool = (unsigned)mi.z >> SF_MPOOL_SHIFT;
   L.smask = (unsigned)mi.w & SF_MASK_LOW;
@@ -418,22 +419,27 @@ __device__ __forceinline__ LaneLate load_lane_late(const unsigned char* tb, cons
   LaneLate t;
   t.ta = SF_LD(i4_t, SF_CHUNK(timers_a, 0), o.o16);
   t.sc = SF_LD(i4_t, SF_CHUNK(score, 0), o.o16);
-  t.cn = SF_LD(i4_t, SF_CHUNK(counts, 0), o.o16);
   return t;
 }
 __device__ __forceinline__ void unpack_lane_late(const LaneLate& t, Lane& L) {
-  L.prev_vlner = t.ta.x;
-  L.fire_t = t.ta.y;
-  L.thrust_t = t.ta.z;
-  L.left_t = t.ta.w;
+  const unsigned w_pvl = (unsigned)t.ta.x, w_fire = (unsigned)t.ta.y, w_thr = (unsigned)t.ta.z, w_left = (unsigned)t.ta.w;
+  const unsigned w_vl = (unsigned)t.sc.z, w_time = (unsigned)t.sc.w;
+  L.prev_vlner = (int)(w_pvl & 0xFFFu);
+  L.c_incs = (w_pvl >> 12) & 0xFFFu;
+  L.c_big = w_pvl >> 24;
+  L.fire_t = (int)(int16_t)(w_fire & 0xFFFFu);
+  L.c_resets = w_fire >> 16;
+  L.thrust_t = (int)(int16_t)(w_thr & 0xFFFFu);
+  L.c_missed = w_thr >> 16;
+  L.left_t = (int)(int16_t)(w_left & 0xFFFFu);
+  L.ep_return = (int)((unsigned)L.ep_return | (w_left >> 16));  // the high half came with timers_b
   L.points = __int_as_float(t.sc.x);
   L.raw = __int_as_float(t.sc.y);
-  L.vlner = t.sc.z;
-  L.time = t.sc.w;
-  L.ep_return = t.cn.x;
-  L.cnt_a = (unsigned)t.cn.y;
-  L.cnt_b = (unsigned)t.cn.z;
-  L.cnt_c = (unsigned)t.cn.w;
+  L.vlner = (int)(w_vl & 0xFFFu);
+  L.c_maxv = (w_vl >> 12) & 0xFFFu;
+  L.c_small = w_vl >> 24;
+  L.time = (int)(w_time & 0xFFFFFFu);
+  L.c_shell = w_time >> 24;
 }
 
 // The lane's seven chunks back to the tile, through the wave's descriptor: the chunk offsets ride in the scalar
@@ -444,12 +450,18 @@ __device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const 
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, o.o16, SF_GOFF(group, 0), aux)
   SF_BST16(ship_pos, (d2_t{L.sx, L.sy}));
   SF_BST16(ship_vel, (d2_t{L.vx, L.vy}));
-  SF_BST16(timers_a, (i4_t{L.prev_vlner, L.fire_t, L.thrust_t, L.left_t}));
-  SF_BST16(timers_b, (i4_t{L.right_t, L.fort_t, L.fort_death_t, L.fort_vuln_t}));
-  SF_BST16(score, (i4_t{__float_as_int(L.points), __float_as_int(L.raw), L.vlner, L.time}));
-  SF_BST16(misc, (i4_t{L.death_t, (int)L.cursor, (int)(L.mmask | (L.mpool << SF_MPOOL_SHIFT)),
+  // the packed words of sf_layout.h (SF_W_*): a value below, a per-episode counter above
+  const unsigned er = (unsigned)L.ep_return;
+  SF_BST16(timers_a, (i4_t{(int)(((unsigned)L.prev_vlner & 0xFFFu) | ((L.c_incs & 0xFFFu) << 12) | (L.c_big << 24)),
+                           (int)(((unsigned)L.fire_t & 0xFFFFu) | (L.c_resets << 16)),
+                           (int)(((unsigned)L.thrust_t & 0xFFFFu) | (L.c_missed << 16)),
+                           (int)(((unsigned)L.left_t & 0xFFFFu) | (er << 16))}));
+  SF_BST16(timers_b, (i4_t{(int)(((unsigned)L.right_t & 0xFFFFu) | (er & 0xFFFF0000u)), L.fort_t, L.fort_death_t, L.fort_vuln_t}));
+  SF_BST16(score, (i4_t{__float_as_int(L.points), __float_as_int(L.raw),
+                        (int)(((unsigned)L.vlner & 0xFFFu) | ((L.c_maxv & 0xFFFu) << 12) | (L.c_small << 24)),
+                        (int)(((unsigned)L.time & 0xFFFFFFu) | (L.c_shell << 24))}));
+  SF_BST16(misc, (i4_t{L.death_t, (int)((L.cursor & 0xFFFFFFu) | (L.c_destroyed << 24)), (int)(L.mmask | (L.mpool << SF_MPOOL_SHIFT)),
                        (int)(L.smask | (L.ep_kills << SF_KILLS_SHIFT))}));
-  SF_BST16(counts, (i4_t{L.ep_return, (int)L.cnt_a, (int)L.cnt_b, (int)L.cnt_c}));
 #undef SF_BST16
   __builtin_amdgcn_raw_buffer_store_b128(
       u4_t{(unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16),
@@ -747,7 +759,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
     L.cursor = cursor0 + cursor_stride * i;
   } else {
     const i4_t mi = SF_LD(i4_t, SF_CHUNK(misc, 0), o.o16);
-    L.prev_vlner = SF_LD(int, SF_CHUNK(timers_a, 0), o.o16);
+    L.prev_vlner = SF_LD(int, SF_CHUNK(timers_a, 0), o.o16) & 0xFFF;
     L.cursor = (unsigned)mi.y;
   }
   new_game(a, L);
@@ -1369,21 +1381,21 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 
   SF_STAMP(10, false);
   // ================= statistics and the vec-env worker's auto-reset (rl/train.py:80-88) ======
-  // The tick's share of the per-episode counters, added to the packed fields of the lane's `counts` chunk
-  // (sf_layout.h: SF_CNT_*; every delta is 0 or small, the fields cannot carry into each other within an episode)
+  // The tick's share of the per-episode counters (they ride above the timers, vlner, time and the cursor: sf_layout.h)
   L.ep_return += r;
   L.ep_kills += (unsigned)fort_kill;
-  L.cnt_a += (unsigned)S.resets | ((unsigned)S.missed << 16);
-  {
-    const unsigned mv = L.cnt_b >> 16, nv = (unsigned)S.max_vlner > mv ? (unsigned)S.max_vlner : mv;  // counter 12: a running maximum
-    L.cnt_b = ((L.cnt_b + (unsigned)S.vlner_incs) & 0xFFFFu) | (nv << 16);
-  }
-  L.cnt_c += (unsigned)S.big_hex_deaths | ((unsigned)S.small_hex_deaths << 8) | ((unsigned)S.shell_deaths << 16) |
-             ((unsigned)S.destroyed << 24);
+  L.c_resets += (unsigned)S.resets;
+  L.c_missed += (unsigned)S.missed;
+  L.c_incs += (unsigned)S.vlner_incs;
+  L.c_maxv = (unsigned)S.max_vlner > L.c_maxv ? (unsigned)S.max_vlner : L.c_maxv;  // counter 12: a running maximum
+  L.c_big += (unsigned)S.big_hex_deaths;
+  L.c_small += (unsigned)S.small_hex_deaths;
+  L.c_shell += (unsigned)S.shell_deaths;
+  L.c_destroyed += (unsigned)S.destroyed;
   if (done && a.auto_reset) {
     // episode totals (rl/train.py:81-88,161-164), this tick's share included
     const int ep_ret = L.ep_return, ep_kil = (int)L.ep_kills;
-    const int deaths = (int)((L.cnt_c & 0xFFu) + ((L.cnt_c >> 8) & 0xFFu) + ((L.cnt_c >> 16) & 0xFFu));  // killShip's three call sites
+    const int deaths = (int)(L.c_big + L.c_small + L.c_shell);  // killShip's three call sites
     const int shots = (int)(L.kc0 & 0xFFFFu);  // this tick's press included
     if (real) {
       atomicAdd(&a.acc[0], 1ull);
@@ -1525,54 +1537,76 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_field_copy_kernel(unsigned char* 
 
 // sf_get_field / sf_set_field for the fields that are not one element at a fixed place of a chunk (sf_layout.h: SF_FK_*).
 
-// "stats": the reference's 13 ints (SRC/game.hh:29-43) from / to the narrow counters of the `counts` and `small` chunks;
-// ship deaths (row 3) is the sum of rows 0-2 and is not stored (a value written to it is ignored).
+// "stats": the reference's 13 ints (SRC/game.hh:29-43) from / to their bit fields (sf_layout.h: SF_W_*); ship deaths
+// (row 3) is the sum of rows 0-2 and is not stored (a value written to it is ignored).
 __global__ __launch_bounds__(SF_BLOCK) void sf_stats_copy_kernel(unsigned char* state, int n_envs, int32_t* linear,
                                                                 int to_linear) {
   const long e = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
   if (e >= n_envs) return;
   unsigned char* tile = state + (e >> 6) * sfl::kTileBytes;
-  uint16_t* kc = reinterpret_cast<uint16_t*>(tile + sfl::chunk_offset(SF_G_small, 0) + (e & 63) * 16 + SF_KEYCOUNT_BYTE);
-  unsigned char* cn = tile + sfl::chunk_offset(SF_G_counts, 0) + (e & 63) * 16;
-  uint16_t* c16 = reinterpret_cast<uint16_t*>(cn + SF_CNT_U16_BYTE);  // resets, missed, vlner_incs, max_vlner
-  uint8_t* c8 = cn + SF_CNT_U8_BYTE;                                   // big-hex, small-hex, shell deaths, destroyed
+  const long lo = (e & 63) * 16;
+  uint16_t* kc = reinterpret_cast<uint16_t*>(tile + sfl::chunk_offset(SF_G_small, 0) + lo + SF_KEYCOUNT_BYTE);
+  uint32_t* ta = reinterpret_cast<uint32_t*>(tile + sfl::chunk_offset(SF_G_timers_a, 0) + lo);  // pvl, fire, thrust, left
+  uint32_t* sc = reinterpret_cast<uint32_t*>(tile + sfl::chunk_offset(SF_G_score, 0) + lo);     // .., .., vlner, time
+  uint32_t* mi = reinterpret_cast<uint32_t*>(tile + sfl::chunk_offset(SF_G_misc, 0) + lo);      // .., cursor, .., ..
 #define SF_ROW(k) linear[(long)(k) * n_envs + e]
+#define SF_PUT(word, shift, bits, k) word = (word & ~((((1u << (bits)) - 1u)) << (shift))) | (((uint32_t)SF_ROW(k) & ((1u << (bits)) - 1u)) << (shift))
   if (to_linear) {
-    SF_ROW(SF_ST_BIG_HEX_DEATHS) = c8[0];
-    SF_ROW(SF_ST_SMALL_HEX_DEATHS) = c8[1];
-    SF_ROW(SF_ST_SHELL_DEATHS) = c8[2];
-    SF_ROW(SF_ST_SHIP_DEATHS) = (int)c8[0] + c8[1] + c8[2];
-    SF_ROW(SF_ST_RESETS) = c16[0];
-    SF_ROW(SF_ST_DESTROYED) = c8[3];
-    SF_ROW(SF_ST_MISSED) = c16[1];
+    const int big = (int)(ta[0] >> 24), sml = (int)(sc[2] >> 24), shl = (int)(sc[3] >> 24);
+    SF_ROW(SF_ST_BIG_HEX_DEATHS) = big;
+    SF_ROW(SF_ST_SMALL_HEX_DEATHS) = sml;
+    SF_ROW(SF_ST_SHELL_DEATHS) = shl;
+    SF_ROW(SF_ST_SHIP_DEATHS) = big + sml + shl;
+    SF_ROW(SF_ST_RESETS) = (int)(ta[1] >> 16);
+    SF_ROW(SF_ST_DESTROYED) = (int)(mi[1] >> 24);
+    SF_ROW(SF_ST_MISSED) = (int)(ta[2] >> 16);
     for (int c = 0; c < SF_ST_KEY_COUNT; c++) SF_ROW(SF_ST_KEY_FIRST + c) = kc[c];
-    SF_ROW(SF_ST_VLNER_INCS) = c16[2];
-    SF_ROW(SF_ST_MAX_VLNER) = c16[3];
+    SF_ROW(SF_ST_VLNER_INCS) = (int)((ta[0] >> 12) & 0xFFFu);
+    SF_ROW(SF_ST_MAX_VLNER) = (int)((sc[2] >> 12) & 0xFFFu);
   } else {
-    c8[0] = (uint8_t)SF_ROW(SF_ST_BIG_HEX_DEATHS);
-    c8[1] = (uint8_t)SF_ROW(SF_ST_SMALL_HEX_DEATHS);
-    c8[2] = (uint8_t)SF_ROW(SF_ST_SHELL_DEATHS);
-    c16[0] = (uint16_t)SF_ROW(SF_ST_RESETS);
-    c8[3] = (uint8_t)SF_ROW(SF_ST_DESTROYED);
-    c16[1] = (uint16_t)SF_ROW(SF_ST_MISSED);
+    SF_PUT(ta[0], 24, 8, SF_ST_BIG_HEX_DEATHS);
+    SF_PUT(sc[2], 24, 8, SF_ST_SMALL_HEX_DEATHS);
+    SF_PUT(sc[3], 24, 8, SF_ST_SHELL_DEATHS);
+    SF_PUT(ta[1], 16, 16, SF_ST_RESETS);
+    SF_PUT(mi[1], 24, 8, SF_ST_DESTROYED);
+    SF_PUT(ta[2], 16, 16, SF_ST_MISSED);
     for (int c = 0; c < SF_ST_KEY_COUNT; c++) kc[c] = (uint16_t)SF_ROW(SF_ST_KEY_FIRST + c);
-    c16[2] = (uint16_t)SF_ROW(SF_ST_VLNER_INCS);
-    c16[3] = (uint16_t)SF_ROW(SF_ST_MAX_VLNER);
+    SF_PUT(ta[0], 12, 12, SF_ST_VLNER_INCS);
+    SF_PUT(sc[2], 12, 12, SF_ST_MAX_VLNER);
   }
+#undef SF_PUT
 #undef SF_ROW
 }
 
-// "missile_mask" / "shell_mask" (the low SF_MASK_BITS bits of a misc word) and "ep_kills" (the top byte of the shell word)
-__global__ __launch_bounds__(SF_BLOCK) void sf_bits_copy_kernel(unsigned char* state, int n_envs, int byte_in_chunk,
-                                                               int shift, unsigned mask, uint32_t* linear, int to_linear) {
+// a bit field of a 32-bit word of the lane's chunk (sf_layout.h: SF_BITFIELDS) from / to a linear int32 buffer
+__global__ __launch_bounds__(SF_BLOCK) void sf_bits_copy_kernel(unsigned char* state, int n_envs, long tile_off, int shift,
+                                                               int bits, int is_signed, uint32_t* linear, int to_linear) {
   const long e = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
   if (e >= n_envs) return;
-  uint32_t* w = reinterpret_cast<uint32_t*>(state + (e >> 6) * sfl::kTileBytes + sfl::chunk_offset(SF_G_misc, 0) +
-                                            (e & 63) * 16 + byte_in_chunk);
-  if (to_linear)
-    linear[e] = (*w >> shift) & mask;
-  else
+  uint32_t* w = reinterpret_cast<uint32_t*>(state + (e >> 6) * sfl::kTileBytes + tile_off + (e & 63) * 16);
+  const uint32_t mask = bits >= 32 ? ~0u : ((1u << bits) - 1u);
+  if (to_linear) {
+    uint32_t v = (*w >> shift) & mask;
+    if (is_signed && bits < 32 && (v >> (bits - 1))) v |= ~mask;
+    linear[e] = v;
+  } else {
     *w = (*w & ~(mask << shift)) | ((linear[e] & mask) << shift);
+  }
+}
+// "ep_return": int32, bits 0..15 above the left timer, bits 16..31 above the right timer
+__global__ __launch_bounds__(SF_BLOCK) void sf_epret_copy_kernel(unsigned char* state, int n_envs, int32_t* linear, int to_linear) {
+  const long e = (long)blockIdx.x * SF_BLOCK + threadIdx.x;
+  if (e >= n_envs) return;
+  unsigned char* tile = state + (e >> 6) * sfl::kTileBytes;
+  uint32_t* wl = reinterpret_cast<uint32_t*>(tile + sfl::chunk_offset(SF_G_timers_a, 0) + (e & 63) * 16 + 12);
+  uint32_t* wr = reinterpret_cast<uint32_t*>(tile + sfl::chunk_offset(SF_G_timers_b, 0) + (e & 63) * 16);
+  if (to_linear) {
+    linear[e] = (int32_t)((*wl >> 16) | (*wr & 0xFFFF0000u));
+  } else {
+    const uint32_t v = (uint32_t)linear[e];
+    *wl = (*wl & 0xFFFFu) | (v << 16);
+    *wr = (*wr & 0xFFFFu) | (v & 0xFFFF0000u);
+  }
 }
 
 // The missile fields, per env and slot as the reference has them (mMissiles[i], SRC/game.hh:90), from / to the tile's pool.
@@ -1687,10 +1721,14 @@ hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, uns
     hipLaunchKernelGGL(sf_stats_copy_kernel, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, (int32_t*)linear, to_linear);
     return hipGetLastError();
   }
-  if (m.kind == SF_FK_MASK || m.kind == SF_FK_KILLS) {
-    const bool kills = m.kind == SF_FK_KILLS;
-    hipLaunchKernelGGL(sf_bits_copy_kernel, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, kills ? 12 : m.byte_in_chunk,
-                       kills ? SF_KILLS_SHIFT : 0, kills ? 0xFFu : SF_MASK_LOW, (uint32_t*)linear, to_linear);
+  if (m.kind == SF_FK_BITS) {
+    const sfl::BitField bf = sfl::bit_field(field);
+    hipLaunchKernelGGL(sf_bits_copy_kernel, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs,
+                       sfl::group_offset(m.group) + m.byte_in_chunk, bf.shift, bf.bits, bf.is_signed, (uint32_t*)linear, to_linear);
+    return hipGetLastError();
+  }
+  if (m.kind == SF_FK_EPRET) {
+    hipLaunchKernelGGL(sf_epret_copy_kernel, dim3(grid), dim3(SF_BLOCK), 0, stream, state, n_envs, (int32_t*)linear, to_linear);
     return hipGetLastError();
   }
   if (m.kind == SF_FK_MPOOL) return hipErrorInvalidValue;  // sf_capi.cpp goes through the slot view (sf_launch_mslot_component)

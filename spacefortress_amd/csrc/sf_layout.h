@@ -9,13 +9,13 @@
 //     widest, fully coalesced access the hardware has (the guide's 16 B/lane rule);
 //   * C(group, slot) is a COMPILE-TIME constant: the whole state of a wave hangs off one
 //     scalar base (an SGPR pair) plus one per-lane offset per chunk size;
-//   * the per-episode counters (statistics, episode sums) ride in the lane's own chunks as narrow integers -- an
-//     episode is 5 295 ticks, so 8 / 16 bits hold them (see `counts` below): no atomics, no extra round trips;
+//   * the per-episode counters (statistics, episode sums) ride in the spare bits of words the lane moves anyway -- an
+//     episode is 5 295 ticks, so 8 / 12 / 16 bits hold them (SF_W_* below): no atomics, no extra round trips, no bytes;
 //   * live missiles are NOT stored per env and slot: a tile keeps them as one dense POOL of entries
 //     (x, y | heading, owner lane, slot), `missile_pos` / `missile_meta` rows of 64 entries, which the wave moves a
 //     row at a time, every lane busy, and compacts in place with a ballot + prefix count as entries leave
 //     (per env and slot, two lanes in ten had a missile in a slot the wave had to walk anyway);
-//   * a wave's working set is one 73 KB block: page- and channel-local.
+//   * a wave's working set is one 72 KB block: page- and channel-local.
 // History: batch-wide [field][N] arrays -> a quarter of the instructions
 // were per-field 64-bit address math and SGPR spills; per-tile [field][64] rows -> 24 loads and
 // 23 stores of 1-8 bytes per lane and step; this layout -> 7 + 7.
@@ -32,12 +32,11 @@
 #define SF_GROUPS(G)                                                                            \
   G(ship_pos, 16, 1)              /* ship_x, ship_y */                                          \
   G(ship_vel, 16, 1)              /* ship_vx, ship_vy */                                        \
-  G(timers_a, 16, 1)              /* prev_vlner; fire, thrust, left timers (all first read late in the tick) */                   \
-  G(timers_b, 16, 1)              /* right, fort, fort_death, fort_vuln timers */               \
-  G(score, 16, 1)                 /* points, raw_points, vlner, time */                         \
+  G(timers_a, 16, 1)              /* prev_vlner; fire, thrust, left timers (all first read late in the tick; packed, SF_W_*) */                   \
+  G(timers_b, 16, 1)              /* right (packed, SF_W_*), fort, fort_death, fort_vuln timers */               \
+  G(score, 16, 1)                 /* points, raw_points, vlner, time (the last two packed, SF_W_*) */                         \
   G(misc, 16, 1)                  /* ship_death timer, spawn_cursor, missile word, shell word (SF_MASK_BITS): what the respawn and the slot allocation need first */ \
   G(small, 16, 1)                 /* ship_angle, fort_angle, fort_last_angle (i16), flags (u8), last_reward (i8); then the four key-press counters of `stats` as u16 (see SF_KEYCOUNT_BYTE) */ \
-  G(counts, 16, 1)                /* ep_return (i32); resets, missed, vlner_incs, max_vlner (u16); big-hex, small-hex, shell deaths, destroyed (u8): SF_CNT_* */ \
   G(missile_pos, 16, SF_NSLOT)    /* the tile's missile pool: entry e = row e / 64, lane e % 64: (x, y) */ \
   G(missile_meta, 4, SF_NSLOT)    /* ... and its (heading | owner lane << 9 | slot << 15): SF_MM_* */      \
   G(shell_pos, 16, SF_NSLOT)      /* shell_x, shell_y */                                        \
@@ -53,14 +52,14 @@ enum SfGroupId {
 // X(name, ctype, count, is_float, group, byte offset inside the lane's chunk, kind)
 // `count` = elements per env.  Reference members in the comments.  kind: SF_FK_PLAIN = `count` slots of `group`, one
 // element at `byte offset` of the lane's chunk; the other kinds are assembled by sf_launch_field_copy:
-//   SF_FK_MASK    the low SF_MASK_BITS bits of a misc word (the upper bits carry the pool count / ep_kills)
-//   SF_FK_STATS   the 13 counters of SRC/game.hh:29-43 from `counts`, `small` and (ship deaths) their sum
-//   SF_FK_KILLS   ep_kills, the top byte of the shell word
+//   SF_FK_BITS    a bit field of the 32-bit word at `byte offset` (shift, width, sign: SF_BITFIELDS below)
+//   SF_FK_STATS   the 13 counters of SRC/game.hh:29-43 from their bit fields and (ship deaths) their sum
+//   SF_FK_EPRET   ep_return, an int32 carried as two 16-bit halves
 //   SF_FK_MPOOL   per-slot missile values, gathered from / scattered into the tile's pool by owner and slot
 #define SF_FK_PLAIN 0
-#define SF_FK_MASK 1
+#define SF_FK_BITS 1
 #define SF_FK_STATS 2
-#define SF_FK_KILLS 3
+#define SF_FK_EPRET 3
 #define SF_FK_MPOOL 4
 #define SF_FIELDS(X)                                                                                        \
   X(ship_x, double, 1, 1, ship_pos, 0, SF_FK_PLAIN)           /* mShip.mPos.mX            SRC/object.hh:5 */            \
@@ -74,24 +73,24 @@ enum SfGroupId {
   X(shell_vx, double, SF_NSLOT, 1, shell_vel, 0, SF_FK_PLAIN)                                                           \
   X(shell_vy, double, SF_NSLOT, 1, shell_vel, 8, SF_FK_PLAIN)                                                           \
   X(ship_death_timer, int32_t, 1, 0, misc, 0, SF_FK_PLAIN) /* mShip.mDeathTimer       SRC/game.hh:60-64 */          \
-  X(fire_timer, int32_t, 1, 0, timers_a, 4, SF_FK_PLAIN)                                                                \
-  X(thrust_timer, int32_t, 1, 0, timers_a, 8, SF_FK_PLAIN)                                                              \
-  X(left_timer, int32_t, 1, 0, timers_a, 12, SF_FK_PLAIN)                                                               \
-  X(right_timer, int32_t, 1, 0, timers_b, 0, SF_FK_PLAIN)                                                               \
+  X(fire_timer, int32_t, 1, 0, timers_a, 4, SF_FK_BITS)                                                                 \
+  X(thrust_timer, int32_t, 1, 0, timers_a, 8, SF_FK_BITS)                                                               \
+  X(left_timer, int32_t, 1, 0, timers_a, 12, SF_FK_BITS)                                                                \
+  X(right_timer, int32_t, 1, 0, timers_b, 0, SF_FK_BITS)                                                                \
   X(fort_timer, int32_t, 1, 0, timers_b, 4, SF_FK_PLAIN)      /* mFortress.mTimer         SRC/game.hh:77 */             \
   X(fort_death_timer, int32_t, 1, 0, timers_b, 8, SF_FK_PLAIN)                                                          \
   X(fort_vuln_timer, int32_t, 1, 0, timers_b, 12, SF_FK_PLAIN)                                                          \
   X(points, float, 1, 1, score, 0, SF_FK_PLAIN)               /* mScore                   SRC/game.hh:49-52 */          \
   X(raw_points, float, 1, 1, score, 4, SF_FK_PLAIN)                                                                     \
-  X(vlner, int32_t, 1, 0, score, 8, SF_FK_PLAIN)                                                                        \
-  X(time, int32_t, 1, 0, score, 12, SF_FK_PLAIN)              /* mTime (mTick = mTime / tick_ms) SRC/game.hh:93 */      \
-  X(stats, int32_t, SF_NSTAT, 0, counts, 0, SF_FK_STATS)      /* mStats                   SRC/game.hh:29-43 */          \
-  X(prev_vlner, int32_t, 1, 0, timers_a, 0, SF_FK_PLAIN)       /* SSF_Env.prev_vlner       ENV:92,244 */                 \
-  X(spawn_cursor, uint32_t, 1, 0, misc, 4, SF_FK_PLAIN)       /* position in the process's rand() spawn sequence */     \
-  X(missile_mask, uint32_t, 1, 0, misc, 8, SF_FK_MASK)        /* bit i = mMissiles[i].mAlive */                         \
-  X(shell_mask, uint32_t, 1, 0, misc, 12, SF_FK_MASK)         /* bit i = mShells[i].mAlive */                           \
-  X(ep_return, int32_t, 1, 0, counts, 0, SF_FK_PLAIN)         /* running sum of wrapper rewards (rl/train.py:84) */     \
-  X(ep_kills, int32_t, 1, 0, misc, 15, SF_FK_KILLS)           /* running sum of info (rl/train.py:81) */                \
+  X(vlner, int32_t, 1, 0, score, 8, SF_FK_BITS)                                                                         \
+  X(time, int32_t, 1, 0, score, 12, SF_FK_BITS)               /* mTime (mTick = mTime / tick_ms) SRC/game.hh:93 */      \
+  X(stats, int32_t, SF_NSTAT, 0, misc, 0, SF_FK_STATS)       /* mStats                   SRC/game.hh:29-43 */          \
+  X(prev_vlner, int32_t, 1, 0, timers_a, 0, SF_FK_BITS)        /* SSF_Env.prev_vlner       ENV:92,244 */                 \
+  X(spawn_cursor, uint32_t, 1, 0, misc, 4, SF_FK_BITS)        /* position in the process's rand() spawn sequence */     \
+  X(missile_mask, uint32_t, 1, 0, misc, 8, SF_FK_BITS)        /* bit i = mMissiles[i].mAlive */                         \
+  X(shell_mask, uint32_t, 1, 0, misc, 12, SF_FK_BITS)         /* bit i = mShells[i].mAlive */                           \
+  X(ep_return, int32_t, 1, 0, timers_a, 12, SF_FK_EPRET)         /* running sum of wrapper rewards (rl/train.py:84) */     \
+  X(ep_kills, int32_t, 1, 0, misc, 12, SF_FK_BITS)            /* running sum of info (rl/train.py:81) */                \
   X(ship_angle, int16_t, 1, 0, small, 0, SF_FK_PLAIN)         /* mShip.mAngle: always an integer in [0,360) */          \
   X(fort_angle, int16_t, 1, 0, small, 2, SF_FK_PLAIN)         /* mFortress.mAngle: multiple of the sector size */       \
   X(fort_last_angle, int16_t, 1, 0, small, 4, SF_FK_PLAIN)    /* mFortress.mLastAngle */                                \
@@ -106,22 +105,44 @@ enum SfFieldId {
       SF_F_COUNT
 };
 
-// The 13 statistics of SRC/game.hh:29-43 are per-episode counts (zeroed with a new game); an episode has 5 295 ticks,
-// a key can be pressed once per two ticks, a ship dies at most once per 31 ticks and a fortress once per ~90, so they
-// fit narrow integers inside chunks every step loads and stores anyway -- no atomics, no counter rows:
-//   * shots, thrusts, lefts, rights (stats[7..10]): four uint16 at bytes 8..15 of the lane's `small` chunk;
-//   * `counts` chunk: ep_return int32 | resets, missed, vlner_incs, max_vlner uint16 | big-hex, small-hex, shell
-//     deaths, destroyed uint8 (<= 171 / 58 per episode);
-//   * ship deaths (stats[3]) = big-hex + small-hex + shell deaths: killShip has exactly those three call sites
-//     (SRC/game.cpp:339,345,413), so the sum is not stored;
-//   * ep_kills (sum of info, <= 58) is the top byte of the shell word.
-// sf_get_field / sf_set_field("stats") put the sources together, so the field is the reference's 13 ints.
+// Packed words.  The 13 statistics of SRC/game.hh:29-43 and the two episode sums are per-episode counts (zeroed with a new
+// game); an episode has 5 295 ticks, a key can be pressed once per two ticks, a ship dies at most once per 31 ticks and a
+// fortress once per ~90, so 8 / 12 / 16 bits hold them -- and the words of the lane's chunks have that much room to spare:
+// the key timers move by one per tick (+-5 295), vlner by one per hit, time is 34 ms per tick, the spawn cursor indexes a
+// table of at most 2^24 entries.  No atomics, no counter rows, no bytes of their own.
+//   word                      bits  0..                                   above
+//   timers_a.0  SF_W_PVL      prev_vlner 12                               vlner_incs 12 (<< 12), big-hex deaths 8 (<< 24)
+//   timers_a.4  SF_W_FIRE     fire timer, int16                           resets 16 (<< 16)
+//   timers_a.8  SF_W_THRUST   thrust timer, int16                         missed 16 (<< 16)
+//   timers_a.12 SF_W_LEFT     left timer, int16                           ep_return bits 0..15 (<< 16)
+//   timers_b.0  SF_W_RIGHT    right timer, int16                          ep_return bits 16..31 (<< 16)
+//   score.8     SF_W_VLNER    vlner 12                                    max_vlner 12 (<< 12), small-hex deaths 8 (<< 24)
+//   score.12    SF_W_TIME     time 24 (ms)                                shell deaths 8 (<< 24)
+//   misc.4      SF_W_CURSOR   spawn cursor 24                             destroyed 8 (<< 24)
+//   misc.8                    missile alive mask 20                       the tile's missile pool count 12 (<< 20)
+//   misc.12                   shell alive mask 20                         ep_kills 8 (<< 24)
+//   small.8..15               shots, thrusts, lefts, rights as four uint16 (SF_KEYCOUNT_BYTE)
+// Ship deaths (stats[3]) = big-hex + small-hex + shell deaths: killShip has exactly those three call sites
+// (SRC/game.cpp:339,345,413), so the sum is not stored.  Limits that follow: a key timer saturates nowhere but wraps
+// after 32 767 ticks without an edge of its key (six episodes' worth; every new game zeroes it), `time` after 2^24 ms
+// (4.6 hours of game time without a new game: auto_reset off and a caller that never resets).
+// sf_get_field / sf_set_field see plain ints: SF_BITFIELDS says where each one lives.
 #define SF_KEYCOUNT_BYTE 8
 #define SF_ST_KEY_FIRST 7 /* SF_ST_SHOTS */
 #define SF_ST_KEY_COUNT 4
-#define SF_CNT_RETURN_BYTE 0 /* int32 */
-#define SF_CNT_U16_BYTE 4    /* resets, missed, vlner_incs, max_vlner */
-#define SF_CNT_U8_BYTE 12    /* big-hex, small-hex, shell deaths, destroyed */
+// B(field, shift, bits, is_signed): the bit field of the word at the field's (group, byte offset)
+#define SF_BITFIELDS(B)          \
+  B(prev_vlner, 0, 12, 0)        \
+  B(fire_timer, 0, 16, 1)        \
+  B(thrust_timer, 0, 16, 1)      \
+  B(left_timer, 0, 16, 1)        \
+  B(right_timer, 0, 16, 1)       \
+  B(vlner, 0, 12, 0)             \
+  B(time, 0, 24, 0)              \
+  B(spawn_cursor, 0, 24, 0)      \
+  B(missile_mask, 0, 20, 0)      \
+  B(shell_mask, 0, 20, 0)        \
+  B(ep_kills, 24, 8, 0)
 // misc words: the two alive masks use SF_MASK_BITS bits; above them ride the tile's pool count (the same value in
 // every lane of the tile, so that any lane's chunk tells how many pool entries are live) and ep_kills
 #define SF_MASK_BITS 20
@@ -166,8 +187,8 @@ constexpr long group_offset(int g) {
   for (int i = 0; i < g; i++) o += (long)kGroups[i].chunk * kGroups[i].slots * kTileLanes;
   return o;
 }
-constexpr long kTileBytes = group_offset(SF_G_COUNT);          // 74 752 B
-constexpr long kBytesPerLane = kTileBytes / kTileLanes;        // 1168 B
+constexpr long kTileBytes = group_offset(SF_G_COUNT);          // 73 728 B
+constexpr long kBytesPerLane = kTileBytes / kTileLanes;        // 1152 B
 // byte offset, inside a tile, of lane 0's chunk of (group g, slot s)
 constexpr long chunk_offset(int g, int s = 0) { return group_offset(g) + (long)s * kGroups[g].chunk * kTileLanes; }
 
@@ -175,6 +196,19 @@ struct FieldMeta {
   const char* name;
   int elem_size, count, is_float, group, byte_in_chunk, kind;
 };
+struct BitField {
+  int field, shift, bits, is_signed;
+};
+constexpr BitField kBitFields[] = {
+#define B(name, shift, bits, sgn) {SF_F_##name, shift, bits, sgn},
+    SF_BITFIELDS(B)
+#undef B
+};
+constexpr BitField bit_field(int f) {
+  for (const BitField& b : kBitFields)
+    if (b.field == f) return b;
+  return BitField{-1, 0, 32, 0};
+}
 constexpr FieldMeta kFields[SF_F_COUNT] = {
 #define X(name, ctype, count, isf, group, off, kind) {#name, (int)sizeof(ctype), count, isf, SF_G_##group, off, kind},
     SF_FIELDS(X)

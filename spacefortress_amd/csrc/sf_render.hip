@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   const unsigned mmask = (SF_RENDER_SKIP & 2) ? 0u : ((unsigned)mi.z & SF_MASK_LOW),
                  smask = (SF_RENDER_SKIP & 2) ? 0u : ((unsigned)mi.w & SF_MASK_LOW);
   const int pnts = (int)__int_as_float(sc.x);  // drawScore takes mScore.mPoints as an int (SRC/draw.cpp:190,266)
-  const int vlner = sc.z;
+  const int vlner = sc.z & 0xFFF;  // the low 12 bits of the packed word (sf_layout.h: SF_W_VLNER)
   const int fort_vuln_timer = tb.w;
   const float ship_x = (float)sp.x, ship_y = (float)sp.y;
   const bool ship_alive = flags & SF_FL_SHIP_ALIVE;
