@@ -894,8 +894,19 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // the groups reach well past the common case: the dependent-load loop behind them is for slots hardly ever used.
   // (Missiles need no second round trip: the tile's pool rows came with the first.)
   double shx[SF_SPF], shy[SF_SPF], shvx[SF_SPF], shvy[SF_SPF];
+#ifndef SF_SHELL_INIT
+#define SF_SHELL_INIT 0
+#endif
 #pragma unroll
-  for (int s = 0; s < SF_SPF; s++) shx[s] = shy[s] = shvx[s] = shvy[s] = 0;
+  for (int s = 0; s < SF_SPF; s++) {
+    if (FUSED || SF_SHELL_INIT) {
+      shx[s] = shy[s] = shvx[s] = shvy[s] = 0;
+    } else {
+      // one tick per launch: a slot's registers are read only under the same wave-wide test that loaded them, and what a
+      // lane without a shell in the slot computes from them is masked out (`live`): whatever the registers hold will do
+      asm volatile("" : "=v"(shx[s]), "=v"(shy[s]), "=v"(shvx[s]), "=v"(shvy[s]));
+    }
+  }
   // a dead ship whose explosion is over respawns this tick (SRC/game.cpp:151-157): fetch its
   // entry of the spawn sequence now, not in the middle of the arithmetic
   bool will_respawn = !(L.fl & SF_FL_SHIP_ALIVE) && L.death_t >= sfc::explode_duration;
