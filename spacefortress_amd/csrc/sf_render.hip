@@ -61,22 +61,26 @@ struct Quad {
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
-// mean over t in [0,1] of clamp(ya + t*(yb-ya), 0, 1)
+// mean over t in [0,1] of clamp(ya + t*(yb-ya), 0, 1).  Branch-free on purpose: an `if` on per-pixel data is an
+// exec-mask save / branch / restore (six scalar instructions and two hand-offs) around a dozen vector ones, four
+// times per pixel; both forms are evaluated and one is selected -- the same arithmetic on the path taken, so the
+// same pixels (the discarded form may hold an inf or a NaN: a select does not look at it).
 __device__ __forceinline__ float ramp_mean(float ya, float yb) {
-  float lo = fminf(ya, yb), d = fabsf(yb - ya);  // the mean does not depend on the direction
-  if (d < 1e-6f) return clamp01(lo + 0.5f * d);
+  const float lo = fminf(ya, yb), d = fabsf(yb - ya);  // the mean does not depend on the direction
+  const float flat = clamp01(lo + 0.5f * d);
   const float inv = __builtin_amdgcn_rcpf(d);  // 1 ulp: moves a coverage by 1e-7, far below one grey level
   const float ta = clamp01(-lo * inv), tb = clamp01((1.0f - lo) * inv);
-  return (1.0f - tb) + (tb - ta) * (lo + 0.5f * d * (ta + tb));
+  const float ramp = (1.0f - tb) + (tb - ta) * (lo + 0.5f * d * (ta + tb));
+  return d < 1e-6f ? flat : ramp;
 }
 
 // one directed edge's share of the integral of clamp(y, 0, 1) dx over the pixel at the origin
 __device__ __forceinline__ float edge_term(float x0, float y0, float x1, float y1) {
   const float xa = clamp01(x0), xb = clamp01(x1);
   const float w = xb - xa;
-  if (w == 0.f) return 0.f;
   const float slope = (y1 - y0) * __builtin_amdgcn_rcpf(x1 - x0);
-  return w * ramp_mean(y0 + (xa - x0) * slope, y0 + (xb - x0) * slope);
+  const float t = w * ramp_mean(y0 + (xa - x0) * slope, y0 + (xb - x0) * slope);
+  return w == 0.f ? 0.f : t;
 }
 
 // area of quad /\ pixel [px,px+1]x[py,py+1]:  | sum over edges of the integral of clamp(y,0,1) dx |

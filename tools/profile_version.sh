@@ -34,7 +34,7 @@ tr = glob.glob(os.path.join(out, "kt", "**", "*kernel_trace.csv"), recursive=Tru
 per = {}
 for r in csv.DictReader(open(tr)):
     if "sf_step_kernel" in r["Kernel_Name"]:
-        k = "%s grid %s" % (r["Kernel_Name"].split("(")[0], r["Grid_Size"])
+        k = "%s grid %s" % (r["Kernel_Name"].split("(")[0], r.get("Grid_Size") or r["Grid_Size_X"])
         per.setdefault(k, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 rep = {}
 for k, v in per.items():
