@@ -59,6 +59,8 @@ struct Quad {
   float x[4], y[4];
 };
 
+#include "sf_render_tables.h"  // kArcs[7][12], kGon[12], kSinCosDeg[360]
+
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
 // mean over t in [0,1] of clamp(ya + t*(yb-ya), 0, 1).  Branch-free on purpose: an `if` on per-pixel data is an
@@ -346,8 +348,13 @@ __device__ __forceinline__ Quad line_quad(const float* ln, float ca, float sa, f
   return q;
 }
 
-__device__ __forceinline__ void sincos_deg(float deg, float* s, float* c) {
-  sincosf(deg * 0.017453292519943295f, s, c);
+// every wireframe heading is an integer number of degrees in [0, 360) (the state keeps them as int16; a shell's is
+// truncated to an int like drawWireFrame does): one 8-byte load from a 2.9 KB table instead of a sincosf
+__device__ __forceinline__ void sincos_deg(int deg, float* s, float* c) {
+  deg = deg < 0 ? 0 : (deg > 359 ? 359 : deg);  // (never out of range for a state the step kernel produced)
+  const float2 sc = *reinterpret_cast<const float2*>(kSinCosDeg[deg]);
+  *s = sc.x;
+  *c = sc.y;
 }
 
 // wireframe segments (ax, ay, bx, by), SRC/wireframe.cpp:11-67
@@ -360,7 +367,6 @@ __constant__ float kShellLines[4][4] = {{-8, 0, 0, -6}, {0, -6, 16, 0}, {16, 0, 
 // 30k + 3(i+1) degrees, each its own stroke, then one radius-7 circle.  An arc is one chord quad
 // between radius -/+ half the line width; the circle is ONE stroke: the ring between two regular
 // 12-gons.  cos/sin of every angle involved are compile-time constants.
-#include "sf_render_tables.h"  // kArcs[7][12], kGon[12]
 
 __device__ __forceinline__ Quad arc_quad(const ArcCS& t, float radius, float cx, float cy) {
   const float ri = radius - (float)(SF_LINE_W / 2), ro = radius + (float)(SF_LINE_W / 2);
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
     if (mvalid) {
       const float* t = mtab + 3 * slot;
       float s, c;
-      sincos_deg(t[2], &s, &c);
+      sincos_deg((int)t[2], &s, &c);
       mq = line_quad(kMissileLines[k], c, s, t[0], t[1]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
         double ang = atan2(v.y, v.x) * 180.0 / M_PI;
         if (ang < 0) ang += 360.0;
         float sn, cs;
-        sincos_deg((float)(int)ang, &sn, &cs);
+        sincos_deg((int)ang, &sn, &cs);
         sq[round] = line_quad(kShellLines[k], cs, sn, (float)s.x, (float)s.y);
       }
       svalid[round] = valid;
@@ -786,7 +792,7 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
   if (SF_RENDER_SKIP & 1) {
   } else if (ship_alive) {
     float s, c;
-    sincos_deg((float)ship_angle, &s, &c);
+    sincos_deg(ship_angle, &s, &c);
     const Quad q = line_quad(kShipLines[lane < 3 ? lane : 0], c, s, ship_x, ship_y);
     F.draw_objects(q, 255, lane < 3, 4);
   } else {
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
       fort_patch_copy(F, const_cast<unsigned char*>(a.fpatch) + sector * SF_FP_BYTES, false);
     } else {
       float s, c;
-      sincos_deg((float)fort_angle, &s, &c);
+      sincos_deg(fort_angle, &s, &c);
       const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
       F.draw_quads(q, 255, lane < 4, 64);
     }
@@ -878,7 +884,7 @@ __global__ __launch_bounds__(64) void sf_fort_patch_kernel(const uint32_t* bg, c
   __syncthreads();
   const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, lane, qscr, mscr};
   float s, c;
-  sincos_deg((float)(10 * sector), &s, &c);
+  sincos_deg(10 * sector, &s, &c);
   const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
   F.draw_quads(q, 255, lane < 4, 64);
   // (draw_quads has resampled what the strokes touch; the rest of the patch keeps the background's values,
