@@ -825,7 +825,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // Half of the workgroups (every other one of an XCD's: workgroup i runs on XCD i % 8) start a third of a microsecond
   // late: a launch is a chip-wide load burst, then arithmetic with the fabric idle, then a store burst; staggered, one
   // half's bursts meet the other half's arithmetic.
-  if ((blockIdx.x >> 3) & 1u) __builtin_amdgcn_s_sleep(SF_STAGGER);
+  if (gridDim.x >= 256u && ((blockIdx.x >> 3) & 1u)) __builtin_amdgcn_s_sleep(SF_STAGGER);  // (a grid that leaves CUs idle has no burst to split)
 #endif
   // ================= round trip 1: every unconditional load =================
   auto load_action = [&](int step) __attribute__((always_inline)) -> int {  // ENV:211-212
