@@ -650,7 +650,7 @@ __device__ __forceinline__ void flush_features_f32(const float* stage_w, float* 
     if (k * 64 + 63 < NV || (int)lane + k * 64 < NV) v[k] = reinterpret_cast<const f4_t*>(stage_w)[lane + k * 64];
 #pragma unroll
   for (int k = 0; k < IT; k++)
-    if (k * 64 + 63 < NV || (int)lane + k * 64 < NV) {
+    if (SF_ABL_OBS != 2 && (k * 64 + 63 < NV || (int)lane + k * 64 < NV)) {  // SF_ABL_OBS 2 (timing-only): no global stores
 #if SF_OBS_SC1
       sf_store<f4_t>(reinterpret_cast<f4_t*>(dst_w) + lane + k * 64, v[k]);  // write-through, like the state chunks
 #else
@@ -825,7 +825,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // Half of the workgroups (every other one of an XCD's: workgroup i runs on XCD i % 8) start a third of a microsecond
   // late: a launch is a chip-wide load burst, then arithmetic with the fabric idle, then a store burst; staggered, one
   // half's bursts meet the other half's arithmetic.
-  if (gridDim.x >= 256u && ((blockIdx.x >> 3) & 1u)) __builtin_amdgcn_s_sleep(SF_STAGGER);  // (a grid that leaves CUs idle has no burst to split)
+  // (a batch that leaves CUs idle has no burst to split; the batch size is a preloaded kernel argument, gridDim is a load)
+  if (n_envs_p > 65536 - 256 && ((blockIdx.x >> 3) & 1u)) __builtin_amdgcn_s_sleep(SF_STAGGER);
 #endif
   // ================= round trip 1: every unconditional load =================
   auto load_action = [&](int step) __attribute__((always_inline)) -> int {  // ENV:211-212
@@ -1477,12 +1478,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
   }
   SF_STAMP(7, false);
-  if constexpr (SF_ABL_OBS != 0) {
+  if constexpr (SF_ABL_OBS == 1) {  // timing-only: no observation at all
   } else if constexpr (OBSK == 1) {  // the host guarantees: features, float32, n_envs % 64 == 0, aligned output (sf_launch_step)
     constexpr int DIM = AUTOTURN ? 17 : 19;
-    const Extras e = compute_extras(a, L, a_pos, a_vel);
     float* stage = reinterpret_cast<float*>(lds + SF_LDS_STAGE);
-    write_features_f32<DIM>(stage + tid * DIM, L, e, a.real_shell_count);
+    if (SF_ABL_OBS != 3) {  // SF_ABL_OBS 3 (timing-only): the stores alone, of whatever the staging rows hold
+      const Extras e = compute_extras(a, L, a_pos, a_vel);
+      write_features_f32<DIM>(stage + tid * DIM, L, e, a.real_shell_count);
+    }
     if ((i & ~63u) < (unsigned)n_envs_p)  // the padding waves behind the batch write nothing
       flush_features_f32<DIM>(stage + (tid & ~63u) * DIM, (float*)obs + (so + (i & ~63u)) * DIM, lane);
   } else if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid
