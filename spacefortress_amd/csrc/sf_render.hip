@@ -622,7 +622,10 @@ __device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned
 
 
 template <bool RESIZE>
-__global__ __launch_bounds__(64) void sf_render_kernel(SfRenderArgs a) {
+#ifndef SF_RENDER_WPE
+#define SF_RENDER_WPE 4 /* waves per SIMD the register budget is held to: 129 VGPRs (3 waves) without it */
+#endif
+__global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
 #if SF_RENDER_TABS_IN_LDS
   __shared__ __attribute__((aligned(16))) uint32_t tabw[RESIZE ? SF_TAB_WORDS : 4];
