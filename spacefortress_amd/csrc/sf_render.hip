@@ -271,8 +271,8 @@ struct Frame {
   // -- the same arithmetic in the same order as stroke by stroke, in about a third of the instructions.
   __device__ __forceinline__ void draw_objects(const Quad& mine, int grey, bool valid, int per) const {
     const Box myb = quad_box(mine);
-    const int mybw = myb.x1 - myb.x0;
-    const int myn = (valid && !myb.empty()) ? mybw * (myb.y1 - myb.y0) : 0;
+    const int mybw = myb.x1 - myb.x0, mybh = myb.y1 - myb.y0;
+    const int myn = (valid && !myb.empty()) ? mybw * mybh : 0;
     unsigned long long live = __ballot(myn > 0);
     while (live) {
       const int lo = (__builtin_ctzll(live) / per) * per;
@@ -289,7 +289,7 @@ struct Frame {
         bx0[k] = __builtin_amdgcn_readlane(myb.x0, src);
         by0[k] = __builtin_amdgcn_readlane(myb.y0, src);
         bw[k] = on ? __builtin_amdgcn_readlane(mybw, src) : 1;
-        bh[k] = on ? n[k] / bw[k] : 0;
+        bh[k] = on ? __builtin_amdgcn_readlane(mybh, src) : 0;  // (not n / bw: a scalar division is two dozen instructions)
         off[k + 1] = off[k] + n[k];
       }
       const int total = off[4];
