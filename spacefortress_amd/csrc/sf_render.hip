@@ -28,7 +28,8 @@
 #include "sf_raster.h"
 
 // diagnostic builds only (tools/render_ablate.py): bit 0 ship+fortress, 1 missiles+shells, 2 score,
-// 3 bar, 4 the resampling -- each bit removes that phase so its cost can be read off
+// 3 bar, 4 the resampling, 5 the coverage pass of draw_objects, 6 its composite pass -- each bit removes that phase so
+// its cost can be read off
 #ifndef SF_RENDER_SKIP
 #define SF_RENDER_SKIP 0
 #endif
@@ -305,7 +306,7 @@ struct Frame {
         }
       }
       __builtin_amdgcn_wave_barrier();
-      for (int i = lane; i < total; i += 64) {
+      for (int i = lane; i < ((SF_RENDER_SKIP & 32) ? 0 : total); i += 64) {
         const int k = (i >= off[1]) + (i >= off[2]) + (i >= off[3]);
         const int j = i - (k == 0 ? off[0] : k == 1 ? off[1] : k == 2 ? off[2] : off[3]);
         const int w = k == 0 ? bw[0] : k == 1 ? bw[1] : k == 2 ? bw[2] : bw[3];
@@ -329,7 +330,7 @@ struct Frame {
         if (n[k]) u.add(bx0[k], by0[k], bx0[k] + bw[k], by0[k] + bh[k]);
       const int uw = u.x1 - u.x0, un = uw * (u.y1 - u.y0);
       const float r_uw = recip_i(uw);
-      for (int pi = lane; pi < un; pi += 64) {
+      for (int pi = lane; pi < ((SF_RENDER_SKIP & 64) ? 0 : un); pi += 64) {
         const DivMod dm = fast_divmod(pi, uw, r_uw);
         const int ry = dm.q, rx = dm.r;
         const int px = u.x0 + rx, py = u.y0 + ry;
