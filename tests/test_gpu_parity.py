@@ -278,14 +278,9 @@ def test_many_shells_and_kill_order(sfa, oracle_mod):
     env.close()
 
 
-@pytest.mark.parametrize("gametype", ["youturn", "autoturn", "test-youturn"])
-def test_fuzzed_states(sfa, oracle_mod, gametype):
-    """Random CONSTRUCTED states (not reachable by play): ships anywhere in the area, arbitrary
-    velocities and timers, up to 20 missiles and 20 shells per lane, fortress dead or alive, any
-    vulnerability -- loaded into both engines, then 40 random ticks in lock-step."""
-    O = oracle_mod
-    n, T = 1024, 40
-    rng = np.random.default_rng(len(gametype) * 7)
+def _fuzz_base(O, gametype, n, rng):
+    """Random CONSTRUCTED states (not reachable by play): ships anywhere in the area, arbitrary velocities and timers,
+    up to 20 missiles and 20 shells per lane, fortress dead or alive, any vulnerability.  Returns (snapshots, prev_vlner)."""
     base = O.OracleVecEnv(gametype, n).snapshots()
     tab = np.load(os.path.join(GOLDEN, "tables.npz"))["missile_vel_by_angle"]
     base["ship_alive"] = rng.integers(0, 2, n)
@@ -339,20 +334,57 @@ def test_fuzzed_states(sfa, oracle_mod, gametype):
     base["shell_x"] = np.where(hit, (base["ship_x"] + base["ship_vx"])[:, None] - base["shell_vx"] + rng.uniform(-14, 14, (n, 20)), base["shell_x"])
     base["shell_y"] = np.where(hit, (base["ship_y"] + base["ship_vy"])[:, None] - base["shell_vy"] + rng.uniform(-14, 14, (n, 20)), base["shell_y"])
     pv = rng.integers(0, 14, n)
+    return base, pv
+
+
+def _lockstep_from(sfa, O, gametype, base, pv, rng, T, fused=False):
+    n = len(base)
     env, orc = _load_both(sfa, O, gametype, base, prev_vlner=pv)
     acts = rng.integers(0, env.n_actions, (T, n)).astype(np.uint8)
     cps = {}
-    obs, rew, done, info = run_device(env, acts, state_every=10, state_cb=lambda t, sd: cps.__setitem__(t, sd))
+    if fused:
+        a = torch.from_numpy(acts).to(env.device)
+        obs, rew, done, info = (x.cpu().numpy() for x in env.rollout(a))
+        done, info = done.astype(bool), info.astype(bool)
+        cps[T - 1] = env.state_dict()
+    else:
+        obs, rew, done, info = run_device(env, acts, state_every=10, state_cb=lambda t, sd: cps.__setitem__(t, sd))
+    n_done = 0
     for t in range(T):
         oo, orw, od, oi = orc.step(acts[t].astype(np.int32))
         assert np.array_equal(rew[t], orw), (t, np.flatnonzero(rew[t] != orw)[:5])
         assert np.array_equal(done[t], od) and np.array_equal(info[t], oi), t
         ok = obs_close(obs[t], oo, True)
         assert ok.all(), (t, np.argwhere(~ok)[:5])
+        n_done += int(od.sum())
         if t in cps:
             bad = compare_state(cps[t], orc.snapshots())
             assert not bad, (t, bad)
     env.close()
+    return n_done
+
+
+@pytest.mark.parametrize("gametype", ["youturn", "autoturn", "test-youturn"])
+def test_fuzzed_states(sfa, oracle_mod, gametype):
+    """Constructed states loaded into both engines, then 40 random ticks in lock-step."""
+    rng = np.random.default_rng(len(gametype) * 7)
+    base, pv = _fuzz_base(oracle_mod, gametype, 1024, rng)
+    _lockstep_from(sfa, oracle_mod, gametype, base, pv, rng, 40)
+
+
+@pytest.mark.parametrize("gametype,fused", [("youturn", False), ("autoturn", False), ("youturn", True)])
+def test_lanes_of_a_tile_finish_at_different_ticks(sfa, oracle_mod, gametype, fused):
+    """Episodes out of step inside one 64-lane tile: every lane's clock is set so that its game ends at a tick of its
+    own within the run, with up to 20 missiles of its own in the tile's shared pool at that moment.  A lane that starts
+    a new game while its neighbours play on must take exactly its entries out of the pool (and nobody else's)."""
+    rng = np.random.default_rng(11 + len(gametype) + int(fused))
+    n, T = 1024, 48
+    base, pv = _fuzz_base(oracle_mod, gametype, n, rng)
+    base["time"] = 180000 - 34 * rng.integers(1, T - 6, n)  # game over (time >= 180000) after 1 .. T-7 more ticks
+    base["time"][::7] = 34 * 100                              # ... and some lanes nowhere near it
+    base["tick"] = base["time"] // 34
+    n_done = _lockstep_from(sfa, oracle_mod, gametype, base, pv, rng, T, fused=fused)
+    assert n_done >= n - n // 7 - 1
 
 
 @pytest.mark.parametrize("n,f64", [(1, False), (63, True), (65, False), (1000, False), (257, True)])

@@ -280,3 +280,16 @@ def test_ship_wireframe_matches_the_references_own_screenshot():
         assert fine[0] >= 0.97, (name, fine[0], fine[2])
         for lo, hi in fine[1]:
             assert lo <= 0.15 and hi >= 0.85, (name, fine)
+
+
+def test_fast_divmod_of_the_pixel_loops_is_exact():
+    """sf_render.hip: fast_divmod -- i / w as (int)((float)i + 0.5f) * rw) with rw = v_rcp_f32(w), which is allowed to be an
+    ulp off.  Exhaustive over every index of a box of the 90x92 surface and every box width, for 1 / w rounded to
+    nearest and for its two neighbours (float32 arithmetic restated with numpy)."""
+    i = np.arange(0, 90 * 92, dtype=np.int64)
+    fi = i.astype(np.float32) + np.float32(0.5)
+    for w in range(1, 93):
+        r0 = np.float32(1.0) / np.float32(w)
+        for rw in (r0, np.nextafter(r0, np.float32(0)), np.nextafter(r0, np.float32(2))):
+            q = (fi * np.float32(rw)).astype(np.int64)  # float32 product, truncation
+            assert np.array_equal(q, i // w), (w, rw)
