@@ -126,6 +126,11 @@ def main():
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed blocks of --steps launches each, every one bracketed by barrier + synchronize; the line "
                          "reports the MEDIAN block (0 = enough blocks for about 2000 launches in all, at most 101)")
+    ap.add_argument("--launch", choices=("auto", "loop", "graph"), default="auto",
+                    help="how a timed block's K sf_step launches are issued: one by one from Python (loop) or as ONE HIP graph "
+                         "captured once and replayed per block (graph); auto = graph for K <= 512.  A block of a few launches "
+                         "issued one by one starts on an idle GPU with the host barely ahead of it (5 us per call against a "
+                         "6.5 us kernel): the first launches wait for their packets")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--gametype", default="youturn")
     ap.add_argument("--obs-type", default="features")
@@ -229,17 +234,44 @@ def main():
     for t in range(args.warmup):
         step(act_rows[t % ring])
     K = args.steps
+    use_graph = args.launch == "graph" or (args.launch == "auto" and K <= 512)
+    graph = None
+    if use_graph:
+        # the K launches of a block, captured once (sf_step is a pure stream operation: tests/test_gpu_capi_native.py::
+        # test_steps_can_be_captured_in_a_hip_graph); every block replays the same K action rows on the state the
+        # previous block left, so episodes still progress and roll over
+        sync()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for t in range(K):
+                    step(act_rows[t % ring])
+        torch.cuda.current_stream(dev).wait_stream(side)
+        sync()
+        graph.replay()  # one untimed replay: the first one uploads the graph
+        sync()
     blocks, periods = [], []
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     tpos = args.warmup
     for rep in range(repeats):
         # ---- one timed block: EXACTLY K launches, barrier + synchronize on both sides, nothing else inside
         barrier()
-        ev0.record()  # HIP events on the launch stream, bracketing exactly the K launches
         t0 = time.perf_counter()
-        for t in range(tpos, tpos + K):
-            step(act_rows[t % ring])
-        ev1.record()
+        if graph is not None:
+            ev0.record()  # HIP events around the replay: K launch periods + the graph's own launch latency
+            graph.replay()
+            ev1.record()
+        else:
+            step(act_rows[tpos % ring])
+            # HIP events on the launch stream: the first one BEHIND the first launch (it completes when that kernel does),
+            # the second behind the last, so that K - 1 launch periods are measured on the GPU's clock and the host's
+            # latency in front of an idle GPU is not counted as kernel time (the wall clock below counts everything)
+            ev0.record()
+            for t in range(tpos + 1, tpos + K):
+                step(act_rows[t % ring])
+            ev1.record()
         while not ev1.query():  # busy-wait for the last launch (a sleeping wait adds its wake-up time to a 160 us block) ...
             pass
         if dist is not None:    # ... then the contract's synchronize (+ barrier + synchronize when there are other ranks)
@@ -253,12 +285,13 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         blocks.append(elapsed)
-        periods.append(ev0.elapsed_time(ev1) / K)
+        periods.append(ev0.elapsed_time(ev1) / (K if graph is not None else max(1, K - 1)))
     order = sorted(range(repeats), key=lambda r: blocks[r])
     med = order[repeats // 2]
     elapsed = blocks[med]
-    # mean launch-to-launch time of sf_step_kernel over the median block (HIP events): the launches are back to
-    # back on one stream, so this is the kernel duration plus the dependent-launch gap -- a launch PERIOD
+    # mean launch-to-launch time of sf_step_kernel over the median block (HIP events, end of the first launch to end
+    # of the last): the launches are back to back on one stream, so this is the kernel duration plus the
+    # dependent-launch gap -- a launch PERIOD
     region_ms = periods[med]
 
     # ---- the only collective of the path, outside the timed blocks and timed on its own: 64 bytes over RCCL
@@ -269,6 +302,18 @@ def main():
     sync()
     stats_reduce_us = (time.perf_counter() - ts) * 1e6
 
+    # ---- the launch period in steady state, outside the timed blocks: a short block starts on an idle GPU (first-launch
+    #      / graph-launch latency, packets barely ahead of the kernels), so its average reads above what the kernel
+    #      sustains; 2000 back-to-back launches between two HIP events, for the record next to the timed region's figure
+    n_steady = max(K, 2000)
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step(act_rows[0])
+    s0.record()
+    for t in range(1, n_steady + 1):
+        step(act_rows[t % ring])
+    s1.record()
+    sync()
+    steady_ms = s0.elapsed_time(s1) / n_steady
     # ---- each launch bracketed by its own event pair (the events themselves add about 2 us, so this reads high)
     k = min(args.kernel_timing_launches, max(1, args.steps))
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(k)]
@@ -392,6 +437,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "repeats": repeats,
+            "launch": "hip_graph (K sf_step launches captured once, one replay per block)" if use_graph else "loop (one Python call per launch)",
             "block_ms": {"median": elapsed * 1e3, "min": blocks[order[0]] * 1e3, "max": blocks[order[-1]] * 1e3,
                          "first": blocks[0] * 1e3,
                          "note": "each block = exactly `steps` launches between barrier + synchronize brackets (max over "
@@ -413,6 +459,9 @@ def main():
                                             "(profiles/%s), not measured by this run" % (prof.get("version"), prof.get("pmc_file")))
                                            if prof else None,
                          "kernel": "sf_step_kernel", "launch_period_ms": region_ms,
+                         "launch_period_steady_ms": steady_ms, "frac_steady": algo / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "steady_note": "%d back-to-back launches outside the timed blocks; `achieved` / `frac` use the timed "
+                                        "region's period, which for a block of a few launches includes its start on an idle GPU" % n_steady,
                          "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
                          "kernel_ms_rocprof_source": ("rocprofv3 --kernel-trace mean of kernel version %s (profiles/%s)"
                                                       % (prof.get("version"), prof.get("trace_file"))) if prof else None,
