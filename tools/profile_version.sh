@@ -17,7 +17,10 @@ cd /tmp && export TMPDIR=/tmp
 B="--steps 2000 --warmup 200 --no-cpu-baseline"
 python3 $R/bench.py --steps 12000 --warmup 200 > $OUT/${RND}_bench_${VER}.json 2> $OUT/bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py $B > $OUT/${RND}_bench_${VER}_under_rocprof.json 2>> $OUT/bench.err
+# the traced run launches its timed blocks as HIP graphs (512 launches per replay): launched one by one under the profiler the
+# kernels are no longer back to back (its per-dispatch work is on the host) and every one starts on an idle chip
+BT="--steps 512 --warmup 100 --repeats 8 --launch graph --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py $BT > $OUT/${RND}_bench_${VER}_under_rocprof.json 2>> $OUT/bench.err
 echo "kernel trace done"
 SF_PMC_CALIB=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pf -- python3 $R/bench.py $B --rollout-k 0 --image-envs 0 > /dev/null 2>> $OUT/bench.err
 SF_PMC_CALIB=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pw -- python3 $R/bench.py $B --rollout-k 0 --image-envs 0 > /dev/null 2>> $OUT/bench.err
@@ -42,7 +45,7 @@ for k, v in per.items():
     rep[k] = {"calls": len(v), "mean_ns": sum(v) / len(v), "median_ns": v[len(v) // 2], "min_ns": v[0], "max_ns": v[-1]}
 rep["note"] = ("per-dispatch durations (End - Start timestamps) from the same rocprofv3 --kernel-trace --stats run as the "
                "kernel_stats csv, whose sf_step_kernel row mixes this workload's launches with those of bench.py's other legs; "
-               "command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline")
+               "command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 512 --warmup 100 --repeats 8 --launch graph --no-cpu-baseline")
 json.dump(rep, open(os.path.join(out, "%s_kernel_trace_%s_step65536.json" % (rnd, ver)), "w"), indent=1)
 main = [k for k in rep if k.endswith("grid 65536") and ", false, 1>" in k]
 t = json.load(open(os.path.join(out, "%s_pmc_traffic_%s.json" % (rnd, ver))))
