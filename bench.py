@@ -274,13 +274,14 @@ def main():
             ev1.record()
         while not ev1.query():  # busy-wait for the last launch (a sleeping wait adds its wake-up time to a 160 us block) ...
             pass
-        if dist is not None:    # ... then the contract's synchronize (+ barrier + synchronize when there are other ranks)
-            barrier()
-        else:
-            sync()
+        sync()                  # ... then the contract's synchronize: this rank's K launches are done, its clock stops
         elapsed = time.perf_counter() - t0
         tpos += K
         if dist is not None:
+            # the closing barrier of the bracket, and the MAX over ranks: the starts were aligned by the opening barrier, so
+            # the slowest rank's (stop - start) is the job's time for the block; the collective's own latency (tens of
+            # microseconds of RCCL against a 160 us block at K = 20) is not part of anybody's K launches
+            barrier()
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
