@@ -263,4 +263,5 @@ void sf_host_fill_consts(const sf_preset& p, double* c) {
   sf_trig_table(c + SF_LDS_TRIG);
   hex_edges(p.big_hex, c + SF_LDS_BIGHEX);
   hex_edges(p.small_hex, c + SF_LDS_SMALLHEX);
+  for (int k = 0; k < SF_ATAB_DOUBLES; k++) c[SF_CONST_ATAB + k] = k <= 16 ? atan((double)k / 16.0) : 0.0;
 }

@@ -61,7 +61,8 @@
 // LDS map (doubles): [0, SF_LDS_DOUBLES) the cos/sin table; then one (hit, out) pair of 32-bit event words per lane,
 // through which the missile pool's entries tell their owner lanes what happened to them; then the observation staging
 #define SF_LDS_EV SF_LDS_DOUBLES
-#define SF_LDS_STAGE (SF_LDS_DOUBLES + SF_BLOCK)
+#define SF_LDS_ATAB (SF_LDS_DOUBLES + SF_BLOCK) /* atan(k / 16), k = 0..16: sf_atan2_core */
+#define SF_LDS_STAGE (SF_LDS_ATAB + SF_ATAB_DOUBLES)
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #ifndef SF_MROWS
 #define SF_MROWS 3 /* rows of the tile's missile pool (64 entries each) loaded up front with the lane's chunks; more live
@@ -253,9 +254,46 @@ __device__ __forceinline__ double deg2rad(double a) { return SF_DIV(a * M_PI, 18
 // (products exact by FMA; phi, cos, sin of k = 0..180 as (hi, lo) pairs, sf_deg_dd.h), D = x cos k + |y| sin k: the
 // correctly rounded value.  glibc's own atan2 is not correctly rounded in 0.08 % of such arguments (0.503-ulp errors,
 // tools/atan2_razor), so agreement there is 99.9 %, not 100 % -- against a coin toss per tick for the plain device libm.
+// atan2 for the step kernel's hot path, half the instructions of the device libm's: no special cases (the arguments are
+// finite coordinate / velocity differences), the quotient q = min / max in [0, 1] by a reciprocal and Newton steps, then
+// one table step atan(q) = atan(k / 16) + atan(t), t = (q - k/16) / (1 + q k/16), |t| <= 1/32, where five terms of the
+// series leave 3e-18.  `atab` = atan(k / 16), k = 0..16, in LDS (host libm, sf_host_fill_consts).  Within 1e-15 rad of
+// the host libm's atan2 (a few ulps; tests/native/atan2_core.c restates it on the host); everything that needs MORE than
+// that -- the axes, the integer degrees -- is decided by sf_atan2's exact forms below, which do not look at this value's
+// last bits.  (0, 0) gives a NaN: the only caller that can pass it, the velocity bearing, discards the value for a ship
+// at rest.
+__device__ __forceinline__ double sf_recip(double d) {  // 1 / d to an ulp or so, d in the normal range
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+__device__ __forceinline__ double sf_atan2_core(double y, double x, const double* atab) {
+  const double ax = fabs(x), ay = fabs(y);
+  const double u = __builtin_fmax(ax, ay), v = __builtin_fmin(ax, ay);
+  const double ru = sf_recip(u);
+  double q = v * ru;
+  q = __builtin_fma(__builtin_fma(-u, q, v), ru, q);
+  const double k = rint(q * 16.0), c = k * 0.0625;
+  const double den = __builtin_fma(q, c, 1.0), num = q - c;
+  const double rd = sf_recip(den);
+  double t = num * rd;
+  t = __builtin_fma(__builtin_fma(-den, t, num), rd, t);
+  const double s = t * t;
+  double p = __builtin_fma(s, 1.0 / 9.0, -1.0 / 7.0);
+  p = __builtin_fma(s, p, 0.2);
+  p = __builtin_fma(s, p, -1.0 / 3.0);
+  double a = atab[(int)k] + __builtin_fma(t, p * s, t);
+  a = ay > ax ? 1.5707963267948966 - a : a;
+  a = x < 0 ? 3.141592653589793 - a : a;
+  return copysign(a, y);
+}
+#ifndef SF_FAST_ATAN
+#define SF_FAST_ATAN 1 /* 0: the device libm's atan2 everywhere (A/B) */
+#endif
+
 template <bool RAZOR>
-__device__ __forceinline__ double sf_atan2(double y, double x) {
-  double r = atan2(y, x);
+__device__ __forceinline__ double sf_atan2(double y, double x, const double* atab = nullptr) {
+  double r = (SF_FAST_ATAN && atab) ? sf_atan2_core(y, x, atab) : atan2(y, x);
   const double ax = fabs(x), ay = fabs(y);
   const bool ny = ax * 0x1p27 < ay;              // next to the y axis (x == 0 included)
   const bool nx = (x < 0) & (ay * 0x1p27 < ax);  // next to the negative x axis (y == 0 included)
@@ -841,6 +879,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   Lane L;
   load_lane_early(tb, o, L);  // before the action: its address needs two more kernel arguments and a branch on the action type
   int act_next = load_action(0);
+  const unsigned atab_pi = min(tid, (unsigned)(SF_ATAB_DOUBLES / 2 - 1));
+  const d2_t atab_piece = SF_LD(d2_t, (const unsigned char*)consts_p, (SF_CONST_ATAB / 2 + atab_pi) * 16u);
   // cos/sin table: 720 doubles = 360 16-byte pieces, six per lane (the last one partial)
   const unsigned char* cb = (const unsigned char*)consts_p;
   // (threads past the end re-load and re-store the last piece: straight-line code, no exec-masked
@@ -889,6 +929,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // OWNER's words (wave-private: only lanes of this wave own entries of this tile; LDS is in order per wave)
   unsigned long long* const evw = reinterpret_cast<unsigned long long*>(lds + SF_LDS_EV) + (tid & ~63u);
   evw[lane] = 0ull;
+  reinterpret_cast<d2_t*>(lds + SF_LDS_ATAB)[atab_pi] = atab_piece;  // (every lane the same nine pieces: no branch)
 
   // ================= round trip 2: live shell slots, predicated by the alive mask ======
   // Slot groups (pairs): a wave ballot skips a group no lane uses.  The kernel lasts as long as its slowest wave, so
@@ -1037,7 +1078,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   if (L.fl & SF_FL_SHIP_ALIVE) {
     if (AUTOTURN) {
       // stdAngle(ceil(angleTo(ship, fortress)))  (SRC/vector.cpp:42-52)
-      double t = sf_atan2<true>(sfc::fort_y - L.sy, sfc::fort_x - L.sx);
+      double t = sf_atan2<true>(sfc::fort_y - L.sy, sfc::fort_x - L.sx, lds + SF_LDS_ATAB);
       if (t < 0) t += M_PI * 2;
       double c = ceil(rad2deg(t));  // in [0, 360]
       int ia = (int)c;
@@ -1076,14 +1117,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 #if SF_ABL_ATAN == 2
   double a_pos = (L.sy - sfc::fort_y) * 0.001 + (L.sx - sfc::fort_x) * 0.002;
 #else
-  double a_pos = sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x);
+  double a_pos = sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x, lds + SF_LDS_ATAB);
 #endif
 #if SF_ABL_ATAN
   double a_vel = L.vy * 0.5 + L.vx;
 #elif SF_AXIS_VEL
   double a_vel = sf_atan2<false>(L.vy, L.vx);
 #else
-  double a_vel = atan2(L.vy, L.vx);
+  double a_vel = SF_FAST_ATAN ? sf_atan2_core(L.vy, L.vx, lds + SF_LDS_ATAB) : atan2(L.vy, L.vx);
 #endif
 
   // ---- updateFortress (SRC/game.cpp:194-216)

@@ -224,7 +224,9 @@ constexpr FieldMeta kFields[SF_F_COUNT] = {
 #define SF_LDS_TRIG 0
 #define SF_LDS_BIGHEX 720
 #define SF_LDS_SMALLHEX 744
-#define SF_CONST_DOUBLES 768
+#define SF_CONST_ATAB 768 /* atan(k / 16), k = 0..16 (+ one pad): the table of the kernel's atan2 (sf_atan2_core) */
+#define SF_ATAB_DOUBLES 18
+#define SF_CONST_DOUBLES (SF_CONST_ATAB + SF_ATAB_DOUBLES)
 #define SF_LDS_DOUBLES 720 /* what a workgroup stages into LDS: the cos/sin table (indexed per lane) */
 
 // The 12 hexagon edges as Hexagon::isInside forms them (SRC/hexagon.cpp:38-42), X(nx, ny, px, py),

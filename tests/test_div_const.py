@@ -50,3 +50,18 @@ def test_near_axis_atan2_is_glibcs(tmp_path):
                            "-o", exe, "-lm"])
     out = subprocess.run([exe, "4000000"], capture_output=True, text=True)
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout
+
+
+def test_table_step_atan2_is_within_1e_15_of_libm(tmp_path):
+    """sf_atan2_core (sf_kernels.hip), the hot path's atan2 -- reciprocal + Newton quotient, one table step, five series
+    terms -- restated on the host with a float-precision reciprocal seed: within 1e-15 rad (2 ulps) of the host libm on
+    position differences, velocities, the spawn lattice and the table's knots; axes and diagonals to the ulp."""
+    exe = str(tmp_path / "atan2_core")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tests", "native", "atan2_core.c"),
+                           "-o", exe, "-lm"])
+    out = subprocess.run([exe, "4000000"], capture_output=True, text=True)
+    assert out.returncode == 0 and "off by more than 1e-15 rad: 0 of" in out.stdout, out.stdout
+    # the kernel's function is the one restated: same series coefficients, same table step
+    src = open(os.path.join(ROOT, "spacefortress_amd", "csrc", "sf_kernels.hip")).read()
+    for needle in ("rint(q * 16.0)", "__builtin_fma(s, 1.0 / 9.0, -1.0 / 7.0)", "__builtin_fma(q, c, 1.0)"):
+        assert needle in src, needle
