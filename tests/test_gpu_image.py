@@ -275,3 +275,42 @@ def test_explosion_cache_is_invisible(sfa, monkeypatch):
     assert torch.equal(plain.render("image-raw"), cached.render("image-raw"))
     plain.close()
     cached.close()
+
+
+def test_config5_at_its_size_against_the_model(sfa, oracle_mod, model):
+    """BASELINE.json configs[4] as written: youturn, 16 384 envs, the 84x84 grey raster with the trainer's 4-frame stack
+    on the device.  160 random steps through FrameStack; on sampled lanes (the first, the last, some in between) the
+    newest frame of the stack is compared with the numpy model's render of the oracle's state of that lane (90x92
+    surface -> INTER_AREA), and the older slots with the frames of the previous steps."""
+    R, hb, hs, bg = model
+    O = oracle_mod
+    N, S, T = 16384, 4, 160
+    rng = np.random.default_rng(23)
+    pick = np.sort(rng.choice(N, 24, replace=False))
+    pick[0], pick[-1] = 0, N - 1
+    ring = rng.integers(0, 5, (64, N)).astype(np.uint8)
+    env = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=1, reuse_buffers=True)
+    orcs = [O.OracleVecEnv("youturn", 1, spawn_skip=int(l)) for l in pick]
+    fs = sfa.FrameStack(env, S)
+    st = fs.reset()
+    assert st.shape == (N, S, 84, 84) and st.dtype == torch.uint8
+    for o in orcs:
+        o.reset()
+    dring = torch.from_numpy(ring).to(env.device)
+    dpick = torch.from_numpy(pick).to(env.device)
+    hist = []  # the model's 84x84 frames of the sampled lanes, newest last
+    for t in range(T):
+        rew, done, info = fs.step(dring[t % 64])
+        frames = []
+        for j, o in enumerate(orcs):
+            o.step(ring[t % 64, pick[j]:pick[j] + 1].astype(np.int32))
+            if t >= T - S:
+                frames.append(R.resize_area(R.render_raw(o.snapshots()[0], hb, hs, bg=bg)))
+        if t >= T - S:
+            hist.append(np.stack(frames))
+    got = fs.stacked()[dpick].cpu().numpy()  # [picked, S, 84, 84], oldest first
+    for k in range(S):
+        for j in range(len(pick)):
+            frames_close(got[j, k], hist[k][j], ("slot", k, "lane", int(pick[j])))
+    assert not bool(done.any())
+    env.close()
