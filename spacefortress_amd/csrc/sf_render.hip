@@ -28,8 +28,8 @@
 #include "sf_raster.h"
 
 // diagnostic builds only (tools/render_ablate.py): bit 0 ship+fortress, 1 missiles+shells, 2 score,
-// 3 bar, 4 the resampling, 5 the coverage pass of draw_objects, 6 its composite pass -- each bit removes that phase so
-// its cost can be read off
+// 3 bar, 4 the resampling, 5 the coverage pass of draw_objects, 6 its composite pass, 7 the live ship, 8 the dead ship's
+// explosion, 9 the fortress -- each bit removes that phase so its cost can be read off
 #ifndef SF_RENDER_SKIP
 #define SF_RENDER_SKIP 0
 #endif
@@ -819,15 +819,17 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // ---- ship (SRC/draw.cpp:233-237)
   if (SF_RENDER_SKIP & 1) {
   } else if (ship_alive) {
+    if (SF_RENDER_SKIP & 128) goto ship_done;  // (diagnostic: the live ship alone)
     float s, c;
     sincos_deg(ship_angle, &s, &c);
     const Quad q = line_quad(kShipLines[lane < 3 ? lane : 0], c, s, ship_x, ship_y);
     F.draw_objects(q, 255, lane < 3, 4);
-  } else {
+  } else if (!(SF_RENDER_SKIP & 256)) {  // (diagnostic bit 8: the dead ship's explosion alone)
     ship_explosion(F, a.xcache ? a.xcache + (size_t)env * SF_XC_BYTES : nullptr, sp.x, sp.y);
   }
+ship_done:
   // ---- fortress (:238-242)
-  if (SF_RENDER_SKIP & 1) {
+  if (SF_RENDER_SKIP & (1 | 512)) {  // (diagnostic bit 9: the fortress alone)
   } else if (flags & SF_FL_FORT_ALIVE) {
     // what was drawn before the fortress: the ship (within 25.5 + 1.5 user units of its position) or its explosion
     Box sb = explosion_box(ship_x, ship_y);
