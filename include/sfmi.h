@@ -333,6 +333,13 @@ int sf_resize_area_tab(int ssize, int dsize, int32_t* first, int32_t* count, flo
  * background; host memory, row-major */
 int sf_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
 
+/* The launch order of sf_render* (image batches).  The step kernel marks, one 64-bit word per tile of 64 envs, the
+ * envs whose ship died in the tick; the next render launch starts those frames first (the first frame of an
+ * explosion is the expensive one).  The words only decide WHEN a frame is drawn, never what it holds; this entry
+ * overwrites them from host memory (words[ceil(n_envs / 64)]), for tests that check exactly that.  SF_ERR_ARG for a
+ * batch without image observations. */
+int sf_set_render_order_hint(sf_batch* b, const uint64_t* words_host, int n_words);
+
 const char* sf_last_error(void);
 int sf_version(void);
 /* hash of the sources and compiler flags this binary was built from (spacefortress_amd/build.py: source_hash) */

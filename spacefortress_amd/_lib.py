@@ -103,6 +103,7 @@ SYMBOLS = {
     "sf_image_static": (C.c_int, [C.c_int, C.c_void_p]),
     "sf_resize_area_tab": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_resize_area_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "sf_set_render_order_hint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "sf_last_error": (C.c_char_p, []),
     "sf_version": (C.c_int, []),
     "sf_build_id": (C.c_char_p, []),

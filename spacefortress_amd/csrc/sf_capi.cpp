@@ -280,6 +280,11 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   static_assert(sfc::max_ticks == (double)(sfc::game_time / sfc::tick_ms), "ENV:165");
   a.acc = b->d_acc;
   a.dbg = nullptr;
+  a.hint = nullptr;
+  if (image && !getenv("SFMI_NO_RENDER_ORDER")) {  // the render kernel's launch order (sf_render.hip: pick_env)
+    HIP_TRY_FREE(hipMalloc((void**)&a.hint, (size_t)(lanes / 64) * sizeof(unsigned long long)));
+    HIP_TRY_FREE(hipMemset(a.hint, 0, (size_t)(lanes / 64) * sizeof(unsigned long long)));
+  }
 #ifdef SF_STAMPS  // diagnostic build (tools/stamps.py): per-wave clock stamps, never in the product
   HIP_TRY_FREE(hipMalloc((void**)&a.dbg, (size_t)(lanes / 64) * 16 * sizeof(unsigned long long)));
   HIP_TRY_FREE(hipMemset(a.dbg, 0, (size_t)(lanes / 64) * 16 * sizeof(unsigned long long)));
@@ -307,7 +312,19 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_xcache) (void)hipFree(b->d_xcache);
   if (b->d_bg84) (void)hipFree(b->d_bg84);
   if (b->args.dbg) (void)hipFree(b->args.dbg);
+  if (b->args.hint) (void)hipFree(b->args.hint);
   delete b;
+  return SF_OK;
+}
+
+extern "C" int sf_set_render_order_hint(sf_batch* b, const uint64_t* words_host, int n_words) {
+  if (!b || !words_host || !b->args.hint || n_words != (b->n_envs + 63) / 64) {
+    sf_set_error("sf_set_render_order_hint: needs an image batch and ceil(n_envs / 64) words");
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(b->args.hint, words_host, (size_t)n_words * sizeof(uint64_t), hipMemcpyHostToDevice));
   return SF_OK;
 }
 
@@ -355,7 +372,7 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
   }
   const unsigned char* fpatch = b->d_xcache ? b->d_xcache + (size_t)b->n_envs * SF_XC_BYTES : nullptr;
   HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache, fpatch,
-                           mode == SF_OBS_IMAGE ? 1 : 0, stack_done, stack_slot, stack_n, stack_prev, stream));
+                           mode == SF_OBS_IMAGE ? 1 : 0, stack_done, stack_slot, stack_n, stack_prev, b->args.hint, stream));
   return SF_OK;
 }
 

@@ -31,7 +31,7 @@ hipError_t sf_launch_group_copy(const unsigned char* state, int n_envs, int grou
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
-                            const uint8_t* stack_prev, hipStream_t stream);
+                            const uint8_t* stack_prev, const unsigned long long* hint, hipStream_t stream);
 hipError_t sf_launch_fort_patches(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
                                   hipStream_t stream);
 

@@ -1543,6 +1543,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
                             obs_vec_ok);
     }
   }
+  if constexpr (OBSK != 1) {
+    // image batches: which ships died this tick, one word per tile.  sf_render_kernel starts those frames first (the
+    // first frame of an explosion costs three ordinary ones, sf_render.hip); a scheduling hint, nothing else reads it
+    if (a.hint) {  // uniform
+      const unsigned long long died = __ballot(real && (S.big_hex_deaths | S.small_hex_deaths | S.shell_deaths) != 0);
+      if (lane == 0) a.hint[i >> 6] = died;
+    }
+  }
   if (!FUSED && a.n_partials) {  // uniform: VecNormalize's reduction rides on the step (sf_step_normalize)
     double my_ret = 0;
     if (a.n_ret && real) {

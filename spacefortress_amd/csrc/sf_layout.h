@@ -294,4 +294,6 @@ struct SfKernelArgs {
   double* n_partials;
   double* n_ret;    // per-env discounted return, ret = ret * n_gamma + reward
   double n_gamma;
+  // image batches only: per tile, the envs whose ship died in the last tick (sf_render_kernel's launch order); else null
+  unsigned long long* hint;
 };

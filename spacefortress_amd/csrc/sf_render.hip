@@ -29,7 +29,8 @@
 
 // diagnostic builds only (tools/render_ablate.py): bit 0 ship+fortress, 1 missiles+shells, 2 score,
 // 3 bar, 4 the resampling, 5 the coverage pass of draw_objects, 6 its composite pass, 7 the live ship, 8 the dead ship's
-// explosion, 9 the fortress -- each bit removes that phase so its cost can be read off
+// explosion, 9 the fortress -- each bit removes that phase so its cost can be read off; 10 = explosion-cache misses
+// take the hit path (wrong pixels: what the first frame of an explosion costs the launch)
 #ifndef SF_RENDER_SKIP
 #define SF_RENDER_SKIP 0
 #endif
@@ -508,7 +509,7 @@ __device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned 
   if (xc) {
     const double kx = *reinterpret_cast<const double*>(xc + kXcKey), ky = *reinterpret_cast<const double*>(xc + kXcKey + 8);
     const unsigned fl = *reinterpret_cast<const unsigned*>(xc + kXcFlags);
-    hit = kx == x && ky == y && (fl & need) == need;
+    hit = (kx == x && ky == y && (fl & need) == need) || (SF_RENDER_SKIP & 1024);  // (bit 10: a miss costs what a hit does)
   }
   const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows;
   if (hit && fits) {
@@ -585,7 +586,63 @@ struct SfRenderArgs {
   // 0 .. stack_n-2 of this one (zeros for a finished env), the new frame is rendered into the last slot: the
   // trainer's update_current_obs + rollouts.insert (rl/train.py:51-56,98) without a separate copy
   const uint8_t* stack_prev;
+  // launch order (pick_env): per tile of 64 envs, the ones whose ship died in the last tick (written by the step
+  // kernel), and the number of workgroups in front of the grid that draw such envs first; null / 0 = env = blockIdx
+  const unsigned long long* hint;
+  int n_front;
 };
+
+// ---- Which env a workgroup draws.  The first frame of a dead ship's explosion costs about three ordinary frames (96
+// strokes, then cached for the other 29); a launch is four rounds of equal waves, so an expensive wave that starts in
+// the last round is the tail of the launch: 14 of 102 us at 16 384 envs.  Workgroups are dispatched in blockIdx order,
+// hence: the grid is n_front + n_envs workgroups; workgroup i < n_front draws the i-th env of the hint words (and
+// leaves if there are fewer), workgroup n_front + e draws env e unless one of the first n_front did.  The hint decides
+// only WHEN a frame is drawn: any content of the words gives every env exactly one workgroup.
+// Order of the hinted envs: by (tile & 63), then tile >> 6, then lane of the tile.  Returns -1 for "nothing to draw".
+__device__ __forceinline__ int hinted_scan(const unsigned long long* hint, int n_tiles, int lane, int* mine) {
+  int c = 0;
+  for (int t = lane; t < n_tiles; t += 64) c += __popcll(hint[t]);
+  *mine = c;
+  int v = c;  // inclusive scan over the lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(v, d);
+    v += lane >= d ? u : 0;
+  }
+  return v;
+}
+
+__device__ __forceinline__ int pick_env(const SfRenderArgs& a, int p, int lane) {
+  const int n_tiles = (a.n_envs + 63) >> 6;
+  if (p >= a.n_front) {
+    const int e = p - a.n_front;
+    const unsigned long long w = a.hint[e >> 6];  // uniform
+    if (!((w >> (e & 63)) & 1ull)) return e;      // (nearly every workgroup: one scalar load)
+    // a hinted env: drawn in front if its rank there is below n_front
+    int mine;
+    const int incl = hinted_scan(a.hint, n_tiles, lane, &mine);
+    const int tile = e >> 6, tl = tile & 63;
+    int rank = __builtin_amdgcn_readlane(incl - mine, tl) + __popcll(w & ((1ull << (e & 63)) - 1ull));
+    for (int t = tl; t < tile; t += 64) rank += __popcll(a.hint[t]);
+    return rank < a.n_front ? -1 : e;
+  }
+  int mine;
+  const int incl = hinted_scan(a.hint, n_tiles, lane, &mine);
+  if (p >= __builtin_amdgcn_readlane(incl, 63)) return -1;
+  const int owner = __builtin_ctzll(__ballot(incl > p));
+  int left = p - __builtin_amdgcn_readlane(incl - mine, owner);
+  for (int t = owner; t < n_tiles; t += 64) {
+    unsigned long long w = a.hint[t];  // uniform
+    const int pc = __popcll(w);
+    if (left < pc) {
+      for (; left > 0; left--) w &= w - 1ull;
+      const int e = t * 64 + __builtin_ctzll(w);
+      return e < a.n_envs ? e : -1;  // (the step kernel never marks a lane behind the batch)
+    }
+    left -= pc;
+  }
+  return -1;
+}
 
 // The fortress never moves and its heading is a multiple of the 10-degree sector (SRC/game.cpp:205-208):
 // 36 pictures.  sf_fort_patch_kernel draws them once per batch with the frame code below (so they are
@@ -660,7 +717,12 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   __shared__ __attribute__((aligned(16))) float qscr[32];
   __shared__ __attribute__((aligned(16))) uint8_t mscr[kMaskScratch];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
-  const int env = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
+  int env = blockIdx.x;
+  if (a.hint) {
+    env = pick_env(a, (int)blockIdx.x, lane);
+    if (env < 0) return;  // uniform, before any barrier
+  }
   uint8_t* const frame_out = a.out + (size_t)env * a.out_stride;
 
 #if SF_RENDER_TABS_IN_LDS
@@ -947,12 +1009,17 @@ hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uin
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
-                            const uint8_t* stack_prev, hipStream_t stream) {
+                            const uint8_t* stack_prev, const unsigned long long* hint, hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
-  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n, stack_prev};
+  // the front of the grid: a sixteenth of the batch (ships die in about 1.3 % of the ticks of random play); batches
+  // whose hint words no longer fit a short scan (> 32 per lane) are drawn in env order
+  const int n_front = hint && n_envs <= 64 * 64 * 32 ? (n_envs / 16 > 64 ? n_envs / 16 : 64) : 0;
+  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n, stack_prev,
+                 n_front ? hint : nullptr, n_front};
+  const unsigned grid = (unsigned)(n_envs + n_front);
   if (resize)
-    hipLaunchKernelGGL(sf_render_kernel<true>, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(sf_render_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
   else
-    hipLaunchKernelGGL(sf_render_kernel<false>, dim3((unsigned)n_envs), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(sf_render_kernel<false>, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }

@@ -277,6 +277,47 @@ def test_explosion_cache_is_invisible(sfa, monkeypatch):
     cached.close()
 
 
+def test_launch_order_hint_is_invisible(sfa, monkeypatch):
+    """The step kernel tells the render launch which ships just died, and those frames start first (sf_render.hip:
+    pick_env).  The words decide only when a frame is drawn: a batch without them, the batch's own, and every pattern
+    written over them -- none, all, random at several densities, more marked envs than the front of the grid holds,
+    a ragged last tile -- give the same frames, every env drawn exactly once (the canvas is pre-filled with a value no
+    frame is made of whole, so an env nobody drew shows)."""
+    import ctypes as C
+    from spacefortress_amd import _lib
+    N, T = 1000, 140  # not a multiple of 64: the last tile is ragged
+    rng = np.random.default_rng(31)
+    acts = torch.from_numpy(rng.integers(0, 5, (T, N)).astype(np.uint8)).cuda()
+    monkeypatch.setenv("SFMI_NO_RENDER_ORDER", "1")
+    plain = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=5)
+    monkeypatch.delenv("SFMI_NO_RENDER_ORDER")
+    hinted = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=5)
+    L = _lib.lib()
+    words = (N + 63) // 64
+    assert L.sf_set_render_order_hint(plain._h, (C.c_uint64 * words)(), words) == _lib.SF_ERR_ARG  # no words to write
+    deaths = 0
+    for t in range(T):
+        o1, *_ = plain.step_tensors(acts[t])
+        o2, *_ = hinted.step_tensors(acts[t])
+        assert torch.equal(o1, o2), t
+        deaths += int((torch.from_numpy(hinted.get_field("flags")) & 1 == 0).sum())
+    assert deaths > 50
+    want84, want_raw = plain.render("image"), plain.render("image-raw")
+    valid = np.zeros(words * 64, bool)
+    valid[:N] = True
+    for density in (0.0, 1.0, 0.01, 0.05, 0.3, 0.9):
+        bits = (rng.random(words * 64) < density) & valid  # (the step kernel never marks a lane behind the batch)
+        w = np.packbits(bits.reshape(words, 64), axis=1, bitorder="little").view(np.uint64).reshape(words)
+        assert int(bits.sum()) == sum(bin(int(x)).count("1") for x in w)
+        _lib.check(L.sf_set_render_order_hint(hinted._h, w.ctypes.data_as(C.c_void_p), words))
+        for mode, want in (("image", want84), ("image-raw", want_raw)):
+            out = torch.full_like(want, 7)
+            got = hinted.render(mode, out=out)
+            assert torch.equal(got, want), (density, mode)
+    plain.close()
+    hinted.close()
+
+
 def test_config5_at_its_size_against_the_model(sfa, oracle_mod, model):
     """BASELINE.json configs[4] as written: youturn, 16 384 envs, the 84x84 grey raster with the trainer's 4-frame stack
     on the device.  160 random steps through FrameStack; on sampled lanes (the first, the last, some in between) the

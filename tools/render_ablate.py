@@ -4,7 +4,10 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {"full": 0, "no_shipfort": 1, "no_projectiles": 2, "no_score": 4, "no_bar": 8, "no_resample": 16,
-            "only_copy": 31, "only_resample": 15, "no_cover": 32, "no_composite": 64, "no_cover_composite_resample": 112, "no_live_ship": 128, "no_dead_ship": 256, "no_fortress": 512}
+            "only_copy": 31, "only_resample": 15, "no_cover": 32, "no_composite": 64, "no_cover_composite_resample": 112, "no_live_ship": 128, "no_dead_ship": 256, "no_fortress": 512, "miss_as_hit": 1024}
+ONLY = [a for a in sys.argv[1:] if a in VARIANTS]
+if ONLY:
+    VARIANTS = {k: VARIANTS[k] for k in ONLY}
 if "--build" in sys.argv:
     from spacefortress_amd import build as B
     os.makedirs(os.path.join(ROOT, "build/abl"), exist_ok=True)
