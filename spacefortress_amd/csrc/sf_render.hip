@@ -848,10 +848,18 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const bool baked_bar = vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8);
   const int variant = (baked_text ? 1 : 0) | (baked_bar ? 2 : 0);
   {
+    // the surface starts as the background: nine loads that write LDS directly (1 KiB each: lane i's 16 bytes land at
+    // base + 16 i), all in flight at once and without registers.  As a loop through registers the compiler waits for
+    // each 16 bytes before it asks for the next: nine L2 round trips one after the other, a third of the wave's life.
     const uint32_t* bgv = a.bg + variant * (SF_BG_STRIDE / 4);
-    const uint4* src = reinterpret_cast<const uint4*>(bgv);
-    uint4* dst = reinterpret_cast<uint4*>(fbw);
-    for (int i = lane; i < kFbVec; i += 64) dst[i] = src[i];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const char* src = reinterpret_cast<const char*>(bgv) + lane * 16;
+    constexpr int kRounds = (kFbVec + 63) / 64;
+#pragma unroll
+    for (int k = 0; k < kRounds; k++)
+      if (k < kRounds - 1 || lane < kFbVec - 64 * (kRounds - 1))
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 1024), (lptr_t)(reinterpret_cast<char*>(fbw) + k * 1024), 16, 0, 0);
     for (int i = 4 * kFbVec + lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bgv[i] : 0u;
   }
   if (RESIZE && a.stack_prev) {
@@ -872,9 +880,10 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     const uint4* src = reinterpret_cast<const uint4*>(a.bg84 + variant * (kOutBytes / 4));
     uint4* dst = reinterpret_cast<uint4*>(frame_out);
     for (int i = lane; i < kOutBytes / 16; i += 64) dst[i] = src[i];
-    // the byte stores that follow must land on top of these: wait until L2 has them (vmcnt counts stores on gfx9)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  // the byte stores that follow must land on top of the frame's: wait until L2 has them (vmcnt counts stores on gfx9);
+  // and the surface must be in LDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const Frame<RESIZE> F{fb, frame_out, tabw, lane, qscr, mscr};
 
