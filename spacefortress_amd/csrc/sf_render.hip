@@ -567,6 +567,26 @@ __device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned 
 
 }  // namespace
 
+// Up to 7 x 64 pieces of 16 bytes (an 84x84 frame is 441) from src to dst, global memory both: every load in flight
+// before the first store.  (Left as a loop, the compiler waits for each piece before it asks for the next -- seven L2
+// round trips one after the other; with the pieces in an array it parks them in scratch.  Hence seven named registers,
+// loads clamped into the range instead of predicated.)
+constexpr int kFrameRounds = (kOutBytes / 16 + 63) / 64;
+static_assert(kFrameRounds == 7, "copy_pieces is written out for seven rounds");
+__device__ __forceinline__ void copy_pieces(const uint4* src, uint4* dst, int n, int lane) {
+  const int last = n - 1;
+  const uint4 v0 = src[min(lane, last)], v1 = src[min(lane + 64, last)], v2 = src[min(lane + 128, last)],
+              v3 = src[min(lane + 192, last)], v4 = src[min(lane + 256, last)], v5 = src[min(lane + 320, last)],
+              v6 = src[min(lane + 384, last)];
+  if (lane < n) dst[lane] = v0;
+  if (lane + 64 < n) dst[lane + 64] = v1;
+  if (lane + 128 < n) dst[lane + 128] = v2;
+  if (lane + 192 < n) dst[lane + 192] = v3;
+  if (lane + 256 < n) dst[lane + 256] = v4;
+  if (lane + 320 < n) dst[lane + 320] = v5;
+  if (lane + 384 < n) dst[lane + 384] = v6;
+}
+
 struct SfRenderArgs {
   const unsigned char* state;
   int n_envs;
@@ -867,7 +887,13 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     const uint4 z = {0u, 0u, 0u, 0u};
     const uint4* src = reinterpret_cast<const uint4*>(a.stack_prev + (size_t)env * a.out_stride + kOutBytes);
     uint4* dst = reinterpret_cast<uint4*>(frame_out - (ptrdiff_t)a.stack_slot * kOutBytes);
-    for (int i = lane; i < (a.stack_n - 1) * (kOutBytes / 16); i += 64) dst[i] = fin ? z : src[i];
+    const int n = (a.stack_n - 1) * (kOutBytes / 16);
+    if (fin) {
+      for (int i = lane; i < n; i += 64) dst[i] = z;
+    } else {
+      // a frame's worth of loads in flight, then its stores (a plain loop waits for each 16 bytes before the next load)
+      for (int base = 0; base < n; base += 64 * kFrameRounds) copy_pieces(src + base, dst + base, n - base, lane);
+    }
   } else if (RESIZE && a.stack_done && a.stack_done[env]) {
     const uint4 z = {0u, 0u, 0u, 0u};
     for (int sl = 0; sl < a.stack_n; sl++) {
@@ -879,7 +905,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   if (RESIZE) {
     const uint4* src = reinterpret_cast<const uint4*>(a.bg84 + variant * (kOutBytes / 4));
     uint4* dst = reinterpret_cast<uint4*>(frame_out);
-    for (int i = lane; i < kOutBytes / 16; i += 64) dst[i] = src[i];
+    copy_pieces(src, dst, kOutBytes / 16, lane);
   }
   // the byte stores that follow must land on top of the frame's: wait until L2 has them (vmcnt counts stores on gfx9);
   // and the surface must be in LDS
