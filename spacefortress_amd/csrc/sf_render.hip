@@ -356,8 +356,15 @@ struct Frame {
 
 // Stroke of the segment A-B (wireframe coordinates), butt caps, width SF_LINE_W, under
 // translate(pos) rotate(angle) (drawWireFrame, SRC/draw.cpp:112-129)
+struct Seg {  // a wireframe segment with its transform: everything line_quad reads from memory
+  float ax, ay, bx, by, ca, sa, posx, posy;
+};
+__device__ __forceinline__ Quad line_quad(const Seg& g);
 __device__ __forceinline__ Quad line_quad(const float* ln, float ca, float sa, float posx, float posy) {
-  const float ax = ln[0], ay = ln[1], bx = ln[2], by = ln[3];
+  return line_quad(Seg{ln[0], ln[1], ln[2], ln[3], ca, sa, posx, posy});
+}
+__device__ __forceinline__ Quad line_quad(const Seg& g) {
+  const float ax = g.ax, ay = g.ay, bx = g.bx, by = g.by, ca = g.ca, sa = g.sa, posx = g.posx, posy = g.posy;
   const float ux = bx - ax, uy = by - ay;
   const float inv = (float)(SF_LINE_W / 2) / sqrtf(ux * ux + uy * uy);
   const float nx = -uy * inv, ny = ux * inv;
@@ -573,18 +580,25 @@ __device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned 
 // loads clamped into the range instead of predicated.)
 constexpr int kFrameRounds = (kOutBytes / 16 + 63) / 64;
 static_assert(kFrameRounds == 7, "copy_pieces is written out for seven rounds");
-__device__ __forceinline__ void copy_pieces(const uint4* src, uint4* dst, int n, int lane) {
+struct Pieces {
+  uint4 v0, v1, v2, v3, v4, v5, v6;
+};
+__device__ __forceinline__ Pieces load_pieces(const uint4* src, int n, int lane) {
   const int last = n - 1;
-  const uint4 v0 = src[min(lane, last)], v1 = src[min(lane + 64, last)], v2 = src[min(lane + 128, last)],
-              v3 = src[min(lane + 192, last)], v4 = src[min(lane + 256, last)], v5 = src[min(lane + 320, last)],
-              v6 = src[min(lane + 384, last)];
-  if (lane < n) dst[lane] = v0;
-  if (lane + 64 < n) dst[lane + 64] = v1;
-  if (lane + 128 < n) dst[lane + 128] = v2;
-  if (lane + 192 < n) dst[lane + 192] = v3;
-  if (lane + 256 < n) dst[lane + 256] = v4;
-  if (lane + 320 < n) dst[lane + 320] = v5;
-  if (lane + 384 < n) dst[lane + 384] = v6;
+  return Pieces{src[min(lane, last)],       src[min(lane + 64, last)],  src[min(lane + 128, last)], src[min(lane + 192, last)],
+                src[min(lane + 256, last)], src[min(lane + 320, last)], src[min(lane + 384, last)]};
+}
+__device__ __forceinline__ void store_pieces(const Pieces& p, uint4* dst, int n, int lane) {
+  if (lane < n) dst[lane] = p.v0;
+  if (lane + 64 < n) dst[lane + 64] = p.v1;
+  if (lane + 128 < n) dst[lane + 128] = p.v2;
+  if (lane + 192 < n) dst[lane + 192] = p.v3;
+  if (lane + 256 < n) dst[lane + 256] = p.v4;
+  if (lane + 320 < n) dst[lane + 320] = p.v5;
+  if (lane + 384 < n) dst[lane + 384] = p.v6;
+}
+__device__ __forceinline__ void copy_pieces(const uint4* src, uint4* dst, int n, int lane) {
+  store_pieces(load_pieces(src, n, lane), dst, n, lane);
 }
 
 struct SfRenderArgs {
@@ -772,10 +786,76 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const float ship_x = (float)sp.x, ship_y = (float)sp.y;
   const bool ship_alive = flags & SF_FL_SHIP_ALIVE;
 
-  // ---- projectile strokes first: one lane per wireframe segment (missiles: slot*3 + k; shells: two
-  // rounds of slot*4 + k), because what they touch decides which background variant the frame
-  // starts from
-  Quad mq = {}, sq[2] = {{}, {}};
+  // ---- The frame starts as a copy of the static background: the 92x90 surface into LDS, its 84x84 image into the
+  // caller's frame.  Which variant (score / bar baked in) depends on what the projectiles touch, known only after their
+  // strokes are built -- but nearly always it is what the score, the bar and the dead ship's explosion say, and the
+  // copies are made for that guess.  A wave's memory round trips come back in the order they were asked for, so the
+  // order below is: the frame's seven loads; the pool and the tables behind them (one round trip for all of it); the
+  // frame's stores and the surface's direct-to-LDS loads; the stroke arithmetic with those in flight; one wait.
+  auto start_surface = [&](int variant) {
+    // Ten loads that write LDS directly (global_load_lds: lane i's 16 bytes land at M0 + offset + 16 i; the offset
+    // moves both addresses), all in flight at once and without registers: 8 x 1 KiB, the 5 whole pieces behind them,
+    // and the last 26 words one per lane (the spare row's taps have weight zero: any byte will do, so the source
+    // index is clamped into the variant).  Written as one asm statement because the compiler, once it knows of such a
+    // load in flight, drains everything (vmcnt(0)) before each later store or use of a loaded value -- and left as a
+    // loop through registers it waits for each 16 bytes before it asks for the next, nine round trips one after the
+    // other.  Unknown to the compiler they only make its own counted waits stricter; the wait that matters, before the
+    // surface is first read, is the explicit vmcnt(0) in front of the barrier below.
+    static_assert(kFbVec == 8 * 64 + 5 && kFbPadWords - 4 * kFbVec == 26 && SF_BG_STRIDE / 4 > 4 * kFbVec,
+                  "the copy below is written out for the 92x90 surface");
+    const char* bgv = reinterpret_cast<const char*>(a.bg) + variant * SF_BG_STRIDE;
+    const char* p0 = bgv + lane * 16;
+    const char* p1 = p0 + 4096;
+    const char* p2 = p0 + 8192;
+    const char* p3 = bgv + 4 * min(4 * kFbVec + lane, SF_BG_STRIDE / 4 - 1) - (4 * 4 * kFbVec - 8192);
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)fbw;
+    unsigned keep_m0;
+    unsigned long long keep_exec;
+    asm volatile(
+        "s_mov_b32 %[km], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[p0], off\n\t"
+        "global_load_lds_dwordx4 %[p0], off offset:1024\n\t"
+        "global_load_lds_dwordx4 %[p0], off offset:2048\n\t"
+        "global_load_lds_dwordx4 %[p0], off offset:3072\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[p1], off\n\t"
+        "global_load_lds_dwordx4 %[p1], off offset:1024\n\t"
+        "global_load_lds_dwordx4 %[p1], off offset:2048\n\t"
+        "global_load_lds_dwordx4 %[p1], off offset:3072\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_mov_b64 %[ke], exec\n\t"
+        "s_and_b64 exec, %[ke], 0x1f\n\t"
+        "global_load_lds_dwordx4 %[p2], off\n\t"
+        "s_and_b64 exec, %[ke], 0x3ffffff\n\t"
+        "global_load_lds_dword %[p3], off offset:80\n\t"
+        "s_mov_b64 exec, %[ke]\n\t"
+        "s_mov_b32 m0, %[km]"
+        : [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)
+        : [lds] "s"(lds), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3)
+        : "memory", "scc");
+  };
+  const Box tbox{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1};
+  const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
+  bool near_text = false, near_bar = false;
+  if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
+    // 3 pixels wider than what the explosion paints: the 84x84 pixels recomputed (or restored from the
+    // cache) for it read that far, and must not depend on whether the score / bar were baked in
+    Box eb = explosion_box(ship_x, ship_y);
+    eb.x0 -= 3; eb.y0 -= 3; eb.x1 += 3; eb.y1 += 3;
+    near_text = eb.meets(tbox);
+    near_bar = eb.meets(bbox);
+  }
+  const int variant0 = ((pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4)) ? 1 : 0) |
+                       ((vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8)) ? 2 : 0);
+  start_surface(variant0);
+  Pieces frame0 = {};
+  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant0 * (kOutBytes / 4)), kOutBytes / 16, lane);
+  // ---- projectile strokes: one lane per wireframe segment (missiles: slot*3 + k; shells: two rounds of slot*4 + k);
+  // first everything that reads memory (the pool, the tables of sines and of segments, the shells' state)
+  Seg mg = {}, sg[2] = {{}, {}};
   bool mvalid = false, svalid[2] = {false, false};
   if (mmask) {
     // The tile keeps its live missiles as one dense pool (sf_layout.h); this env's are the entries whose owner is its
@@ -803,7 +883,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       const float* t = mtab + 3 * slot;
       float s, c;
       sincos_deg((int)t[2], &s, &c);
-      mq = line_quad(kMissileLines[k], c, s, t[0], t[1]);
+      mg = Seg{kMissileLines[k][0], kMissileLines[k][1], kMissileLines[k][2], kMissileLines[k][3], c, s, t[0], t[1]};
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the scratch goes back to the coverage masks
@@ -826,62 +906,13 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
         if (ang < 0) ang += 360.0;
         float sn, cs;
         sincos_deg((int)ang, &sn, &cs);
-        sq[round] = line_quad(kShellLines[k], cs, sn, (float)s.x, (float)s.y);
+        sg[round] = Seg{kShellLines[k][0], kShellLines[k][1], kShellLines[k][2], kShellLines[k][3], cs, sn, (float)s.x, (float)s.y};
       }
       svalid[round] = valid;
     }
   }
-
-  // ---- background variant.  The score and the bar are drawn LAST (SRC/draw.cpp:266-268); when they
-  // show 0000000 / an empty bar and nothing drawn before them reaches their pixels, the result is the
-  // static picture the host baked (same arithmetic, sf_raster.h).  A live ship and the fortress never
-  // reach them (the ship is inside the big hexagon, rows 12.2 .. 81.6 +- 5.4 px).
-  const Box tbox{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1};
-  const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
-  bool near_text = false, near_bar = false;
-  if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
-    // 3 pixels wider than what the explosion paints: the 84x84 pixels recomputed (or restored from the
-    // cache) for it read that far, and must not depend on whether the score / bar were baked in
-    Box eb = explosion_box(ship_x, ship_y);
-    eb.x0 -= 3; eb.y0 -= 3; eb.x1 += 3; eb.y1 += 3;
-    near_text = eb.meets(tbox);
-    near_bar = eb.meets(bbox);
-  }
-  {
-    bool t = false, b = false;
-    if (mvalid) {
-      const Box qb = quad_box(mq);
-      t = t || qb.meets(tbox);
-      b = b || qb.meets(bbox);
-    }
-#pragma unroll
-    for (int round = 0; round < 2; round++)
-      if (svalid[round]) {
-        const Box qb = quad_box(sq[round]);
-        t = t || qb.meets(tbox);
-        b = b || qb.meets(bbox);
-      }
-    near_text = near_text || __any(t);
-    near_bar = near_bar || __any(b);
-  }
-  const bool baked_text = pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4);
-  const bool baked_bar = vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8);
-  const int variant = (baked_text ? 1 : 0) | (baked_bar ? 2 : 0);
-  {
-    // the surface starts as the background: nine loads that write LDS directly (1 KiB each: lane i's 16 bytes land at
-    // base + 16 i), all in flight at once and without registers.  As a loop through registers the compiler waits for
-    // each 16 bytes before it asks for the next: nine L2 round trips one after the other, a third of the wave's life.
-    const uint32_t* bgv = a.bg + variant * (SF_BG_STRIDE / 4);
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const char* src = reinterpret_cast<const char*>(bgv) + lane * 16;
-    constexpr int kRounds = (kFbVec + 63) / 64;
-#pragma unroll
-    for (int k = 0; k < kRounds; k++)
-      if (k < kRounds - 1 || lane < kFbVec - 64 * (kRounds - 1))
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 1024), (lptr_t)(reinterpret_cast<char*>(fbw) + k * 1024), 16, 0, 0);
-    for (int i = 4 * kFbVec + lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bgv[i] : 0u;
-  }
+  if (RESIZE) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
+  // the frame stack's older slots (independent of the variant)
   if (RESIZE && a.stack_prev) {
     const bool fin = a.stack_done && a.stack_done[env];
     const uint4 z = {0u, 0u, 0u, 0u};
@@ -902,10 +933,44 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       for (int i = lane; i < kOutBytes / 16; i += 64) dst[i] = z;
     }
   }
-  if (RESIZE) {
-    const uint4* src = reinterpret_cast<const uint4*>(a.bg84 + variant * (kOutBytes / 4));
-    uint4* dst = reinterpret_cast<uint4*>(frame_out);
-    copy_pieces(src, dst, kOutBytes / 16, lane);
+
+  Quad mq = {}, sq[2] = {{}, {}};
+  if (mvalid) mq = line_quad(mg);
+  if (smask) {
+    if (svalid[0]) sq[0] = line_quad(sg[0]);
+    if (svalid[1]) sq[1] = line_quad(sg[1]);
+  }
+
+  // ---- background variant.  The score and the bar are drawn LAST (SRC/draw.cpp:266-268); when they
+  // show 0000000 / an empty bar and nothing drawn before them reaches their pixels, the result is the
+  // static picture the host baked (same arithmetic, sf_raster.h).  A live ship and the fortress never
+  // reach them (the ship is inside the big hexagon, rows 12.2 .. 81.6 +- 5.4 px).
+  {
+    bool t = false, b = false;
+    if (mvalid) {
+      const Box qb = quad_box(mq);
+      t = t || qb.meets(tbox);
+      b = b || qb.meets(bbox);
+    }
+#pragma unroll
+    for (int round = 0; round < 2; round++)
+      if (svalid[round]) {
+        const Box qb = quad_box(sq[round]);
+        t = t || qb.meets(tbox);
+        b = b || qb.meets(bbox);
+      }
+    near_text = near_text || __any(t);
+    near_bar = near_bar || __any(b);
+  }
+  const bool baked_text = pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4);
+  const bool baked_bar = vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8);
+  const int variant = (baked_text ? 1 : 0) | (baked_bar ? 2 : 0);
+  if (variant != variant0) {  // a projectile over the score or the bar (rare): start again from the right picture
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    start_surface(variant);
+    if (RESIZE)
+      copy_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant * (kOutBytes / 4)), reinterpret_cast<uint4*>(frame_out),
+                  kOutBytes / 16, lane);
   }
   // the byte stores that follow must land on top of the frame's: wait until L2 has them (vmcnt counts stores on gfx9);
   // and the surface must be in LDS
