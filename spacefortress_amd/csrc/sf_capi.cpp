@@ -365,9 +365,10 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
   if (!b->d_xcache && !getenv("SFMI_NO_EXPLOSION_CACHE")) {
     // first frame of this batch: the per-env explosion cache (feature-only batches never pay for it)
     // ... followed by the 36 fortress pictures, drawn here once
-    const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES;
-    HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes + 36 * SF_FP_BYTES));
-    HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes + 36 * SF_FP_BYTES, stream));
+    // ... and by the destroyed fortress's explosion, in the layout of an env's cache entry
+    const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES, tail = 36 * SF_FP_BYTES + SF_XC_BYTES;
+    HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes + tail));
+    HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes + tail, stream));
     HIP_TRY(sf_launch_fort_patches(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes, stream));
   }
   const unsigned char* fpatch = b->d_xcache ? b->d_xcache + (size_t)b->n_envs * SF_XC_BYTES : nullptr;

@@ -507,7 +507,8 @@ constexpr int kXcKey = 0, kXcFlags = 16, kXcFb = 32, kXcRow = 28, kXcFbRows = 27
 static_assert(kXcOut % 4 == 0 && kXcOut + kXcOutRows * kXcRow <= SF_XC_BYTES, "explosion cache layout");
 
 template <bool RESIZE>
-__device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned char* xc, double x, double y) {
+__device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned char* xc, double x, double y,
+                                               const bool fill = true) {
   const float cx = (float)x, cy = (float)y;
   const Box b = explosion_box(cx, cy), o = out_box(b);
   const int lane = F.lane;
@@ -558,7 +559,7 @@ __device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned 
     return;
   }
   draw_explosion(F, cx, cy);
-  if (xc && fits) {
+  if (xc && fits && fill) {
     for (int i = lane; i < kXcFbRows * kXcRow; i += 64) {
       const int r = i / kXcRow, c = i - r * kXcRow;
       if (r < b.y1 - b.y0 && c < b.x1 - b.x0) xc[kXcFb + i] = F.fb[(b.y0 + r) * SF_IMG_W + b.x0 + c];
@@ -992,13 +993,14 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
 ship_done:
   // ---- fortress (:238-242)
   if (SF_RENDER_SKIP & (1 | 512)) {  // (diagnostic bit 9: the fortress alone)
-  } else if (flags & SF_FL_FORT_ALIVE) {
+  } else {
     // what was drawn before the fortress: the ship (within 25.5 + 1.5 user units of its position) or its explosion
     Box sb = explosion_box(ship_x, ship_y);
     if (ship_alive) {
       const float gx = dev_x(ship_x), gy = dev_y(ship_y), ext = 27.f * (float)SF_SCALE;
       sb = Box{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
     }
+   if (flags & SF_FL_FORT_ALIVE) {
     const int sector = fort_angle / 10;
     if (a.fpatch && fort_angle >= 0 && fort_angle < 360 && sector * 10 == fort_angle &&
         !sb.meets(Box{kFpX0 - 3, kFpY0 - 3, kFpX1 + 3, kFpY1 + 3})) {  // + what the patch's 84x84 pixels read
@@ -1009,8 +1011,17 @@ ship_done:
       const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
       F.draw_quads(q, 255, lane < 4, 64);
     }
-  } else {
-    draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);
+   } else {
+    // The destroyed fortress explodes for 1000 ms where it stands: one more picture drawn once per batch, in the
+    // layout of the per-env explosion cache (a trained agent destroys it every few seconds -- 30 frames each time).
+    // Restored when what the ship drew stays clear of it (3 pixels wider: what its 84x84 pixels read); else in place.
+    Box fe = explosion_box((float)sfc::fort_x, (float)sfc::fort_y);
+    fe.x0 -= 3; fe.y0 -= 3; fe.x1 += 3; fe.y1 += 3;
+    if (a.fpatch && !sb.meets(fe))
+      ship_explosion(F, const_cast<unsigned char*>(a.fpatch) + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y, false);
+    else
+      draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);
+   }
   }
   // ---- missiles (:243-247), shells (:248-253): slot order
   if (mmask) F.draw_objects(mq, 255, mvalid, 3);
@@ -1075,6 +1086,10 @@ __global__ __launch_bounds__(64) void sf_fort_patch_kernel(const uint32_t* bg, c
   for (int i = lane; i < SF_TAB_WORDS; i += 64) tabw[i] = tabs[i];
   __syncthreads();
   const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, lane, qscr, mscr};
+  if (sector == 36) {  // the destroyed fortress's explosion, behind the 36 headings
+    ship_explosion(F, fpatch + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y);  // (a zeroed entry: draws and fills it)
+    return;
+  }
   float s, c;
   sincos_deg(10 * sector, &s, &c);
   const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
@@ -1087,7 +1102,7 @@ __global__ __launch_bounds__(64) void sf_fort_patch_kernel(const uint32_t* bg, c
 
 hipError_t sf_launch_fort_patches(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
                                   hipStream_t stream) {
-  hipLaunchKernelGGL(sf_fort_patch_kernel, dim3(36), dim3(64), 0, stream, bg, bg84, tabs, fpatch);
+  hipLaunchKernelGGL(sf_fort_patch_kernel, dim3(37), dim3(64), 0, stream, bg, bg84, tabs, fpatch);
   return hipGetLastError();
 }
 

@@ -277,6 +277,35 @@ def test_explosion_cache_is_invisible(sfa, monkeypatch):
     cached.close()
 
 
+def test_fortress_explosion_picture_is_invisible(sfa, monkeypatch):
+    """The destroyed fortress's explosion is one picture per batch, restored while the ship's pixels stay clear of it
+    and drawn in place otherwise.  Replaying the recorded run that destroys the fortress (twice), a batch with the
+    pictures and one that draws everything in place give identical frames in both sizes at every tick."""
+    z = np.load(os.path.join(GOLDEN, "autoturn_destroy.npz"))
+    meta = json.loads(str(z["meta"]))
+    N = 3
+    mk = lambda: sfa.SFVecEnv(N, gametype=meta["gametype"], action_set=meta["action_set"], seed=meta["seed"],
+                              spawn_skip=meta["spawn_skip"], obs_type="image")
+    monkeypatch.setenv("SFMI_NO_EXPLOSION_CACHE", "1")
+    plain = mk()
+    plain.render("image")  # the switch is read by a batch's first frame
+    monkeypatch.delenv("SFMI_NO_EXPLOSION_CACHE")
+    cached = mk()
+    acts = torch.from_numpy(np.repeat(z["actions"][:, None], N, 1).astype(np.uint8)).cuda()
+    dead = 0
+    for t in range(len(acts)):
+        o1, *_ = plain.step_tensors(acts[t])
+        o2, *_ = cached.step_tensors(acts[t])
+        assert torch.equal(o1, o2), t
+        fort_dead = int((torch.from_numpy(cached.get_field("flags")) & 2 == 0).sum())
+        dead += fort_dead
+        if fort_dead:
+            assert torch.equal(plain.render("image-raw"), cached.render("image-raw")), t
+    assert dead >= 20 * N, dead
+    plain.close()
+    cached.close()
+
+
 def test_launch_order_hint_is_invisible(sfa, monkeypatch):
     """The step kernel tells the render launch which ships just died, and those frames start first (sf_render.hip:
     pick_env).  The words decide only when a frame is drawn: a batch without them, the batch's own, and every pattern
