@@ -45,7 +45,7 @@ constexpr int kFbWords = kFbBytes / 4;                 // 2070
 constexpr int kFbPadWords = (SF_IMG_W * (SF_IMG_H + 1) + 3) / 4 + 1;  // one spare row for zero-weight taps
 constexpr int kFbVec = kFbBytes / 16;                  // 517 (+ 8 bytes)
 constexpr int kOutBytes = SF_OUT * SF_OUT;             // 7056 = 441 * 16
-constexpr int kMaskScratch = 256;                      // coverage masks of one small object (draw_objects)
+constexpr int kMaskScratch = 256;                      // the missile slot table of the prologue
 
 struct d2_t {
   double x, y;
@@ -183,7 +183,7 @@ struct Frame {
   const uint32_t* tab;  // LDS copy of the tap tables (sf_raster.h)
   int lane;
   float* qscr;          // LDS: 4 quads of the object being drawn (draw_objects)
-  uint8_t* mscr;        // LDS: kMaskScratch coverage masks
+  uint8_t* mscr;        // LDS: kMaskScratch bytes of scratch
 
   // cv2.resize(..., INTER_AREA) restricted to the destination pixels that read source pixels of `b`
   // (OpenCV's resizeArea_ arithmetic: per source row buf = sum alpha * S, then sum += beta * buf in
@@ -266,11 +266,13 @@ struct Frame {
     resample(dirty);
   }
 
-  // Small objects (missiles: 3 strokes, shells: 4) -- lanes [k*per, (k+1)*per) hold the strokes of object k.
-  // A stroke covers a dozen pixels, so walking strokes one by one leaves most of the wave idle.  Per object:
-  //   1. all (stroke, pixel) pairs of the object at once: coverage masks into LDS;
-  //   2. a lane per pixel of the object's box composites the strokes that cover it, in stroke order
-  // -- the same arithmetic in the same order as stroke by stroke, in about a third of the instructions.
+  // Small objects (the ship: 3 strokes, missiles: 3, shells: 4) -- lanes [k*per, (k+1)*per) hold the strokes of object
+  // k.  A stroke covers a dozen pixels, so walking strokes one by one leaves most of the wave idle.  Per object the
+  // lanes take all its (stroke, pixel) pairs at once, stroke-major: each computes its coverage, keeps it in a register,
+  // and then the strokes composite one after the other -- the lanes of stroke 0 first, then those of stroke 1 ... (no
+  // two lanes of one stroke share a pixel; where strokes meet, a pixel is touched once per stroke, in stroke order).
+  // The same arithmetic in the same order as stroke by stroke.  (Round 1 parked the coverages in LDS and composited
+  // with a lane per pixel of the object's box, four box tests and mask reads each: a second pass as dear as the first.)
   __device__ __forceinline__ void draw_objects(const Quad& mine, int grey, bool valid, int per) const {
     const Box myb = quad_box(mine);
     const int mybw = myb.x1 - myb.x0, mybh = myb.y1 - myb.y0;
@@ -295,10 +297,6 @@ struct Frame {
         off[k + 1] = off[k] + n[k];
       }
       const int total = off[4];
-      if (total > kMaskScratch) {  // cannot happen for a missile or a shell (<= 7 x 7 pixels a stroke); stay correct anyway
-        draw_quads(mine, grey, valid && lane >= lo && lane < lo + per, per);
-        continue;
-      }
       if (lane >= lo && lane < lo + per) {
 #pragma unroll
         for (int v = 0; v < 4; v++) {
@@ -307,48 +305,41 @@ struct Frame {
         }
       }
       __builtin_amdgcn_wave_barrier();
-      for (int i = lane; i < ((SF_RENDER_SKIP & 32) ? 0 : total); i += 64) {
-        const int k = (i >= off[1]) + (i >= off[2]) + (i >= off[3]);
-        const int j = i - (k == 0 ? off[0] : k == 1 ? off[1] : k == 2 ? off[2] : off[3]);
-        const int w = k == 0 ? bw[0] : k == 1 ? bw[1] : k == 2 ? bw[2] : bw[3];
-        const int x0 = k == 0 ? bx0[0] : k == 1 ? bx0[1] : k == 2 ? bx0[2] : bx0[3];
-        const int y0 = k == 0 ? by0[0] : k == 1 ? by0[1] : k == 2 ? by0[2] : by0[3];
-        const DivMod dm = fast_divmod(j, w, recip_i(w));
-        const int ry = dm.q, rx = dm.r;
-        Quad q;
+      for (int base = 0; base < total; base += 64) {
+        const int i = base + lane;
+        int k = 0, m = 0;
+        uint8_t* p = fb;
+        if (i < total) {
+          k = (i >= off[1]) + (i >= off[2]) + (i >= off[3]);
+          const int j = i - (k == 0 ? off[0] : k == 1 ? off[1] : k == 2 ? off[2] : off[3]);
+          const int w = k == 0 ? bw[0] : k == 1 ? bw[1] : k == 2 ? bw[2] : bw[3];
+          const int x0 = k == 0 ? bx0[0] : k == 1 ? bx0[1] : k == 2 ? bx0[2] : bx0[3];
+          const int y0 = k == 0 ? by0[0] : k == 1 ? by0[1] : k == 2 ? by0[2] : by0[3];
+          const DivMod dm = fast_divmod(j, w, recip_i(w));
+          const int px = x0 + dm.r, py = y0 + dm.q;
+          Quad q;
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
-          q.x[v] = qscr[k * 8 + v];
-          q.y[v] = qscr[k * 8 + 4 + v];
+          for (int v = 0; v < 4; v++) {
+            q.x[v] = qscr[k * 8 + v];
+            q.y[v] = qscr[k * 8 + 4 + v];
+          }
+          if (!(SF_RENDER_SKIP & 32)) m = cover_to_mask(quad_cover(q, (float)px, (float)py));
+          p = fb + py * SF_IMG_W + px;
         }
-        mscr[i] = (uint8_t)cover_to_mask(quad_cover(q, (float)(x0 + rx), (float)(y0 + ry)));
+        // the strokes that have pixels in this round, in order (stroke-major rounds: a later round holds later strokes)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          if (kk < per && !(SF_RENDER_SKIP & 64) && off[kk] < base + 64 && off[kk + 1] > base) {  // uniform
+            if (k == kk && m > 0) *p = (uint8_t)sfr::over_un8(*p, grey, m);
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
       }
-      __builtin_amdgcn_wave_barrier();
       Box u;
       u.clear();
 #pragma unroll
       for (int k = 0; k < 4; k++)
         if (n[k]) u.add(bx0[k], by0[k], bx0[k] + bw[k], by0[k] + bh[k]);
-      const int uw = u.x1 - u.x0, un = uw * (u.y1 - u.y0);
-      const float r_uw = recip_i(uw);
-      for (int pi = lane; pi < ((SF_RENDER_SKIP & 64) ? 0 : un); pi += 64) {
-        const DivMod dm = fast_divmod(pi, uw, r_uw);
-        const int ry = dm.q, rx = dm.r;
-        const int px = u.x0 + rx, py = u.y0 + ry;
-        uint8_t* p = fb + py * SF_IMG_W + px;
-        int d = *p;
-        const int d0 = d;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int cx = px - bx0[k], cy = py - by0[k];
-          if (n[k] && cx >= 0 && cx < bw[k] && cy >= 0 && cy < bh[k]) {
-            const int m = mscr[off[k] + cy * bw[k] + cx];
-            if (m > 0) d = sfr::over_un8(d, grey, m);
-          }
-        }
-        if (d != d0) *p = (uint8_t)d;
-      }
-      __builtin_amdgcn_wave_barrier();
       resample(u);
     }
   }
