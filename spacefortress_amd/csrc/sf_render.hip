@@ -93,24 +93,43 @@ __device__ __forceinline__ float ramp_mean(float ya, float yb) {
   return d < 1e-6f ? flat : ramp;
 }
 
-// one directed edge's share of the integral of clamp(y, 0, 1) dx over the pixel at the origin
-__device__ __forceinline__ float edge_term(float x0, float y0, float x1, float y1) {
+// one directed edge's share of the integral of clamp(y, 0, 1) dx over the pixel at the origin; `slope` = dy / dx of
+// the edge: a property of the stroke, not of the pixel (quad_slopes) -- computed per pixel it was four reciprocals
+// and a dozen instructions of the 165 a pixel costs
+__device__ __forceinline__ float edge_term(float x0, float y0, float x1, float slope) {
   const float xa = clamp01(x0), xb = clamp01(x1);
   const float w = xb - xa;
-  const float slope = (y1 - y0) * __builtin_amdgcn_rcpf(x1 - x0);
   const float t = w * ramp_mean(y0 + (xa - x0) * slope, y0 + (xb - x0) * slope);
-  return w == 0.f ? 0.f : t;
+  return w == 0.f ? 0.f : t;  // (a vertical edge: slope inf or NaN, w = 0)
+}
+__device__ __forceinline__ float edge_slope(float x0, float y0, float x1, float y1) {
+  return (y1 - y0) * __builtin_amdgcn_rcpf(x1 - x0);
+}
+struct Slopes {
+  float s[4];
+};
+__device__ __forceinline__ Slopes quad_slopes(const Quad& q) {
+  Slopes sl;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int f = (e + 1) & 3;
+    sl.s[e] = edge_slope(q.x[e], q.y[e], q.x[f], q.y[f]);
+  }
+  return sl;
 }
 
 // area of quad /\ pixel [px,px+1]x[py,py+1]:  | sum over edges of the integral of clamp(y,0,1) dx |
-__device__ __forceinline__ float quad_cover(const Quad& q, float px, float py) {
+__device__ __forceinline__ float quad_cover(const Quad& q, const Slopes& sl, float px, float py) {
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const int f = (e + 1) & 3;
-    s += edge_term(q.x[e] - px, q.y[e] - py, q.x[f] - px, q.y[f] - py);
+    s += edge_term(q.x[e] - px, q.y[e] - py, q.x[f] - px, sl.s[e]);
   }
   return fabsf(s);
+}
+__device__ __forceinline__ float quad_cover(const Quad& q, float px, float py) {  // (callers whose quad is fixed over their
+  return quad_cover(q, quad_slopes(q), px, py);                                   //  pixel loop: the compiler hoists the slopes)
 }
 
 using sfr::cover_to_mask;
@@ -182,7 +201,7 @@ struct Frame {
   uint8_t* obuf;        // 84 x 84, row stride SF_OUT (global memory; LDS in sf_fort_patch_kernel)
   const uint32_t* tab;  // LDS copy of the tap tables (sf_raster.h)
   int lane;
-  float* qscr;          // LDS: 4 quads of the object being drawn (draw_objects)
+  float* qscr;          // LDS: 4 quads of the object being drawn, with their edge slopes (draw_objects)
   uint8_t* mscr;        // LDS: kMaskScratch bytes of scratch
 
   // cv2.resize(..., INTER_AREA) restricted to the destination pixels that read source pixels of `b`
@@ -298,10 +317,12 @@ struct Frame {
       }
       const int total = off[4];
       if (lane >= lo && lane < lo + per) {
+        const Slopes ms = quad_slopes(mine);
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-          qscr[(lane - lo) * 8 + v] = mine.x[v];
-          qscr[(lane - lo) * 8 + 4 + v] = mine.y[v];
+          qscr[(lane - lo) * 12 + v] = mine.x[v];
+          qscr[(lane - lo) * 12 + 4 + v] = mine.y[v];
+          qscr[(lane - lo) * 12 + 8 + v] = ms.s[v];
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -318,12 +339,14 @@ struct Frame {
           const DivMod dm = fast_divmod(j, w, recip_i(w));
           const int px = x0 + dm.r, py = y0 + dm.q;
           Quad q;
+          Slopes sl;
 #pragma unroll
           for (int v = 0; v < 4; v++) {
-            q.x[v] = qscr[k * 8 + v];
-            q.y[v] = qscr[k * 8 + 4 + v];
+            q.x[v] = qscr[k * 12 + v];
+            q.y[v] = qscr[k * 12 + 4 + v];
+            sl.s[v] = qscr[k * 12 + 8 + v];
           }
-          if (!(SF_RENDER_SKIP & 32)) m = cover_to_mask(quad_cover(q, (float)px, (float)py));
+          if (!(SF_RENDER_SKIP & 32)) m = cover_to_mask(quad_cover(q, sl, (float)px, (float)py));
           p = fb + py * SF_IMG_W + px;
         }
         // the strokes that have pixels in this round, in order (stroke-major rounds: a later round holds later strokes)
@@ -407,7 +430,7 @@ __device__ __forceinline__ float gon_cover(float gx, float gy, float r, float px
 #pragma unroll
   for (int k = 1; k <= 12; k++) {
     const float x1 = gx + r * kGon[k % 12][0] - px, y1 = gy + r * kGon[k % 12][1] - py;
-    s += edge_term(x0, y0, x1, y1);
+    s += edge_term(x0, y0, x1, edge_slope(x0, y0, x1, y1));
     x0 = x1;
     y0 = y1;
   }
@@ -740,7 +763,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
 #else
   const uint32_t* const tabw = a.tabs;  // 2.7 KB read by every wave: L1/L2 resident; LDS is better spent on waves
 #endif
-  __shared__ __attribute__((aligned(16))) float qscr[32];
+  __shared__ __attribute__((aligned(16))) float qscr[48];
   __shared__ __attribute__((aligned(16))) uint8_t mscr[kMaskScratch];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int lane = threadIdx.x;
@@ -1069,7 +1092,7 @@ __global__ __launch_bounds__(64) void sf_fort_patch_kernel(const uint32_t* bg, c
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
   __shared__ __attribute__((aligned(16))) uint32_t obufw[kOutBytes / 4];
   __shared__ __attribute__((aligned(16))) uint32_t tabw[SF_TAB_WORDS];
-  __shared__ __attribute__((aligned(16))) float qscr[32];
+  __shared__ __attribute__((aligned(16))) float qscr[48];
   __shared__ __attribute__((aligned(16))) uint8_t mscr[kMaskScratch];
   const int lane = threadIdx.x, sector = blockIdx.x;
   for (int i = lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bg[i] : 0u;
