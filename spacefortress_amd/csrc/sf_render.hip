@@ -1023,7 +1023,7 @@ ship_done:
       float s, c;
       sincos_deg(fort_angle, &s, &c);
       const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
-      F.draw_quads(q, 255, lane < 4, 64);
+      F.draw_objects(q, 255, lane < 4, 4);  // (a fifth of the frames of random play: one object of four strokes)
     }
    } else {
     // The destroyed fortress explodes for 1000 ms where it stands: one more picture drawn once per batch, in the
