@@ -511,6 +511,18 @@ __device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, float cx,
   F.resample(explosion_box(cx, cy));
 }
 
+// four bytes of a cached rectangle to p (any alignment; global memory and LDS both take an unaligned 32-bit store),
+// or the first n of them when the rectangle ends inside the word
+__device__ __forceinline__ void put_bytes(uint8_t* p, uint32_t w, int n) {
+  if (n >= 4) {
+    __builtin_memcpy(p, &w, 4);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (k < n) p[k] = (uint8_t)(w >> (8 * k));
+  }
+}
+
 // ---- A dead ship stays where it died for the 1000 ms of its explosion (30 frames), and the
 // explosion is the first thing drawn on the static background: its pixels -- and the 84x84 pixels
 // that read them -- are a function of the position alone.  Each env keeps them in HBM, keyed by that
@@ -550,23 +562,13 @@ __device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned 
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int d = lane + 64 * j, r = d / kRowW, c4 = (d - r * kRowW) * 4;
-      if (r < bh) {
-        uint8_t* p = F.fb + (b.y0 + r) * SF_IMG_W + b.x0 + c4;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (c4 + k < bw) p[k] = (uint8_t)(wf[j] >> (8 * k));
-      }
+      if (r < bh) put_bytes(F.fb + (b.y0 + r) * SF_IMG_W + b.x0 + c4, wf[j], bw - c4);
     }
     if (RESIZE) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int d = lane + 64 * j, r = d / kRowW, c4 = (d - r * kRowW) * 4;
-        if (r < oh) {
-          uint8_t* p = F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4;
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            if (c4 + k < ow) p[k] = (uint8_t)(wo[j] >> (8 * k));
-        }
+        if (r < oh) put_bytes(F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4, wo[j], ow - c4);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -716,19 +718,12 @@ __device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned
       v[0] = g32[kFpOutAt / 4 + lane];
       if (64 + lane < (kFpOutRow / 4) * oh) v[1] = g32[kFpOutAt / 4 + 64 + lane];
     }
-    uint8_t* p = F.fb + (kFpY0 + (lane >> 2)) * SF_IMG_W + kFpX0 + (lane & 3) * 4;
-#pragma unroll
-    for (int k = 0; k < 4; k++) p[k] = (uint8_t)(w >> (8 * k));
+    put_bytes(F.fb + (kFpY0 + (lane >> 2)) * SF_IMG_W + kFpX0 + (lane & 3) * 4, w, 4);
     if (RESIZE) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int d = lane + 64 * j, r = d / (kFpOutRow / 4), c4 = (d - r * (kFpOutRow / 4)) * 4;
-        if (r < oh) {
-          uint8_t* q = F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4;
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            if (c4 + k < ow) q[k] = (uint8_t)(v[j] >> (8 * k));
-        }
+        if (r < oh) put_bytes(F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4, v[j], ow - c4);
       }
     }
     __builtin_amdgcn_wave_barrier();
