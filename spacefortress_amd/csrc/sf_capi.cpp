@@ -366,14 +366,17 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
     // first frame of this batch: the per-env explosion cache (feature-only batches never pay for it)
     // ... followed by the 36 fortress pictures, drawn here once
     // ... and by the destroyed fortress's explosion, in the layout of an env's cache entry
-    const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES, tail = 36 * SF_FP_BYTES + SF_XC_BYTES;
+    // ... and by the score / bar pictures
+    const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES, tail = 36 * SF_FP_BYTES + SF_XC_BYTES + SF_HUD_BYTES;
     HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes + tail));
     HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes + tail, stream));
+    HIP_TRY(sf_launch_hud_pictures(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes + 36 * SF_FP_BYTES + SF_XC_BYTES, stream));
     HIP_TRY(sf_launch_fort_patches(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes, stream));
   }
   const unsigned char* fpatch = b->d_xcache ? b->d_xcache + (size_t)b->n_envs * SF_XC_BYTES : nullptr;
   HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache, fpatch,
-                           mode == SF_OBS_IMAGE ? 1 : 0, stack_done, stack_slot, stack_n, stack_prev, b->args.hint, stream));
+                           mode == SF_OBS_IMAGE ? 1 : 0, stack_done, stack_slot, stack_n, stack_prev, b->args.hint,
+                           fpatch ? fpatch + 36 * SF_FP_BYTES + SF_XC_BYTES : nullptr, stream));
   return SF_OK;
 }
 

@@ -31,7 +31,11 @@ hipError_t sf_launch_group_copy(const unsigned char* state, int n_envs, int grou
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
-                            const uint8_t* stack_prev, const unsigned long long* hint, hipStream_t stream);
+                            const uint8_t* stack_prev, const unsigned long long* hint, const unsigned char* hud,
+                            hipStream_t stream);
+// the score / bar pictures (SF_HUD_BYTES, sf_raster.h)
+hipError_t sf_launch_hud_pictures(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* hud,
+                                  hipStream_t stream);
 hipError_t sf_launch_fort_patches(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
                                   hipStream_t stream);
 

@@ -44,6 +44,16 @@
 #define SF_BG_STRIDE 8288
 // per-env cache of the dead ship's explosion pixels (sf_render.hip: ship_explosion)
 #define SF_XC_BYTES 1600
+// The score and the bar drawn on the bare background, one picture per value (sf_render.hip: hud pictures): the score
+// for -SF_HUD_SCORE_HALF <= points < SF_HUD_SCORE_HALF, the bar for its 12 states (0..10 tenths, and the kill-ready
+// white one).  A picture = the rows of the surface box, SF_HUD_*_ROW bytes apart, then the rows of the 84x84 box.
+#define SF_HUD_SCORE_HALF 512
+#define SF_HUD_SCORE_ROW 28
+#define SF_HUD_SCORE_BYTES 320
+#define SF_HUD_BAR_STATES 12
+#define SF_HUD_BAR_ROW 40
+#define SF_HUD_BAR_BYTES 384
+#define SF_HUD_BYTES (2 * SF_HUD_SCORE_HALF * SF_HUD_SCORE_BYTES + SF_HUD_BAR_STATES * SF_HUD_BAR_BYTES)
 // one fortress picture (sf_render.hip: fort_patch_copy): 16 x 16 of the surface, 18 rows x 20 of the 84x84 image
 #define SF_FP_BYTES 640
 

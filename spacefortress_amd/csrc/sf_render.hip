@@ -641,6 +641,7 @@ struct SfRenderArgs {
   // kernel), and the number of workgroups in front of the grid that draw such envs first; null / 0 = env = blockIdx
   const unsigned long long* hint;
   int n_front;
+  const unsigned char* hud;  // SF_HUD_BYTES: the score / bar pictures (sf_hud_kernel), or null
 };
 
 // ---- Which env a workgroup draws.  The first frame of a dead ship's explosion costs about three ordinary frames (96
@@ -746,6 +747,98 @@ __device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned
   __builtin_amdgcn_wave_barrier();
 }
 
+
+// ---- score (drawScore, SRC/draw.cpp:190-203): "%07d", grey .5, seven-segment digits; a lane per pixel of the box
+template <bool RESIZE>
+__device__ __forceinline__ void draw_score(const Frame<RESIZE>& F, int pnts) {
+  const unsigned long long masks = sfr::score_masks(pnts);
+  constexpr int w = SF_TXT_BOX_X1 - SF_TXT_BOX_X0, h = SF_TXT_BOX_Y1 - SF_TXT_BOX_Y0;
+  static_assert(SF_TXT_BOX_X0 <= (SF_TXT_X0 + SF_TXT_PAD - SF_VP_X) * SF_SCALE &&
+                SF_TXT_BOX_X1 >= (SF_TXT_X0 + 6 * SF_TXT_ADV + SF_TXT_PAD + SF_TXT_W - SF_VP_X) * SF_SCALE &&
+                SF_TXT_BOX_Y0 <= (SF_TXT_TOP - SF_VP_Y) * SF_SCALE &&
+                SF_TXT_BOX_Y1 >= (SF_TXT_TOP + SF_TXT_H - SF_VP_Y) * SF_SCALE, "text box");
+  for (int i = F.lane; i < w * h; i += 64) {
+    const int ry = i / w, rx = i - ry * w;
+    uint8_t* p = F.fb + (SF_TXT_BOX_Y0 + ry) * SF_IMG_W + SF_TXT_BOX_X0 + rx;
+    *p = (uint8_t)sfr::text_pixel(SF_TXT_BOX_X0 + rx, SF_TXT_BOX_Y0 + ry, masks, *p);
+  }
+  __builtin_amdgcn_wave_barrier();
+  F.resample(Box{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1});
+}
+// ---- vulnerability bar (drawVlner, :205-225): two filled rectangles, a lane per pixel of the box.  `state`: 0..10
+// tenths in grey .66, 11 = full and white (kill-ready, :268)
+__device__ __forceinline__ int bar_state(int vlner, int fort_vuln_timer) {
+  const bool kill = vlner > 10 && fort_vuln_timer < sfc::vuln_time;
+  return kill ? 11 : (vlner > 10 ? 10 : vlner);
+}
+template <bool RESIZE>
+__device__ __forceinline__ void draw_bar(const Frame<RESIZE>& F, int state) {
+  const int v = state > 10 ? 10 : state, vg = state > 10 ? 255 : 168;
+  constexpr int w = SF_BAR_BOX_X1 - SF_BAR_BOX_X0, h = SF_BAR_BOX_Y1 - SF_BAR_BOX_Y0;
+  static_assert(SF_BAR_BOX_X0 == (int)((255 - SF_VP_X) * SF_SCALE) && SF_BAR_BOX_X1 == (int)((455 - SF_VP_X) * SF_SCALE) &&
+                SF_BAR_BOX_Y0 <= (522 - SF_VP_Y) * SF_SCALE && SF_BAR_BOX_Y1 >= (532 - SF_VP_Y) * SF_SCALE, "bar box");
+  for (int i = F.lane; i < w * h; i += 64) {
+    const int ry = i / w, rx = i - ry * w;
+    uint8_t* p = F.fb + (SF_BAR_BOX_Y0 + ry) * SF_IMG_W + SF_BAR_BOX_X0 + rx;
+    *p = (uint8_t)sfr::bar_pixel(SF_BAR_BOX_X0 + rx, SF_BAR_BOX_Y0 + ry, v, vg, *p);
+  }
+  __builtin_amdgcn_wave_barrier();
+  F.resample(Box{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1});
+}
+
+// The score and the bar are drawn last, over pixels nothing else has touched (else: in place), and what they draw is
+// a function of the points / of the bar's state alone: pictures drawn once per batch by the code above
+// (sf_hud_kernel), like the fortress's.  One picture = the box of the surface, then the box of the 84x84 image that
+// reads it, rows `row` bytes apart; at most 64 words each: a lane per word, all loads before the first store.
+template <bool RESIZE>
+__device__ __forceinline__ void hud_picture(const Frame<RESIZE>& F, unsigned char* pic, int row, const Box b, bool store,
+                                            const bool with_out = true) {
+  const Box o = out_box(b);
+  const int lane = F.lane, wpr = row / 4;
+  const int bw = b.x1 - b.x0, bh = b.y1 - b.y0, ow = o.x1 - o.x0, oh = o.y1 - o.y0;
+  const int r = lane / wpr, c4 = (lane - r * wpr) * 4;
+  uint8_t* pf = F.fb + (b.y0 + r) * SF_IMG_W + b.x0 + c4;
+  uint8_t* po = F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4;
+  uint32_t* gf = reinterpret_cast<uint32_t*>(pic) + lane;
+  uint32_t* go = reinterpret_cast<uint32_t*>(pic + ((bh * row + 15) & ~15)) + lane;
+  if (store) {
+    uint32_t wf = 0, wo = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (r < bh && c4 + k < bw) wf |= (uint32_t)pf[k] << (8 * k);
+      if (RESIZE && r < oh && c4 + k < ow) wo |= (uint32_t)po[k] << (8 * k);
+    }
+    if (r < bh) *gf = wf;
+    if (RESIZE && r < oh) *go = wo;
+    return;
+  }
+  const uint32_t wf = r < bh ? *gf : 0u, wo = (RESIZE && with_out && r < oh) ? *go : 0u;
+  if (r < bh && c4 < bw) put_bytes(pf, wf, bw - c4);
+  if (RESIZE && with_out && r < oh && c4 < ow) put_bytes(po, wo, ow - c4);
+  __builtin_amdgcn_wave_barrier();
+  // (something within 3 pixels, not on the box: the surface part of the picture still holds, the 84x84 pixels are taken
+  //  from the surface as it is now)
+  if (RESIZE && !with_out) F.resample(b);
+}
+__device__ __forceinline__ unsigned char* hud_score_picture(const unsigned char* hud, int pnts) {
+  return const_cast<unsigned char*>(hud) + (size_t)(pnts + SF_HUD_SCORE_HALF) * SF_HUD_SCORE_BYTES;
+}
+__device__ __forceinline__ unsigned char* hud_bar_picture(const unsigned char* hud, int state) {
+  return const_cast<unsigned char*>(hud) + (size_t)2 * SF_HUD_SCORE_HALF * SF_HUD_SCORE_BYTES + (size_t)state * SF_HUD_BAR_BYTES;
+}
+// (out_box of the two boxes: 27 x 6 and 39 x 6 pixels of the 84x84 image)
+constexpr int kHudScoreOutW = (SF_TXT_BOX_X1 * 14) / 15 + 1 - ((SF_TXT_BOX_X0 - 1) * 14) / 15,
+              kHudScoreOutH = (SF_TXT_BOX_Y1 * 21) / 23 + 1 - (SF_TXT_BOX_Y0 >= 2 ? ((SF_TXT_BOX_Y0 - 2) * 21) / 23 : 0),
+              kHudBarOutW = (SF_BAR_BOX_X1 * 14) / 15 + 1 - ((SF_BAR_BOX_X0 - 1) * 14) / 15,
+              kHudBarOutH = SF_OUT - ((SF_BAR_BOX_Y0 - 2) * 21) / 23;
+static_assert(((SF_TXT_BOX_Y1 - SF_TXT_BOX_Y0) * SF_HUD_SCORE_ROW + 15) / 16 * 16 + kHudScoreOutH * SF_HUD_SCORE_ROW <= SF_HUD_SCORE_BYTES &&
+              SF_HUD_SCORE_ROW >= kHudScoreOutW && SF_HUD_SCORE_ROW >= SF_TXT_BOX_X1 - SF_TXT_BOX_X0 &&
+              kHudScoreOutH * (SF_HUD_SCORE_ROW / 4) <= 64 && (SF_TXT_BOX_Y1 - SF_TXT_BOX_Y0) * (SF_HUD_SCORE_ROW / 4) <= 64,
+              "score picture layout");
+static_assert(((SF_BAR_BOX_Y1 - SF_BAR_BOX_Y0) * SF_HUD_BAR_ROW + 15) / 16 * 16 + kHudBarOutH * SF_HUD_BAR_ROW <= SF_HUD_BAR_BYTES &&
+              SF_HUD_BAR_ROW >= kHudBarOutW && SF_HUD_BAR_ROW >= SF_BAR_BOX_X1 - SF_BAR_BOX_X0 &&
+              kHudBarOutH * (SF_HUD_BAR_ROW / 4) <= 64 && (SF_BAR_BOX_Y1 - SF_BAR_BOX_Y0) * (SF_HUD_BAR_ROW / 4) <= 64,
+              "bar picture layout");
 
 template <bool RESIZE>
 #ifndef SF_RENDER_WPE
@@ -955,12 +1048,25 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // show 0000000 / an empty bar and nothing drawn before them reaches their pixels, the result is the
   // static picture the host baked (same arithmetic, sf_raster.h).  A live ship and the fortress never
   // reach them (the ship is inside the big hexagon, rows 12.2 .. 81.6 +- 5.4 px).
+  // A score / bar that is not baked in is one of the pictures (hud_picture) unless something comes within 3 pixels
+  // of its box: the picture's 84x84 pixels read that far, and it is restored after everything else was resampled.
+  const Box tbox3{SF_TXT_BOX_X0 - 3, SF_TXT_BOX_Y0 - 3, SF_TXT_BOX_X1 + 3, SF_TXT_BOX_Y1 + 3};
+  const Box bbox3{SF_BAR_BOX_X0 - 3, SF_BAR_BOX_Y0 - 3, SF_BAR_BOX_X1 + 3, SF_BAR_BOX_Y1 + 3};
+  bool close_text = near_text, close_bar = near_bar;  // (the explosion's box above is already 3 pixels wider)
+  if (ship_alive) {  // (the ship stays inside the big hexagon: rows 12.2 .. 81.6 +- 5.4 px -- never on the bar, but close)
+    const float gx = dev_x(ship_x), gy = dev_y(ship_y), ext = 27.f * (float)SF_SCALE;
+    const Box shb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
+    close_text = close_text || shb.meets(tbox3);
+    close_bar = close_bar || shb.meets(bbox3);
+  }
   {
-    bool t = false, b = false;
+    bool t = false, b = false, t3 = false, b3 = false;
     if (mvalid) {
       const Box qb = quad_box(mq);
       t = t || qb.meets(tbox);
       b = b || qb.meets(bbox);
+      t3 = t3 || qb.meets(tbox3);
+      b3 = b3 || qb.meets(bbox3);
     }
 #pragma unroll
     for (int round = 0; round < 2; round++)
@@ -968,9 +1074,13 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
         const Box qb = quad_box(sq[round]);
         t = t || qb.meets(tbox);
         b = b || qb.meets(bbox);
+        t3 = t3 || qb.meets(tbox3);
+        b3 = b3 || qb.meets(bbox3);
       }
     near_text = near_text || __any(t);
     near_bar = near_bar || __any(b);
+    close_text = close_text || __any(t3);
+    close_bar = close_bar || __any(b3);
   }
   const bool baked_text = pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4);
   const bool baked_bar = vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8);
@@ -1038,37 +1148,20 @@ ship_done:
     F.draw_objects(sq[0], 255, svalid[0], 4);
     F.draw_objects(sq[1], 255, svalid[1], 4);
   }
-  // ---- score (drawScore, :190-203): "%07d", grey .5, seven-segment digits; a lane per pixel of the box
+  // ---- score and bar, last (SRC/draw.cpp:266-268): baked into the background already (0000000 / empty), or one of
+  // the pictures, or -- something else touches their pixels, or the points are off the table -- in place
   if (!baked_text && !(SF_RENDER_SKIP & 4)) {
-    const unsigned long long masks = sfr::score_masks(pnts);
-    constexpr int w = SF_TXT_BOX_X1 - SF_TXT_BOX_X0, h = SF_TXT_BOX_Y1 - SF_TXT_BOX_Y0;
-    static_assert(SF_TXT_BOX_X0 <= (SF_TXT_X0 + SF_TXT_PAD - SF_VP_X) * SF_SCALE &&
-                  SF_TXT_BOX_X1 >= (SF_TXT_X0 + 6 * SF_TXT_ADV + SF_TXT_PAD + SF_TXT_W - SF_VP_X) * SF_SCALE &&
-                  SF_TXT_BOX_Y0 <= (SF_TXT_TOP - SF_VP_Y) * SF_SCALE &&
-                  SF_TXT_BOX_Y1 >= (SF_TXT_TOP + SF_TXT_H - SF_VP_Y) * SF_SCALE, "text box");
-    for (int i = lane; i < w * h; i += 64) {
-      const int ry = i / w, rx = i - ry * w;
-      uint8_t* p = fb + (SF_TXT_BOX_Y0 + ry) * SF_IMG_W + SF_TXT_BOX_X0 + rx;
-      *p = (uint8_t)sfr::text_pixel(SF_TXT_BOX_X0 + rx, SF_TXT_BOX_Y0 + ry, masks, *p);
-    }
-    __builtin_amdgcn_wave_barrier();
-    F.resample(tbox);
+    if (a.hud && !near_text && pnts >= -SF_HUD_SCORE_HALF && pnts < SF_HUD_SCORE_HALF)
+      hud_picture(F, hud_score_picture(a.hud, pnts), SF_HUD_SCORE_ROW, tbox, false, !close_text);
+    else
+      draw_score(F, pnts);
   }
-  // ---- vulnerability bar (drawVlner, :205-225): two filled rectangles, a lane per pixel of the box
   if (!baked_bar && !(SF_RENDER_SKIP & 8)) {
-    const bool kill = vlner > 10 && fort_vuln_timer < sfc::vuln_time;  // :268
-    const int v = vlner > 10 ? 10 : vlner;
-    const int vg = kill ? 255 : 168;
-    constexpr int w = SF_BAR_BOX_X1 - SF_BAR_BOX_X0, h = SF_BAR_BOX_Y1 - SF_BAR_BOX_Y0;
-    static_assert(SF_BAR_BOX_X0 == (int)((255 - SF_VP_X) * SF_SCALE) && SF_BAR_BOX_X1 == (int)((455 - SF_VP_X) * SF_SCALE) &&
-                  SF_BAR_BOX_Y0 <= (522 - SF_VP_Y) * SF_SCALE && SF_BAR_BOX_Y1 >= (532 - SF_VP_Y) * SF_SCALE, "bar box");
-    for (int i = lane; i < w * h; i += 64) {
-      const int ry = i / w, rx = i - ry * w;
-      uint8_t* p = fb + (SF_BAR_BOX_Y0 + ry) * SF_IMG_W + SF_BAR_BOX_X0 + rx;
-      *p = (uint8_t)sfr::bar_pixel(SF_BAR_BOX_X0 + rx, SF_BAR_BOX_Y0 + ry, v, vg, *p);
-    }
-    __builtin_amdgcn_wave_barrier();
-    F.resample(bbox);
+    const int state = bar_state(vlner, fort_vuln_timer);
+    if (a.hud && !near_bar)
+      hud_picture(F, hud_bar_picture(a.hud, state), SF_HUD_BAR_ROW, bbox, false, !close_bar);
+    else
+      draw_bar(F, state);
   }
   __syncthreads();
 
@@ -1115,6 +1208,38 @@ hipError_t sf_launch_fort_patches(const uint32_t* bg, const uint32_t* bg84, cons
   return hipGetLastError();
 }
 
+// one workgroup per picture: the score for blockIdx - SF_HUD_SCORE_HALF points, then the bar's states, drawn on the
+// bare background by the frames' own code and saved for hud_picture
+__global__ __launch_bounds__(64) void sf_hud_kernel(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs,
+                                                    unsigned char* hud) {
+  __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
+  __shared__ __attribute__((aligned(16))) uint32_t obufw[kOutBytes / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t tabw[SF_TAB_WORDS];
+  const int lane = threadIdx.x, pic = blockIdx.x;
+  for (int i = lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bg[i] : 0u;
+  for (int i = lane; i < kOutBytes / 4; i += 64) obufw[i] = bg84[i];
+  for (int i = lane; i < SF_TAB_WORDS; i += 64) tabw[i] = tabs[i];
+  __syncthreads();
+  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, lane, nullptr, nullptr};
+  if (pic < 2 * SF_HUD_SCORE_HALF) {
+    const int pnts = pic - SF_HUD_SCORE_HALF;
+    draw_score(F, pnts);
+    __syncthreads();
+    hud_picture(F, hud_score_picture(hud, pnts), SF_HUD_SCORE_ROW, Box{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1}, true);
+  } else {
+    const int state = pic - 2 * SF_HUD_SCORE_HALF;
+    draw_bar(F, state);
+    __syncthreads();
+    hud_picture(F, hud_bar_picture(hud, state), SF_HUD_BAR_ROW, Box{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1}, true);
+  }
+}
+
+hipError_t sf_launch_hud_pictures(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* hud,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(sf_hud_kernel, dim3(2 * SF_HUD_SCORE_HALF + SF_HUD_BAR_STATES), dim3(64), 0, stream, bg, bg84, tabs, hud);
+  return hipGetLastError();
+}
+
 // current_obs *= masks (rl/train.py:92-93) for a [n][bytes_per_env] uint8 stack: only finished envs are touched
 __global__ __launch_bounds__(256) void sf_stack_clear_kernel(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n) {
   const int env = blockIdx.x;
@@ -1133,13 +1258,14 @@ hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uin
 hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
-                            const uint8_t* stack_prev, const unsigned long long* hint, hipStream_t stream) {
+                            const uint8_t* stack_prev, const unsigned long long* hint, const unsigned char* hud,
+                            hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
   // the front of the grid: a sixteenth of the batch (ships die in about 1.3 % of the ticks of random play); batches
   // whose hint words no longer fit a short scan (> 32 per lane) are drawn in env order
   const int n_front = hint && n_envs <= 64 * 64 * 32 ? (n_envs / 16 > 64 ? n_envs / 16 : 64) : 0;
   SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n, stack_prev,
-                 n_front ? hint : nullptr, n_front};
+                 n_front ? hint : nullptr, n_front, hud};
   const unsigned grid = (unsigned)(n_envs + n_front);
   if (resize)
     hipLaunchKernelGGL(sf_render_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
