@@ -8,17 +8,28 @@ from spacefortress_amd import SFVecEnv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-for mode in (sys.argv[3:] or ["image", "image-raw"]):
-    env = SFVecEnv(n, gametype="youturn", obs_type=mode, spawn_stride=1, reuse_buffers=True)
+args = sys.argv[3:]
+hunter = "hunter" in args  # a firing pattern that destroys the fortress every few seconds (tools/soak.py), autoturn game
+args = [a for a in args if a != "hunter"]
+for mode in (args or ["image", "image-raw"]):
+    env = SFVecEnv(n, gametype="autoturn" if hunter else "youturn", obs_type=mode, spawn_stride=1, reuse_buffers=True)
     env.reset()
-    acts = torch.randint(0, 5, (64, n), device=env.device, dtype=torch.uint8)
+    acts = torch.randint(0, env.n_actions, (64, n), device=env.device, dtype=torch.uint8)
+    if hunter:
+        rng = np.random.default_rng(1)
+        pat = np.array(([1] + [0] * 7) * 11 + [1, 0, 1, 0] + [0] * 4, np.uint8)
+        assert len(pat) == 96
+        ph = rng.integers(0, 96, n)
+        rows = np.stack([np.where(rng.random(n) < 0.1, rng.integers(0, env.n_actions, n), pat[(t + ph) % 96]) for t in range(96)])
+        acts = torch.from_numpy(rows.astype(np.uint8)).to(env.device)
+    ring = acts.shape[0]
     for t in range(400):  # get into mid-episode states (missiles, shells, explosions)
-        env.step_tensors(acts[t % 64])
+        env.step_tensors(acts[t % ring])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for t in range(steps):
-        env.step_tensors(acts[t % 64])
+        env.step_tensors(acts[t % ring])
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
@@ -29,6 +40,6 @@ for mode in (sys.argv[3:] or ["image", "image-raw"]):
     e1.record()
     torch.cuda.synchronize()
     ms_r = e0.elapsed_time(e1) / steps
-    print("%s n=%d: step+render %.1f us (%.3g frames/s), render alone %.1f us, output %.2f GB/s" %
+    print(("hunter " if hunter else "") + "%s n=%d: step+render %.1f us (%.3g frames/s), render alone %.1f us, output %.2f GB/s" %
           (mode, n, ms * 1e3, n / ms * 1e3, ms_r * 1e3, out.numel() / ms_r / 1e6))
     env.close()
