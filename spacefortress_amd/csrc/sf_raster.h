@@ -43,7 +43,9 @@
 // baked in) at byte offset v * SF_BG_STRIDE (92x90) and v * 84*84 (resampled)
 #define SF_BG_STRIDE 8288
 // per-env cache of the dead ship's explosion pixels (sf_render.hip: ship_explosion)
-#define SF_XC_BYTES 1600
+// ... followed by the score box and the bar box as they end up when only that explosion is on them (keyed by the points /
+// the bar's state): SF_XC_BYTES = 1600 + 320 + 384
+#define SF_XC_BYTES 2304
 // The score and the bar drawn on the bare background, one picture per value (sf_render.hip: hud pictures): the score
 // for -SF_HUD_SCORE_HALF <= points < SF_HUD_SCORE_HALF, the bar for its 12 states (0..10 tenths, and the kill-ready
 // white one).  A picture = the rows of the surface box, SF_HUD_*_ROW bytes apart, then the rows of the 84x84 box.

@@ -530,20 +530,33 @@ __device__ __forceinline__ void put_bytes(uint8_t* p, uint32_t w, int n) {
 // x 28 of the 84x84 image}.  29 of 30 explosion frames become two small copies.
 constexpr int kXcKey = 0, kXcFlags = 16, kXcFb = 32, kXcRow = 28, kXcFbRows = 27, kXcOut = kXcFb + kXcFbRows * kXcRow + 12,
               kXcOutRows = 28;
-static_assert(kXcOut % 4 == 0 && kXcOut + kXcOutRows * kXcRow <= SF_XC_BYTES, "explosion cache layout");
+// ... and, for an explosion that reaches the score or the bar (a ship lost through the upper or lower edge of the big
+// hexagon: a sixth of the losses each), what their boxes end up as with the score / bar drawn over it: the points (int) and
+// the bar's state (int) they were drawn for at kXcHudKeys, the two pictures (hud_picture's layout) behind.  Flags: 1, 2 =
+// the explosion's surface / 84x84 part; 4, 8 = the score box's; 16, 32 = the bar box's.
+constexpr int kXcHudKeys = 1584, kXcScore = 1600, kXcBar = kXcScore + SF_HUD_SCORE_BYTES;
+static_assert(kXcOut % 4 == 0 && kXcOut + kXcOutRows * kXcRow <= kXcHudKeys && kXcBar + SF_HUD_BAR_BYTES <= SF_XC_BYTES,
+              "explosion cache layout");
+struct XcState {
+  unsigned flags;  // of the entry as it is after ship_explosion (0: no usable entry)
+  int points, bar; // the keys of its score / bar pictures
+};
 
 template <bool RESIZE>
-__device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned char* xc, double x, double y,
-                                               const bool fill = true) {
+__device__ __forceinline__ XcState ship_explosion(const Frame<RESIZE>& F, unsigned char* xc, double x, double y,
+                                                  const bool fill = true) {
   const float cx = (float)x, cy = (float)y;
   const Box b = explosion_box(cx, cy), o = out_box(b);
   const int lane = F.lane;
   const unsigned need = RESIZE ? 3u : 1u;
   bool hit = false;
+  XcState st{0u, 0, 0};
   if (xc) {
     const double kx = *reinterpret_cast<const double*>(xc + kXcKey), ky = *reinterpret_cast<const double*>(xc + kXcKey + 8);
     const unsigned fl = *reinterpret_cast<const unsigned*>(xc + kXcFlags);
+    const int2 keys = *reinterpret_cast<const int2*>(xc + kXcHudKeys);
     hit = (kx == x && ky == y && (fl & need) == need) || (SF_RENDER_SKIP & 1024);  // (bit 10: a miss costs what a hit does)
+    st = XcState{fl, keys.x, keys.y};
   }
   const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows;
   if (hit && fits) {
@@ -572,9 +585,10 @@ __device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned 
       }
     }
     __builtin_amdgcn_wave_barrier();
-    return;
+    return st;
   }
   draw_explosion(F, cx, cy);
+  st.flags = 0;
   if (xc && fits && fill) {
     for (int i = lane; i < kXcFbRows * kXcRow; i += 64) {
       const int r = i / kXcRow, c = i - r * kXcRow;
@@ -586,7 +600,9 @@ __device__ __forceinline__ void ship_explosion(const Frame<RESIZE>& F, unsigned 
       *reinterpret_cast<double*>(xc + kXcKey + 8) = y;
       *reinterpret_cast<unsigned*>(xc + kXcFlags) = need;
     }
+    st.flags = need;  // (a new explosion: whatever score / bar picture the entry held belongs to the old one)
   }
+  return st;
 }
 
 }  // namespace
@@ -1052,12 +1068,13 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // of its box: the picture's 84x84 pixels read that far, and it is restored after everything else was resampled.
   const Box tbox3{SF_TXT_BOX_X0 - 3, SF_TXT_BOX_Y0 - 3, SF_TXT_BOX_X1 + 3, SF_TXT_BOX_Y1 + 3};
   const Box bbox3{SF_BAR_BOX_X0 - 3, SF_BAR_BOX_Y0 - 3, SF_BAR_BOX_X1 + 3, SF_BAR_BOX_Y1 + 3};
-  bool close_text = near_text, close_bar = near_bar;  // (the explosion's box above is already 3 pixels wider)
+  const bool ex_text = near_text, ex_bar = near_bar;  // the explosion's share (its box above is already 3 pixels wider)
+  bool other_text = false, other_bar = false;          // anything else within 3 pixels: the live ship, projectiles
   if (ship_alive) {  // (the ship stays inside the big hexagon: rows 12.2 .. 81.6 +- 5.4 px -- never on the bar, but close)
     const float gx = dev_x(ship_x), gy = dev_y(ship_y), ext = 27.f * (float)SF_SCALE;
     const Box shb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
-    close_text = close_text || shb.meets(tbox3);
-    close_bar = close_bar || shb.meets(bbox3);
+    other_text = shb.meets(tbox3);
+    other_bar = shb.meets(bbox3);
   }
   {
     bool t = false, b = false, t3 = false, b3 = false;
@@ -1079,9 +1096,10 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       }
     near_text = near_text || __any(t);
     near_bar = near_bar || __any(b);
-    close_text = close_text || __any(t3);
-    close_bar = close_bar || __any(b3);
+    other_text = other_text || __any(t3);
+    other_bar = other_bar || __any(b3);
   }
+  const bool close_text = ex_text || other_text, close_bar = ex_bar || other_bar;
   const bool baked_text = pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4);
   const bool baked_bar = vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8);
   const int variant = (baked_text ? 1 : 0) | (baked_bar ? 2 : 0);
@@ -1099,6 +1117,8 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const Frame<RESIZE> F{fb, frame_out, tabw, lane, qscr, mscr};
 
   // ---- ship (SRC/draw.cpp:233-237)
+  unsigned char* const xc_mine = a.xcache ? a.xcache + (size_t)env * SF_XC_BYTES : nullptr;
+  XcState xst{0u, 0, 0};
   if (SF_RENDER_SKIP & 1) {
   } else if (ship_alive) {
     if (SF_RENDER_SKIP & 128) goto ship_done;  // (diagnostic: the live ship alone)
@@ -1107,7 +1127,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     const Quad q = line_quad(kShipLines[lane < 3 ? lane : 0], c, s, ship_x, ship_y);
     F.draw_objects(q, 255, lane < 3, 4);
   } else if (!(SF_RENDER_SKIP & 256)) {  // (diagnostic bit 8: the dead ship's explosion alone)
-    ship_explosion(F, a.xcache ? a.xcache + (size_t)env * SF_XC_BYTES : nullptr, sp.x, sp.y);
+    xst = ship_explosion(F, xc_mine, sp.x, sp.y);
   }
 ship_done:
   // ---- fortress (:238-242)
@@ -1150,18 +1170,55 @@ ship_done:
   }
   // ---- score and bar, last (SRC/draw.cpp:266-268): baked into the background already (0000000 / empty), or one of
   // the pictures, or -- something else touches their pixels, or the points are off the table -- in place
+  // When the only thing on them is the dead ship's explosion (a ship lost through the upper or lower edge of the big
+  // hexagon, right under the score / over the bar: a sixth of the losses each, 30 frames a time), what the box ends up as
+  // belongs to (where the ship died, the points / the bar's state): drawn in place once, kept in the env's explosion
+  // cache entry, restored for the other frames.
+  // (one call site each for drawing and for the picture copy: what to do is decided first)
   if (!baked_text && !(SF_RENDER_SKIP & 4)) {
-    if (a.hud && !near_text && pnts >= -SF_HUD_SCORE_HALF && pnts < SF_HUD_SCORE_HALF)
-      hud_picture(F, hud_score_picture(a.hud, pnts), SF_HUD_SCORE_ROW, tbox, false, !close_text);
-    else
-      draw_score(F, pnts);
+    constexpr unsigned kBits = RESIZE ? 12u : 4u;
+    unsigned char* pic = nullptr;
+    bool draw = true, save = false, with_out = true;
+    if (a.hud && !near_text && pnts >= -SF_HUD_SCORE_HALF && pnts < SF_HUD_SCORE_HALF) {
+      pic = hud_score_picture(a.hud, pnts);
+      draw = false;
+      with_out = !close_text;
+    } else if (xst.flags && ex_text && !other_text) {
+      pic = xc_mine + kXcScore;
+      draw = save = !((xst.flags & kBits) == kBits && xst.points == pnts);
+    }
+    if (draw) draw_score(F, pnts);
+    if (pic) hud_picture(F, pic, SF_HUD_SCORE_ROW, tbox, save, with_out);
+    if (save) {
+      xst.flags |= kBits;
+      if (lane == 0) {
+        *reinterpret_cast<int*>(xc_mine + kXcHudKeys) = pnts;
+        *reinterpret_cast<unsigned*>(xc_mine + kXcFlags) = xst.flags;
+      }
+    }
   }
   if (!baked_bar && !(SF_RENDER_SKIP & 8)) {
+    constexpr unsigned kBits = RESIZE ? 48u : 16u;
     const int state = bar_state(vlner, fort_vuln_timer);
-    if (a.hud && !near_bar)
-      hud_picture(F, hud_bar_picture(a.hud, state), SF_HUD_BAR_ROW, bbox, false, !close_bar);
-    else
-      draw_bar(F, state);
+    unsigned char* pic = nullptr;
+    bool draw = true, save = false, with_out = true;
+    if (a.hud && !near_bar) {
+      pic = hud_bar_picture(a.hud, state);
+      draw = false;
+      with_out = !close_bar;
+    } else if (xst.flags && ex_bar && !other_bar) {
+      pic = xc_mine + kXcBar;
+      draw = save = !((xst.flags & kBits) == kBits && xst.bar == state);
+    }
+    if (draw) draw_bar(F, state);
+    if (pic) hud_picture(F, pic, SF_HUD_BAR_ROW, bbox, save, with_out);
+    if (save) {
+      xst.flags |= kBits;
+      if (lane == 0) {
+        *reinterpret_cast<int*>(xc_mine + kXcHudKeys + 4) = state;
+        *reinterpret_cast<unsigned*>(xc_mine + kXcFlags) = xst.flags;
+      }
+    }
   }
   __syncthreads();
 
