@@ -211,6 +211,13 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
           uint32_t* t = &tabs[4 * (ax * SF_OUT + i)];
           t[0] = (uint32_t)first[i];
           memcpy(t + 1, alpha + 4 * i, 3 * sizeof(float));
+          // ... and what its exact dirty box relies on (sf_render.hip: out_box): a source cell s is read with a weight
+          // that is not zero only by the destinations floor(N s / D) ... ceil(N (s + 1) / D) - 1, N / D = 14/15, 21/23
+          const int N = ax == 0 ? 14 : 21, D = ax == 0 ? 15 : 23;
+          for (int j = 0; j < count[i]; j++) {
+            const int sc = first[i] + j;
+            if (alpha[4 * i + j] != 0.0f) ok = ok && i >= (sc * N) / D && i < ((sc + 1) * N + D - 1) / D;
+          }
         }
       }
       if (!ok) {

@@ -178,16 +178,17 @@ __device__ __forceinline__ Box explosion_box(float cx, float cy) {
   return b;
 }
 
-// Destination pixels of the 84x84 image that read source pixels of `b`.  Destination column dx reads
-// source columns first, first+1 with first in [dx*15/14 - 1, dx*15/14]; row dy reads up to three rows
-// from first in [dy*23/21 - 1, dy*23/21] (checked against the tables in sf_create) -- hence these
-// conservative bounds.
+// Destination pixels of the 84x84 image that read source pixels of `b`, exactly: INTER_AREA gives destination
+// column dx the source interval [dx * 15/14, (dx + 1) * 15/14), so source column s is read (with a weight that is
+// not zero) by the destination columns floor(14 s / 15) ... ceil(14 (s + 1) / 15) - 1, and likewise 21/23 for the rows
+// -- checked for every source column and row against the tap tables in sf_create.  (Round 1's bound was a column and
+// two rows wider: a missile's 8 x 9 destination pixels, two rounds of lanes, are really 7 x 7.)
 __device__ __forceinline__ Box out_box(const Box& b) {
   Box o;
-  o.x0 = max(((b.x0 - 1) * 14) / 15, 0);
-  o.x1 = min((b.x1 * 14) / 15 + 1, SF_OUT);
-  o.y0 = max(((b.y0 - 2) * 21) / 23, 0);
-  o.y1 = min((b.y1 * 21) / 23 + 1, SF_OUT);
+  o.x0 = max((b.x0 * 14) / 15, 0);
+  o.x1 = min((b.x1 * 14 + 14) / 15, SF_OUT);
+  o.y0 = max((b.y0 * 21) / 23, 0);
+  o.y1 = min((b.y1 * 21 + 22) / 23, SF_OUT);
   return o;
 }
 
@@ -842,11 +843,11 @@ __device__ __forceinline__ unsigned char* hud_score_picture(const unsigned char*
 __device__ __forceinline__ unsigned char* hud_bar_picture(const unsigned char* hud, int state) {
   return const_cast<unsigned char*>(hud) + (size_t)2 * SF_HUD_SCORE_HALF * SF_HUD_SCORE_BYTES + (size_t)state * SF_HUD_BAR_BYTES;
 }
-// (out_box of the two boxes: 27 x 6 and 39 x 6 pixels of the 84x84 image)
-constexpr int kHudScoreOutW = (SF_TXT_BOX_X1 * 14) / 15 + 1 - ((SF_TXT_BOX_X0 - 1) * 14) / 15,
-              kHudScoreOutH = (SF_TXT_BOX_Y1 * 21) / 23 + 1 - (SF_TXT_BOX_Y0 >= 2 ? ((SF_TXT_BOX_Y0 - 2) * 21) / 23 : 0),
-              kHudBarOutW = (SF_BAR_BOX_X1 * 14) / 15 + 1 - ((SF_BAR_BOX_X0 - 1) * 14) / 15,
-              kHudBarOutH = SF_OUT - ((SF_BAR_BOX_Y0 - 2) * 21) / 23;
+// (out_box of the two boxes)
+constexpr int kHudScoreOutW = (SF_TXT_BOX_X1 * 14 + 14) / 15 - (SF_TXT_BOX_X0 * 14) / 15,
+              kHudScoreOutH = (SF_TXT_BOX_Y1 * 21 + 22) / 23 - (SF_TXT_BOX_Y0 * 21) / 23,
+              kHudBarOutW = (SF_BAR_BOX_X1 * 14 + 14) / 15 - (SF_BAR_BOX_X0 * 14) / 15,
+              kHudBarOutH = SF_OUT - (SF_BAR_BOX_Y0 * 21) / 23;
 static_assert(((SF_TXT_BOX_Y1 - SF_TXT_BOX_Y0) * SF_HUD_SCORE_ROW + 15) / 16 * 16 + kHudScoreOutH * SF_HUD_SCORE_ROW <= SF_HUD_SCORE_BYTES &&
               SF_HUD_SCORE_ROW >= kHudScoreOutW && SF_HUD_SCORE_ROW >= SF_TXT_BOX_X1 - SF_TXT_BOX_X0 &&
               kHudScoreOutH * (SF_HUD_SCORE_ROW / 4) <= 64 && (SF_TXT_BOX_Y1 - SF_TXT_BOX_Y0) * (SF_HUD_SCORE_ROW / 4) <= 64,
