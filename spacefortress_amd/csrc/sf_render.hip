@@ -183,6 +183,10 @@ __device__ __forceinline__ Box explosion_box(float cx, float cy) {
 // not zero) by the destination columns floor(14 s / 15) ... ceil(14 (s + 1) / 15) - 1, and likewise 21/23 for the rows
 // -- checked for every source column and row against the tap tables in sf_create.  (Round 1's bound was a column and
 // two rows wider: a missile's 8 x 9 destination pixels, two rounds of lanes, are really 7 x 7.)
+// ... and the other way round: a destination pixel reads two adjacent source columns and up to three adjacent rows, so the
+// destination pixels that read `b` read nothing further than this outside it.  A picture saved with its 84x84 part is
+// good where nothing else is drawn within that reach of its box (kReachX, kReachY).
+constexpr int kReachX = 1, kReachY = 2;
 __device__ __forceinline__ Box out_box(const Box& b) {
   Box o;
   o.x0 = max((b.x0 * 14) / 15, 0);
@@ -833,7 +837,7 @@ __device__ __forceinline__ void hud_picture(const Frame<RESIZE>& F, unsigned cha
   if (r < bh && c4 < bw) put_bytes(pf, wf, bw - c4);
   if (RESIZE && with_out && r < oh && c4 < ow) put_bytes(po, wo, ow - c4);
   __builtin_amdgcn_wave_barrier();
-  // (something within 3 pixels, not on the box: the surface part of the picture still holds, the 84x84 pixels are taken
+  // (something within that reach, not on the box: the surface part of the picture still holds, the 84x84 pixels are taken
   //  from the surface as it is now)
   if (RESIZE && !with_out) F.resample(b);
 }
@@ -961,10 +965,10 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
   bool near_text = false, near_bar = false;
   if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
-    // 3 pixels wider than what the explosion paints: the 84x84 pixels recomputed (or restored from the
+    // wider by the reach (kReachX, kReachY) than what the explosion paints: the 84x84 pixels recomputed (or restored from the
     // cache) for it read that far, and must not depend on whether the score / bar were baked in
     Box eb = explosion_box(ship_x, ship_y);
-    eb.x0 -= 3; eb.y0 -= 3; eb.x1 += 3; eb.y1 += 3;
+    eb.x0 -= kReachX; eb.y0 -= kReachY; eb.x1 += kReachX; eb.y1 += kReachY;
     near_text = eb.meets(tbox);
     near_bar = eb.meets(bbox);
   }
@@ -1065,12 +1069,12 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // show 0000000 / an empty bar and nothing drawn before them reaches their pixels, the result is the
   // static picture the host baked (same arithmetic, sf_raster.h).  A live ship and the fortress never
   // reach them (the ship is inside the big hexagon, rows 12.2 .. 81.6 +- 5.4 px).
-  // A score / bar that is not baked in is one of the pictures (hud_picture) unless something comes within 3 pixels
+  // A score / bar that is not baked in is one of the pictures (hud_picture) unless something comes within reach (kReachX, kReachY)
   // of its box: the picture's 84x84 pixels read that far, and it is restored after everything else was resampled.
-  const Box tbox3{SF_TXT_BOX_X0 - 3, SF_TXT_BOX_Y0 - 3, SF_TXT_BOX_X1 + 3, SF_TXT_BOX_Y1 + 3};
-  const Box bbox3{SF_BAR_BOX_X0 - 3, SF_BAR_BOX_Y0 - 3, SF_BAR_BOX_X1 + 3, SF_BAR_BOX_Y1 + 3};
-  const bool ex_text = near_text, ex_bar = near_bar;  // the explosion's share (its box above is already 3 pixels wider)
-  bool other_text = false, other_bar = false;          // anything else within 3 pixels: the live ship, projectiles
+  const Box tbox3{SF_TXT_BOX_X0 - kReachX, SF_TXT_BOX_Y0 - kReachY, SF_TXT_BOX_X1 + kReachX, SF_TXT_BOX_Y1 + kReachY};
+  const Box bbox3{SF_BAR_BOX_X0 - kReachX, SF_BAR_BOX_Y0 - kReachY, SF_BAR_BOX_X1 + kReachX, SF_BAR_BOX_Y1 + kReachY};
+  const bool ex_text = near_text, ex_bar = near_bar;  // the explosion's share (its box above is already wider by the reach)
+  bool other_text = false, other_bar = false;          // anything else within reach: the live ship, projectiles
   if (ship_alive) {  // (the ship stays inside the big hexagon: rows 12.2 .. 81.6 +- 5.4 px -- never on the bar, but close)
     const float gx = dev_x(ship_x), gy = dev_y(ship_y), ext = 27.f * (float)SF_SCALE;
     const Box shb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
@@ -1143,7 +1147,7 @@ ship_done:
    if (flags & SF_FL_FORT_ALIVE) {
     const int sector = fort_angle / 10;
     if (a.fpatch && fort_angle >= 0 && fort_angle < 360 && sector * 10 == fort_angle &&
-        !sb.meets(Box{kFpX0 - 3, kFpY0 - 3, kFpX1 + 3, kFpY1 + 3})) {  // + what the patch's 84x84 pixels read
+        !sb.meets(Box{kFpX0 - kReachX, kFpY0 - kReachY, kFpX1 + kReachX, kFpY1 + kReachY})) {  // + what the picture's 84x84 pixels read
       fort_patch_copy(F, const_cast<unsigned char*>(a.fpatch) + sector * SF_FP_BYTES, false);
     } else {
       float s, c;
@@ -1154,9 +1158,9 @@ ship_done:
    } else {
     // The destroyed fortress explodes for 1000 ms where it stands: one more picture drawn once per batch, in the
     // layout of the per-env explosion cache (a trained agent destroys it every few seconds -- 30 frames each time).
-    // Restored when what the ship drew stays clear of it (3 pixels wider: what its 84x84 pixels read); else in place.
+    // Restored when what the ship drew stays clear of it (wider by the reach: what its 84x84 pixels read); else in place.
     Box fe = explosion_box((float)sfc::fort_x, (float)sfc::fort_y);
-    fe.x0 -= 3; fe.y0 -= 3; fe.x1 += 3; fe.y1 += 3;
+    fe.x0 -= kReachX; fe.y0 -= kReachY; fe.x1 += kReachX; fe.y1 += kReachY;
     if (a.fpatch && !sb.meets(fe))
       ship_explosion(F, const_cast<unsigned char*>(a.fpatch) + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y, false);
     else
