@@ -306,6 +306,47 @@ def test_fortress_explosion_picture_is_invisible(sfa, monkeypatch):
     cached.close()
 
 
+@pytest.mark.parametrize("gametype,policy,N,T", [("test-autoturn", "hunter", 1024, 700), ("youturn", "random", 2048, 400)])
+def test_every_shortcut_of_the_render_kernel_is_invisible(sfa, monkeypatch, gametype, policy, N, T):
+    """tools/render_soak.py in small: the product batch (explosion cache with the score / bar boxes under an explosion, the
+    pictures drawn once per batch -- fortress headings, fortress explosion, scores, bar states --, launch-order words, exact
+    dirty boxes) against a batch that draws every frame in place in env order, same actions: every 84x84 frame identical
+    at every step, the 92x90 ones on sampled steps.  The firing pattern of the first case destroys the fortress hundreds
+    of times: scores up to the hundreds, every state of the bar, the fortress's explosion."""
+    monkeypatch.setenv("SFMI_NO_EXPLOSION_CACHE", "1")
+    monkeypatch.setenv("SFMI_NO_RENDER_ORDER", "1")
+    plain = sfa.SFVecEnv(N, gametype=gametype, obs_type="image", spawn_stride=3)
+    plain.render("image")  # the switches are read at create / by the first frame
+    monkeypatch.delenv("SFMI_NO_EXPLOSION_CACHE")
+    monkeypatch.delenv("SFMI_NO_RENDER_ORDER")
+    prod = sfa.SFVecEnv(N, gametype=gametype, obs_type="image", spawn_stride=3)
+    rng = np.random.default_rng(5)
+    phase = rng.integers(0, 96, N)
+    pat = np.array(([1] + [0] * 7) * 11 + [1, 0, 1, 0] + [0] * 4, np.uint8)  # (tools/soak.py: hunter)
+    scores, bars, fort_dead = set(), set(), 0
+    for t in range(T):
+        acts = rng.integers(0, prod.n_actions, N).astype(np.uint8)
+        if policy == "hunter":
+            acts = np.where(rng.random(N) < 0.1, acts, pat[(t + phase) % len(pat)]).astype(np.uint8)
+        a = torch.from_numpy(acts).cuda()
+        o1, *_ = plain.step_tensors(a)
+        o2, *_ = prod.step_tensors(a)
+        assert torch.equal(o1, o2), (t, (o1 != o2).flatten(1).any(1).nonzero().flatten()[:8].tolist())
+        if t % 16 == 0:
+            assert torch.equal(plain.render("image-raw"), prod.render("image-raw")), t
+        if t % 50 == 0:
+            scores.update(np.unique(prod.get_field("points").astype(np.int64)).tolist())
+            bars.update(np.unique(np.minimum(prod.get_field("vlner"), 11)).tolist())
+            fort_dead += int(((prod.get_field("flags").astype(np.int64) & 2) == 0).sum())
+    if policy == "hunter":
+        assert len(scores) > 20 and max(scores) >= 100 and fort_dead > 100, (sorted(scores)[-3:], fort_dead)
+        assert bars >= set(range(0, 12)), bars
+    else:
+        assert len(bars) >= 3, bars
+    plain.close()
+    prod.close()
+
+
 def test_launch_order_hint_is_invisible(sfa, monkeypatch):
     """The step kernel tells the render launch which ships just died, and those frames start first (sf_render.hip:
     pick_env).  The words decide only when a frame is drawn: a batch without them, the batch's own, and every pattern

@@ -59,6 +59,37 @@ def test_resize_tables_follow_opencv_area():
                                 i32.ctypes.data_as(C.c_void_p)) < 0  # scale >= 2: not this table's path
 
 
+def test_dirty_boxes_of_the_resampling_are_exact():
+    """What the render kernel's sparse resampling rests on (sf_render.hip: out_box, kReachX / kReachY), from the tap
+    tables themselves: source cell s is read with a weight that is not zero by the destinations floor(N s / D) ...
+    ceil(N (s + 1) / D) - 1 and by no other (N / D = 14/15 for the columns, 21/23 for the rows) -- both ends attained --
+    and a destination's taps are adjacent cells, two in a row and at most three in a column: the destinations that read a
+    box read nothing further than one column and two rows outside it.  (sf_create asserts the same on the device side.)"""
+    L = _lib()
+    for ss, ds, N, D, reach in ((90, 84, 14, 15, 1), (92, 84, 21, 23, 2)):
+        f, c, a = np.zeros(ds, np.int32), np.zeros(ds, np.int32), np.zeros((ds, 4), np.float32)
+        assert L.sf_resize_area_tab(ss, ds, f.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
+                                    a.ctypes.data_as(C.c_void_p)) == 0
+        readers = [[] for _ in range(ss)]
+        for d in range(ds):
+            assert c[d] <= reach + 1
+            for j in range(c[d]):
+                if a[d, j] != 0:
+                    readers[f[d] + j].append(d)
+        for s in range(ss):
+            lo, hi = (s * N) // D, ((s + 1) * N + D - 1) // D
+            assert readers[s] and min(readers[s]) == lo and max(readers[s]) == hi - 1, (ss, s, readers[s], lo, hi)
+        # the kernel's box arithmetic: destinations of the source range [s0, s1)
+        for s0 in range(ss):
+            for s1 in range(s0 + 1, min(s0 + 30, ss) + 1):
+                want = sorted({d for s in range(s0, s1) for d in readers[s]})
+                assert want == list(range((s0 * N) // D, min((s1 * N + D - 1) // D, ds))), (ss, s0, s1)
+                # ... and what those destinations read lies within `reach` cells of the range
+                for d in want:
+                    taps = [f[d] + j for j in range(c[d]) if a[d, j] != 0]
+                    assert min(taps) >= s0 - reach and max(taps) <= s1 - 1 + reach, (ss, s0, s1, d, taps)
+
+
 def test_host_resize_matches_model():
     """The library's own INTER_AREA (used for the static background) against the numpy model."""
     from oracle import render_np as R
