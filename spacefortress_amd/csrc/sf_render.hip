@@ -979,8 +979,8 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant0 * (kOutBytes / 4)), kOutBytes / 16, lane);
   // ---- projectile strokes: one lane per wireframe segment (missiles: slot*3 + k; shells: two rounds of slot*4 + k);
   // first everything that reads memory (the pool, the tables of sines and of segments, the shells' state)
-  Seg mg = {}, sg[2] = {{}, {}};
-  bool mvalid = false, svalid[2] = {false, false};
+  Seg mg = {};
+  bool mvalid = false;
   if (mmask) {
     // The tile keeps its live missiles as one dense pool (sf_layout.h); this env's are the entries whose owner is its
     // lane.  The wave scans the pool's meta words, 64 entries at a time, and files what it finds by slot -- the
@@ -1013,26 +1013,22 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     __builtin_amdgcn_wave_barrier();  // the scratch goes back to the coverage masks
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  // shells (14 % of the frames have one): here only where they are -- a shell's wireframe stays within 16 + 1.5 user
+  // units of its position -- for the tests on the score's and the bar's boxes below; their strokes are built where they
+  // are drawn, at the end (two quads per lane kept alive from here to there cost the pixel loops their registers)
+  bool sh_t = false, sh_b = false, sh_t3 = false, sh_b3 = false;
   if (smask) {
-#pragma unroll
-    for (int round = 0; round < 2; round++) {
-      const int p = round * 64 + lane;
-      const int slot = p >> 2, k = p & 3;
-      bool valid = p < 4 * SF_NSLOT && ((smask >> slot) & 1u);
-      if (valid) {
-        const d2_t s = R_LD(d2_t, R_CHUNK(shell_pos, slot), o16);
-        const d2_t v = R_LD(d2_t, R_CHUNK(shell_vel, slot), o16);
-        const double dx = s.x - sfc::fort_x, dy = s.y - sfc::fort_y;
-        valid = sqrt(dx * dx + dy * dy) > 21.0;  // drawn only once clear of the fortress (SRC/draw.cpp:249-250)
-        // mAngle = stdAngle(rad2deg(atan2(dy, dx))) at launch (SRC/game.cpp:263); the velocity kept in
-        // the state has that direction.  drawWireFrame takes it as an int (truncation).
-        double ang = atan2(v.y, v.x) * 180.0 / M_PI;
-        if (ang < 0) ang += 360.0;
-        float sn, cs;
-        sincos_deg((int)ang, &sn, &cs);
-        sg[round] = Seg{kShellLines[k][0], kShellLines[k][1], kShellLines[k][2], kShellLines[k][3], cs, sn, (float)s.x, (float)s.y};
-      }
-      svalid[round] = valid;
+    const Box tb0{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1}, bb0{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
+    const Box tb3{SF_TXT_BOX_X0 - kReachX, SF_TXT_BOX_Y0 - kReachY, SF_TXT_BOX_X1 + kReachX, SF_TXT_BOX_Y1 + kReachY};
+    const Box bb3{SF_BAR_BOX_X0 - kReachX, SF_BAR_BOX_Y0 - kReachY, SF_BAR_BOX_X1 + kReachX, SF_BAR_BOX_Y1 + kReachY};
+    if (lane < SF_NSLOT && ((smask >> lane) & 1u)) {
+      const d2_t sp1 = R_LD(d2_t, R_CHUNK(shell_pos, lane), o16);
+      const float gx = dev_x((float)sp1.x), gy = dev_y((float)sp1.y), ext = 17.5f * (float)SF_SCALE + 0.01f;
+      const Box shb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
+      sh_t = shb.meets(tb0);
+      sh_b = shb.meets(bb0);
+      sh_t3 = shb.meets(tb3);
+      sh_b3 = shb.meets(bb3);
     }
   }
   if (RESIZE) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
@@ -1058,12 +1054,8 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     }
   }
 
-  Quad mq = {}, sq[2] = {{}, {}};
+  Quad mq = {};
   if (mvalid) mq = line_quad(mg);
-  if (smask) {
-    if (svalid[0]) sq[0] = line_quad(sg[0]);
-    if (svalid[1]) sq[1] = line_quad(sg[1]);
-  }
 
   // ---- background variant.  The score and the bar are drawn LAST (SRC/draw.cpp:266-268); when they
   // show 0000000 / an empty bar and nothing drawn before them reaches their pixels, the result is the
@@ -1090,15 +1082,10 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       t3 = t3 || qb.meets(tbox3);
       b3 = b3 || qb.meets(bbox3);
     }
-#pragma unroll
-    for (int round = 0; round < 2; round++)
-      if (svalid[round]) {
-        const Box qb = quad_box(sq[round]);
-        t = t || qb.meets(tbox);
-        b = b || qb.meets(bbox);
-        t3 = t3 || qb.meets(tbox3);
-        b3 = b3 || qb.meets(bbox3);
-      }
+    t = t || sh_t;
+    b = b || sh_b;
+    t3 = t3 || sh_t3;
+    b3 = b3 || sh_b3;
     near_text = near_text || __any(t);
     near_bar = near_bar || __any(b);
     other_text = other_text || __any(t3);
@@ -1170,8 +1157,27 @@ ship_done:
   // ---- missiles (:243-247), shells (:248-253): slot order
   if (mmask) F.draw_objects(mq, 255, mvalid, 3);
   if (smask) {
-    F.draw_objects(sq[0], 255, svalid[0], 4);
-    F.draw_objects(sq[1], 255, svalid[1], 4);
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+      const int p = round * 64 + lane;
+      const int slot = p >> 2, k = p & 3;
+      bool valid = p < 4 * SF_NSLOT && ((smask >> slot) & 1u);
+      Quad sq = {};
+      if (valid) {
+        const d2_t s = R_LD(d2_t, R_CHUNK(shell_pos, slot), o16);
+        const d2_t v = R_LD(d2_t, R_CHUNK(shell_vel, slot), o16);
+        const double dx = s.x - sfc::fort_x, dy = s.y - sfc::fort_y;
+        valid = sqrt(dx * dx + dy * dy) > 21.0;  // drawn only once clear of the fortress (SRC/draw.cpp:249-250)
+        // mAngle = stdAngle(rad2deg(atan2(dy, dx))) at launch (SRC/game.cpp:263); the velocity kept in
+        // the state has that direction.  drawWireFrame takes it as an int (truncation).
+        double ang = atan2(v.y, v.x) * 180.0 / M_PI;
+        if (ang < 0) ang += 360.0;
+        float sn, cs;
+        sincos_deg((int)ang, &sn, &cs);
+        sq = line_quad(kShellLines[k], cs, sn, (float)s.x, (float)s.y);
+      }
+      if (round == 0 || (smask >> 16)) F.draw_objects(sq, 255, valid, 4);  // (the second round: slots 16 .. 19)
+    }
   }
   // ---- score and bar, last (SRC/draw.cpp:266-268): baked into the background already (0000000 / empty), or one of
   // the pictures, or -- something else touches their pixels, or the points are off the table -- in place
