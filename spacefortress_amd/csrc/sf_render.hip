@@ -863,7 +863,7 @@ static_assert(((SF_BAR_BOX_Y1 - SF_BAR_BOX_Y0) * SF_HUD_BAR_ROW + 15) / 16 * 16 
 
 template <bool RESIZE>
 #ifndef SF_RENDER_WPE
-#define SF_RENDER_WPE 4 /* waves per SIMD the register budget is held to: 129 VGPRs (3 waves) without it */
+#define SF_RENDER_WPE 5 /* waves per SIMD the register budget is held to (96 VGPRs; LDS allows 18 workgroups per CU = 4.5) */
 #endif
 __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
