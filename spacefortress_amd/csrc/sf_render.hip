@@ -7,17 +7,19 @@
 //
 // Here: ONE WAVEFRONT PER ENV.  The 90x92 frame lives in LDS as bytes (8.3 KB: 18 waves per CU), starts
 // as a copy of the static background (hexagons; score 0000000 / empty bar baked in when nothing can
-// reach them), and every stroke of the reference's draw order is a convex quad (a line with butt
-// caps, an arc chord, a filled rectangle) composited OVER it with 8-bit arithmetic, like the image
-// backend does.  Quads are built one per lane; the ship's are walked in order (ballot + readlane, no
-// LDS list) with the lanes on the pixels of the quad's bounding box -- exact area coverage from an edge
-// integral (no arrays, no scratch); missiles and shells take two phases (all coverage masks of an object
-// at once, then a lane per pixel composites them in stroke order); explosions go ring by ring, twelve
-// arcs at once, and a dead ship's explosion is cached per env; the live fortress is one of 36 pictures
-// drawn once per batch.  The 84x84 frame is built IN PLACE in the caller's buffer in HBM: it starts as
-// the resampled background (host-made) and after every object the wave re-evaluates INTER_AREA only for
-// the output pixels whose footprint the object's bounding box touches -- a frame is a few dozen changed
-// pixels on a static picture.  VALU-bound (2.2 k instructions per frame), not memory-bound.
+// reach them; ten direct-to-LDS loads), and every stroke of the reference's draw order is a convex quad (a line
+// with butt caps, an arc chord, a filled rectangle) composited OVER it with 8-bit arithmetic, like the image
+// backend does.  Quads are built one per lane.  The small objects -- ship, missiles, shells, the fortress when
+// it has to be drawn in place -- are drawn one object at a time with the lanes on all its (stroke, pixel) pairs:
+// exact area coverage from an edge integral, kept in a register, then the strokes composite one after the
+// other (draw_objects); explosions go ring by ring, twelve arcs at once.  Whatever is a function of little is
+// drawn once and copied afterwards: a dead ship's explosion (per env, keyed by where the ship died; with the
+// score / bar box under it), and once per batch the live fortress at its 36 headings, the destroyed fortress's
+// explosion, 1 024 scores and the bar's 12 states.  The 84x84 frame is built IN PLACE in the caller's buffer in
+// HBM: it starts as the resampled background (host-made) and after every object the wave re-evaluates INTER_AREA
+// for exactly the output pixels that read the object's box (out_box) -- a frame is a few dozen changed pixels on
+// a static picture.  The frames whose ship just died (the expensive ones) are started first (pick_env).
+// Issue-bound (1.35 k vector instructions per frame), not memory-bound.
 //
 // Pixel values: what is drawn where, in which order and grey follows the reference; the
 // anti-aliasing model is ours (cairo is not in this image).  Pixel parity with cairo + cv2 is
@@ -984,7 +986,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   if (mmask) {
     // The tile keeps its live missiles as one dense pool (sf_layout.h); this env's are the entries whose owner is its
     // lane.  The wave scans the pool's meta words, 64 entries at a time, and files what it finds by slot -- the
-    // reference draws in slot order (SRC/draw.cpp:243-247) -- in the (still unused) mask scratch.
+    // reference draws in slot order (SRC/draw.cpp:243-247) -- in the scratch area.
     const unsigned n_pool = (unsigned)mi.z >> SF_MPOOL_SHIFT;
     float* const mtab = reinterpret_cast<float*>(mscr);  // [slot] (x, y, heading)
     static_assert(SF_NSLOT * 3 * sizeof(float) <= kMaskScratch, "slot table fits the scratch");
@@ -1010,7 +1012,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       mg = Seg{kMissileLines[k][0], kMissileLines[k][1], kMissileLines[k][2], kMissileLines[k][3], c, s, t[0], t[1]};
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // the scratch goes back to the coverage masks
+    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   // shells (14 % of the frames have one): here only where they are -- a shell's wireframe stays within 16 + 1.5 user
