@@ -12,30 +12,43 @@ with action decoding, reward shaping, the 19-float observation and auto-reset.  
 BASELINE.json's metric config -- youturn, 65 536 envs per GPU, features obs (f32), uniform
 random discrete actions pre-generated in HBM (a ring of 64 action batches).  N > 1: one
 process per GPU, each with its own 65 536-lane shard (weak scaling, no data-path
-collective); RCCL all-reduces the 8-element episode-statistics vector once at the end of
-the timed region.
+collective); RCCL all-gathers the 8-element episode-statistics vector once, after the
+timed region.
 
 The JSON line also carries
-  roofline     the step kernel against the HBM roofline: algorithmic bytes per launch
-               (464 B/env-step youturn, 408 autoturn) / mean launch duration,
-               measured here with HIP events on the launch stream;
-  cpu_baseline the REAL reference engine (oracle/_ref, bare C++ tick loop) -- or the C
-               restatement if that build is absent -- timed on the host cores, one process
-               per core as the reference itself parallelises, ~10 s sample.  Runs before
-               the GPU is touched.  Reported baseline, not the target.
+  roofline      the step kernel against the HBM roofline: algorithmic bytes per launch
+                (464 B/env-step youturn, 408 autoturn) / mean launch duration,
+                measured here with HIP events on the launch stream;
+  cpu_baseline  the REAL reference engine (oracle/_ref, bare C++ tick loop) -- or the C
+                restatement if that build is absent -- timed on the host cores, one process
+                per core as the reference itself parallelises, ~10 s sample.  Runs before
+                the GPU is touched (N > 1: in the launcher before the ranks start, or on
+                rank 0 before it joins the process group).  Reported baseline, not the target;
+  value_with_action_gen   the same timed blocks with the actions DRAWN INSIDE the launch
+                (sf_step_sampled: Philox4x32-10 per lane and tick, SURVEY 8d "action
+                generation on device ... report both"; rl/train.py:76-80 has the policy's
+                sample there);
+  configs       every other BASELINE.json configuration, each a few HIP-graph blocks on
+                this GPU (N = 1 only): youturn 4 096, autoturn 65 536, youturn 32 768
+                (configs[3]'s per-GPU share), youturn 262 144, and the image config;
+  ranks         per rank: device index, PCI bus id, its own median block time -- one
+                all-gather, so that the line shows N distinct GPUs.
 """
 import argparse
 import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {"youturn": 464, "autoturn": 408, "test-youturn": 464, "test-autoturn": 408}  # SURVEY 8(d)
+IMAGE_ALGO_BYTES = 7448  # SURVEY 8(d): one new 84x84 frame instead of the feature row
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+METRIC = "env-steps/sec (whole node), youturn random-action rollout @65536 envs/GPU"
 
 
 def cpu_baseline(gametype, seconds, cores):
@@ -56,12 +69,12 @@ def cpu_baseline(gametype, seconds, cores):
     what = ("reference C++ engine (oracle/_ref: Game::pressKey/releaseKey + stepOneTick(34) loop, new Game at game over)"
             if kind == "reference" else "C restatement of the engine (oracle/sf_oracle.c), same loop")
     out = {"value": total, "unit": "env-steps/s", "cores": cores, "kind": kind,
-           "sample": "%s, %s, uniform random actions, one process per core x %d, %.0f s each; "
+           "sample": "%s, %s, uniform random actions, one process per core x %d, %.1f s each; "
                      "bare engine only (no Python wrapper, no IPC)" % (what, gametype, cores, seconds)}
     # the reference's actual shape: SubprocVecEnv (one process per env, Pipe IPC, Python wrapper, rl/train.py:30-32)
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "subproc_bench.py"), "--procs", str(cores),
-                            "--gametype", gametype, "--seconds", str(max(2.0, seconds / 2))],
+                            "--gametype", gametype, "--seconds", str(max(0.5, seconds / 2))],
                            stdout=subprocess.PIPE, text=True, timeout=120)
         j = json.loads(r.stdout.strip().splitlines()[-1])
         out["subproc_vecenv"] = {"value": j["steps"] / j["seconds"], "unit": "env-steps/s", "procs": j["procs"],
@@ -71,6 +84,15 @@ def cpu_baseline(gametype, seconds, cores):
     except Exception as e:  # the baseline is informative, never fatal
         out["subproc_vecenv"] = {"error": str(e)}
     return out
+
+
+def baseline_cores(args):
+    try:
+        share = len(os.sched_getaffinity(0))
+    except AttributeError:
+        share = os.cpu_count() or 1
+    # a one-GPU box owns 16 host cores of the node whatever os.cpu_count() says
+    return args.cpu_cores or max(1, min(share, 16))
 
 
 def committed_profile(gametype, envs, obs_type):
@@ -97,25 +119,69 @@ def free_port():
     return port
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, args):
     """`python bench.py --gpus N` on its own: start the N ranks as FRESH child processes (nothing here has touched
     the GPU, and nothing is re-exec'ed), one per GPU, with the torch.distributed environment set; rank 0 prints the
-    JSON line.  The reference starts its N workers from one command as well (rl/train.py:30-32)."""
+    JSON line.  The reference starts its N workers from one command as well (rl/train.py:30-32).
+    The CPU baseline is timed HERE, before the ranks exist (this process never touches a GPU), and handed to rank 0
+    through a file.  All children are polled together: the first one that fails takes the others down with it (a rank
+    that dies at start-up would otherwise leave its peers in a collective until the NCCL timeout), and the whole job
+    has a deadline."""
+    env_common = dict(os.environ)
+    tmp = None
+    dry = os.environ.get("SF_BENCH_FORCE_DIST", "") == "gloo"
+    if not args.no_cpu_baseline:
+        base = cpu_baseline(args.gametype, args.cpu_seconds, baseline_cores(args))
+        fd, tmp = tempfile.mkstemp(prefix="sf_bench_cpu_", suffix=".json")
+        with os.fdopen(fd, "w") as f:
+            json.dump(base, f)
+        env_common["SF_BENCH_CPU_BASELINE_FILE"] = tmp
     port = os.environ.get("MASTER_PORT") or str(free_port())
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        env = dict(env_common, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    deadline = time.time() + float(os.environ.get("SF_BENCH_TIMEOUT", "300" if dry else "1500"))
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:  # one rank failed: do not leave the others waiting in a collective
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [c for c in codes if c not in (None, 0)]
+            if failed:
+                rc = failed[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                sys.stderr.write("bench.py: the ranks did not finish in time; stopping them\n")
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:  # a failed / late job: nobody is left waiting in a collective
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5
         for p in procs:
+            while p.poll() is None and time.time() < t_end:
+                time.sleep(0.05)
             if p.poll() is None:
                 p.kill()
+        if tmp:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
     return rc
+
+
+def device_identity(torch, local_rank):
+    p = torch.cuda.get_device_properties(local_rank)
+    dom, bus, devn = (getattr(p, k, -1) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return {"device_index": local_rank, "name": p.name,
+            "pci_bus_id": "%04x:%02x:%02x.0" % (dom, bus, devn) if bus >= 0 else None,
+            "uuid": str(getattr(p, "uuid", "")) or None}
 
 
 def main():
@@ -130,7 +196,8 @@ def main():
                     help="how a timed block's K sf_step launches are issued: one by one from Python (loop) or as ONE HIP graph "
                          "captured once and replayed per block (graph); auto = graph for K <= 512.  A block of a few launches "
                          "issued one by one starts on an idle GPU with the host barely ahead of it (5 us per call against a "
-                         "6.5 us kernel): the first launches wait for their packets")
+                         "6.5 us kernel): the first launches wait for their packets.  The line says which (`launch`) and, for "
+                         "a graph, carries the loop-issued figure beside it (`loop_issue`)")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--gametype", default="youturn")
     ap.add_argument("--obs-type", default="features")
@@ -138,19 +205,24 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="baseline processes (0 = this box's share, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timing-launches", type=int, default=200)
+    ap.add_argument("--steady-seconds", type=float, default=3.0,
+                    help="length of the steady-state loop outside the timed blocks (back-to-back launches from the Python "
+                         "loop): long enough for an external GPU-utilisation sampler to see it, and for every lane to "
+                         "finish episodes, so that the statistics all-gather carries something")
     ap.add_argument("--rollout-k", type=int, default=64, metavar="K",
                     help="also time the fused open-loop path (sf_rollout: K ticks per launch, all actions known up "
                          "front, same per-tick outputs); reported as rollout_fused, never as value; 0 = skip")
-    ap.add_argument("--numpy-api", type=int, default=0, metavar="K",
-                    help="also time K steps through the host-buffer (numpy) API: actions H2D, results D2H every "
-                         "step -- the PCIe-inclusive rate, reported as host_api, never as value")
+    ap.add_argument("--numpy-api", type=int, default=200, metavar="K",
+                    help="also time K steps through the host-buffer (numpy) API -- what rl/train.py:79-80 calls: actions "
+                         "H2D, results D2H every step -- the PCIe-inclusive rate, reported as host_api, never as value; 0 = skip")
     ap.add_argument("--image-envs", type=int, default=16384, metavar="N",
                     help="also time N envs stepping with the image observation (BASELINE cfg 5: sf_step + sf_render, "
                          "uint8 [N,1,84,84] per step); reported as image_obs, never as value; 0 = skip")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (`configs`)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not os.environ.get("SF_BENCH_NO_SPAWN"):
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -163,16 +235,17 @@ def main():
     force = os.environ.get("SF_BENCH_FORCE_DIST", "")
     dry = force == "gloo"
 
+    if os.environ.get("SF_BENCH_TEST_FAIL_RANK") == str(rank):  # tests/test_stats_gloo.py: a rank that dies at start-up
+        sys.exit(3)
     base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
-        # before anything initialises the GPU in this process (children are plain CPU processes)
-        try:
-            share = len(os.sched_getaffinity(0))
-        except AttributeError:
-            share = os.cpu_count() or 1
-        # a one-GPU box owns 16 host cores of the node whatever os.cpu_count() says
-        cores = args.cpu_cores or max(1, min(share, 16))
-        base = cpu_baseline(args.gametype, args.cpu_seconds, cores)
+    if rank == 0 and not args.no_cpu_baseline:
+        handed = os.environ.get("SF_BENCH_CPU_BASELINE_FILE")
+        if handed and os.path.exists(handed):  # timed by the launcher before the ranks started
+            base = json.load(open(handed))
+        else:
+            # before anything initialises the GPU in this process (children are plain CPU processes); under a foreign
+            # launcher (torchrun) the other ranks wait for rank 0 in init_process_group meanwhile
+            base = cpu_baseline(args.gametype, args.cpu_seconds, baseline_cores(args))
 
     import numpy as np
     import torch
@@ -189,39 +262,84 @@ def main():
     lane0, lane1 = shard_lanes(n * world, world, rank)
     repeats = args.repeats or max(1, min(101, -(-2000 // max(1, args.steps))))
 
+    def gather_ranks(mine):
+        if dist is None:
+            return [mine]
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        return rows
+
     if dry:
         dist.init_process_group("gloo")
         local = torch.tensor([rank + 1, 10 * (rank + 1), 100, rank, 2, 3, -5 - rank, 7 + rank], dtype=torch.int64)
         stats = reduce_episode_stats(local)
         tt = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ranks = gather_ranks({"rank": rank, "device_index": None, "pci_bus_id": None, "block_ms_median": 1.0 + rank,
+                              "lanes": [lane0, lane1]})
         if rank == 0:
-            print(json.dumps({"metric": "env-steps/sec (whole node), youturn random-action rollout @65536 envs/GPU",
-                              "dry_run": True, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "repeats": repeats, "lanes_rank0": [lane0, lane1], "max_over_ranks": float(tt.item()),
+            print(json.dumps({"metric": METRIC, "dry_run": True, "value": None, "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "repeats": repeats, "lanes_rank0": [lane0, lane1],
+                              "max_over_ranks": float(tt.item()), "ranks": ranks, "cpu_baseline": base,
                               "episode_stats": summarize(stats)}))
         dist.destroy_process_group()
         return
 
     from spacefortress_amd import SFVecEnv
 
+    # (device_count() does not initialise the GPU on this image: a job with more ranks than GPUs ends here, at once,
+    #  and the launcher stops the other ranks)
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d has no GPU (%d visible for --gpus %d)" % (local_rank, torch.cuda.device_count(), world))
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
-    assert local_rank < torch.cuda.device_count(), "rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if dist is not None:
-        dist.init_process_group("nccl", device_id=dev)
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def capture(fn, count):
+        """`count` calls of fn(k) as ONE HIP graph (sf_step is a pure stream operation: tests/test_gpu_capi_native.py::
+        test_steps_can_be_captured_in_a_hip_graph).  Thread-local capture mode: other threads of the process (a
+        process group's watchdog) may make HIP calls meanwhile."""
+        sync()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                for k in range(count):
+                    fn(k)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        sync()
+        graph.replay()  # one untimed replay: the first one uploads the graph
+        sync()
+        return graph
 
     env = SFVecEnv(n, gametype=args.gametype, obs_type=args.obs_type, device=dev, spawn_stride=1,
                    spawn_skip=lane0, reuse_buffers=True)
+    env.seed_actions(1234, first_lane=lane0)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     ring = 64
     actions = torch.randint(0, env.n_actions, (ring, n), device=dev, dtype=torch.uint8, generator=g)
     env.reset()
 
-    def sync():
-        torch.cuda.synchronize()
+    act_rows = [actions[k] for k in range(ring)]  # the views made once: the launch loop must not be what is measured
+    step = env.step_tensors
+    step_sampled = env.step_sampled
+    for t in range(args.warmup):
+        step(act_rows[t % ring])
+    K = args.steps
+    use_graph = args.launch == "graph" or (args.launch == "auto" and K <= 512)
+    # Every graph is captured BEFORE the process group exists: a capture next to a live NCCL communicator and its watchdog
+    # thread is the classic "operation not permitted when stream is capturing"; replays are ordinary launches.
+    # Every block replays the same K action rows on the state the previous block left, so episodes still progress.
+    graph = capture(lambda k: step(act_rows[k % ring]), K) if use_graph else None
+    graph_sampled = capture(lambda k: step_sampled(), K) if use_graph else None
+
+    if dist is not None:
+        dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         sync()
@@ -229,64 +347,52 @@ def main():
             dist.barrier()
         sync()
 
-    act_rows = [actions[k] for k in range(ring)]  # the views made once: the launch loop must not be what is measured
-    step = env.step_tensors
-    for t in range(args.warmup):
-        step(act_rows[t % ring])
-    K = args.steps
-    use_graph = args.launch == "graph" or (args.launch == "auto" and K <= 512)
-    graph = None
-    if use_graph:
-        # the K launches of a block, captured once (sf_step is a pure stream operation: tests/test_gpu_capi_native.py::
-        # test_steps_can_be_captured_in_a_hip_graph); every block replays the same K action rows on the state the
-        # previous block left, so episodes still progress and roll over
-        sync()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                for t in range(K):
-                    step(act_rows[t % ring])
-        torch.cuda.current_stream(dev).wait_stream(side)
-        sync()
-        graph.replay()  # one untimed replay: the first one uploads the graph
-        sync()
-    blocks, periods = [], []
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    tpos = args.warmup
-    for rep in range(repeats):
-        # ---- one timed block: EXACTLY K launches, barrier + synchronize on both sides, nothing else inside
-        barrier()
-        t0 = time.perf_counter()
-        if graph is not None:
-            ev0.record()  # HIP events around the replay: K launch periods + the graph's own launch latency
-            graph.replay()
-            ev1.record()
-        else:
-            step(act_rows[tpos % ring])
-            # HIP events on the launch stream: the first one BEHIND the first launch (it completes when that kernel does),
-            # the second behind the last, so that K - 1 launch periods are measured on the GPU's clock and the host's
-            # latency in front of an idle GPU is not counted as kernel time (the wall clock below counts everything)
-            ev0.record()
-            for t in range(tpos + 1, tpos + K):
-                step(act_rows[t % ring])
-            ev1.record()
-        while not ev1.query():  # busy-wait for the last launch (a sleeping wait adds its wake-up time to a 160 us block) ...
-            pass
-        sync()                  # ... then the contract's synchronize: this rank's K launches are done, its clock stops
-        elapsed = time.perf_counter() - t0
-        tpos += K
-        if dist is not None:
-            # the closing barrier of the bracket, and the MAX over ranks: the starts were aligned by the opening barrier, so
-            # the slowest rank's (stop - start) is the job's time for the block; the collective's own latency (tens of
-            # microseconds of RCCL against a 160 us block at K = 20) is not part of anybody's K launches
+
+    def timed_blocks(graph_, launch, reps):
+        """reps timed blocks of EXACTLY K launches, barrier + synchronize on both sides, nothing else inside; returns
+        (block seconds -- max over ranks --, this rank's own block seconds, launch periods from HIP events)."""
+        blocks, own, periods = [], [], []
+        for rep in range(reps):
             barrier()
-            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        blocks.append(elapsed)
-        periods.append(ev0.elapsed_time(ev1) / (K if graph is not None else max(1, K - 1)))
+            t0 = time.perf_counter()
+            if graph_ is not None:
+                ev0.record()  # HIP events around the replay: K launch periods + the graph's own launch latency
+                graph_.replay()
+                ev1.record()
+            else:
+                launch(0)
+                # HIP events on the launch stream: the first one BEHIND the first launch (it completes when that kernel
+                # does), the second behind the last, so that K - 1 launch periods are measured on the GPU's clock and the
+                # host's latency in front of an idle GPU is not counted as kernel time (the wall clock counts everything)
+                ev0.record()
+                for t in range(1, K):
+                    launch(t)
+                ev1.record()
+            while not ev1.query():  # busy-wait for the last launch (a sleeping wait adds its wake-up time to a 160 us block) ...
+                pass
+            sync()                  # ... then the contract's synchronize: this rank's K launches are done, its clock stops
+            elapsed = time.perf_counter() - t0
+            own.append(elapsed)
+            if dist is not None:
+                # the closing barrier of the bracket, and the MAX over ranks: the starts were aligned by the opening barrier,
+                # so the slowest rank's (stop - start) is the job's time for the block; the collective's own latency (tens
+                # of microseconds of RCCL against a 160 us block at K = 20) is not part of anybody's K launches
+                barrier()
+                tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                elapsed = float(tt.item())
+            blocks.append(elapsed)
+            periods.append(ev0.elapsed_time(ev1) / (K if graph_ is not None else max(1, K - 1)))
+        return blocks, own, periods
+
+    tpos = [args.warmup]
+
+    def launch_ring(t):
+        step(act_rows[(tpos[0] + t) % ring])
+
+    blocks, own_blocks, periods = timed_blocks(graph, launch_ring, repeats)
+    tpos[0] += K * repeats
     order = sorted(range(repeats), key=lambda r: blocks[r])
     med = order[repeats // 2]
     elapsed = blocks[med]
@@ -294,6 +400,39 @@ def main():
     # of the last): the launches are back to back on one stream, so this is the kernel duration plus the
     # dependent-launch gap -- a launch PERIOD
     region_ms = periods[med]
+
+    # ---- the same blocks with the actions drawn inside the launch (sf_step_sampled)
+    s_blocks, _, s_periods = timed_blocks(graph_sampled, lambda t: step_sampled(), repeats)
+    s_med = sorted(range(repeats), key=lambda r: s_blocks[r])[repeats // 2]
+    # ---- ... and, when the blocks above were HIP graphs, a few blocks issued one by one from Python: the per-call host path
+    loop_issue = None
+    if graph is not None:
+        l_blocks, _, l_periods = timed_blocks(None, launch_ring, max(3, repeats // 8))
+        l_med = sorted(range(len(l_blocks)), key=lambda r: l_blocks[r])[len(l_blocks) // 2]
+        loop_issue = {"value": float(n) * K * world / l_blocks[l_med], "ms_per_step": l_blocks[l_med] / K * 1e3,
+                      "launch_period_ms": l_periods[l_med], "blocks": len(l_blocks),
+                      "note": "the same K-launch blocks issued one by one from Python (one env.step_tensors call per launch) "
+                              "instead of one graph replay: what a caller's per-step loop pays at this block length"}
+
+    # ---- the launch period in steady state, outside the timed blocks: a short block starts on an idle GPU (first-launch
+    #      / graph-launch latency, packets barely ahead of the kernels), so its average reads above what the kernel
+    #      sustains.  Back-to-back launches from the Python loop for --steady-seconds, in chunks between HIP events: every
+    #      lane plays through whole episodes meanwhile (the statistics below are not zeros), and a utilisation sampler
+    #      outside this process gets to see the GPU busy.
+    chunk = 4096
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step(act_rows[0])
+    sync()
+    n_steady, steady_total_ms, t_begin = 0, 0.0, time.perf_counter()
+    while n_steady < max(K, 2000) or time.perf_counter() - t_begin < args.steady_seconds:
+        s0.record()
+        for t in range(chunk):
+            step(act_rows[t % ring])
+        s1.record()
+        sync()
+        steady_total_ms += s0.elapsed_time(s1)
+        n_steady += chunk
+    steady_ms = steady_total_ms / n_steady
 
     # ---- the only collective of the path, outside the timed blocks and timed on its own: 64 bytes over RCCL
     sync()
@@ -303,18 +442,11 @@ def main():
     sync()
     stats_reduce_us = (time.perf_counter() - ts) * 1e6
 
-    # ---- the launch period in steady state, outside the timed blocks: a short block starts on an idle GPU (first-launch
-    #      / graph-launch latency, packets barely ahead of the kernels), so its average reads above what the kernel
-    #      sustains; 2000 back-to-back launches between two HIP events, for the record next to the timed region's figure
-    n_steady = max(K, 2000)
-    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    step(act_rows[0])
-    s0.record()
-    for t in range(1, n_steady + 1):
-        step(act_rows[t % ring])
-    s1.record()
-    sync()
-    steady_ms = s0.elapsed_time(s1) / n_steady
+    # ---- who ran: one all-gather of (rank, device, PCI bus id, this rank's own median block)
+    mine = dict(device_identity(torch, local_rank), rank=rank, lanes=[lane0, lane1],
+                block_ms_median=sorted(own_blocks)[len(own_blocks) // 2] * 1e3, launch_period_steady_ms=steady_ms)
+    ranks = gather_ranks(mine)
+
     # ---- each launch bracketed by its own event pair (the events themselves add about 2 us, so this reads high)
     k = min(args.kernel_timing_launches, max(1, args.steps))
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(k)]
@@ -354,22 +486,14 @@ def main():
                          "ticks resident up front, obs/reward/done/info written for every tick; bit-identical to K "
                          "sf_step launches (tests/test_gpu_parity.py::test_fused_rollout_equals_single_steps)"}
         del ro_out
-    host_api = None
-    if args.numpy_api > 0 and rank == 0:
-        np_actions = actions.cpu().numpy().astype(np.int64)  # what rl/train.py:79 hands over
-        env.step(np_actions[0])
-        th = time.perf_counter()
-        for t in range(args.numpy_api):
-            env.step(np_actions[t % ring])
-        dt = time.perf_counter() - th
-        host_api = {"value": n * args.numpy_api / dt, "unit": "env-steps/s", "ms_per_step": dt / args.numpy_api * 1e3,
-                    "note": "numpy int64 actions in, numpy obs/reward/done/info out every step (PCIe both ways)"}
+    solo = rank == 0 and world == 1  # the single-GPU extras: not part of an N > 1 run (its ranks would wait for rank 0)
     # a measured ceiling beside the 8 TB/s spec peak: device-to-device copy of 1 GiB, read + write bytes
     copy_gbs = None
-    if rank == 0:
+    if solo:
         src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         dst = torch.empty_like(src)
-        dst.copy_(src)
+        for _ in range(3):
+            dst.copy_(src)
         torch.cuda.synchronize()
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record()
@@ -380,7 +504,7 @@ def main():
         copy_gbs = 2.0 * src.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src, dst
     image_obs = None
-    if args.image_envs > 0 and rank == 0:
+    if args.image_envs > 0 and solo:
         ni = args.image_envs
         from spacefortress_amd import FrameStack
         ienv = SFVecEnv(ni, gametype=args.gametype, obs_type="image", device=dev, spawn_stride=1, reuse_buffers=True)
@@ -400,14 +524,74 @@ def main():
         torch.cuda.synchronize()
         ims = e0.elapsed_time(e1) / isteps
         floor_us = (ni * (84 * 84 + 1200)) / 6.3e12 * 1e6  # 7 056 B written + about 1.2 KB of state read per env at 6.3 TB/s
+        i_ach = IMAGE_ALGO_BYTES * ni / (ims * 1e-3) / 1e9
         image_obs = {"value": ni / ims * 1e3, "unit": "env-steps/s", "envs": ni, "steps": isteps, "us_per_step": ims * 1e3,
                      "frame_bytes_per_step": ni * 84 * 84, "frames_GBps": ni * 84 * 84 / ims / 1e6,
                      "output_floor_us": floor_us, "frac_of_output_floor": floor_us / (ims * 1e3),
+                     "roofline": {"bound": "hbm", "achieved": i_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": i_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": IMAGE_ALGO_BYTES,
+                                  "note": "SURVEY 8(d)'s 7 448 B per env-step over the whole step (sf_step + sf_render_stack); "
+                                          "the render kernel is issue-bound, not memory-bound (DESIGN.md 10)"},
                      "note": "BASELINE configs[4]: youturn image obs, 84x84 grey raster + 4-frame stack (device ring "
                              "[N,4,84,84], one new frame per env and step), sf_step + sf_frame_stack_clear + sf_render "
                              "per step; one wave per env rasterises the 90x92 frame in LDS (INTER_AREA to 84x84); HIP "
                              "events; pixel model pinned to the numpy restatement, not to cairo/cv2 (DESIGN.md 10)"}
         ienv.close()
+    configs = None
+    if solo and not args.no_configs:
+        # every other configuration of BASELINE.json, each a few graph-replayed blocks on this GPU (they are parity-test
+        # sizes, not the metric: `value` above stays on the metric's configuration)
+        configs = []
+        cases = [("configs[1]: youturn, 4096 envs, features obs", "youturn", 4096),
+                 ("configs[2]: autoturn, 65536 envs (reduced action set)", "autoturn", 65536),
+                 ("configs[3]: youturn, 262144 envs over 8 GPUs -- one GPU's share, 32768 envs, per-lane auto-reset", "youturn", 32768),
+                 ("youturn, 262144 envs on ONE GPU (the largest single-GPU batch: no longer Infinity-Cache resident)", "youturn", 262144)]
+        KC, reps = 256, 7
+        for name, gt, ne in cases:
+            if gt == args.gametype and ne == n:
+                continue
+            cenv = SFVecEnv(ne, gametype=gt, obs_type="features", device=dev, spawn_stride=1, reuse_buffers=True)
+            cacts = torch.randint(0, cenv.n_actions, (ring, ne), device=dev, dtype=torch.uint8, generator=g)
+            crows = [cacts[k] for k in range(ring)]
+            cenv.reset()
+            for t in range(64):
+                cenv.step_tensors(crows[t % ring])
+            cg = capture(lambda k: cenv.step_tensors(crows[k % ring]), KC)
+            ms = []
+            for _ in range(reps):
+                ev0.record()
+                cg.replay()
+                ev1.record()
+                sync()
+                ms.append(ev0.elapsed_time(ev1) / KC)
+            ms.sort()
+            m = ms[len(ms) // 2]
+            ach = ALGO_BYTES[gt] * ne / (m * 1e-3) / 1e9
+            configs.append({"name": name, "gametype": gt, "envs": ne, "ms_per_step": m, "value": ne / m * 1e3,
+                            "unit": "env-steps/s", "launches_per_block": KC, "blocks": reps,
+                            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ALGO_BYTES[gt] * ne}})
+            cenv.check_actions()
+            del cg
+            cenv.close()
+        if image_obs is not None:
+            configs.append({"name": "configs[4]: youturn image obs, 84x84 grey raster + 4-frame stack, %d envs" % image_obs["envs"],
+                            "gametype": args.gametype, "envs": image_obs["envs"], "ms_per_step": image_obs["us_per_step"] * 1e-3,
+                            "value": image_obs["value"], "unit": "env-steps/s", "roofline": image_obs["roofline"]})
+    # (last of the extras: its per-step synchronise leaves the GPU idle most of the time and the clocks drop -- whatever ran
+    #  right behind it measured the ramp-up, e.g. a 1 GiB copy at 0.7 TB/s)
+    host_api = None
+    if args.numpy_api > 0 and solo:
+        np_actions = actions.cpu().numpy().astype(np.int64)  # what rl/train.py:79 hands over
+        env.step(np_actions[0])
+        th = time.perf_counter()
+        for t in range(args.numpy_api):
+            env.step(np_actions[t % ring])
+        dt = time.perf_counter() - th
+        host_api = {"value": n * args.numpy_api / dt, "unit": "env-steps/s", "ms_per_step": dt / args.numpy_api * 1e3,
+                    "steps": args.numpy_api,
+                    "note": "envs.step(cpu_actions) as rl/train.py:79-80 calls it: numpy int64 actions in, numpy "
+                            "obs/reward/done/info out every step (PCIe both ways, a synchronise per step)"}
     if os.environ.get("SF_PMC_CALIB"):
         # known-byte calibration dispatches for the rocprofv3 --pmc passes (tools/pmc_report.py):
         # sf_group_copy_kernel reads n*20*16 bytes in the step kernel's own access pattern
@@ -425,7 +609,7 @@ def main():
         achieved = algo / (region_ms * 1e-3) / 1e9
         prof = committed_profile(args.gametype, n, args.obs_type)
         out = {
-            "metric": "env-steps/sec (whole node), youturn random-action rollout @65536 envs/GPU",
+            "metric": METRIC,
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -439,10 +623,19 @@ def main():
             "data": "synthetic",
             "repeats": repeats,
             "launch": "hip_graph (K sf_step launches captured once, one replay per block)" if use_graph else "loop (one Python call per launch)",
+            "loop_issue": loop_issue,
             "block_ms": {"median": elapsed * 1e3, "min": blocks[order[0]] * 1e3, "max": blocks[order[-1]] * 1e3,
                          "first": blocks[0] * 1e3,
                          "note": "each block = exactly `steps` launches between barrier + synchronize brackets (max over "
                                  "ranks); value and ms_per_step come from the median block"},
+            "value_with_action_gen": total_steps / s_blocks[s_med],
+            "action_gen": {"value": total_steps / s_blocks[s_med], "unit": "env-steps/s", "ms_per_step": s_blocks[s_med] / K * 1e3,
+                           "launch_period_ms": s_periods[s_med],
+                           "note": "the same timed blocks through sf_step_sampled: every lane draws its action inside the "
+                                   "launch (Philox4x32-10 keyed by seed, counter (lane of the job, tick); the tick counter "
+                                   "lives on the device, so every graph replay plays new actions); no action tensor is "
+                                   "generated, stored or loaded (SURVEY 8d: 'action generation on device ... report both'; "
+                                   "tests/test_gpu_sampled.py replays the sampled actions through the oracle)"},
             "stats_reduce_us": stats_reduce_us,
             "config": {"workload": "%s, %d envs/GPU, %s obs (f32), uniform random discrete actions resident in HBM, "
                                    "per-lane auto-reset" % (args.gametype, n, args.obs_type),
@@ -461,17 +654,20 @@ def main():
                                            if prof else None,
                          "kernel": "sf_step_kernel", "launch_period_ms": region_ms,
                          "launch_period_steady_ms": steady_ms, "frac_steady": algo / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "steady_note": "%d back-to-back launches outside the timed blocks; `achieved` / `frac` use the timed "
-                                        "region's period, which for a block of a few launches includes its start on an idle GPU" % n_steady,
+                         "steady_note": "%d back-to-back launches (%.1f s of the Python loop) outside the timed blocks; `achieved` / "
+                                        "`frac` use the timed region's period, which for a block of a few launches includes its "
+                                        "start on an idle GPU" % (n_steady, steady_total_ms * 1e-3),
                          "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
                          "kernel_ms_rocprof_source": ("rocprofv3 --kernel-trace mean of kernel version %s (profiles/%s)"
                                                       % (prof.get("version"), prof.get("trace_file"))) if prof else None,
                          "kernel_ms_event_pair_mean": kern_ms, "kernel_ms_event_pair_median": kern_ms_med,
                          "algorithmic_bytes_per_launch": algo, "launches_timed": K},
             "cpu_baseline": base,
+            "ranks": ranks,
             "rollout_fused": fused,
             "host_api": host_api,
             "image_obs": image_obs,
+            "configs": configs,
             "episode_stats": summarize(stats.cpu()),
         }
         print(json.dumps(out))

@@ -52,7 +52,9 @@ typedef enum {
   SF_ERR_HIP = -3,       /* a HIP call failed */
   SF_ERR_NO_DEVICE = -4, /* no GPU visible: the product path never falls back to the CPU */
   SF_ERR_ACTION = -5,    /* an action index was out of range (reference: IndexError/KeyError, ENV:211-212) */
-  SF_ERR_FIELD = -6      /* unknown field id / size mismatch in sf_get_field / sf_set_field */
+  SF_ERR_FIELD = -6,     /* unknown field id / size mismatch in sf_get_field / sf_set_field */
+  SF_ERR_STATE = -7      /* sf_check_state: a per-episode counter or timer outgrew its packed width (the reference keeps
+                            plain ints, SRC/game.hh:29-43; only batches with SF_FLAG_NO_AUTO_RESET can get there) */
 } sf_status;
 
 /* obs_type of SSF_Env (ENV:50-52) */
@@ -125,6 +127,22 @@ int sf_reset(sf_batch* b, void* obs_dev, void* stream);
 int sf_step(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
             uint8_t* done_dev, uint8_t* info_dev, void* stream);
 
+/* ---- VecEnv.step on actions the lanes draw themselves, inside the same launch: what the random-action rollout of
+ *      BASELINE.json does with `torch.randint` per step, and what stands where the reference's loop has the policy's
+ *      sample (rl/train.py:76-80), without an action array to generate, store and load.  Lane l of tile t plays
+ *      floor(x * n_actions / 2^32), x = the first word of Philox4x32-10 with key = the 64-bit seed and counter
+ *      (first_lane + 64 t + l, tick, 0, 0); `tick` counts this batch's sampled steps since sf_seed_actions (kept per
+ *      tile on the device, so the call is a pure stream operation: capturable in a HIP graph, every replay draws new
+ *      actions).  actions_out_dev, uint8 [n_envs] (may be NULL), receives what was played -- replaying those through
+ *      sf_step from the same state gives the same results (tests/test_gpu_sampled.py).  sf_create seeds with
+ *      (params.seed, first_lane 0); sf_seed_actions restarts the sequence at tick 0 (synchronises `stream`).
+ *      sf_rollout_sampled: the fused n_steps form, actions_out_dev uint8 [n_steps][n_envs]. ---- */
+int sf_seed_actions(sf_batch* b, uint64_t seed, uint32_t first_lane, void* stream);
+int sf_step_sampled(sf_batch* b, uint8_t* actions_out_dev, void* obs_dev, int32_t* reward_dev, uint8_t* done_dev,
+                    uint8_t* info_dev, void* stream);
+int sf_rollout_sampled(sf_batch* b, int n_steps, uint8_t* actions_out_dev, void* obs_dev, int32_t* reward_dev,
+                       uint8_t* done_dev, uint8_t* info_dev, void* stream);
+
 /* ---- K VecEnv.step calls whose actions are all known up front (open-loop rollouts: random-action
  *      benchmarks, replaying recorded action sequences, evaluating fixed plans), fused into ONE
  *      launch: each wave keeps its environments in registers between ticks, so a tick costs
@@ -195,6 +213,16 @@ int sf_set_event_output(sf_batch* b, uint32_t* events_dev);
 /* Out-of-range actions are executed as NOOP and counted on the device; this reads and clears the
  * count (synchronises `stream`).  Returns SF_ERR_ACTION if any were seen since the last call. */
 int sf_check_actions(sf_batch* b, void* stream);
+
+/* The per-episode statistics and the key timers live in bit fields sized for one episode (5 295 ticks).  A batch created
+ * with SF_FLAG_NO_AUTO_RESET keeps ticking past game over like the bare SSF_Env (ENV:246) until sf_reset; if it is stepped
+ * for several episodes' worth of ticks a field can outgrow its bits (deaths / kills: 255 per game; resets, misses, key
+ * presses: 65 535; vlner: 4 095; a key timer: +-32 767 ticks without an edge; time: 2^24 ms).  Every env-tick on which
+ * that is the case is counted on the device; this reads and clears the count (synchronises `stream`) and returns
+ * SF_ERR_STATE if any were seen -- the values sf_get_field returns for those envs have wrapped.  Auto-resetting batches
+ * start every field over at each episode end and cannot get there.  sf_set_field refuses (SF_ERR_ARG) values that do
+ * not fit a field, and a `stats` row 3 (ship deaths) that is not the sum of rows 0-2. */
+int sf_check_state(sf_batch* b, void* stream);
 
 /* ---- state access: the 37 read-only attributes of `Game` (SRC/pymodule.cpp:372-411) in batched
  *      form, plus writes for checkpoint/restore and constructed test states.  `host` is HOST memory,

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFMI_LIB_PATH") or os.path.join(HERE, "libsfmi.so")
 
 SF_OK = 0
-SF_ERR_PRESET, SF_ERR_ARG, SF_ERR_HIP, SF_ERR_NO_DEVICE, SF_ERR_ACTION, SF_ERR_FIELD = -1, -2, -3, -4, -5, -6
+SF_ERR_PRESET, SF_ERR_ARG, SF_ERR_HIP, SF_ERR_NO_DEVICE, SF_ERR_ACTION, SF_ERR_FIELD, SF_ERR_STATE = -1, -2, -3, -4, -5, -6, -7
 OBS_TYPES = {"features": 0, "normalized-features": 1, "monitors": 2, "none": 3, "image": 4, "image-raw": 5}
 IMAGE_W, IMAGE_H, IMAGE_OUT = 90, 92, 84
 # SF_EV_* (include/sfmi.h): bit -> the reference's event string, in the order Game::stepOneTick can emit them
@@ -72,6 +72,10 @@ SYMBOLS = {
     "sf_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_check_actions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sf_check_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sf_seed_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "sf_step_sampled": (C.c_int, [C.c_void_p] * 7),
+    "sf_rollout_sampled": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "sf_n_fields": (C.c_int, []),
     "sf_field_info": (C.c_int, [C.c_int, C.POINTER(FieldDesc)]),
     "sf_field_id": (C.c_int, [C.c_char_p]),
@@ -146,6 +150,8 @@ def check(rc):
         raise IndexError(msg)  # ENV:211-212
     if rc == SF_ERR_FIELD:
         raise KeyError(msg)
+    if rc == SF_ERR_STATE:
+        raise OverflowError(msg)
     raise SfmiError("libsfmi: %s (status %d)" % (msg, rc))
 
 

@@ -38,6 +38,7 @@ struct sf_batch {
   unsigned char* d_ms_pos;
   int32_t* d_ms_ang;
   bool mslots_dirty;
+  uint32_t* d_actrec;        // sf_step_sampled: one (tick, key0, key1, first lane) record per tile
 };
 
 namespace {
@@ -76,8 +77,24 @@ int flush_missile_view(sf_batch* b, hipStream_t stream) {
     if (rc_ != SF_OK) return rc_;                                  \
   } while (0)
 
-const unsigned long long kAccInit[SF_EPISODE_STATS_LEN + 1] = {
-    0, 0, 0, 0, 0, 0, (unsigned long long)LLONG_MAX, (unsigned long long)LLONG_MIN, 0};
+const unsigned long long kAccInit[SF_ACC_WORDS] = {
+    0, 0, 0, 0, 0, 0, (unsigned long long)LLONG_MAX, (unsigned long long)LLONG_MIN, 0, 0};
+static_assert(SF_ACC_BAD_ACTION == SF_EPISODE_STATS_LEN && SF_ACC_OVERFLOW == SF_EPISODE_STATS_LEN + 1, "acc layout");
+
+// the sampler records of sf_step_sampled (sf_layout.h: SF_ACT_SAMPLED): per tile (tick, key0, key1, first lane of the job)
+int write_action_records(sf_batch* b, uint64_t seed, uint32_t first_lane, hipStream_t stream) {
+  const size_t tiles = (size_t)(b->args.lanes / 64);
+  std::vector<uint32_t> rec(4 * tiles);
+  for (size_t t = 0; t < tiles; t++) {
+    rec[4 * t + 0] = 0u;
+    rec[4 * t + 1] = (uint32_t)seed;
+    rec[4 * t + 2] = (uint32_t)(seed >> 32);
+    rec[4 * t + 3] = first_lane + (uint32_t)(64 * t);
+  }
+  HIP_TRY(hipMemcpyAsync(b->d_actrec, rec.data(), rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipStreamSynchronize(stream));  // `rec` is pageable host memory that dies with this call
+  return SF_OK;
+}
 
 bool is_pow2(long v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -183,6 +200,7 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   HIP_TRY_FREE(hipMemcpy(b->d_consts, consts.data(), consts.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY_FREE(hipMemcpy(b->d_spawn, spawn.data(), spawn.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   HIP_TRY_FREE(hipMemcpy(b->d_acc, kAccInit, sizeof(kAccInit), hipMemcpyHostToDevice));
+  HIP_TRY_FREE(hipMalloc((void**)&b->d_actrec, (size_t)(lanes / 64) * 16));
   {
     // image observation tables (sf_image.cpp): 11 KB, built for every batch so that sf_render works
     // whatever obs_type the batch steps with (the reference's render(), ENV:190-193)
@@ -288,6 +306,11 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   a.acc = b->d_acc;
   a.dbg = nullptr;
   a.hint = nullptr;
+  a.act_out = nullptr;
+  if (write_action_records(b, p->seed, 0u, nullptr) != SF_OK) {  // sf_step_sampled's default stream: (seed, lane, tick 0)
+    sf_destroy(b);
+    return SF_ERR_HIP;
+  }
   if (image && !getenv("SFMI_NO_RENDER_ORDER")) {  // the render kernel's launch order (sf_render.hip: pick_env)
     HIP_TRY_FREE(hipMalloc((void**)&a.hint, (size_t)(lanes / 64) * sizeof(unsigned long long)));
     HIP_TRY_FREE(hipMemset(a.hint, 0, (size_t)(lanes / 64) * sizeof(unsigned long long)));
@@ -311,6 +334,7 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_consts) (void)hipFree(b->d_consts);
   if (b->d_spawn) (void)hipFree(b->d_spawn);
   if (b->d_acc) (void)hipFree(b->d_acc);
+  if (b->d_actrec) (void)hipFree(b->d_actrec);
   if (b->d_scratch) (void)hipFree(b->d_scratch);
   if (b->d_ms_pos) (void)hipFree(b->d_ms_pos);
   if (b->d_ms_ang) (void)hipFree(b->d_ms_ang);
@@ -549,6 +573,70 @@ extern "C" int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, in
   return SF_OK;
 }
 
+extern "C" int sf_seed_actions(sf_batch* b, uint64_t seed, uint32_t first_lane, void* stream) {
+  if (!b) {
+    sf_set_error("sf_seed_actions: null batch");
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  return write_action_records(b, seed, first_lane, (hipStream_t)stream);
+}
+
+extern "C" int sf_step_sampled(sf_batch* b, uint8_t* actions_out_dev, void* obs_dev, int32_t* reward_dev, uint8_t* done_dev,
+                               uint8_t* info_dev, void* stream) {
+  if (!b) {
+    sf_set_error("sf_step_sampled: null batch");
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  const bool image = is_image(b);
+  SfKernelArgs args = b->args;
+  args.act_out = actions_out_dev;
+  SF_FLUSH_VIEW(b, stream);
+  HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, b->d_actrec, SF_ACT_SAMPLED, image ? nullptr : obs_dev,
+                         reward_dev, done_dev, info_dev, 1, false, (hipStream_t)stream));
+  if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
+  return SF_OK;
+}
+
+extern "C" int sf_rollout_sampled(sf_batch* b, int n_steps, uint8_t* actions_out_dev, void* obs_dev, int32_t* reward_dev,
+                                  uint8_t* done_dev, uint8_t* info_dev, void* stream) {
+  if (!b) {
+    sf_set_error("sf_rollout_sampled: null batch");
+    return SF_ERR_ARG;
+  }
+  if (is_image(b) && obs_dev) {
+    sf_set_error("sf_rollout_sampled: image observations are rendered one frame per sf_step; pass obs_dev = NULL");
+    return SF_ERR_ARG;
+  }
+  if (n_steps <= 0 || (double)n_steps * b->n_envs * 8.0 >= 4294967296.0) {
+    sf_set_error("sf_rollout_sampled: n_steps must be positive and n_steps * n_envs * 8 < 2^32 (got %d)", n_steps);
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  SfKernelArgs args = b->args;
+  args.act_out = actions_out_dev;
+  SF_FLUSH_VIEW(b, stream);
+  HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, b->d_actrec, SF_ACT_SAMPLED, obs_dev, reward_dev, done_dev,
+                         info_dev, n_steps, true, (hipStream_t)stream));
+  return SF_OK;
+}
+
+extern "C" int sf_check_state(sf_batch* b, void* stream) {
+  if (!b) return SF_ERR_ARG;
+  DeviceGuard guard(b->device);
+  unsigned long long bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, b->d_acc + SF_ACC_OVERFLOW, sizeof(bad), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if (bad) {
+    HIP_TRY(hipMemsetAsync(b->d_acc + SF_ACC_OVERFLOW, 0, sizeof(bad), (hipStream_t)stream));
+    sf_set_error("%llu env-ticks ran with a per-episode counter or timer beyond its packed width (a batch without "
+                 "auto-reset stepped for several episodes without sf_reset): stats / timers of those envs have wrapped", bad);
+    return SF_ERR_STATE;
+  }
+  return SF_OK;
+}
+
 extern "C" int sf_set_event_output(sf_batch* b, uint32_t* events_dev) {
   if (!b) return SF_ERR_ARG;
   if (((uintptr_t)events_dev & 3) != 0) {
@@ -623,6 +711,39 @@ static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host
   if (bytes != total) {
     sf_set_error("field %s: expected %zu bytes, got %zu", m.name, total, bytes);
     return SF_ERR_FIELD;
+  }
+  if (!to_host && (m.kind == SF_FK_BITS || m.kind == SF_FK_STATS)) {
+    // these fields live in bit fields of packed words (sf_layout.h: SF_W_*): a value that does not fit is an error, not a
+    // silent truncation (the reference keeps plain ints, SRC/game.hh:29-43)
+    const int32_t* v = (const int32_t*)host;
+    const long n = b->n_envs;
+    auto fits = [](long x, int bits, int sgn) { return sgn ? (x >= -(1l << (bits - 1)) && x < (1l << (bits - 1))) : (x >= 0 && x < (1l << bits)); };
+    if (m.kind == SF_FK_BITS) {
+      const sfl::BitField bf = sfl::bit_field(f);
+      const bool uns32 = m.elem_size == 4 && !bf.is_signed;
+      for (long e = 0; e < n; e++) {
+        const long x = uns32 ? (long)(uint32_t)v[e] : (long)v[e];
+        if (!fits(x, bf.bits, bf.is_signed)) {
+          sf_set_error("sf_set_field(%s): value %ld of env %ld does not fit the field's %d bits", m.name, x, e, bf.bits);
+          return SF_ERR_ARG;
+        }
+      }
+    } else {
+      static const int kStatBits[SF_NSTAT] = {8, 8, 8, 10, 16, 8, 16, 16, 16, 16, 16, 12, 12};  // sf_layout.h: SF_W_*
+      for (int k = 0; k < SF_NSTAT; k++)
+        for (long e = 0; e < n; e++)
+          if (!fits(v[(long)k * n + e], kStatBits[k], 0)) {
+            sf_set_error("sf_set_field(stats): stats[%d] = %d of env %ld does not fit its %d bits", k, v[(long)k * n + e], e,
+                         kStatBits[k]);
+            return SF_ERR_ARG;
+          }
+      for (long e = 0; e < n; e++)
+        if (v[3 * n + e] != v[e] + v[n + e] + v[2 * n + e]) {  // killShip's three call sites (SRC/game.cpp:339,345,413)
+          sf_set_error("sf_set_field(stats): ship deaths (stats[3] = %d) of env %ld must be the sum of the big-hex, small-hex "
+                       "and shell deaths (%d): it is not stored separately", v[3 * n + e], e, v[e] + v[n + e] + v[2 * n + e]);
+          return SF_ERR_ARG;
+        }
+    }
   }
   DeviceGuard guard(b->device);
   HIP_TRY(hipDeviceSynchronize());

@@ -325,6 +325,25 @@ __device__ __forceinline__ double sf_atan2(double y, double x, const double* ata
   return r;
 }
 
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123 constants): counter
+// (c0, c1, 0, 0), key (k0, k1); the first output word.  The reference's rollout gets its actions from the policy
+// (rl/train.py:76-80); the random-action benchmark draws them here: action = floor(x * n_actions / 2^32).
+__device__ __forceinline__ unsigned sf_philox4x32_10(unsigned c0, unsigned c1, unsigned k0, unsigned k1) {
+  unsigned c2 = 0u, c3 = 0u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+    const unsigned lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
 // Game::reward (SRC/game.cpp:97-102): three float32 adds in this order, points clamped at 0.
 __device__ __forceinline__ void score(float amount, float& rew, Lane& L) {
   rew += amount;
@@ -867,8 +886,24 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   if (n_envs_p > 65536 - 256 && ((blockIdx.x >> 3) & 1u)) __builtin_amdgcn_s_sleep(SF_STAGGER);
 #endif
   // ================= round trip 1: every unconditional load =================
+  // act_type SF_ACT_SAMPLED: no action array -- `actions` is this batch's sampler records (SfActRec, one per tile) and the
+  // lane draws its action itself: Philox4x32-10 keyed by the seed, counter (lane of the whole job, tick).  The record is
+  // ONE scalar load off a preloaded kernel argument, back long before the early set, and the ten rounds run while the
+  // wave would otherwise sit in that wait.  (constant address space = s_load; the tile's tick is rewritten by lane 0 after
+  // the last tick of the launch, nothing reads it again in between.)
+  u4_t act_rec = {0u, 0u, 0u, 0u};
+  if (act_type == SF_ACT_SAMPLED)
+    act_rec = *(reinterpret_cast<const __attribute__((address_space(4))) u4_t*>(
+                    reinterpret_cast<const __attribute__((address_space(4))) void*>((unsigned long long)actions)) +
+                __builtin_amdgcn_readfirstlane(i >> 6));
+  // (its own variable, never the destination of a load: joined with the loaded action in one register, the compiler
+  //  waits for every outstanding load -- vmcnt(0) -- in front of the ten rounds instead of running them under that wait)
+  auto sample_action = [&](int step) __attribute__((always_inline)) -> int {
+    const unsigned x = sf_philox4x32_10(act_rec.w + lane, act_rec.x + (unsigned)step, act_rec.y, act_rec.z);
+    return real ? (int)__umulhi(x, (unsigned)a.n_actions) : 0;
+  };
   auto load_action = [&](int step) __attribute__((always_inline)) -> int {  // ENV:211-212
-    if (!real) return 0;
+    if (!real || act_type == SF_ACT_SAMPLED) return 0;
     const unsigned char* ab = (const unsigned char*)actions;
     const unsigned e = (unsigned)step * (unsigned)n_envs_p + i;
     if (act_type == 8) return (int)SF_LD(long long, ab, e * 8u);
@@ -892,6 +927,9 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     cpi[k] = min(tid + k * SF_BLOCK, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
     cst[k] = SF_LD(d2_t, cb, cpi[k] * 16u);
   }
+  // (behind the last load of the early set: the ten rounds run while those are in flight)
+  int act_sampled = 0;
+  if (act_type == SF_ACT_SAMPLED) act_sampled = sample_action(0);  // uniform branch, VALU only
   // lane l takes entry 64 r + l if the pool has that many (`n_pool`: the tile's count, known once the early set is in;
   // ~0u = not known yet, take everything): the instructions are unconditional, the bytes are not
 #define SF_LOAD_POOL_ROWS(aux, n_pool)                                                                                        \
@@ -1002,9 +1040,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   unpack_lane_late(late, L);  // names only: the wait for the late set sits at the first real use
   const int n_iter = FUSED ? n_steps : 1;
   for (int step = 0; step < n_iter; step++) {
-  int act = act_next;
+  int act = act_type == SF_ACT_SAMPLED ? act_sampled : act_next;
   if (FUSED) {
-    if (step + 1 < n_iter) act_next = load_action(step + 1);  // in flight while this tick computes
+    if (step + 1 < n_iter) {
+      act_next = load_action(step + 1);  // in flight while this tick computes
+      if (act_type == SF_ACT_SAMPLED) act_sampled = sample_action(step + 1);
+    }
     if (step > 0) {
       // the pool rows the previous tick compacted in place: agent-scope loads (they bypass the wave's L1, where the rows
       // read a tick ago may still sit), in flight under the key / ship / fortress / shell arithmetic
@@ -1017,7 +1058,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 
   const int act_raw = act;  // what rollouts.actions[step] records
   if (act < 0 || act >= a.n_actions) {
-    atomicAdd(&a.acc[8], 1ull);  // reference: IndexError; here NOOP + counted (sf_check_actions)
+    atomicAdd(&a.acc[SF_ACC_BAD_ACTION], 1ull);  // reference: IndexError; here NOOP + counted (sf_check_actions)
     act = 0;
   }
   const unsigned keys = (unsigned)(a.action_keys >> (4 * act)) & 0xFu;
@@ -1445,6 +1486,20 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   L.c_small += (unsigned)S.small_hex_deaths;
   L.c_shell += (unsigned)S.shell_deaths;
   L.c_destroyed += (unsigned)S.destroyed;
+  if (!a.auto_reset) {  // uniform
+    // The packed per-episode counters (sf_layout.h: SF_W_*) are sized for ONE episode.  A batch without auto-reset
+    // keeps ticking past game over like the bare SSF_Env / Game (ENV:246) until the caller resets, and the reference's
+    // plain ints keep counting: a field that no longer fits its bits is counted here (sticky: sf_check_state) instead
+    // of wrapping silently.  Auto-resetting batches zero every field at 5 295 ticks, long before any of them fills up.
+    const unsigned ov = ((L.c_resets | L.c_missed) >> 16) | ((L.c_incs | L.c_maxv | (unsigned)L.vlner) >> 12) |
+                        ((L.c_big | L.c_small | L.c_shell | L.c_destroyed | L.ep_kills) >> 8) | ((unsigned)L.time >> 24) |
+                        (((unsigned)(L.fire_t + 32768) | (unsigned)(L.thrust_t + 32768) | (unsigned)(L.left_t + 32768) |
+                          (unsigned)(L.right_t + 32768)) >> 16) |
+                        (unsigned)(S.shots && (L.kc0 & 0xFFFFu) == 0u) | (unsigned)(S.thrusts && (L.kc0 >> 16) == 0u) |
+                        (unsigned)(S.lefts && (L.kc1 & 0xFFFFu) == 0u) | (unsigned)(S.rights && (L.kc1 >> 16) == 0u);
+    if (__ballot(ov != 0u) != 0ull)
+      if (ov != 0u && real) atomicAdd(&a.acc[SF_ACC_OVERFLOW], 1ull);
+  }
   if (done && a.auto_reset) {
     // episode totals (rl/train.py:81-88,161-164), this tick's share included
     const int ep_ret = L.ep_return, ep_kil = (int)L.ep_kills;
@@ -1501,6 +1556,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     if (done_out) SF_ST(uint8_t, (unsigned char*)(done_out + so), g.o1, (uint8_t)done);
     if (info_out) SF_ST(uint8_t, (unsigned char*)(info_out + so), g.o1, (uint8_t)fort_kill);
     if (a.events) SF_ST(uint32_t, (unsigned char*)(a.events + so), g.o4, evmask);
+    if (a.act_out) SF_ST(uint8_t, (unsigned char*)(a.act_out + so), g.o1, (uint8_t)act_raw);  // what the lane played (sampled or given)
     SF_STAMP(15, false);
     if (a.t_reward) {  // uniform; the same float32 operations in the same order as rl/train.py:82-88
       const float rf = (float)r, mask = done ? 0.0f : 1.0f;
@@ -1566,6 +1622,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   }
   }  // tick loop
   if (FUSED) store_lane_buf(rs, o, L);
+  if (act_type == SF_ACT_SAMPLED && lane == 0)  // the tile's tick counter moves on by the ticks of this launch
+    reinterpret_cast<unsigned*>(const_cast<void*>(actions))[4 * (size_t)(i >> 6)] = act_rec.x + (unsigned)n_iter;
   SF_STAMP(8, false);
   SF_STAMP(9, true);
 #ifdef SF_STAMPS

@@ -278,7 +278,7 @@ struct SfKernelArgs {
   // observation
   int obs_type, obs_f64, real_shell_count, obs_dim, auto_reset;
   // episode accumulators / error counter (device)
-  unsigned long long* acc;   // SF_EPISODE_STATS_LEN + 1 words; [8] = bad-action count
+  unsigned long long* acc;   // SF_ACC_WORDS words: the episode statistics, then the two sticky error counters
   unsigned long long* dbg;   // SF_STAMPS diagnostic builds only: [wave][16] clock stamps; else null
   unsigned* events;          // optional per-tick event bitmask output (SF_EV_*), [n_steps][n_envs]; else null
   // optional trainer bookkeeping of rl/train.py:82-88 + rollouts.insert (sf_step_record): reward as float and
@@ -296,4 +296,15 @@ struct SfKernelArgs {
   double n_gamma;
   // image batches only: per tile, the envs whose ship died in the last tick (sf_render_kernel's launch order); else null
   unsigned long long* hint;
+  // optional: the action every env played this tick as uint8 [n_steps][n_envs] (the sampled ones of sf_step_sampled); else null
+  unsigned char* act_out;
 };
+
+// words of SfKernelArgs::acc behind the SF_EPISODE_STATS_LEN (8) episode statistics
+#define SF_ACC_BAD_ACTION 8 /* actions outside [0, n_actions) that ran as NOOP (sf_check_actions) */
+#define SF_ACC_OVERFLOW 9   /* env-ticks on which a packed per-episode field no longer fitted its bits (sf_check_state) */
+#define SF_ACC_WORDS 10
+
+// act_type of the step kernel when the lanes draw their own actions (sf_step_sampled): `actions` then points at one
+// record per tile, (tick, key0, key1, the tile's first lane in the whole job) -- sf_kernels.hip: sf_philox4x32_10
+#define SF_ACT_SAMPLED 0

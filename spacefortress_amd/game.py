@@ -206,11 +206,15 @@ class Game:
 
     @property
     def stats(self):
+        # the reference's counters are plain ints (SRC/game.hh:29-43); here they ride in bit fields sized for one game,
+        # and a Game that is ticked for several games' worth without a new one is told so instead of reading wrapped values
+        self._vec.check_state()
         st = self._state()
         return tuple(int(v) for v in st["stats"]) + (float(st["points"]), float(st["raw_points"]))
 
     @property
     def timers(self):
+        self._vec.check_state()  # a key timer wraps after 32 767 ticks without an edge of its key
         st = self._state()
         return tuple(int(st[k]) for k in ("fire_timer", "thrust_timer", "left_timer", "right_timer"))
 

@@ -165,6 +165,46 @@ class SFVecEnv:
             _lib.check(self._L.sf_set_event_output(self._h, C.c_void_p(self.events.data_ptr())))
         return obs, rew, done, info
 
+    def seed_actions(self, seed, first_lane=0):
+        """Restart the on-device action sampler of `step_sampled` at tick 0 (sfmi.h: sf_seed_actions): lane i then plays
+        Philox4x32-10(key = seed, counter = (first_lane + i, tick)) scaled to [0, n_actions).  `first_lane` = this shard's
+        first lane in a job of several batches, so that shards draw what the one big batch would."""
+        _lib.check(self._L.sf_seed_actions(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_lane) & 0xFFFFFFFF, self._stream()))
+
+    def step_sampled(self, out=None, actions_out=None):
+        """One step on actions the lanes draw themselves inside the launch (sfmi.h: sf_step_sampled) -- the random-action
+        rollout without an action tensor.  Returns (obs, reward, done, info) like `step_tensors`; `actions_out` (uint8 [N]
+        on this device, optional) receives what was played."""
+        if out is None and self._bufs is not None and self.reuse_buffers:
+            bufs, ptrs = self._bufs, self._buf_ptrs
+        else:
+            bufs = out if out is not None else self._alloc()
+            ptrs = tuple(C.c_void_p(t.data_ptr()) for t in bufs)
+        ao = None
+        if actions_out is not None:
+            if actions_out.device != self.device or actions_out.dtype != torch.uint8 or not actions_out.is_contiguous() \
+                    or actions_out.numel() != self.num_envs:
+                raise ValueError("actions_out must be a contiguous uint8 tensor of %d elements on %s" % (self.num_envs, self.device))
+            ao = C.c_void_p(actions_out.data_ptr())
+        _lib.check(self._L.sf_step_sampled(self._h, ao, ptrs[0], ptrs[1], ptrs[2], ptrs[3], self._stream()))
+        return bufs
+
+    def rollout_sampled(self, n_steps, want_obs=True, want_actions=True):
+        """`rollout` on sampled actions: K ticks in one launch.  Returns (obs, reward, done, info, actions uint8 [K, N])."""
+        K, n = int(n_steps), self.num_envs
+        if self.is_image and want_obs:
+            raise ValueError("image frames are rendered one per step(): pass want_obs=False")
+        obs = torch.empty((K, n) + self.obs_shape, dtype=self.obs_dtype, device=self.device) if want_obs else None
+        rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
+        done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
+        info = torch.empty((K, n), dtype=torch.uint8, device=self.device)
+        acts = torch.empty((K, n), dtype=torch.uint8, device=self.device) if want_actions else None
+        _lib.check(self._L.sf_rollout_sampled(self._h, K, C.c_void_p(acts.data_ptr()) if acts is not None else None,
+                                              C.c_void_p(obs.data_ptr()) if obs is not None else None,
+                                              C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
+                                              C.c_void_p(info.data_ptr()), self._stream()))
+        return obs, rew, done, info, acts
+
     def step_async(self, actions):
         if torch.is_tensor(actions):
             self._pending = (self.step_tensors(actions), False)
@@ -228,6 +268,12 @@ class SFVecEnv:
     def check_actions(self):
         """Raise IndexError if any action since the last call was out of range (device path)."""
         _lib.check(self._L.sf_check_actions(self._h, self._stream()))
+
+    def check_state(self):
+        """Raise OverflowError if a per-episode counter or key timer outgrew its packed width since the last call
+        (sfmi.h: sf_check_state): only a batch with auto_reset=False that is stepped for several episodes' worth of
+        ticks without reset() can get there; the reference's plain ints keep counting (SRC/game.hh:29-43)."""
+        _lib.check(self._L.sf_check_state(self._h, self._stream()))
 
     def episode_stats(self, clear=False):
         """Device-accumulated episode statistics as an int64 tensor of 8 (see sfmi.h)."""

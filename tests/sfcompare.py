@@ -13,6 +13,13 @@ EXACT_F_FIELDS = [("ship_x", "ship_x"), ("ship_y", "ship_y"), ("ship_vx", "ship_
                   ("points", "points"), ("raw_points", "raw_points")]
 
 
+def obs_close(a, b, f64):
+    """Device observation vs the oracle's float64 one: 1e-9 relative for float64 batches, float32 rounding otherwise."""
+    tol = 1e-9 if f64 else 1e-5
+    scale = np.maximum(1.0, np.abs(b))
+    return np.abs(a.astype(np.float64) - b) <= tol * scale + (0 if f64 else 4e-5)
+
+
 def mask_bits(mask, n=20):
     return ((mask[None, :] >> np.arange(n, dtype=np.uint32)[:, None]) & 1).astype(bool)  # [slot, env]
 

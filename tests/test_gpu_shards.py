@@ -155,19 +155,51 @@ def test_config4_shard_through_the_auto_reset(sfa, oracle_mod):
     env.close()
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _bench_rccl(extra):
+    env = dict(os.environ, SF_BENCH_FORCE_DIST="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SF_BENCH_CPU_BASELINE_FILE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--envs", "4096", "--no-cpu-baseline",
+                        "--rollout-k", "0", "--image-envs", "0", "--numpy-api", "0", "--no-configs", "--steady-seconds", "0.3",
+                        "--kernel-timing-launches", "10"] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
 def test_bench_rccl_path_on_one_rank():
     """bench.py's multi-rank control flow over RCCL (backend "nccl"), rehearsed with the ONE rank this box has:
     process group on the device, NCCL barriers around every timed block, the MAX all-reduce of the block time and the
     all-gather of the 64-byte statistics vector.  (Two ranks cannot share a device under RCCL; the two-rank flow runs
     on gloo in tests/test_stats_gloo.py.)"""
-    env = dict(os.environ, SF_BENCH_FORCE_DIST="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300),
-               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5400", "--warmup", "10",
-                        "--envs", "4096", "--no-cpu-baseline", "--rollout-k", "0", "--image-envs", "0",
-                        "--kernel-timing-launches", "10"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert j["n_gpus"] == 1 and j["steps"] == 5400 and j["repeats"] == 1
-    assert j["episode_stats"]["episodes"] == 4096  # every lane finished one episode inside the window
+    j = _bench_rccl(["--steps", "5400", "--warmup", "10"])
+    assert j["n_gpus"] == 1 and j["steps"] == 5400 and j["repeats"] == 1 and j["launch"].startswith("loop")
+    es = j["episode_stats"]  # every lane finished whole episodes inside the run, in step with one another
+    assert es["episodes"] >= 2 * 4096 and es["episodes"] % 4096 == 0
     assert j["value"] > 1e8 and j["stats_reduce_us"] > 0
+
+
+def test_the_drivers_scale_command_on_one_rank():
+    """What the driver runs for its scaling table -- `bench.py --gpus N --steps 20 --warmup 5` under one rank per GPU
+    with an initialised RCCL process group -- takes the HIP-GRAPH path (K <= 512), which VERDICT r2 found never
+    executed next to a live communicator: the graphs are captured before init_process_group (thread-local capture
+    mode), replayed between NCCL barriers.  The line must say who ran (`ranks`: device, PCI bus id, per-rank block time)
+    and carry the action-generation figure."""
+    j = _bench_rccl(["--steps", "20", "--warmup", "5"])
+    assert j["n_gpus"] == 1 and j["steps"] == 20 and j["repeats"] == 100 and j["launch"].startswith("hip_graph")
+    assert j["value"] > 1e8 and 0 < j["ms_per_step"] < 0.1
+    assert j["value_with_action_gen"] > 1e8 and j["action_gen"]["ms_per_step"] > 0
+    assert j["loop_issue"]["value"] > 1e7
+    (rk,) = j["ranks"]
+    assert rk["rank"] == 0 and rk["device_index"] == 0 and rk["lanes"] == [0, 4096] and rk["block_ms_median"] > 0
+    assert rk["pci_bus_id"] is None or len(rk["pci_bus_id"]) >= 7
+    assert j["episode_stats"]["episodes"] >= 4096  # the steady-state loop plays whole episodes: the all-gather carries counts

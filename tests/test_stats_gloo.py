@@ -106,14 +106,16 @@ def test_single_process_reduce_is_identity():
 def test_bench_gpus_flag_starts_the_ranks_itself():
     """`python bench.py --gpus 2` with no WORLD_SIZE must start two ranks on its own (rl/train.py:30-32: N workers from
     one command).  SF_BENCH_FORCE_DIST=gloo runs the multi-rank control flow on CPU tensors: nothing is timed, the
-    line says "dry_run", but n_gpus, the shard cut and the one-collective reduction are the real code."""
+    line says "dry_run", but n_gpus, the shard cut, the one-collective reduction, the per-rank evidence gathered from
+    every rank and the CPU baseline handed from the launcher to rank 0 are the real code."""
     import json
     import subprocess
 
     env = dict(os.environ, SF_BENCH_FORCE_DIST="gloo")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "SF_BENCH_CPU_BASELINE_FILE"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--cpu-seconds", "0.4", "--cpu-cores", "2"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -124,8 +126,33 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert j["max_over_ranks"] == 2.0  # MAX over ranks of (1 + rank)
     es = j["episode_stats"]  # sums of (rank + 1, 10 (rank + 1), ...), min of -5 - rank, max of 7 + rank
     assert es["episodes"] == 3 and es["fortress_kills"] == 1 and es["min_return"] == -6 and es["max_return"] == 8
+    # one entry per rank, gathered from the ranks themselves
+    assert [x["rank"] for x in j["ranks"]] == [0, 1]
+    assert [x["lanes"] for x in j["ranks"]] == [[0, 65536], [65536, 131072]]
+    assert [x["block_ms_median"] for x in j["ranks"]] == [1.0, 2.0]
+    # the CPU baseline of an N > 1 job: timed by the launcher before the ranks start, carried by rank 0's line
+    cb = j["cpu_baseline"]
+    assert cb is not None and cb["cores"] == 2 and cb["value"] > 1e4 and cb["kind"] in ("reference", "port")
     # a WORLD_SIZE that disagrees with --gpus is an error, not a silent single shard
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r2.returncode != 0 and "WORLD_SIZE" in r2.stderr
+
+
+def test_a_rank_that_dies_takes_the_job_down_at_once():
+    """the launcher used to wait for rank 0 first, so a rank that died at start-up left its peers in
+    init_process_group / a collective until the store's timeout (tens of minutes).  All ranks are polled now: the first
+    failure stops the others and its exit code is the job's."""
+    import subprocess
+    import time
+
+    env = dict(os.environ, SF_BENCH_FORCE_DIST="gloo", SF_BENCH_TEST_FAIL_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "SF_BENCH_CPU_BASELINE_FILE"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 60  # not a rendezvous timeout
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # and no line from a half-run job
