@@ -229,6 +229,12 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
           uint32_t* t = &tabs[4 * (ax * SF_OUT + i)];
           t[0] = (uint32_t)first[i];
           memcpy(t + 1, alpha + 4 * i, 3 * sizeof(float));
+          // ... and that the taps repeat exactly (90 / 84 = 15 / 14, 92 / 84 = 23 / 21): the frame kernel keeps ONE period in
+          // LDS (sf_render.hip: resample_into)
+          const int P = ax == 0 ? 14 : 21, Q = ax == 0 ? 15 : 23;
+          if (i >= P)
+            ok = ok && first[i] == first[i - P] + Q && count[i] == count[i - P] &&
+                 memcmp(alpha + 4 * i, alpha + 4 * (i - P), 3 * sizeof(float)) == 0;
           // ... and what its exact dirty box relies on (sf_render.hip: out_box): a source cell s is read with a weight
           // that is not zero only by the destinations floor(N s / D) ... ceil(N (s + 1) / D) - 1, N / D = 14/15, 21/23
           const int N = ax == 0 ? 14 : 21, D = ax == 0 ? 15 : 23;

@@ -182,7 +182,14 @@ constexpr GroupMeta kGroups[SF_G_COUNT] = {
 #undef G
 };
 // byte offset, inside a tile, of (group g, slot 0, lane 0)
-constexpr long group_offset(int g) {
+// (always_inline: with a run-time slot the device compiler otherwise may emit a CALL to these -- a real function with a loop
+//  over a table in memory, and a kernel with calls in it: sf_render_kernel once ran 40 % slower for exactly that)
+#if defined(__GNUC__) || defined(__clang__)
+#define SF_ALWAYS_INLINE __attribute__((always_inline))
+#else
+#define SF_ALWAYS_INLINE
+#endif
+SF_ALWAYS_INLINE constexpr long group_offset(int g) {
   long o = 0;
   for (int i = 0; i < g; i++) o += (long)kGroups[i].chunk * kGroups[i].slots * kTileLanes;
   return o;
@@ -190,7 +197,7 @@ constexpr long group_offset(int g) {
 constexpr long kTileBytes = group_offset(SF_G_COUNT);          // 73 728 B
 constexpr long kBytesPerLane = kTileBytes / kTileLanes;        // 1152 B
 // byte offset, inside a tile, of lane 0's chunk of (group g, slot s)
-constexpr long chunk_offset(int g, int s = 0) { return group_offset(g) + (long)s * kGroups[g].chunk * kTileLanes; }
+SF_ALWAYS_INLINE constexpr long chunk_offset(int g, int s = 0) { return group_offset(g) + (long)s * kGroups[g].chunk * kTileLanes; }
 
 struct FieldMeta {
   const char* name;

@@ -36,6 +36,12 @@
 #ifndef SF_RENDER_SKIP
 #define SF_RENDER_SKIP 0
 #endif
+// diagnostic builds only: the frame kernel returns behind phase N (1 the prologue up to the barrier, 2 the restored
+// pictures, 3 the fresh explosions, 4 the strokes of ship / fortress / missiles, 5 the shells) -- instruction counts of the
+// phases by difference (tools/pmc_render_variants.sh)
+#ifndef SF_RENDER_STOP
+#define SF_RENDER_STOP 0
+#endif
 #ifndef SF_RENDER_TABS_IN_LDS
 #define SF_RENDER_TABS_IN_LDS 0
 #endif
@@ -47,7 +53,6 @@ constexpr int kFbWords = kFbBytes / 4;                 // 2070
 constexpr int kFbPadWords = (SF_IMG_W * (SF_IMG_H + 1) + 3) / 4 + 1;  // one spare row for zero-weight taps
 constexpr int kFbVec = kFbBytes / 16;                  // 517 (+ 8 bytes)
 constexpr int kOutBytes = SF_OUT * SF_OUT;             // 7056 = 441 * 16
-constexpr int kMaskScratch = 256;                      // the missile slot table of the prologue
 
 struct d2_t {
   double x, y;
@@ -189,6 +194,7 @@ __device__ __forceinline__ Box explosion_box(float cx, float cy) {
 // destination pixels that read `b` read nothing further than this outside it.  A picture saved with its 84x84 part is
 // good where nothing else is drawn within that reach of its box (kReachX, kReachY).
 constexpr int kReachX = 1, kReachY = 2;
+constexpr int kTapColPeriod = 14, kTapRowPeriod = 21;  // destination columns / rows after which the INTER_AREA taps repeat
 __device__ __forceinline__ Box out_box(const Box& b) {
   Box o;
   o.x0 = max((b.x0 * 14) / 15, 0);
@@ -206,10 +212,11 @@ template <bool RESIZE>
 struct Frame {
   uint8_t* fb;
   uint8_t* obuf;        // 84 x 84, row stride SF_OUT (global memory; LDS in sf_fort_patch_kernel)
-  const uint32_t* tab;  // LDS copy of the tap tables (sf_raster.h)
+  const uint32_t* tab;  // the tap tables (sf_raster.h): global memory, or an LDS copy (the picture kernels)
+  const uint32_t* ptab; // LDS: one PERIOD of the tap tables, or null (then `tab` is read): see resample_into
   int lane;
-  float* qscr;          // LDS: 4 quads of the object being drawn, with their edge slopes (draw_objects)
-  uint8_t* mscr;        // LDS: kMaskScratch bytes of scratch
+  float* srec;          // LDS: kChunk stroke records of kRecFloats floats (draw_strokes)
+  uint32_t* slist;      // LDS: kListCap touched (stroke, x, y) entries (draw_strokes)
 
   // cv2.resize(..., INTER_AREA) restricted to the destination pixels that read source pixels of `b`
   // (OpenCV's resizeArea_ arithmetic: per source row buf = sum alpha * S, then sum += beta * buf in
@@ -228,10 +235,28 @@ struct Frame {
       const DivMod dm = fast_divmod(i, ow, r_ow);
       const int ry = dm.q, rx = dm.r;
       const int dx = ox0 + rx, dy = oy0 + ry;
-      const int fx = (int)tab[4 * dx];
-      const float a0 = tabf[4 * dx + 1], a1 = tabf[4 * dx + 2];
-      const int fy = (int)tab[4 * (SF_OUT + dy)];
-      const float b0 = tabf[4 * (SF_OUT + dy) + 1], b1 = tabf[4 * (SF_OUT + dy) + 2], b2 = tabf[4 * (SF_OUT + dy) + 3];
+      int fx, fy;
+      float a0, a1, b0, b1, b2;
+      if (ptab) {  // uniform
+        // 90 / 84 = 15 / 14 and 92 / 84 = 23 / 21: the taps repeat exactly every 14 columns / 21 rows (checked entry by
+        // entry in sf_create), the first source cell moving on by 15 / 23.  One period sits in LDS: the frame kernel's
+        // resampling then has no load from global memory -- and a wave's loads are counted with its stores: behind every
+        // object's byte stores to the caller's frame, the next object's table reads waited for those stores to be
+        // acknowledged, a memory round trip per object.
+        const int qx = (dx * 37) >> 9, px_ = dx - 14 * qx;   // dx / 14, dx % 14 for dx < 84
+        const int qy = (dy * 49) >> 10, py_ = dy - 21 * qy;  // dy / 21, dy % 21 for dy < 84
+        const uint4 tc = *reinterpret_cast<const uint4*>(ptab + 4 * px_);
+        const uint4 tr = *reinterpret_cast<const uint4*>(ptab + 4 * (kTapColPeriod + py_));
+        fx = (int)tc.x + 15 * qx;
+        fy = (int)tr.x + 23 * qy;
+        a0 = __uint_as_float(tc.y); a1 = __uint_as_float(tc.z);
+        b0 = __uint_as_float(tr.y); b1 = __uint_as_float(tr.z); b2 = __uint_as_float(tr.w);
+      } else {
+        fx = (int)tab[4 * dx];
+        a0 = tabf[4 * dx + 1]; a1 = tabf[4 * dx + 2];
+        fy = (int)tab[4 * (SF_OUT + dy)];
+        b0 = tabf[4 * (SF_OUT + dy) + 1]; b1 = tabf[4 * (SF_OUT + dy) + 2]; b2 = tabf[4 * (SF_OUT + dy) + 3];
+      }
       const uint8_t* r0 = fb + fy * SF_IMG_W + fx;
       const uint8_t* r1 = r0 + SF_IMG_W;
       const uint8_t* r2 = r1 + SF_IMG_W;
@@ -292,86 +317,188 @@ struct Frame {
     resample(dirty);
   }
 
-  // Small objects (the ship: 3 strokes, missiles: 3, shells: 4) -- lanes [k*per, (k+1)*per) hold the strokes of object
-  // k.  A stroke covers a dozen pixels, so walking strokes one by one leaves most of the wave idle.  Per object the
-  // lanes take all its (stroke, pixel) pairs at once, stroke-major: each computes its coverage, keeps it in a register,
-  // and then the strokes composite one after the other -- the lanes of stroke 0 first, then those of stroke 1 ... (no
-  // two lanes of one stroke share a pixel; where strokes meet, a pixel is touched once per stroke, in stroke order).
-  // The same arithmetic in the same order as stroke by stroke.  (Round 1 parked the coverages in LDS and composited
-  // with a lane per pixel of the object's box, four box tests and mask reads each: a second pass as dear as the first.)
-  __device__ __forceinline__ void draw_objects(const Quad& mine, int grey, bool valid, int per) const {
+  // ---- Small objects: the ship (3 strokes), the fortress drawn in place (4), missiles (3 each), shells (4 each).
+  // Lane s holds stroke s of the frame's draw order (`mine`, `valid`); `obj0` = the first lane of the stroke's object.
+  //
+  // A stroke is a 0.6 x 3.6 .. 7.2 pixel rectangle at any angle: its bounding box holds two to four times the pixels it
+  // touches, and an object is a couple of dozen touched pixels -- a third of a wave.  Round 2 drew one object at a time,
+  // every lane on a (stroke, box pixel) pair paying the full edge integrals (165 vector instructions) whether the pixel
+  // is touched or not: the ship's 70 box pixels took two rounds of lanes, every missile one.  Here, for up to kChunk
+  // strokes of ANY objects at once:
+  //   1. the strokes' owners put a record in LDS: box, the stroke's two axes for a separating-axis test, the quad and its
+  //      edge slopes;
+  //   2. cheap rounds: a lane per box pixel of all the chunk's strokes tests pixel-square against stroke-rectangle (the
+  //      box is the other two axes: the test is exact, made conservative by a margin) -- a dozen instructions -- and the
+  //      touched ones are appended, ballot + prefix count, to a list in LDS: (stroke, x, y), in stroke order;
+  //   3. dense rounds over the list: the exact coverage (quad_cover: the same arithmetic on the same operands as before, so
+  //      the same pixels), kept in a register, then the strokes present in the round composite one after the other in
+  //      stroke order -- no two lanes of a stroke share a pixel, and LDS is in order per wave;
+  //   4. every object's box of the 84x84 image is resampled once everything is drawn (a destination pixel that reads a
+  //      changed source pixel lies in some object's out_box, and is evaluated after the last change).
+  // A live ship and a missile or two are one dense round instead of three or four sparse ones.
+  static constexpr int kChunk = 8, kListCap = 128;
+  static constexpr int kRecFloats = 24;  // [0,12) quad x, y, slopes; [12,20) nx, ny, cn, hn, ux, uy, cu, hu; [20,23) x0 | y0 << 8, w, offset (ints); [23] 1 / w
+  __device__ __forceinline__ void flush_list(int cnt) const {
+    for (int base = 0; base < cnt; base += 64) {
+      const int i = base + lane;
+      int k = -1, m = 0;
+      uint8_t* p = fb;
+      if (i < cnt) {
+        const uint32_t ent = slist[i];
+        k = (int)(ent >> 16);
+        const int px = (int)(ent & 255u), py = (int)((ent >> 8) & 255u);
+        const float* g = srec + k * kRecFloats;
+        Quad q;
+        Slopes sl;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          q.x[v] = g[v];
+          q.y[v] = g[4 + v];
+          sl.s[v] = g[8 + v];
+        }
+        if (!(SF_RENDER_SKIP & 32)) m = cover_to_mask(quad_cover(q, sl, (float)px, (float)py));
+        p = fb + py * SF_IMG_W + px;
+      }
+      // the list is in stroke order: this round holds the strokes klo .. khi, composited one after the other
+      const int klo = __builtin_amdgcn_readfirstlane(k);
+      const int last = min(cnt - base, 64) - 1;
+      const int khi = __builtin_amdgcn_readlane(k, last);
+      for (int kk = klo; kk <= khi; kk++) {
+        if (!(SF_RENDER_SKIP & 64) && k == kk && m > 0) *p = (uint8_t)sfr::over_un8(*p, 255, m);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  __device__ __forceinline__ void draw_strokes(const Quad& mine, bool valid, int obj0, unsigned long long* dbg = nullptr) const {
+#define SF_DS_STAMP(k) do { if (dbg) { asm volatile("" ::: "memory"); dbg[k] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
     const Box myb = quad_box(mine);
     const int mybw = myb.x1 - myb.x0, mybh = myb.y1 - myb.y0;
     const int myn = (valid && !myb.empty()) ? mybw * mybh : 0;
     unsigned long long live = __ballot(myn > 0);
+    const unsigned long long drawn = live;
+    // the stroke's frame: edge 0 -> 1 runs along the stroke, edge 1 -> 2 across it (line_quad's vertex order)
+    float nx, ny, cn, hn, ux, uy, cu, hu;
+    {
+      const float ex = mine.x[1] - mine.x[0], ey = mine.y[1] - mine.y[0];
+      const float fx = mine.x[2] - mine.x[1], fy = mine.y[2] - mine.y[1];
+      // (v_rsq / v_rcp: an ulp or two, far inside the margin below; the IEEE forms are ten instructions each)
+      const float ie = __builtin_amdgcn_rsqf(ex * ex + ey * ey), jf = __builtin_amdgcn_rsqf(fx * fx + fy * fy);
+      const float le = __builtin_amdgcn_rcpf(ie), lf = __builtin_amdgcn_rcpf(jf);
+      ux = ex * ie; uy = ey * ie;
+      nx = fx * jf; ny = fy * jf;
+      const float mx = 0.25f * ((mine.x[0] + mine.x[1]) + (mine.x[2] + mine.x[3]));
+      const float my = 0.25f * ((mine.y[0] + mine.y[1]) + (mine.y[2] + mine.y[3]));
+      // |u . (c - m)| <= len / 2 + the pixel square's half extent along u (and likewise across); c = pixel centre.  The
+      // margin makes float rounding err on the side of keeping a pixel: a kept pixel outside the stroke gets coverage 0.
+      cu = -(ux * mx + uy * my);
+      cn = -(nx * mx + ny * my);
+      hu = 0.5f * le + 0.5f * (fabsf(ux) + fabsf(uy)) + 1e-3f;
+      hn = 0.5f * lf + 0.5f * (fabsf(nx) + fabsf(ny)) + 1e-3f;
+    }
+    SF_DS_STAMP(0);
     while (live) {
-      const int lo = (__builtin_ctzll(live) / per) * per;
-      const unsigned objmask = (unsigned)(live >> lo) & ((1u << per) - 1u);
-      live &= ~((unsigned long long)objmask << lo);
-      // the object's strokes: geometry through LDS (owners write, everybody reads), boxes as scalars
-      int n[4], bx0[4], by0[4], bw[4], bh[4], off[5];
+      // this chunk: the lowest kChunk strokes still to draw
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u));
+      const bool own = ((live >> lane) & 1ull) && rank < kChunk;
+      const unsigned long long chunk = __ballot(own);
+      live &= ~chunk;
+      int off[kChunk + 1];
       off[0] = 0;
+      {
+        unsigned long long mm = chunk;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const bool on = k < per && ((objmask >> k) & 1u);
-        const int src = lo + (k < per ? k : 0);
-        n[k] = on ? __builtin_amdgcn_readlane(myn, src) : 0;
-        bx0[k] = __builtin_amdgcn_readlane(myb.x0, src);
-        by0[k] = __builtin_amdgcn_readlane(myb.y0, src);
-        bw[k] = on ? __builtin_amdgcn_readlane(mybw, src) : 1;
-        bh[k] = on ? __builtin_amdgcn_readlane(mybh, src) : 0;  // (not n / bw: a scalar division is two dozen instructions)
-        off[k + 1] = off[k] + n[k];
+        for (int r = 0; r < kChunk; r++) {
+          int n = 0;
+          if (mm) {  // uniform
+            n = __builtin_amdgcn_readlane(myn, __builtin_ctzll(mm));
+            mm &= mm - 1;
+          }
+          off[r + 1] = off[r] + n;
+        }
       }
-      const int total = off[4];
-      if (lane >= lo && lane < lo + per) {
+      const int total = off[kChunk];
+      if (own) {
+        int myoff = 0;
+#pragma unroll
+        for (int r = 1; r < kChunk; r++) myoff = rank == r ? off[r] : myoff;
         const Slopes ms = quad_slopes(mine);
+        float* g = srec + rank * kRecFloats;
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-          qscr[(lane - lo) * 12 + v] = mine.x[v];
-          qscr[(lane - lo) * 12 + 4 + v] = mine.y[v];
-          qscr[(lane - lo) * 12 + 8 + v] = ms.s[v];
+          g[v] = mine.x[v];
+          g[4 + v] = mine.y[v];
+          g[8 + v] = ms.s[v];
         }
+        g[12] = nx; g[13] = ny; g[14] = cn; g[15] = hn;
+        g[16] = ux; g[17] = uy; g[18] = cu; g[19] = hu;
+        int* gi = reinterpret_cast<int*>(g + 20);
+        gi[0] = myb.x0 | (myb.y0 << 8); gi[1] = mybw; gi[2] = myoff;
+        g[23] = recip_i(mybw);  // (per stroke, not per box pixel: a quarter-rate instruction)
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      SF_DS_STAMP(1);
+      int cnt = 0;
       for (int base = 0; base < total; base += 64) {
         const int i = base + lane;
-        int k = 0, m = 0;
-        uint8_t* p = fb;
+        bool touched = false;
+        uint32_t ent = 0;
         if (i < total) {
-          k = (i >= off[1]) + (i >= off[2]) + (i >= off[3]);
-          const int j = i - (k == 0 ? off[0] : k == 1 ? off[1] : k == 2 ? off[2] : off[3]);
-          const int w = k == 0 ? bw[0] : k == 1 ? bw[1] : k == 2 ? bw[2] : bw[3];
-          const int x0 = k == 0 ? bx0[0] : k == 1 ? bx0[1] : k == 2 ? bx0[2] : bx0[3];
-          const int y0 = k == 0 ? by0[0] : k == 1 ? by0[1] : k == 2 ? by0[2] : by0[3];
-          const DivMod dm = fast_divmod(j, w, recip_i(w));
+          int k = 0;
+#pragma unroll
+          for (int r = 1; r < kChunk; r++) k += (i >= off[r]) ? 1 : 0;
+          const float* g = srec + k * kRecFloats;
+          const int* gi = reinterpret_cast<const int*>(g + 20);
+          const int x0 = gi[0] & 255, y0 = gi[0] >> 8, w = gi[1], j = i - gi[2];
+          const DivMod dm = fast_divmod(j, w, g[23]);
           const int px = x0 + dm.r, py = y0 + dm.q;
-          Quad q;
-          Slopes sl;
-#pragma unroll
-          for (int v = 0; v < 4; v++) {
-            q.x[v] = qscr[k * 12 + v];
-            q.y[v] = qscr[k * 12 + 4 + v];
-            sl.s[v] = qscr[k * 12 + 8 + v];
-          }
-          if (!(SF_RENDER_SKIP & 32)) m = cover_to_mask(quad_cover(q, sl, (float)px, (float)py));
-          p = fb + py * SF_IMG_W + px;
+          const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+          touched = (fabsf(g[12] * cx + g[13] * cy + g[14]) <= g[15]) & (fabsf(g[16] * cx + g[17] * cy + g[18]) <= g[19]);
+          ent = ((uint32_t)k << 16) | ((uint32_t)py << 8) | (uint32_t)px;
         }
-        // the strokes that have pixels in this round, in order (stroke-major rounds: a later round holds later strokes)
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          if (kk < per && !(SF_RENDER_SKIP & 64) && off[kk] < base + 64 && off[kk + 1] > base) {  // uniform
-            if (k == kk && m > 0) *p = (uint8_t)sfr::over_un8(*p, grey, m);
-            __builtin_amdgcn_wave_barrier();
-          }
+        const unsigned long long tb = __ballot(touched);
+        if (touched)
+          slist[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tb, 0u))] = ent;
+        cnt += (int)__popcll(tb);
+        if (cnt > kListCap - 64) {  // uniform: no room for another round's worth -- draw what is listed
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          flush_list(cnt);
+          cnt = 0;
         }
       }
-      Box u;
-      u.clear();
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (n[k]) u.add(bx0[k], by0[k], bx0[k] + bw[k], by0[k] + bh[k]);
-      resample(u);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      SF_DS_STAMP(2);
+      flush_list(cnt);
+      SF_DS_STAMP(3);
+      // (the next chunk's records overwrite these: every listed pixel has been drawn)
     }
+    // the 84x84 pixels that read what was drawn, object by object (an object = the strokes that share `obj0`)
+    if (RESIZE && !(SF_RENDER_SKIP & 16)) {
+      unsigned long long todo = drawn;
+      while (todo) {
+        const int first = __builtin_ctzll(todo);
+        const int o = __builtin_amdgcn_readlane(obj0, first);
+        const unsigned long long mates = __ballot(obj0 == o) & drawn;
+        todo &= ~mates;
+        Box u;
+        u.clear();
+        unsigned long long mm = mates;
+        while (mm) {  // at most four strokes
+          const int src = __builtin_ctzll(mm);
+          mm &= mm - 1;
+          u.add(__builtin_amdgcn_readlane(myb.x0, src), __builtin_amdgcn_readlane(myb.y0, src),
+                __builtin_amdgcn_readlane(myb.x1, src), __builtin_amdgcn_readlane(myb.y1, src));
+        }
+        resample(u);
+      }
+    }
+    SF_DS_STAMP(4);
+#undef SF_DS_STAMP
   }
 };
 
@@ -409,11 +536,29 @@ __device__ __forceinline__ void sincos_deg(int deg, float* s, float* c) {
   *c = sc.y;
 }
 
-// wireframe segments (ax, ay, bx, by), SRC/wireframe.cpp:11-67
-__constant__ float kShipLines[3][4] = {{-18, 0, 18, 0}, {-18, 18, 0, 0}, {0, 0, -18, -18}};
-__constant__ float kFortLines[4][4] = {{0, 0, 36, 0}, {0, -18, 18, -18}, {18, -18, 18, 18}, {18, 18, 0, 18}};
-__constant__ float kMissileLines[3][4] = {{0, 0, -25, 0}, {0, 0, -5, 5}, {0, 0, -5, -5}};
-__constant__ float kShellLines[4][4] = {{-8, 0, 0, -6}, {0, -6, 16, 0}, {16, 0, 0, 6}, {0, 6, -8, 0}};
+// wireframe segments (ax, ay, bx, by), SRC/wireframe.cpp:11-67.  As functions of the stroke index, not tables in memory:
+// a table indexed by the lane is a vector load from .rodata, a dependent round trip in front of every object (small whole
+// numbers: the selects give the same floats).
+struct Line {
+  float ax, ay, bx, by;
+};
+__device__ __forceinline__ Line ship_line(int k) {     // {-18, 0, 18, 0}, {-18, 18, 0, 0}, {0, 0, -18, -18}
+  return Line{k == 2 ? 0.f : -18.f, k == 1 ? 18.f : 0.f, k == 0 ? 18.f : (k == 1 ? 0.f : -18.f), k == 2 ? -18.f : 0.f};
+}
+__device__ __forceinline__ Line fort_line(int k) {     // {0, 0, 36, 0}, {0, -18, 18, -18}, {18, -18, 18, 18}, {18, 18, 0, 18}
+  return Line{k >= 2 ? 18.f : 0.f, k == 0 ? 0.f : (k == 3 ? 18.f : -18.f), k == 0 ? 36.f : (k == 3 ? 0.f : 18.f),
+              k == 0 ? 0.f : (k == 1 ? -18.f : 18.f)};
+}
+__device__ __forceinline__ Line missile_line(int k) {  // {0, 0, -25, 0}, {0, 0, -5, 5}, {0, 0, -5, -5}
+  return Line{0.f, 0.f, k == 0 ? -25.f : -5.f, k == 0 ? 0.f : (k == 1 ? 5.f : -5.f)};
+}
+__device__ __forceinline__ Line shell_line(int k) {    // {-8, 0, 0, -6}, {0, -6, 16, 0}, {16, 0, 0, 6}, {0, 6, -8, 0}
+  return Line{k == 0 ? -8.f : (k == 2 ? 16.f : 0.f), k == 1 ? -6.f : (k == 3 ? 6.f : 0.f), k == 1 ? 16.f : (k == 3 ? -8.f : 0.f),
+              k == 0 ? -6.f : (k == 2 ? 6.f : 0.f)};
+}
+__device__ __forceinline__ Quad line_quad(const Line& ln, float ca, float sa, float posx, float posy) {
+  return line_quad(Seg{ln.ax, ln.ay, ln.bx, ln.by, ca, sa, posx, posy});
+}
 
 // drawExplosion (SRC/draw.cpp:145-175): 7 rings (radius 15 + 8i) of twelve 10-degree arcs starting at
 // 30k + 3(i+1) degrees, each its own stroke, then one radius-7 circle.  An arc is one chord quad
@@ -434,7 +579,7 @@ __device__ __forceinline__ Quad arc_quad(const ArcCS& t, float radius, float cx,
 __device__ __forceinline__ float gon_cover(float gx, float gy, float r, float px, float py) {
   float s = 0.f;
   float x0 = gx + r * kGon[0][0] - px, y0 = gy + r * kGon[0][1] - py;
-#pragma unroll
+#pragma unroll 1
   for (int k = 1; k <= 12; k++) {
     const float x1 = gx + r * kGon[k % 12][0] - px, y1 = gy + r * kGon[k % 12][1] - py;
     s += edge_term(x0, y0, x1, edge_slope(x0, y0, x1, y1));
@@ -470,7 +615,9 @@ __device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, float cx,
       const float fpx = (float)px, fpy = (float)py;
       int d = fb[py * SF_IMG_W + px];
       const int d0 = d;
-#pragma unroll
+      // (rolled on purpose, like the two loops below: unrolled, the twelve arcs' integrals are interleaved and want 130+
+      //  vector registers -- of a kernel whose every other path lives in 96; a fresh explosion is one frame in seventy)
+#pragma unroll 1
       for (int k = 0; k < 12; k++) {
         const Quad q = arc_quad(kArcs[0][k], 15.f, cx, cy);
         if (quad_misses_pixel(q, fpx, fpy)) continue;
@@ -488,6 +635,7 @@ __device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, float cx,
     __builtin_amdgcn_wave_barrier();
   }
   const int arc = lane / 5, sub = lane - arc * 5;
+#pragma unroll 1
   for (int ring = 1; ring < 7; ring++) {
     const int radius = 15 + 8 * ring;
     const int grey = radius < 60 ? 191 : 128;  // .75 / .5
@@ -551,14 +699,14 @@ struct XcState {
 
 template <bool RESIZE>
 __device__ __forceinline__ XcState ship_explosion(const Frame<RESIZE>& F, unsigned char* xc, double x, double y,
-                                                  const bool fill = true) {
+                                                  const bool fill = true, const bool skip_lookup = false) {
   const float cx = (float)x, cy = (float)y;
   const Box b = explosion_box(cx, cy), o = out_box(b);
   const int lane = F.lane;
   const unsigned need = RESIZE ? 3u : 1u;
   bool hit = false;
   XcState st{0u, 0, 0};
-  if (xc) {
+  if (xc && !skip_lookup) {  // (skip_lookup: the caller has looked already -- xc_fetch / xc_apply -- and it was a miss)
     const double kx = *reinterpret_cast<const double*>(xc + kXcKey), ky = *reinterpret_cast<const double*>(xc + kXcKey + 8);
     const unsigned fl = *reinterpret_cast<const unsigned*>(xc + kXcFlags);
     const int2 keys = *reinterpret_cast<const int2*>(xc + kXcHudKeys);
@@ -610,6 +758,59 @@ __device__ __forceinline__ XcState ship_explosion(const Frame<RESIZE>& F, unsign
     st.flags = need;  // (a new explosion: whatever score / bar picture the entry held belongs to the old one)
   }
   return st;
+}
+
+// ship_explosion's lookup in two halves, for the frame kernel: the entry's key AND its pixels are asked for in the
+// prologue's one round trip (xc_fetch: 16 + 12 + 28 bytes per lane, whether or not the key will match), and used right
+// behind the surface's arrival (xc_apply) -- instead of a round trip for the key and, on a hit, another for the pixels.
+struct XcFetch {
+  double kx, ky;
+  unsigned fl;
+  int2 keys;
+  uint32_t wf[3], wo[4];
+};
+constexpr int kXcRowW = kXcRow / 4;  // 7 dwords a row
+template <bool RESIZE>
+__device__ __forceinline__ XcFetch xc_fetch(const unsigned char* xc, int lane) {
+  XcFetch f;
+  f.kx = *reinterpret_cast<const double*>(xc + kXcKey);
+  f.ky = *reinterpret_cast<const double*>(xc + kXcKey + 8);
+  f.fl = *reinterpret_cast<const unsigned*>(xc + kXcFlags);
+  f.keys = *reinterpret_cast<const int2*>(xc + kXcHudKeys);
+  const uint32_t* gf = reinterpret_cast<const uint32_t*>(xc + kXcFb);
+  const uint32_t* go = reinterpret_cast<const uint32_t*>(xc + kXcOut);
+#pragma unroll
+  for (int j = 0; j < 3; j++) f.wf[j] = (lane + 64 * j < kXcFbRows * kXcRowW) ? gf[lane + 64 * j] : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; j++) f.wo[j] = (RESIZE && lane + 64 * j < kXcOutRows * kXcRowW) ? go[lane + 64 * j] : 0u;
+  return f;
+}
+// true: the entry was this explosion's and its pixels are in the frame (*st = the entry's flags and keys); false: draw it
+template <bool RESIZE>
+__device__ __forceinline__ bool xc_apply(const Frame<RESIZE>& F, const XcFetch& f, double x, double y, XcState* st) {
+  const float cx = (float)x, cy = (float)y;
+  const Box b = explosion_box(cx, cy), o = out_box(b);
+  const int lane = F.lane;
+  const unsigned need = RESIZE ? 3u : 1u;
+  const bool hit = (f.kx == x && f.ky == y && (f.fl & need) == need) || (SF_RENDER_SKIP & 1024);
+  const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows;
+  if (!(hit && fits)) return false;
+  const int bw = b.x1 - b.x0, bh = b.y1 - b.y0, ow = o.x1 - o.x0, oh = o.y1 - o.y0;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int d = lane + 64 * j, r = d / kXcRowW, c4 = (d - r * kXcRowW) * 4;
+    if (r < bh) put_bytes(F.fb + (b.y0 + r) * SF_IMG_W + b.x0 + c4, f.wf[j], bw - c4);
+  }
+  if (RESIZE) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int d = lane + 64 * j, r = d / kXcRowW, c4 = (d - r * kXcRowW) * 4;
+      if (r < oh) put_bytes(F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4, f.wo[j], ow - c4);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  *st = XcState{f.fl, f.keys.x, f.keys.y};
+  return true;
 }
 
 }  // namespace
@@ -771,6 +972,36 @@ __device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned
 }
 
 
+// fort_patch_copy's restore in two halves (the frame kernel asks for the picture in its prologue's round trip)
+struct FortPic {
+  uint32_t w, v0, v1;
+};
+template <bool RESIZE>
+__device__ __forceinline__ FortPic fort_patch_fetch(const unsigned char* gp, int lane) {
+  constexpr int oh = (kFpY1 * 21 + 22) / 23 - (kFpY0 * 21) / 23;  // rows of out_box of the picture's box
+  const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gp);
+  FortPic f;
+  f.w = g32[lane];
+  f.v0 = RESIZE ? g32[kFpOutAt / 4 + lane] : 0u;
+  f.v1 = (RESIZE && 64 + lane < (kFpOutRow / 4) * oh) ? g32[kFpOutAt / 4 + 64 + lane] : 0u;
+  return f;
+}
+template <bool RESIZE>
+__device__ __forceinline__ void fort_patch_put(const Frame<RESIZE>& F, const FortPic& f) {
+  const Box b{kFpX0, kFpY0, kFpX1, kFpY1}, o = out_box(b);
+  const int lane = F.lane, ow = o.x1 - o.x0, oh = o.y1 - o.y0;
+  put_bytes(F.fb + (kFpY0 + (lane >> 2)) * SF_IMG_W + kFpX0 + (lane & 3) * 4, f.w, 4);
+  if (RESIZE) {
+    const uint32_t v[2] = {f.v0, f.v1};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int d = lane + 64 * j, r = d / (kFpOutRow / 4), c4 = (d - r * (kFpOutRow / 4)) * 4;
+      if (r < oh) put_bytes(F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4, v[j], ow - c4);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---- score (drawScore, SRC/draw.cpp:190-203): "%07d", grey .5, seven-segment digits; a lane per pixel of the box
 template <bool RESIZE>
 __device__ __forceinline__ void draw_score(const Frame<RESIZE>& F, int pnts) {
@@ -813,9 +1044,20 @@ __device__ __forceinline__ void draw_bar(const Frame<RESIZE>& F, int state) {
 // a function of the points / of the bar's state alone: pictures drawn once per batch by the code above
 // (sf_hud_kernel), like the fortress's.  One picture = the box of the surface, then the box of the 84x84 image that
 // reads it, rows `row` bytes apart; at most 64 words each: a lane per word, all loads before the first store.
+struct HudWords {  // a picture's two words of this lane, asked for in the prologue (hud_fetch)
+  uint32_t wf, wo;
+};
+template <bool RESIZE>
+__device__ __forceinline__ HudWords hud_fetch(const unsigned char* pic, int row, const Box b, int lane) {
+  const Box o = out_box(b);
+  const int wpr = row / 4, bh = b.y1 - b.y0, oh = o.y1 - o.y0, r = lane / wpr;
+  const uint32_t* gf = reinterpret_cast<const uint32_t*>(pic) + lane;
+  const uint32_t* go = reinterpret_cast<const uint32_t*>(pic + ((bh * row + 15) & ~15)) + lane;
+  return HudWords{r < bh ? *gf : 0u, (RESIZE && r < oh) ? *go : 0u};
+}
 template <bool RESIZE>
 __device__ __forceinline__ void hud_picture(const Frame<RESIZE>& F, unsigned char* pic, int row, const Box b, bool store,
-                                            const bool with_out = true) {
+                                            const bool with_out = true, const bool have_pre = false, const HudWords pre = HudWords{0u, 0u}) {
   const Box o = out_box(b);
   const int lane = F.lane, wpr = row / 4;
   const int bw = b.x1 - b.x0, bh = b.y1 - b.y0, ow = o.x1 - o.x0, oh = o.y1 - o.y0;
@@ -835,7 +1077,11 @@ __device__ __forceinline__ void hud_picture(const Frame<RESIZE>& F, unsigned cha
     if (RESIZE && r < oh) *go = wo;
     return;
   }
-  const uint32_t wf = r < bh ? *gf : 0u, wo = (RESIZE && with_out && r < oh) ? *go : 0u;
+  uint32_t wf = pre.wf, wo = pre.wo;
+  if (!have_pre) {  // uniform
+    wf = r < bh ? *gf : 0u;
+    wo = (RESIZE && with_out && r < oh) ? *go : 0u;
+  }
   if (r < bh && c4 < bw) put_bytes(pf, wf, bw - c4);
   if (RESIZE && with_out && r < oh && c4 < ow) put_bytes(po, wo, ow - c4);
   __builtin_amdgcn_wave_barrier();
@@ -865,7 +1111,7 @@ static_assert(((SF_BAR_BOX_Y1 - SF_BAR_BOX_Y0) * SF_HUD_BAR_ROW + 15) / 16 * 16 
 
 template <bool RESIZE>
 #ifndef SF_RENDER_WPE
-#define SF_RENDER_WPE 5 /* waves per SIMD the register budget is held to (96 VGPRs; LDS allows 18 workgroups per CU = 4.5) */
+#define SF_RENDER_WPE 4 /* waves per SIMD the register budget is held to (128 VGPRs); LDS -- 9.9 KB per frame -- allows 16 workgroups per CU = 4 per SIMD */
 #endif
 __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
@@ -874,14 +1120,35 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
 #else
   const uint32_t* const tabw = a.tabs;  // 2.7 KB read by every wave: L1/L2 resident; LDS is better spent on waves
 #endif
-  __shared__ __attribute__((aligned(16))) float qscr[48];
-  __shared__ __attribute__((aligned(16))) uint8_t mscr[kMaskScratch];
+  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats];
+  __shared__ __attribute__((aligned(16))) uint32_t slist[Frame<RESIZE>::kListCap];
+  __shared__ __attribute__((aligned(16))) uint32_t ptab[RESIZE ? 4 * (kTapColPeriod + kTapRowPeriod) : 4];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int lane = threadIdx.x;
+#ifdef SF_DBG_FLAGS
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_pa = 0, dbg_pb = 0, dbg_pc = 0, dbg_pd = 0;
+  unsigned long long dbg_ds[5] = {0, 0, 0, 0, 0};
+#define SF_DBG_STAMP(v) do { asm volatile("" ::: "memory"); v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define SF_DBG_STAMP(v)
+#endif
+  // one period of the tap tables into LDS (resample_into): 35 entries of 16 bytes, asked for before anything else
+  uint4 ptab_e = {0u, 0u, 0u, 0u};
+  if (RESIZE && lane < kTapColPeriod + kTapRowPeriod)
+    ptab_e = reinterpret_cast<const uint4*>(a.tabs)[lane < kTapColPeriod ? lane : SF_OUT + (lane - kTapColPeriod)];
+  // ---- which env (pick_env).  Nearly every workgroup behind the front draws env = its index - n_front, and learns that
+  // from one word of the hint: the state loads go out for that env at once, next to the word's load, instead of behind it.
   int env = blockIdx.x;
+  bool recheck = false;
   if (a.hint) {
-    env = pick_env(a, (int)blockIdx.x, lane);
-    if (env < 0) return;  // uniform, before any barrier
+    if ((int)blockIdx.x >= a.n_front) {
+      env = (int)blockIdx.x - a.n_front;
+      recheck = true;
+    } else {
+      env = pick_env(a, (int)blockIdx.x, lane);
+      if (env < 0) return;  // uniform, before any barrier
+    }
   }
   uint8_t* const frame_out = a.out + (size_t)env * a.out_stride;
 
@@ -901,9 +1168,19 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const i4_t tb = R_LD(i4_t, R_CHUNK(timers_b, 0), o16);
   const i4_t sc = R_LD(i4_t, R_CHUNK(score, 0), o16);
   const i4_t mi = R_LD(i4_t, R_CHUNK(misc, 0), o16);
-  const int ship_angle = R_LD(int16_t, R_CHUNK(small, 0), o16);  // `small` is a 16-byte chunk (sf_layout.h)
-  const int fort_angle = R_LD(int16_t, R_CHUNK(small, 0), o16 + 2);
-  const unsigned flags = R_LD(uint8_t, R_CHUNK(small, 0), o16 + 6);
+  const i4_t sm = R_LD(i4_t, R_CHUNK(small, 0), o16);  // ship_angle, fort_angle (int16), .., flags (uint8 at byte 6): sf_layout.h
+  // (a frame stack's done flag of this env: asked for here, read where the older slots are handled)
+  unsigned fin_b = 0;
+  if (RESIZE && a.stack_done) fin_b = a.stack_done[env];
+  if (recheck) {
+    const unsigned long long w = a.hint[env >> 6];  // uniform: a scalar load, in flight beside the vector loads above
+    if ((w >> (env & 63)) & 1ull)                    // a hinted env: one of the front workgroups may be drawing it
+      if (pick_env(a, (int)blockIdx.x, lane) < 0) return;
+  }
+  if (RESIZE && lane < kTapColPeriod + kTapRowPeriod) reinterpret_cast<uint4*>(ptab)[lane] = ptab_e;
+  const int ship_angle = (int)(int16_t)(sm.x & 0xFFFF);
+  const int fort_angle = (int)(int16_t)((unsigned)sm.x >> 16);
+  const unsigned flags = ((unsigned)sm.y >> 16) & 0xFFu;
   const unsigned mmask = (SF_RENDER_SKIP & 2) ? 0u : ((unsigned)mi.z & SF_MASK_LOW),
                  smask = (SF_RENDER_SKIP & 2) ? 0u : ((unsigned)mi.w & SF_MASK_LOW);
   const int pnts = (int)__int_as_float(sc.x);  // drawScore takes mScore.mPoints as an int (SRC/draw.cpp:190,266)
@@ -912,12 +1189,79 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const float ship_x = (float)sp.x, ship_y = (float)sp.y;
   const bool ship_alive = flags & SF_FL_SHIP_ALIVE;
 
+  SF_DBG_STAMP(dbg_pa);
+  // ---- ROUND TRIP 2: everything else this frame reads from memory, asked for at once now that the state says what that
+  // is -- a wave's loads come back in the order they were issued, so what is needed first goes first: (1) the tile's
+  // missile pool, meta AND position of up to three rows whether or not an entry turns out to be this env's (an env's
+  // missiles used to cost two dependent trips: the meta words, then the positions of the matches); the shells' positions;
+  // the sines of the two headings; (2) what is restored right after the surface is in: the dead ship's cached explosion
+  // -- key and pixels together, the pixels used if the key matches -- and the fortress's picture; (3) the 84x84
+  // background's seven pieces; (4) LAST, the surface's direct-to-LDS loads.  Until round 2 each of these was a round trip
+  // of its own, one behind the other: 30 % of a wave's life was this skeleton (profiles/r02_pmc_render_variants_v22.txt,
+  // `only_copy`).
+  constexpr int kPoolRows = 3;
+  // (unconditional instructions: under `if (mmask)` the compiler merges the loaded registers with their defaults right
+  //  behind the loads, i.e. waits for them there; a frame without missiles -- one in five -- reads six rows for nothing)
+  unsigned pmeta[kPoolRows];
+  d2_t ppos[kPoolRows];
+  const unsigned n_pool = (unsigned)mi.z >> SF_MPOOL_SHIFT;
+#pragma unroll
+  for (int r = 0; r < kPoolRows; r++) {
+    const unsigned e = 64u * r + (unsigned)lane;  // (always inside the tile's pool rows: SF_NSLOT rows of 64 entries)
+    pmeta[r] = R_LD(uint32_t, R_CHUNK(missile_meta, 0), e * 4u);
+    ppos[r] = R_LD(d2_t, R_CHUNK(missile_pos, 0), e * 16u);
+  }
+  // shells: lane 4 s + k will draw stroke k of slot s (slots 0 .. 15; the last four slots -- seventeen live shells -- have a
+  // late round of their own): position and velocity of its slot
+  d2_t shell_p = R_LD(d2_t, R_CHUNK(shell_pos, lane >> 2), o16);
+  d2_t shell_v = R_LD(d2_t, R_CHUNK(shell_vel, lane >> 2), o16);
+  float ship_s, ship_c, fort_s, fort_c;
+  sincos_deg(ship_angle, &ship_s, &ship_c);
+  sincos_deg(fort_angle, &fort_s, &fort_c);
+
+  // what was drawn before the fortress: the ship (within 25.5 + 1.5 user units of its position) or its explosion
+  Box sb = explosion_box(ship_x, ship_y);
+  if (ship_alive) {
+    const float gx = dev_x(ship_x), gy = dev_y(ship_y), ext = 27.f * (float)SF_SCALE;
+    sb = Box{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
+  }
+  const bool fort_alive = flags & SF_FL_FORT_ALIVE;
+  const int sector = fort_angle / 10;
+  // the fortress's picture is good when nothing the ship drew comes within reach of its box (+ what its 84x84 pixels read);
+  // the two then touch no pixel in common, in either size, so the picture may go in BEFORE the ship is drawn
+  const bool fort_pic = !(SF_RENDER_SKIP & (1 | 512)) && fort_alive && a.fpatch && fort_angle >= 0 && fort_angle < 360 &&
+                        sector * 10 == fort_angle && !sb.meets(Box{kFpX0 - kReachX, kFpY0 - kReachY, kFpX1 + kReachX, kFpY1 + kReachY});
+  unsigned char* const xc_mine = a.xcache ? a.xcache + (size_t)env * SF_XC_BYTES : nullptr;
+  const bool dead_ship = !ship_alive && !(SF_RENDER_SKIP & (1 | 256));
+  // the score's and the bar's pictures, when they will not be the baked-in 0000000 / empty ones: used last, asked for now
+  const Box tbox{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1};
+  const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
+  const int bstate = bar_state(vlner, fort_vuln_timer);
+#ifndef SF_HUD_PREFETCH
+#define SF_HUD_PREFETCH 1
+#endif
+  const bool score_pre = SF_HUD_PREFETCH && a.hud && pnts != 0 && pnts >= -SF_HUD_SCORE_HALF && pnts < SF_HUD_SCORE_HALF && !(SF_RENDER_SKIP & 4);
+  const bool bar_pre = SF_HUD_PREFETCH && a.hud && vlner != 0 && !(SF_RENDER_SKIP & 8);
+  bool near_text = false, near_bar = false;
+  if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
+    // wider by the reach (kReachX, kReachY) than what the explosion paints: the 84x84 pixels recomputed (or restored from the
+    // cache) for it read that far, and must not depend on whether the score / bar were baked in
+    Box eb = explosion_box(ship_x, ship_y);
+    eb.x0 -= kReachX; eb.y0 -= kReachY; eb.x1 += kReachX; eb.y1 += kReachY;
+    near_text = eb.meets(tbox);
+    near_bar = eb.meets(bbox);
+  }
+  const int variant0 = ((pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4)) ? 1 : 0) |
+                       ((vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8)) ? 2 : 0);
+  // ... and the 84x84 background's seven pieces, for the variant the score, the bar and the dead ship's explosion call for
+  // (nearly always the final one: a projectile over the score or the bar starts again below)
+  Pieces frame0 = {};
+  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant0 * (kOutBytes / 4)), kOutBytes / 16, lane);
+
   // ---- The frame starts as a copy of the static background: the 92x90 surface into LDS, its 84x84 image into the
   // caller's frame.  Which variant (score / bar baked in) depends on what the projectiles touch, known only after their
   // strokes are built -- but nearly always it is what the score, the bar and the dead ship's explosion say, and the
-  // copies are made for that guess.  A wave's memory round trips come back in the order they were asked for, so the
-  // order below is: the frame's seven loads; the pool and the tables behind them (one round trip for all of it); the
-  // frame's stores and the surface's direct-to-LDS loads; the stroke arithmetic with those in flight; one wait.
+  // copies are made for that guess.
   auto start_surface = [&](int variant) {
     // Ten loads that write LDS directly (global_load_lds: lane i's 16 bytes land at M0 + offset + 16 i; the offset
     // moves both addresses), all in flight at once and without registers: 8 x 1 KiB, the 5 whole pieces behind them,
@@ -926,7 +1270,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     // load in flight, drains everything (vmcnt(0)) before each later store or use of a loaded value -- and left as a
     // loop through registers it waits for each 16 bytes before it asks for the next, nine round trips one after the
     // other.  Unknown to the compiler they only make its own counted waits stricter; the wait that matters, before the
-    // surface is first read, is the explicit vmcnt(0) in front of the barrier below.
+    // surface is first read, is the explicit one in front of the barrier below.
     static_assert(kFbVec == 8 * 64 + 5 && kFbPadWords - 4 * kFbVec == 26 && SF_BG_STRIDE / 4 > 4 * kFbVec,
                   "the copy below is written out for the 92x90 surface");
     const char* bgv = reinterpret_cast<const char*>(a.bg) + variant * SF_BG_STRIDE;
@@ -963,80 +1307,127 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
         : [lds] "s"(lds), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3)
         : "memory", "scc");
   };
-  const Box tbox{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1};
-  const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
-  bool near_text = false, near_bar = false;
-  if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
-    // wider by the reach (kReachX, kReachY) than what the explosion paints: the 84x84 pixels recomputed (or restored from the
-    // cache) for it read that far, and must not depend on whether the score / bar were baked in
-    Box eb = explosion_box(ship_x, ship_y);
-    eb.x0 -= kReachX; eb.y0 -= kReachY; eb.x1 += kReachX; eb.y1 += kReachY;
-    near_text = eb.meets(tbox);
-    near_bar = eb.meets(bbox);
-  }
-  const int variant0 = ((pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4)) ? 1 : 0) |
-                       ((vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8)) ? 2 : 0);
-  start_surface(variant0);
-  Pieces frame0 = {};
-  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant0 * (kOutBytes / 4)), kOutBytes / 16, lane);
-  // ---- projectile strokes: one lane per wireframe segment (missiles: slot*3 + k; shells: two rounds of slot*4 + k);
-  // first everything that reads memory (the pool, the tables of sines and of segments, the shells' state)
+
+  // ---- projectile strokes: one lane per wireframe segment (missiles: slot*3 + k; shells: two rounds of slot*4 + k)
+  constexpr int kFirstMissileLane = 7;
+  static_assert(kFirstMissileLane + 3 * 19 == 64, "slots 0 .. 18 fill the wave behind the ship's and the fortress's strokes");
   Seg mg = {};
+  float m19x = 0.f, m19y = 0.f, m19a = 0.f;
   bool mvalid = false;
   if (mmask) {
     // The tile keeps its live missiles as one dense pool (sf_layout.h); this env's are the entries whose owner is its
-    // lane.  The wave scans the pool's meta words, 64 entries at a time, and files what it finds by slot -- the
-    // reference draws in slot order (SRC/draw.cpp:243-247) -- in the scratch area.
-    const unsigned n_pool = (unsigned)mi.z >> SF_MPOOL_SHIFT;
-    float* const mtab = reinterpret_cast<float*>(mscr);  // [slot] (x, y, heading)
-    static_assert(SF_NSLOT * 3 * sizeof(float) <= kMaskScratch, "slot table fits the scratch");
-    for (unsigned e = lane; e < n_pool; e += 64) {
-      const unsigned meta = R_LD(uint32_t, R_CHUNK(missile_meta, 0), e * 4u);
-      if (SF_MM_OWNER(meta) == (unsigned)l) {
-        const d2_t m = R_LD(d2_t, R_CHUNK(missile_pos, 0), e * 16u);
+    // lane.  The wave looks at the pool's entries, 64 at a time, and files its own by slot -- the reference draws in
+    // slot order (SRC/draw.cpp:243-247) -- in the scratch area.
+    float* const mtab = reinterpret_cast<float*>(slist);  // [slot] (x, y, heading): the stroke list's LDS, not yet in use
+    static_assert(SF_NSLOT * 3 * sizeof(float) <= sizeof(slist), "slot table fits the scratch");
+    auto file_entry = [&](unsigned e, unsigned meta, const d2_t& m) {
+      if (e < n_pool && SF_MM_OWNER(meta) == (unsigned)l) {
         float* t = mtab + 3 * SF_MM_SLOT(meta);
         t[0] = (float)m.x;
         t[1] = (float)m.y;
         t[2] = (float)SF_MM_ANGLE(meta);
       }
-    }
+    };
+    // (opaque to the optimiser up to here: it would otherwise convert the positions where they are loaded -- and wait for
+    //  them there, in front of the loads that follow)
+    asm volatile("" : "+v"(pmeta[0]), "+v"(pmeta[1]), "+v"(pmeta[2]));
+#pragma unroll
+    for (int r = 0; r < kPoolRows; r++) asm volatile("" : "+v"(ppos[r].x), "+v"(ppos[r].y));
+#pragma unroll
+    for (int r = 0; r < kPoolRows; r++) file_entry(64u * r + (unsigned)lane, pmeta[r], ppos[r]);
+    for (unsigned e = 64u * kPoolRows + lane; e < n_pool; e += 64)  // (more than 192 live missiles in the tile: rare)
+      file_entry(e, R_LD(uint32_t, R_CHUNK(missile_meta, 0), e * 4u), R_LD(d2_t, R_CHUNK(missile_pos, 0), e * 16u));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int slot = lane / 3, k = lane - slot * 3;
-    mvalid = lane < 3 * SF_NSLOT && ((mmask >> slot) & 1u);
+    // lanes 7 .. 63 take the strokes of slots 0 .. 18 (lanes 0 .. 6 are the ship's and the fortress's: draw order);
+    // slot 19 -- twenty live missiles -- has a round of its own at the end of the list
+    const int pl = lane - kFirstMissileLane, slot = pl / 3, k = pl - slot * 3;
+    mvalid = pl >= 0 && ((mmask >> slot) & 1u);
     if (mvalid) {
       const float* t = mtab + 3 * slot;
       float s, c;
       sincos_deg((int)t[2], &s, &c);
-      mg = Seg{kMissileLines[k][0], kMissileLines[k][1], kMissileLines[k][2], kMissileLines[k][3], c, s, t[0], t[1]};
+      const Line ml = missile_line(k);
+      mg = Seg{ml.ax, ml.ay, ml.bx, ml.by, c, s, t[0], t[1]};
+    }
+    if (mmask >> 19) {  // uniform, all but never: its strokes are built where they are drawn
+      m19x = mtab[3 * 19];
+      m19y = mtab[3 * 19 + 1];
+      m19a = mtab[3 * 19 + 2];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  // shells (14 % of the frames have one): here only where they are -- a shell's wireframe stays within 16 + 1.5 user
-  // units of its position -- for the tests on the score's and the bar's boxes below; their strokes are built where they
-  // are drawn, at the end (two quads per lane kept alive from here to there cost the pixel loops their registers)
+  // shells (14 % of the frames have one): their strokes, built here with the surface's loads in flight (round 2 built them
+  // where they are drawn, behind two loads and a double-precision atan2 at the end of the frame: the slowest frames of a
+  // launch)
   bool sh_t = false, sh_b = false, sh_t3 = false, sh_b3 = false;
+  Quad sq0 = {};
+  bool sq0_valid = false;
+  auto shell_quad = [&](d2_t s, d2_t v, int k, bool have, Quad* q) -> bool {
+    const double dx = s.x - sfc::fort_x, dy = s.y - sfc::fort_y;
+    const bool valid = have && sqrt(dx * dx + dy * dy) > 21.0;  // drawn only once clear of the fortress (SRC/draw.cpp:249-250)
+    if (valid) {
+      // mAngle = stdAngle(rad2deg(atan2(dy, dx))) at launch (SRC/game.cpp:263); the velocity kept in
+      // the state has that direction.  drawWireFrame takes it as an int (truncation).
+      double ang = atan2(v.y, v.x) * 180.0 / M_PI;
+      if (ang < 0) ang += 360.0;
+      float sn, cs;
+      sincos_deg((int)ang, &sn, &cs);
+      *q = line_quad(shell_line(k), cs, sn, (float)s.x, (float)s.y);
+    }
+    return valid;
+  };
   if (smask) {
     const Box tb0{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1}, bb0{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
     const Box tb3{SF_TXT_BOX_X0 - kReachX, SF_TXT_BOX_Y0 - kReachY, SF_TXT_BOX_X1 + kReachX, SF_TXT_BOX_Y1 + kReachY};
     const Box bb3{SF_BAR_BOX_X0 - kReachX, SF_BAR_BOX_Y0 - kReachY, SF_BAR_BOX_X1 + kReachX, SF_BAR_BOX_Y1 + kReachY};
-    if (lane < SF_NSLOT && ((smask >> lane) & 1u)) {
-      const d2_t sp1 = R_LD(d2_t, R_CHUNK(shell_pos, lane), o16);
-      const float gx = dev_x((float)sp1.x), gy = dev_y((float)sp1.y), ext = 17.5f * (float)SF_SCALE + 0.01f;
-      const Box shb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
+    asm volatile("" : "+v"(shell_p.x), "+v"(shell_p.y), "+v"(shell_v.x), "+v"(shell_v.y));
+    sq0_valid = shell_quad(shell_p, shell_v, lane & 3, (smask >> (lane >> 2)) & 1u, &sq0);
+    if (sq0_valid) {
+      const Box shb = quad_box(sq0);
       sh_t = shb.meets(tb0);
       sh_b = shb.meets(bb0);
       sh_t3 = shb.meets(tb3);
       sh_b3 = shb.meets(bb3);
     }
+    if ((smask >> 16) && lane < 4 && ((smask >> (16 + lane)) & 1u)) {  // (slots 16 .. 19: within 16 + 1.5 user units of the position)
+      const d2_t sp1 = R_LD(d2_t, R_CHUNK(shell_pos, 16 + lane), o16);
+      const float gx = dev_x((float)sp1.x), gy = dev_y((float)sp1.y), ext = 17.5f * (float)SF_SCALE + 0.01f;
+      const Box shb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
+      sh_t = sh_t || shb.meets(tb0);
+      sh_b = sh_b || shb.meets(bb0);
+      sh_t3 = sh_t3 || shb.meets(tb3);
+      sh_b3 = sh_b3 || shb.meets(bb3);
+    }
   }
+  // ---- ROUND TRIP 3: the surface's direct-to-LDS loads, BEHIND the last dependent load of the prologue (the missiles' and
+  // shells' sines): a wave's loads come back in issue order and the compiler does not know of these ten, so every wait it
+  // counts out for something older is in effect a wait for them -- the sines arrive with the surface, not behind it.  And
+  // the 84x84 background's seven stores behind THEM: stores count like loads, in the same order; issued in front, the
+  // wait for the sines would be a wait for their acknowledgement from HBM.  (Measured with clock stamps per wave,
+  // tools/dbg_render_flags.py: with the background's loads issued after the projectile tests the prologue was three memory
+  // round trips longer -- the surface, the background's loads, the first store's acknowledgement -- 26 000 of a wave's
+  // 40 000 clocks.)
+  SF_DBG_STAMP(dbg_pb);
+  // (in front of them, for what is restored right behind the barrier or at the very end: the dead ship's cached
+  //  explosion -- key and pixels together, the pixels used if the key matches --, the fortress's picture, the score's and
+  //  the bar's: not needed before the surface is, so not held in registers through the arithmetic above)
+  XcFetch xf = {};
+  if (dead_ship && xc_mine) xf = xc_fetch<RESIZE>(xc_mine, lane);
+  FortPic fpic = {};
+  if (fort_pic) fpic = fort_patch_fetch<RESIZE>(a.fpatch + sector * SF_FP_BYTES, lane);
+  HudWords hscore = {}, hbar = {};
+  if (score_pre) hscore = hud_fetch<RESIZE>(hud_score_picture(a.hud, pnts), SF_HUD_SCORE_ROW, tbox, lane);
+  if (bar_pre) hbar = hud_fetch<RESIZE>(hud_bar_picture(a.hud, bstate), SF_HUD_BAR_ROW, bbox, lane);
+  start_surface(variant0);
   if (RESIZE) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
   // the frame stack's older slots (independent of the variant)
+  const bool stack_traffic = RESIZE && (a.stack_prev || fin_b != 0);  // more loads / stores behind the seven: see the wait below
   if (RESIZE && a.stack_prev) {
-    const bool fin = a.stack_done && a.stack_done[env];
+    const bool fin = fin_b != 0;
     const uint4 z = {0u, 0u, 0u, 0u};
     const uint4* src = reinterpret_cast<const uint4*>(a.stack_prev + (size_t)env * a.out_stride + kOutBytes);
     uint4* dst = reinterpret_cast<uint4*>(frame_out - (ptrdiff_t)a.stack_slot * kOutBytes);
@@ -1047,7 +1438,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       // a frame's worth of loads in flight, then its stores (a plain loop waits for each 16 bytes before the next load)
       for (int base = 0; base < n; base += 64 * kFrameRounds) copy_pieces(src + base, dst + base, n - base, lane);
     }
-  } else if (RESIZE && a.stack_done && a.stack_done[env]) {
+  } else if (RESIZE && fin_b != 0) {
     const uint4 z = {0u, 0u, 0u, 0u};
     for (int sl = 0; sl < a.stack_n; sl++) {
       if (sl == a.stack_slot) continue;
@@ -1056,8 +1447,19 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     }
   }
 
+  // the frame's strokes in draw order, one per lane: the live ship's three, the fortress's four when it has to be drawn
+  // in place, the missiles' (SRC/draw.cpp:233-247); one line_quad for all of them
+  const bool ship_strokes = ship_alive && !(SF_RENDER_SKIP & (1 | 128));
+  const bool fort_strokes = !(SF_RENDER_SKIP & (1 | 512)) && fort_alive && !fort_pic;
+  {
+    const Line sl = ship_line(lane), fl = fort_line(lane - 3);
+    if (lane < 3) mg = Seg{sl.ax, sl.ay, sl.bx, sl.by, ship_c, ship_s, ship_x, ship_y};
+    else if (lane < kFirstMissileLane) mg = Seg{fl.ax, fl.ay, fl.bx, fl.by, fort_c, fort_s, (float)sfc::fort_x, (float)sfc::fort_y};
+  }
+  const bool svalid = lane < 3 ? ship_strokes : (lane < kFirstMissileLane ? fort_strokes : mvalid);
+  const int sobj = lane < 3 ? 0 : (lane < kFirstMissileLane ? 3 : kFirstMissileLane + 3 * ((lane - kFirstMissileLane) / 3));
   Quad mq = {};
-  if (mvalid) mq = line_quad(mg);
+  if (svalid) mq = line_quad(mg);
 
   // ---- background variant.  The score and the bar are drawn LAST (SRC/draw.cpp:266-268); when they
   // show 0000000 / an empty bar and nothing drawn before them reaches their pixels, the result is the
@@ -1070,13 +1472,19 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const bool ex_text = near_text, ex_bar = near_bar;  // the explosion's share (its box above is already wider by the reach)
   bool other_text = false, other_bar = false;          // anything else within reach: the live ship, projectiles
   if (ship_alive) {  // (the ship stays inside the big hexagon: rows 12.2 .. 81.6 +- 5.4 px -- never on the bar, but close)
-    const float gx = dev_x(ship_x), gy = dev_y(ship_y), ext = 27.f * (float)SF_SCALE;
-    const Box shb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
-    other_text = shb.meets(tbox3);
-    other_bar = shb.meets(bbox3);
+    other_text = sb.meets(tbox3);
+    other_bar = sb.meets(bbox3);
   }
   {
     bool t = false, b = false, t3 = false, b3 = false;
+    if ((mmask >> 19) && lane == 0) {  // (the twentieth missile: within 25 + 1.5 user units of its position)
+      const float gx = dev_x(m19x), gy = dev_y(m19y), ext = 26.5f * (float)SF_SCALE + 0.01f;
+      const Box qb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
+      t = qb.meets(tbox);
+      b = qb.meets(bbox);
+      t3 = qb.meets(tbox3);
+      b3 = qb.meets(bbox3);
+    }
     if (mvalid) {
       const Box qb = quad_box(mq);
       t = t || qb.meets(tbox);
@@ -1093,6 +1501,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     other_text = other_text || __any(t3);
     other_bar = other_bar || __any(b3);
   }
+  SF_DBG_STAMP(dbg_pc);
   const bool close_text = ex_text || other_text, close_bar = ex_bar || other_bar;
   const bool baked_text = pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4);
   const bool baked_bar = vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8);
@@ -1104,83 +1513,86 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       copy_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant * (kOutBytes / 4)), reinterpret_cast<uint4*>(frame_out),
                   kOutBytes / 16, lane);
   }
-  // the byte stores that follow must land on top of the frame's: wait until L2 has them (vmcnt counts stores on gfx9);
-  // and the surface must be in LDS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const Frame<RESIZE> F{fb, frame_out, tabw, lane, qscr, mscr};
-
-  // ---- ship (SRC/draw.cpp:233-237)
-  unsigned char* const xc_mine = a.xcache ? a.xcache + (size_t)env * SF_XC_BYTES : nullptr;
-  XcState xst{0u, 0, 0};
-  if (SF_RENDER_SKIP & 1) {
-  } else if (ship_alive) {
-    if (SF_RENDER_SKIP & 128) goto ship_done;  // (diagnostic: the live ship alone)
-    float s, c;
-    sincos_deg(ship_angle, &s, &c);
-    const Quad q = line_quad(kShipLines[lane < 3 ? lane : 0], c, s, ship_x, ship_y);
-    F.draw_objects(q, 255, lane < 3, 4);
-  } else if (!(SF_RENDER_SKIP & 256)) {  // (diagnostic bit 8: the dead ship's explosion alone)
-    xst = ship_explosion(F, xc_mine, sp.x, sp.y);
-  }
-ship_done:
-  // ---- fortress (:238-242)
-  if (SF_RENDER_SKIP & (1 | 512)) {  // (diagnostic bit 9: the fortress alone)
+  // The 84x84 background's seven stores are the LAST vector-memory instructions in front of this wait (but for a frame
+  // stack's shifted / cleared slots): vmcnt counts loads, stores and LDS-DMA together in issue order, so `vmcnt(7)` =
+  // everything but these stores is done -- the surface is in LDS -- without waiting for the stores to be acknowledged.  The
+  // byte stores that follow land on top of them anyway: one wave's stores to one address are performed in program order.
+  static_assert(kFrameRounds == 7 && 6 * 64 < kOutBytes / 16, "all seven stores have lanes to do");
+  SF_DBG_STAMP(dbg_pd);
+  if (RESIZE && !stack_traffic) {
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   } else {
-    // what was drawn before the fortress: the ship (within 25.5 + 1.5 user units of its position) or its explosion
-    Box sb = explosion_box(ship_x, ship_y);
-    if (ship_alive) {
-      const float gx = dev_x(ship_x), gy = dev_y(ship_y), ext = 27.f * (float)SF_SCALE;
-      sb = Box{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
-    }
-   if (flags & SF_FL_FORT_ALIVE) {
-    const int sector = fort_angle / 10;
-    if (a.fpatch && fort_angle >= 0 && fort_angle < 360 && sector * 10 == fort_angle &&
-        !sb.meets(Box{kFpX0 - kReachX, kFpY0 - kReachY, kFpX1 + kReachX, kFpY1 + kReachY})) {  // + what the picture's 84x84 pixels read
-      fort_patch_copy(F, const_cast<unsigned char*>(a.fpatch) + sector * SF_FP_BYTES, false);
-    } else {
-      float s, c;
-      sincos_deg(fort_angle, &s, &c);
-      const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
-      F.draw_objects(q, 255, lane < 4, 4);  // (a fifth of the frames of random play: one object of four strokes)
-    }
-   } else {
-    // The destroyed fortress explodes for 1000 ms where it stands: one more picture drawn once per batch, in the
-    // layout of the per-env explosion cache (a trained agent destroys it every few seconds -- 30 frames each time).
-    // Restored when what the ship drew stays clear of it (wider by the reach: what its 84x84 pixels read); else in place.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const Frame<RESIZE> F{fb, frame_out, tabw, RESIZE ? ptab : nullptr, lane, srec, slist};
+#ifdef SF_DBG_FLAGS
+  dbg_t1 = __builtin_amdgcn_s_memtime();
+#endif
+  if (SF_RENDER_STOP == 1) return;
+
+  // ---- what is restored from round trip 2's registers: the dead ship's explosion if its cache entry is this one, and
+  // the fortress's picture
+  XcState xst{0u, 0, 0};
+  bool explosion_done = false;
+  if (dead_ship && xc_mine) explosion_done = xc_apply(F, xf, sp.x, sp.y, &xst);
+  if (fort_pic) fort_patch_put(F, fpic);
+  if (SF_RENDER_STOP == 2) return;
+
+  // ---- ship (SRC/draw.cpp:233-237): a dead ship's explosion that was not in the cache is the first thing drawn
+  if (dead_ship && !explosion_done) xst = ship_explosion(F, xc_mine, sp.x, sp.y, true, /*skip_lookup=*/true);
+  // ---- fortress (:238-242), destroyed: it explodes for 1000 ms where it stands: one more picture drawn once per batch, in
+  // the layout of the per-env explosion cache (a trained agent destroys it every few seconds -- 30 frames each time).
+  // Restored when what the ship drew stays clear of it (wider by the reach: what its 84x84 pixels read) -- the two touch no
+  // pixel in common then, so it may go in before the ship --; else drawn in place between the ship and the missiles.
+  bool fort_explodes_in_place = false;
+  if (!fort_alive && !(SF_RENDER_SKIP & (1 | 512))) {
     Box fe = explosion_box((float)sfc::fort_x, (float)sfc::fort_y);
     fe.x0 -= kReachX; fe.y0 -= kReachY; fe.x1 += kReachX; fe.y1 += kReachY;
     if (a.fpatch && !sb.meets(fe))
       ship_explosion(F, const_cast<unsigned char*>(a.fpatch) + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y, false);
     else
-      draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);
-   }
+      fort_explodes_in_place = true;
   }
-  // ---- missiles (:243-247), shells (:248-253): slot order
-  if (mmask) F.draw_objects(mq, 255, mvalid, 3);
+  if (SF_RENDER_STOP == 3) return;
+  // ---- the live ship, the fortress in place, the missiles (:233-247): all their strokes at once
+  if (!fort_explodes_in_place) {
+#ifdef SF_DBG_FLAGS
+    F.draw_strokes(mq, svalid, sobj, dbg_ds);
+#else
+    F.draw_strokes(mq, svalid, sobj);
+#endif
+  } else {  // (rare: the ship, or its explosion, next to an exploding fortress)
+    F.draw_strokes(mq, svalid && lane < 3, sobj);
+    draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);
+    F.draw_strokes(mq, svalid && lane >= kFirstMissileLane, sobj);
+  }
+  if (mmask >> 19) {  // (the twentieth missile)
+    float s19, c19;
+    sincos_deg((int)m19a, &s19, &c19);
+    F.draw_strokes(line_quad(missile_line(lane < 3 ? lane : 0), c19, s19, m19x, m19y), lane < 3, 0);
+  }
+  if (SF_RENDER_STOP == 4) return;
+#ifdef SF_DBG_FLAGS
+  dbg_t2 = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- shells (:248-253): slot order
   if (smask) {
-#pragma unroll
-    for (int round = 0; round < 2; round++) {
-      const int p = round * 64 + lane;
-      const int slot = p >> 2, k = p & 3;
-      bool valid = p < 4 * SF_NSLOT && ((smask >> slot) & 1u);
+    F.draw_strokes(sq0, sq0_valid, lane & ~3);
+    if (smask >> 16) {  // (slots 16 .. 19)
+      const int slot = 16 + (lane >> 2);
+      const bool have = lane < 16 && ((smask >> slot) & 1u);
       Quad sq = {};
-      if (valid) {
-        const d2_t s = R_LD(d2_t, R_CHUNK(shell_pos, slot), o16);
-        const d2_t v = R_LD(d2_t, R_CHUNK(shell_vel, slot), o16);
-        const double dx = s.x - sfc::fort_x, dy = s.y - sfc::fort_y;
-        valid = sqrt(dx * dx + dy * dy) > 21.0;  // drawn only once clear of the fortress (SRC/draw.cpp:249-250)
-        // mAngle = stdAngle(rad2deg(atan2(dy, dx))) at launch (SRC/game.cpp:263); the velocity kept in
-        // the state has that direction.  drawWireFrame takes it as an int (truncation).
-        double ang = atan2(v.y, v.x) * 180.0 / M_PI;
-        if (ang < 0) ang += 360.0;
-        float sn, cs;
-        sincos_deg((int)ang, &sn, &cs);
-        sq = line_quad(kShellLines[k], cs, sn, (float)s.x, (float)s.y);
-      }
-      if (round == 0 || (smask >> 16)) F.draw_objects(sq, 255, valid, 4);  // (the second round: slots 16 .. 19)
+      const d2_t s = R_LD(d2_t, R_CHUNK(shell_pos, have ? slot : 0), o16);
+      const d2_t v = R_LD(d2_t, R_CHUNK(shell_vel, have ? slot : 0), o16);
+      const bool valid = shell_quad(s, v, lane & 3, have, &sq);
+      F.draw_strokes(sq, valid, lane & ~3);
     }
   }
+  if (SF_RENDER_STOP == 5) return;
+#ifdef SF_DBG_FLAGS
+  dbg_t3 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- score and bar, last (SRC/draw.cpp:266-268): baked into the background already (0000000 / empty), or one of
   // the pictures, or -- something else touches their pixels, or the points are off the table -- in place
   // When the only thing on them is the dead ship's explosion (a ship lost through the upper or lower edge of the big
@@ -1192,16 +1604,18 @@ ship_done:
     constexpr unsigned kBits = RESIZE ? 12u : 4u;
     unsigned char* pic = nullptr;
     bool draw = true, save = false, with_out = true;
+    bool pre = false;
     if (a.hud && !near_text && pnts >= -SF_HUD_SCORE_HALF && pnts < SF_HUD_SCORE_HALF) {
       pic = hud_score_picture(a.hud, pnts);
       draw = false;
       with_out = !close_text;
+      pre = score_pre;
     } else if (xst.flags && ex_text && !other_text) {
       pic = xc_mine + kXcScore;
       draw = save = !((xst.flags & kBits) == kBits && xst.points == pnts);
     }
     if (draw) draw_score(F, pnts);
-    if (pic) hud_picture(F, pic, SF_HUD_SCORE_ROW, tbox, save, with_out);
+    if (pic) hud_picture(F, pic, SF_HUD_SCORE_ROW, tbox, save, with_out, pre, hscore);
     if (save) {
       xst.flags |= kBits;
       if (lane == 0) {
@@ -1212,19 +1626,20 @@ ship_done:
   }
   if (!baked_bar && !(SF_RENDER_SKIP & 8)) {
     constexpr unsigned kBits = RESIZE ? 48u : 16u;
-    const int state = bar_state(vlner, fort_vuln_timer);
+    const int state = bstate;
     unsigned char* pic = nullptr;
-    bool draw = true, save = false, with_out = true;
+    bool draw = true, save = false, with_out = true, pre = false;
     if (a.hud && !near_bar) {
       pic = hud_bar_picture(a.hud, state);
       draw = false;
       with_out = !close_bar;
+      pre = bar_pre;
     } else if (xst.flags && ex_bar && !other_bar) {
       pic = xc_mine + kXcBar;
       draw = save = !((xst.flags & kBits) == kBits && xst.bar == state);
     }
     if (draw) draw_bar(F, state);
-    if (pic) hud_picture(F, pic, SF_HUD_BAR_ROW, bbox, save, with_out);
+    if (pic) hud_picture(F, pic, SF_HUD_BAR_ROW, bbox, save, with_out, pre, hbar);
     if (save) {
       xst.flags |= kBits;
       if (lane == 0) {
@@ -1234,6 +1649,30 @@ ship_done:
     }
   }
   __syncthreads();
+#ifdef SF_DBG_FLAGS  // diagnostic builds only: the frame's decisions in its first bytes, its wave's life (shader clocks) behind
+  if (lane == 0) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    const unsigned dt = (unsigned)(t_end - dbg_t0), d1 = (unsigned)(dbg_t1 - dbg_t0), d2 = (unsigned)(dbg_t2 - dbg_t0), d3 = (unsigned)(dbg_t3 - dbg_t0);
+    __builtin_memcpy(frame_out + 4, &dt, 4);
+    __builtin_memcpy(frame_out + 8, &d1, 4);
+    __builtin_memcpy(frame_out + 12, &d2, 4);
+    __builtin_memcpy(frame_out + 16, &d3, 4);
+    const unsigned pa = (unsigned)(dbg_pa - dbg_t0), pb = (unsigned)(dbg_pb - dbg_t0), pc = (unsigned)(dbg_pc - dbg_t0), pd = (unsigned)(dbg_pd - dbg_t0);
+    __builtin_memcpy(frame_out + 20, &pa, 4);
+    __builtin_memcpy(frame_out + 24, &pb, 4);
+    __builtin_memcpy(frame_out + 28, &pc, 4);
+    __builtin_memcpy(frame_out + 32, &pd, 4);
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const unsigned v = (unsigned)(dbg_ds[k] - dbg_t0);
+      __builtin_memcpy(frame_out + 36 + 4 * k, &v, 4);
+    }
+    frame_out[0] = (uint8_t)((baked_text ? 1 : 0) | (baked_bar ? 2 : 0) | (near_text ? 4 : 0) | (near_bar ? 8 : 0) | (close_text ? 16 : 0) |
+                             (close_bar ? 32 : 0) | (ship_alive ? 64 : 0) | (explosion_done ? 128 : 0));
+    frame_out[1] = (uint8_t)((variant != variant0 ? 1 : 0) | (fort_pic ? 2 : 0) | (fort_alive ? 4 : 0) | (smask ? 8 : 0) | (mmask ? 16 : 0) |
+                             (pnts != 0 ? 32 : 0) | (vlner != 0 ? 64 : 0) | (xst.flags ? 128 : 0));
+  }
+#endif
 
   // ---- epilogue: the 84x84 frame is already where it belongs; the raw one leaves LDS (8280 = 1035 * 8)
   if (!RESIZE) {
@@ -1250,21 +1689,19 @@ __global__ __launch_bounds__(64) void sf_fort_patch_kernel(const uint32_t* bg, c
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
   __shared__ __attribute__((aligned(16))) uint32_t obufw[kOutBytes / 4];
   __shared__ __attribute__((aligned(16))) uint32_t tabw[SF_TAB_WORDS];
-  __shared__ __attribute__((aligned(16))) float qscr[48];
-  __shared__ __attribute__((aligned(16))) uint8_t mscr[kMaskScratch];
   const int lane = threadIdx.x, sector = blockIdx.x;
   for (int i = lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bg[i] : 0u;
   for (int i = lane; i < kOutBytes / 4; i += 64) obufw[i] = bg84[i];
   for (int i = lane; i < SF_TAB_WORDS; i += 64) tabw[i] = tabs[i];
   __syncthreads();
-  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, lane, qscr, mscr};
+  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr};
   if (sector == 36) {  // the destroyed fortress's explosion, behind the 36 headings
     ship_explosion(F, fpatch + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y);  // (a zeroed entry: draws and fills it)
     return;
   }
   float s, c;
   sincos_deg(10 * sector, &s, &c);
-  const Quad q = line_quad(kFortLines[lane < 4 ? lane : 0], c, s, (float)sfc::fort_x, (float)sfc::fort_y);
+  const Quad q = line_quad(fort_line(lane < 4 ? lane : 0), c, s, (float)sfc::fort_x, (float)sfc::fort_y);
   F.draw_quads(q, 255, lane < 4, 64);
   // (draw_quads has resampled what the strokes touch; the rest of the patch keeps the background's values,
   //  exactly as when the fortress is drawn in place)
@@ -1290,7 +1727,7 @@ __global__ __launch_bounds__(64) void sf_hud_kernel(const uint32_t* bg, const ui
   for (int i = lane; i < kOutBytes / 4; i += 64) obufw[i] = bg84[i];
   for (int i = lane; i < SF_TAB_WORDS; i += 64) tabw[i] = tabs[i];
   __syncthreads();
-  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, lane, nullptr, nullptr};
+  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr};
   if (pic < 2 * SF_HUD_SCORE_HALF) {
     const int pnts = pic - SF_HUD_SCORE_HALF;
     draw_score(F, pnts);

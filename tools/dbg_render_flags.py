@@ -1,0 +1,28 @@
+import sys, numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from spacefortress_amd import SFVecEnv
+n=16384
+env = SFVecEnv(n, gametype="youturn", obs_type="image", spawn_stride=1, reuse_buffers=True)
+env.reset()
+acts = torch.randint(0, env.n_actions, (64, n), device=env.device, dtype=torch.uint8)
+for t in range(400): o,_,_,_ = env.step_tensors(acts[t % 64])
+raw = o.reshape(n, -1)[:, :56].cpu().numpy()
+f = raw[:, :2]
+T = raw[:, 4:20].copy().view(np.uint32).astype(np.float64)  # wave life, to barrier, to after strokes, to after shells
+names0 = ["baked_text","baked_bar","near_text","near_bar","close_text","close_bar","ship_alive","explosion_done"]
+names1 = ["variant_restart","fort_pic","fort_alive","smask","mmask","pnts!=0","vlner!=0","xst.flags"]
+for j,names in enumerate((names0,names1)):
+    for b,nm in enumerate(names): print("%-16s %.3f" % (nm, ((f[:,j]>>b)&1).mean()))
+
+print("wave clocks: total %.0f  | to barrier %.0f  strokes done %.0f  shells done %.0f" % tuple(T.mean(0)))
+cls = {"ship alive": (f[:,0]>>6)&1, "dead": 1-((f[:,0]>>6)&1), "smask": (f[:,1]>>3)&1, "no smask": 1-((f[:,1]>>3)&1), "baked both": ((f[:,0]&3)==3), "bar not baked": ((f[:,0]>>1)&1)==0, "text not baked": (f[:,0]&1)==0}
+for k,m in cls.items():
+    m = m.astype(bool)
+    print("%-16s n=%5d  total %.0f  barrier %.0f strokes %.0f shells %.0f  hud+end %.0f" % ((k, m.sum()) + tuple(T[m].mean(0)) + ((T[m,0]-T[m,3]).mean(),)))
+
+P = raw[:, 20:36].copy().view(np.uint32).astype(np.float64)
+print("prologue stamps (clocks from wave start): state decoded %.0f | mtab+shells done, before DMA %.0f | strokes built+tests %.0f | before final wait %.0f | barrier passed %.0f" % (tuple(P.mean(0)) + (T[:,1].mean(),)))
+
+D = raw[:, 36:56].copy().view(np.uint32).astype(np.float64)
+ok = (D < 1e6).all(1) & (D[:, 4] > 0)
+print("draw_strokes (main call, frames that drew: %d): entry(after setup) %.0f | records written %.0f | cheap rounds done %.0f | list drawn %.0f | resampled %.0f   (barrier passed %.0f)" % ((ok.sum(),) + tuple(D[ok].mean(0)) + (T[ok,1].mean(),)))
