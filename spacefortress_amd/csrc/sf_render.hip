@@ -536,6 +536,27 @@ __device__ __forceinline__ void sincos_deg(int deg, float* s, float* c) {
   *c = sc.y;
 }
 
+// ... and without any load: the frame kernel keeps sin / cos of 0, 10, .. 350 degrees (lane a: kSinCos10[a]) and of 0 .. 9
+// degrees (lane b: kSinCos1[b]) as doubles across its lanes -- two loads per wave, asked for before the state is known --
+// and a lane looks its heading k = 10 a + b up with lane permutes: sin k = sin 10a cos b + cos 10a sin b in double, rounded
+// to float, is kSinCosDeg[k] bit for bit (all 360 asserted by tools/gen_render_tables.py; the double operations are IEEE on
+// both sides).  A table lookup per lane is a vector load, and a wave's vector loads come back in issue order: the missiles'
+// sines were a round trip behind the pool's, with the surface's ten loads queued in between.
+struct SinCosLanes {
+  double s10, c10, s1, c1;
+};
+__device__ __forceinline__ SinCosLanes sincos_lanes_load(int lane) {
+  const int a = lane < 36 ? lane : 35, b = lane < 10 ? lane : 9;
+  return SinCosLanes{kSinCos10[a][0], kSinCos10[a][1], kSinCos1[b][0], kSinCos1[b][1]};
+}
+__device__ __forceinline__ void sincos_lanes(const SinCosLanes& t, int deg, float* s, float* c) {
+  deg = deg < 0 ? 0 : (deg > 359 ? 359 : deg);
+  const int a = (deg * 205) >> 11, b = deg - 10 * a;  // deg / 10 for deg < 1029
+  const double sa = __shfl(t.s10, a), ca = __shfl(t.c10, a), sb = __shfl(t.s1, b), cb = __shfl(t.c1, b);
+  *s = (float)(sa * cb + ca * sb);
+  *c = (float)(ca * cb - sa * sb);
+}
+
 // wireframe segments (ax, ay, bx, by), SRC/wireframe.cpp:11-67.  As functions of the stroke index, not tables in memory:
 // a table indexed by the lane is a vector load from .rodata, a dependent round trip in front of every object (small whole
 // numbers: the selects give the same floats).
@@ -1137,6 +1158,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   uint4 ptab_e = {0u, 0u, 0u, 0u};
   if (RESIZE && lane < kTapColPeriod + kTapRowPeriod)
     ptab_e = reinterpret_cast<const uint4*>(a.tabs)[lane < kTapColPeriod ? lane : SF_OUT + (lane - kTapColPeriod)];
+  const SinCosLanes sct = sincos_lanes_load(lane);  // (sincos_lanes: the headings' sines, looked up without a load)
   // ---- which env (pick_env).  Nearly every workgroup behind the front draws env = its index - n_front, and learns that
   // from one word of the hint: the state loads go out for that env at once, next to the word's load, instead of behind it.
   int env = blockIdx.x;
@@ -1215,9 +1237,6 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // late round of their own): position and velocity of its slot
   d2_t shell_p = R_LD(d2_t, R_CHUNK(shell_pos, lane >> 2), o16);
   d2_t shell_v = R_LD(d2_t, R_CHUNK(shell_vel, lane >> 2), o16);
-  float ship_s, ship_c, fort_s, fort_c;
-  sincos_deg(ship_angle, &ship_s, &ship_c);
-  sincos_deg(fort_angle, &fort_s, &fort_c);
 
   // what was drawn before the fortress: the ship (within 25.5 + 1.5 user units of its position) or its explosion
   Box sb = explosion_box(ship_x, ship_y);
@@ -1233,31 +1252,6 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
                         sector * 10 == fort_angle && !sb.meets(Box{kFpX0 - kReachX, kFpY0 - kReachY, kFpX1 + kReachX, kFpY1 + kReachY});
   unsigned char* const xc_mine = a.xcache ? a.xcache + (size_t)env * SF_XC_BYTES : nullptr;
   const bool dead_ship = !ship_alive && !(SF_RENDER_SKIP & (1 | 256));
-  // the score's and the bar's pictures, when they will not be the baked-in 0000000 / empty ones: used last, asked for now
-  const Box tbox{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1};
-  const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
-  const int bstate = bar_state(vlner, fort_vuln_timer);
-#ifndef SF_HUD_PREFETCH
-#define SF_HUD_PREFETCH 1
-#endif
-  const bool score_pre = SF_HUD_PREFETCH && a.hud && pnts != 0 && pnts >= -SF_HUD_SCORE_HALF && pnts < SF_HUD_SCORE_HALF && !(SF_RENDER_SKIP & 4);
-  const bool bar_pre = SF_HUD_PREFETCH && a.hud && vlner != 0 && !(SF_RENDER_SKIP & 8);
-  bool near_text = false, near_bar = false;
-  if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
-    // wider by the reach (kReachX, kReachY) than what the explosion paints: the 84x84 pixels recomputed (or restored from the
-    // cache) for it read that far, and must not depend on whether the score / bar were baked in
-    Box eb = explosion_box(ship_x, ship_y);
-    eb.x0 -= kReachX; eb.y0 -= kReachY; eb.x1 += kReachX; eb.y1 += kReachY;
-    near_text = eb.meets(tbox);
-    near_bar = eb.meets(bbox);
-  }
-  const int variant0 = ((pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4)) ? 1 : 0) |
-                       ((vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8)) ? 2 : 0);
-  // ... and the 84x84 background's seven pieces, for the variant the score, the bar and the dead ship's explosion call for
-  // (nearly always the final one: a projectile over the score or the bar starts again below)
-  Pieces frame0 = {};
-  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant0 * (kOutBytes / 4)), kOutBytes / 16, lane);
-
   // ---- The frame starts as a copy of the static background: the 92x90 surface into LDS, its 84x84 image into the
   // caller's frame.  Which variant (score / bar baked in) depends on what the projectiles touch, known only after their
   // strokes are built -- but nearly always it is what the score, the bar and the dead ship's explosion say, and the
@@ -1307,6 +1301,46 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
         : [lds] "s"(lds), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3)
         : "memory", "scc");
   };
+  // the score's and the bar's pictures, when they will not be the baked-in 0000000 / empty ones: used last, asked for now
+  const Box tbox{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1};
+  const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
+  const int bstate = bar_state(vlner, fort_vuln_timer);
+#ifndef SF_HUD_PREFETCH
+#define SF_HUD_PREFETCH 1
+#endif
+  const bool score_pre = SF_HUD_PREFETCH && a.hud && pnts != 0 && pnts >= -SF_HUD_SCORE_HALF && pnts < SF_HUD_SCORE_HALF && !(SF_RENDER_SKIP & 4);
+  const bool bar_pre = SF_HUD_PREFETCH && a.hud && vlner != 0 && !(SF_RENDER_SKIP & 8);
+  bool near_text = false, near_bar = false;
+  if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
+    // wider by the reach (kReachX, kReachY) than what the explosion paints: the 84x84 pixels recomputed (or restored from the
+    // cache) for it read that far, and must not depend on whether the score / bar were baked in
+    Box eb = explosion_box(ship_x, ship_y);
+    eb.x0 -= kReachX; eb.y0 -= kReachY; eb.x1 += kReachX; eb.y1 += kReachY;
+    near_text = eb.meets(tbox);
+    near_bar = eb.meets(bbox);
+  }
+  const int variant0 = ((pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4)) ? 1 : 0) |
+                       ((vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8)) ? 2 : 0);
+  // ... and the 84x84 background's seven pieces, for the variant the score, the bar and the dead ship's explosion call for
+  // (nearly always the final one: a projectile over the score or the bar starts again below)
+  Pieces frame0 = {};
+  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant0 * (kOutBytes / 4)), kOutBytes / 16, lane);
+  // (in front of them, for what is restored right behind the barrier or at the very end: the dead ship's cached
+  //  explosion -- key and pixels together, the pixels used if the key matches --, the fortress's picture, the score's and
+  //  the bar's: not needed before the surface is, so not held in registers through the arithmetic above)
+  XcFetch xf = {};
+  if (dead_ship && xc_mine) xf = xc_fetch<RESIZE>(xc_mine, lane);
+  FortPic fpic = {};
+  if (fort_pic) fpic = fort_patch_fetch<RESIZE>(a.fpatch + sector * SF_FP_BYTES, lane);
+  HudWords hscore = {}, hbar = {};
+  if (score_pre) hscore = hud_fetch<RESIZE>(hud_score_picture(a.hud, pnts), SF_HUD_SCORE_ROW, tbox, lane);
+  if (bar_pre) hbar = hud_fetch<RESIZE>(hud_bar_picture(a.hud, bstate), SF_HUD_BAR_ROW, bbox, lane);
+  // ... and LAST of the round trip, the surface's ten direct-to-LDS loads: a wave's loads come back in issue order and the
+  // compiler does not know of these ten, so every wait it counts out for something issued before them stays a wait for
+  // that alone.  Nothing in the prologue depends on a load that depends on a load any more (the headings' sines are looked
+  // up across lanes, sincos_lanes): state -> everything else -> the barrier, two round trips where round 2 had six.
+  start_surface(variant0);
+
 
   // ---- projectile strokes: one lane per wireframe segment (missiles: slot*3 + k; shells: two rounds of slot*4 + k)
   constexpr int kFirstMissileLane = 7;
@@ -1344,12 +1378,10 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     // slot 19 -- twenty live missiles -- has a round of its own at the end of the list
     const int pl = lane - kFirstMissileLane, slot = pl / 3, k = pl - slot * 3;
     mvalid = pl >= 0 && ((mmask >> slot) & 1u);
-    if (mvalid) {
+    if (mvalid) {  // (heading in .ca for now: every stroke's sine is looked up in one go below)
       const float* t = mtab + 3 * slot;
-      float s, c;
-      sincos_deg((int)t[2], &s, &c);
       const Line ml = missile_line(k);
-      mg = Seg{ml.ax, ml.ay, ml.bx, ml.by, c, s, t[0], t[1]};
+      mg = Seg{ml.ax, ml.ay, ml.bx, ml.by, t[2], 0.f, t[0], t[1]};
     }
     if (mmask >> 19) {  // uniform, all but never: its strokes are built where they are drawn
       m19x = mtab[3 * 19];
@@ -1369,15 +1401,18 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   auto shell_quad = [&](d2_t s, d2_t v, int k, bool have, Quad* q) -> bool {
     const double dx = s.x - sfc::fort_x, dy = s.y - sfc::fort_y;
     const bool valid = have && sqrt(dx * dx + dy * dy) > 21.0;  // drawn only once clear of the fortress (SRC/draw.cpp:249-250)
+    int ideg = 0;
     if (valid) {
       // mAngle = stdAngle(rad2deg(atan2(dy, dx))) at launch (SRC/game.cpp:263); the velocity kept in
       // the state has that direction.  drawWireFrame takes it as an int (truncation).
       double ang = atan2(v.y, v.x) * 180.0 / M_PI;
       if (ang < 0) ang += 360.0;
-      float sn, cs;
-      sincos_deg((int)ang, &sn, &cs);
-      *q = line_quad(shell_line(k), cs, sn, (float)s.x, (float)s.y);
+      ideg = (int)ang;
     }
+    // (the lookup permutes lanes: every lane of the wave takes part, whatever it holds)
+    float sn, cs;
+    sincos_lanes(sct, ideg, &sn, &cs);
+    if (valid) *q = line_quad(shell_line(k), cs, sn, (float)s.x, (float)s.y);
     return valid;
   };
   if (smask) {
@@ -1403,26 +1438,8 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       sh_b3 = sh_b3 || shb.meets(bb3);
     }
   }
-  // ---- ROUND TRIP 3: the surface's direct-to-LDS loads, BEHIND the last dependent load of the prologue (the missiles' and
-  // shells' sines): a wave's loads come back in issue order and the compiler does not know of these ten, so every wait it
-  // counts out for something older is in effect a wait for them -- the sines arrive with the surface, not behind it.  And
-  // the 84x84 background's seven stores behind THEM: stores count like loads, in the same order; issued in front, the
-  // wait for the sines would be a wait for their acknowledgement from HBM.  (Measured with clock stamps per wave,
-  // tools/dbg_render_flags.py: with the background's loads issued after the projectile tests the prologue was three memory
-  // round trips longer -- the surface, the background's loads, the first store's acknowledgement -- 26 000 of a wave's
-  // 40 000 clocks.)
-  SF_DBG_STAMP(dbg_pb);
-  // (in front of them, for what is restored right behind the barrier or at the very end: the dead ship's cached
-  //  explosion -- key and pixels together, the pixels used if the key matches --, the fortress's picture, the score's and
-  //  the bar's: not needed before the surface is, so not held in registers through the arithmetic above)
-  XcFetch xf = {};
-  if (dead_ship && xc_mine) xf = xc_fetch<RESIZE>(xc_mine, lane);
-  FortPic fpic = {};
-  if (fort_pic) fpic = fort_patch_fetch<RESIZE>(a.fpatch + sector * SF_FP_BYTES, lane);
-  HudWords hscore = {}, hbar = {};
-  if (score_pre) hscore = hud_fetch<RESIZE>(hud_score_picture(a.hud, pnts), SF_HUD_SCORE_ROW, tbox, lane);
-  if (bar_pre) hbar = hud_fetch<RESIZE>(hud_bar_picture(a.hud, bstate), SF_HUD_BAR_ROW, bbox, lane);
-  start_surface(variant0);
+  // the 84x84 background's seven stores, behind everything: stores count like loads, in the same order -- in front of the
+  // surface's loads, the wait for the surface would be a wait for their acknowledgement from HBM as well
   if (RESIZE) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
   // the frame stack's older slots (independent of the variant)
   const bool stack_traffic = RESIZE && (a.stack_prev || fin_b != 0);  // more loads / stores behind the seven: see the wait below
@@ -1453,8 +1470,12 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const bool fort_strokes = !(SF_RENDER_SKIP & (1 | 512)) && fort_alive && !fort_pic;
   {
     const Line sl = ship_line(lane), fl = fort_line(lane - 3);
-    if (lane < 3) mg = Seg{sl.ax, sl.ay, sl.bx, sl.by, ship_c, ship_s, ship_x, ship_y};
-    else if (lane < kFirstMissileLane) mg = Seg{fl.ax, fl.ay, fl.bx, fl.by, fort_c, fort_s, (float)sfc::fort_x, (float)sfc::fort_y};
+    if (lane < 3) mg = Seg{sl.ax, sl.ay, sl.bx, sl.by, (float)ship_angle, 0.f, ship_x, ship_y};
+    else if (lane < kFirstMissileLane) mg = Seg{fl.ax, fl.ay, fl.bx, fl.by, (float)fort_angle, 0.f, (float)sfc::fort_x, (float)sfc::fort_y};
+    float s_, c_;
+    sincos_lanes(sct, (int)mg.ca, &s_, &c_);
+    mg.ca = c_;
+    mg.sa = s_;
   }
   const bool svalid = lane < 3 ? ship_strokes : (lane < kFirstMissileLane ? fort_strokes : mvalid);
   const int sobj = lane < 3 ? 0 : (lane < kFirstMissileLane ? 3 : kFirstMissileLane + 3 * ((lane - kFirstMissileLane) / 3));
@@ -1569,7 +1590,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   }
   if (mmask >> 19) {  // (the twentieth missile)
     float s19, c19;
-    sincos_deg((int)m19a, &s19, &c19);
+    sincos_lanes(sct, (int)m19a, &s19, &c19);
     F.draw_strokes(line_quad(missile_line(lane < 3 ? lane : 0), c19, s19, m19x, m19y), lane < 3, 0);
   }
   if (SF_RENDER_STOP == 4) return;
