@@ -347,6 +347,50 @@ def test_every_shortcut_of_the_render_kernel_is_invisible(sfa, monkeypatch, game
     prod.close()
 
 
+def test_scores_beyond_the_picture_table_and_under_an_explosion(sfa, monkeypatch):
+    """the equality soaks only saw scores 0..264.  The score has a picture for -512 <= points < 512; beyond that,
+    and for negative points, it is drawn in place -- also when a dead ship's explosion lies under the score box (a ship lost
+    through the top of the big hexagon), where the box is kept in the env's explosion-cache entry keyed by the points.  States
+    with points on, around and far beyond the table's ends, half of the ships freshly dead right under the score: the
+    product batch against one that draws everything in place, 40 ticks (the whole explosion and the respawn), both sizes."""
+    N, T = 384, 40
+    pts = np.array([-100000, -600, -513, -512, -511, -1, 0, 1, 7, 511, 512, 513, 600, 9999999, 1234567, 264], np.float32)
+    monkeypatch.setenv("SFMI_NO_EXPLOSION_CACHE", "1")
+    monkeypatch.setenv("SFMI_NO_RENDER_ORDER", "1")
+    plain = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=3)
+    plain.render("image")  # the switches are read at create / by the first frame
+    monkeypatch.delenv("SFMI_NO_EXPLOSION_CACHE")
+    monkeypatch.delenv("SFMI_NO_RENDER_ORDER")
+    prod = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=3)
+    rng = np.random.default_rng(17)
+    for e in (plain, prod):
+        e.reset()
+    sd = prod.state_dict()
+    sd["points"] = pts[np.arange(N) % len(pts)]
+    sd["raw_points"] = sd["points"].copy()
+    under = (np.arange(N) // len(pts)) % 2 == 1  # every other group: the ship died a moment ago, right under the score
+    sd["ship_x"] = np.where(under, 355 + rng.integers(-60, 61, N), sd["ship_x"]).astype(np.float64)
+    sd["ship_y"] = np.where(under, 150 + rng.integers(0, 12, N), sd["ship_y"]).astype(np.float64)
+    sd["flags"] = np.where(under, sd["flags"] & ~np.uint8(1), sd["flags"]).astype(np.uint8)
+    sd["ship_death_timer"] = np.where(under, 34 * rng.integers(0, 5, N), sd["ship_death_timer"]).astype(np.int32)
+    for e in (plain, prod):
+        e.load_state_dict(sd)
+    assert torch.equal(plain.render("image"), prod.render("image"))
+    assert torch.equal(plain.render("image-raw"), prod.render("image-raw"))
+    lit = plain.render("image-raw")[:, 2:8, 30:60].flatten(1).float().mean(1).cpu().numpy()  # the score's rows: digits everywhere
+    assert (lit > 5).all()
+    for t in range(T):
+        a = torch.from_numpy(rng.integers(0, 5, N).astype(np.uint8)).cuda()
+        o1, *_ = plain.step_tensors(a)
+        o2, *_ = prod.step_tensors(a)
+        assert torch.equal(o1, o2), t
+        if t % 4 == 0:
+            assert torch.equal(plain.render("image-raw"), prod.render("image-raw")), t
+    assert (prod.get_field("flags") & 1).sum() > N // 2  # the explosions ran their course: ships are back
+    plain.close()
+    prod.close()
+
+
 def test_launch_order_hint_is_invisible(sfa, monkeypatch):
     """The step kernel tells the render launch which ships just died, and those frames start first (sf_render.hip:
     pick_env).  The words decide only when a frame is drawn: a batch without them, the batch's own, and every pattern
