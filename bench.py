@@ -219,7 +219,16 @@ def main():
                     help="also time N envs stepping with the image observation (BASELINE cfg 5: sf_step + sf_render, "
                          "uint8 [N,1,84,84] per step); reported as image_obs, never as value; 0 = skip")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (`configs`)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiling runs (tools/profile_version.sh): nothing but the warm-up and the timed blocks of sf_step launches, "
+                         "so that a kernel trace of the run averages those launches alone (no sampled-action blocks, no "
+                         "loop-issued blocks, no steady-state loop, no extras)")
     args = ap.parse_args()
+    if args.timed_only:
+        args.rollout_k = args.numpy_api = args.image_envs = 0
+        args.no_configs = args.no_cpu_baseline = True
+        args.steady_seconds = 0.0
+        args.kernel_timing_launches = 1
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not os.environ.get("SF_BENCH_NO_SPAWN"):
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], args))
@@ -402,11 +411,12 @@ def main():
     region_ms = periods[med]
 
     # ---- the same blocks with the actions drawn inside the launch (sf_step_sampled)
-    s_blocks, _, s_periods = timed_blocks(graph_sampled, lambda t: step_sampled(), repeats)
-    s_med = sorted(range(repeats), key=lambda r: s_blocks[r])[repeats // 2]
+    s_reps = 1 if args.timed_only else repeats
+    s_blocks, _, s_periods = timed_blocks(graph_sampled, lambda t: step_sampled(), s_reps)
+    s_med = sorted(range(s_reps), key=lambda r: s_blocks[r])[s_reps // 2]
     # ---- ... and, when the blocks above were HIP graphs, a few blocks issued one by one from Python: the per-call host path
     loop_issue = None
-    if graph is not None:
+    if graph is not None and not args.timed_only:
         l_blocks, _, l_periods = timed_blocks(None, launch_ring, max(3, repeats // 8))
         l_med = sorted(range(len(l_blocks)), key=lambda r: l_blocks[r])[len(l_blocks) // 2]
         loop_issue = {"value": float(n) * K * world / l_blocks[l_med], "ms_per_step": l_blocks[l_med] / K * 1e3,
@@ -419,12 +429,12 @@ def main():
     #      sustains.  Back-to-back launches from the Python loop for --steady-seconds, in chunks between HIP events: every
     #      lane plays through whole episodes meanwhile (the statistics below are not zeros), and a utilisation sampler
     #      outside this process gets to see the GPU busy.
-    chunk = 4096
+    chunk = 64 if args.timed_only else 4096
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     step(act_rows[0])
     sync()
     n_steady, steady_total_ms, t_begin = 0, 0.0, time.perf_counter()
-    while n_steady < max(K, 2000) or time.perf_counter() - t_begin < args.steady_seconds:
+    while n_steady < (chunk if args.timed_only else max(K, 2000)) or time.perf_counter() - t_begin < args.steady_seconds:
         s0.record()
         for t in range(chunk):
             step(act_rows[t % ring])

@@ -837,7 +837,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 // FUSED = true:  n_steps ticks per launch with the actions of all of them given up front
 // (sf_rollout): the wave keeps its state in registers between ticks, so a tick costs neither the
 // two memory round trips nor a kernel boundary.  Same body, bit-identical results.
-template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK>
+// XTRA = the launch may need what the plain VecEnv.step never does -- actions drawn in the kernel (SF_ACT_SAMPLED), the
+// played actions written out (a.act_out), the packed counters' overflow test of batches without auto-reset: three uniform
+// tests and their code, 0.07 us of a 6.5 us launch when they sit in the one kernel everybody runs (A/B, tools/ab.py)
+template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK, bool XTRA>
 __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
                                                           const void* actions, int n_envs_p, int act_type,
                                                           int32_t* reward_out, uint8_t* done_out, uint8_t* info_out,
@@ -892,7 +895,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // wave would otherwise sit in that wait.  (constant address space = s_load; the tile's tick is rewritten by lane 0 after
   // the last tick of the launch, nothing reads it again in between.)
   u4_t act_rec = {0u, 0u, 0u, 0u};
-  if (act_type == SF_ACT_SAMPLED)
+  if (XTRA && act_type == SF_ACT_SAMPLED)
     act_rec = *(reinterpret_cast<const __attribute__((address_space(4))) u4_t*>(
                     reinterpret_cast<const __attribute__((address_space(4))) void*>((unsigned long long)actions)) +
                 __builtin_amdgcn_readfirstlane(i >> 6));
@@ -903,7 +906,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     return real ? (int)__umulhi(x, (unsigned)a.n_actions) : 0;
   };
   auto load_action = [&](int step) __attribute__((always_inline)) -> int {  // ENV:211-212
-    if (!real || act_type == SF_ACT_SAMPLED) return 0;
+    if (!real || (XTRA && act_type == SF_ACT_SAMPLED)) return 0;
     const unsigned char* ab = (const unsigned char*)actions;
     const unsigned e = (unsigned)step * (unsigned)n_envs_p + i;
     if (act_type == 8) return (int)SF_LD(long long, ab, e * 8u);
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   }
   // (behind the last load of the early set: the ten rounds run while those are in flight)
   int act_sampled = 0;
-  if (act_type == SF_ACT_SAMPLED) act_sampled = sample_action(0);  // uniform branch, VALU only
+  if (XTRA && act_type == SF_ACT_SAMPLED) act_sampled = sample_action(0);  // uniform branch, VALU only
   // lane l takes entry 64 r + l if the pool has that many (`n_pool`: the tile's count, known once the early set is in;
   // ~0u = not known yet, take everything): the instructions are unconditional, the bytes are not
 #define SF_LOAD_POOL_ROWS(aux, n_pool)                                                                                        \
@@ -1040,11 +1043,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   unpack_lane_late(late, L);  // names only: the wait for the late set sits at the first real use
   const int n_iter = FUSED ? n_steps : 1;
   for (int step = 0; step < n_iter; step++) {
-  int act = act_type == SF_ACT_SAMPLED ? act_sampled : act_next;
+  int act = (XTRA && act_type == SF_ACT_SAMPLED) ? act_sampled : act_next;
   if (FUSED) {
     if (step + 1 < n_iter) {
       act_next = load_action(step + 1);  // in flight while this tick computes
-      if (act_type == SF_ACT_SAMPLED) act_sampled = sample_action(step + 1);
+      if (XTRA && act_type == SF_ACT_SAMPLED) act_sampled = sample_action(step + 1);
     }
     if (step > 0) {
       // the pool rows the previous tick compacted in place: agent-scope loads (they bypass the wave's L1, where the rows
@@ -1486,7 +1489,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   L.c_small += (unsigned)S.small_hex_deaths;
   L.c_shell += (unsigned)S.shell_deaths;
   L.c_destroyed += (unsigned)S.destroyed;
-  if (!a.auto_reset) {  // uniform
+  if (XTRA && !a.auto_reset) {  // uniform
     // The packed per-episode counters (sf_layout.h: SF_W_*) are sized for ONE episode.  A batch without auto-reset
     // keeps ticking past game over like the bare SSF_Env / Game (ENV:246) until the caller resets, and the reference's
     // plain ints keep counting: a field that no longer fits its bits is counted here (sticky: sf_check_state) instead
@@ -1556,7 +1559,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     if (done_out) SF_ST(uint8_t, (unsigned char*)(done_out + so), g.o1, (uint8_t)done);
     if (info_out) SF_ST(uint8_t, (unsigned char*)(info_out + so), g.o1, (uint8_t)fort_kill);
     if (a.events) SF_ST(uint32_t, (unsigned char*)(a.events + so), g.o4, evmask);
-    if (a.act_out) SF_ST(uint8_t, (unsigned char*)(a.act_out + so), g.o1, (uint8_t)act_raw);  // what the lane played (sampled or given)
+    if (XTRA && a.act_out) SF_ST(uint8_t, (unsigned char*)(a.act_out + so), g.o1, (uint8_t)act_raw);  // what the lane played (sampled or given)
     SF_STAMP(15, false);
     if (a.t_reward) {  // uniform; the same float32 operations in the same order as rl/train.py:82-88
       const float rf = (float)r, mask = done ? 0.0f : 1.0f;
@@ -1622,7 +1625,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   }
   }  // tick loop
   if (FUSED) store_lane_buf(rs, o, L);
-  if (act_type == SF_ACT_SAMPLED && lane == 0)  // the tile's tick counter moves on by the ticks of this launch
+  if (XTRA && act_type == SF_ACT_SAMPLED && lane == 0)  // the tile's tick counter moves on by the ticks of this launch
     reinterpret_cast<unsigned*>(const_cast<void*>(actions))[4 * (size_t)(i >> 6)] = act_rec.x + (unsigned)n_iter;
   SF_STAMP(8, false);
   SF_STAMP(9, true);
@@ -1894,16 +1897,19 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
   const size_t lds_bytes = SF_LDS_STAGE * sizeof(double) + (size_t)SF_BLOCK * a.obs_dim * elem;
   // 16-byte obs stores need every tick's row of the output to start 16-byte aligned
   const int vec_ok = ((uintptr_t)obs & 15u) == 0 && (!fused || ((size_t)a.n_envs * a.obs_dim * elem) % 16 == 0);
+#define SF_GO1(AT, SH, FU, OK, XT)                                                                                 \
+  hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, OK, XT>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state,  \
+                     a.consts, actions, a.n_envs, act_type, reward, done, info, a, obs, vec_ok, n_steps)
 #define SF_GO(AT, SH, FU)                                                                                          \
-  if (fast_obs)                                                                                                    \
-    hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, 1>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state,    \
-                       a.consts, actions, a.n_envs, act_type, reward, done, info, a, obs, vec_ok, n_steps);       \
-  else                                                                                                             \
-    hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, 0>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state,    \
-                       a.consts, actions, a.n_envs, act_type, reward, done, info, a, obs, vec_ok, n_steps)
+  if (fast_obs) {                                                                                                  \
+    if (xtra) SF_GO1(AT, SH, FU, 1, true); else SF_GO1(AT, SH, FU, 1, false);                                      \
+  } else {                                                                                                         \
+    if (xtra) SF_GO1(AT, SH, FU, 0, true); else SF_GO1(AT, SH, FU, 0, false);                                      \
+  }
   // the default observation has its own instantiations (OBSK = 1): see write_features_f32
   const bool fast_obs = obs != nullptr && a.obs_type == 0 && !a.obs_f64 && vec_ok && a.n_envs % 64 == 0 &&
                         a.obs_dim == (autoturn ? 17 : 19);
+  const bool xtra = act_type == SF_ACT_SAMPLED || a.act_out != nullptr || !a.auto_reset;
   // the four presets of SRC/configs.cpp:51-89 are exactly (autoTurn) x (shaped scoring)
   const int sel = (autoturn ? 4 : 0) | (shaped ? 2 : 0) | (fused ? 1 : 0);
   switch (sel) {
@@ -1917,5 +1923,6 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
     default: SF_GO(true, true, true); break;
   }
 #undef SF_GO
+#undef SF_GO1
   return hipGetLastError();
 }

@@ -42,6 +42,9 @@
 #ifndef SF_RENDER_STOP
 #define SF_RENDER_STOP 0
 #endif
+#ifndef SF_PTAB
+#define SF_PTAB 0 /* 1: resample_into reads one period of the tap tables from LDS instead of the tables through L1 (measured: 73.7 against 72.0 us per step, the 560 bytes of LDS cost more than the loads) */
+#endif
 #ifndef SF_RENDER_TABS_IN_LDS
 #define SF_RENDER_TABS_IN_LDS 0
 #endif
@@ -336,7 +339,10 @@ struct Frame {
   //   4. every object's box of the 84x84 image is resampled once everything is drawn (a destination pixel that reads a
   //      changed source pixel lies in some object's out_box, and is evaluated after the last change).
   // A live ship and a missile or two are one dense round instead of three or four sparse ones.
-  static constexpr int kChunk = 8, kListCap = 128;
+#ifndef SF_LISTCAP
+#define SF_LISTCAP 128
+#endif
+  static constexpr int kChunk = 8, kListCap = SF_LISTCAP;
   static constexpr int kRecFloats = 24;  // [0,12) quad x, y, slopes; [12,20) nx, ny, cn, hn, ux, uy, cu, hu; [20,23) x0 | y0 << 8, w, offset (ints); [23] 1 / w
   __device__ __forceinline__ void flush_list(int cnt) const {
     for (int base = 0; base < cnt; base += 64) {
@@ -1143,7 +1149,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
 #endif
   __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats];
   __shared__ __attribute__((aligned(16))) uint32_t slist[Frame<RESIZE>::kListCap];
-  __shared__ __attribute__((aligned(16))) uint32_t ptab[RESIZE ? 4 * (kTapColPeriod + kTapRowPeriod) : 4];
+  __shared__ __attribute__((aligned(16))) uint32_t ptab[(RESIZE && SF_PTAB) ? 4 * (kTapColPeriod + kTapRowPeriod) : 4];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int lane = threadIdx.x;
 #ifdef SF_DBG_FLAGS
@@ -1156,7 +1162,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
 #endif
   // one period of the tap tables into LDS (resample_into): 35 entries of 16 bytes, asked for before anything else
   uint4 ptab_e = {0u, 0u, 0u, 0u};
-  if (RESIZE && lane < kTapColPeriod + kTapRowPeriod)
+  if (RESIZE && SF_PTAB && lane < kTapColPeriod + kTapRowPeriod)
     ptab_e = reinterpret_cast<const uint4*>(a.tabs)[lane < kTapColPeriod ? lane : SF_OUT + (lane - kTapColPeriod)];
   const SinCosLanes sct = sincos_lanes_load(lane);  // (sincos_lanes: the headings' sines, looked up without a load)
   // ---- which env (pick_env).  Nearly every workgroup behind the front draws env = its index - n_front, and learns that
@@ -1199,7 +1205,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     if ((w >> (env & 63)) & 1ull)                    // a hinted env: one of the front workgroups may be drawing it
       if (pick_env(a, (int)blockIdx.x, lane) < 0) return;
   }
-  if (RESIZE && lane < kTapColPeriod + kTapRowPeriod) reinterpret_cast<uint4*>(ptab)[lane] = ptab_e;
+  if (RESIZE && SF_PTAB && lane < kTapColPeriod + kTapRowPeriod) reinterpret_cast<uint4*>(ptab)[lane] = ptab_e;
   const int ship_angle = (int)(int16_t)(sm.x & 0xFFFF);
   const int fort_angle = (int)(int16_t)((unsigned)sm.x >> 16);
   const unsigned flags = ((unsigned)sm.y >> 16) & 0xFFu;
@@ -1546,7 +1552,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  const Frame<RESIZE> F{fb, frame_out, tabw, RESIZE ? ptab : nullptr, lane, srec, slist};
+  const Frame<RESIZE> F{fb, frame_out, tabw, (RESIZE && SF_PTAB) ? ptab : nullptr, lane, srec, slist};
 #ifdef SF_DBG_FLAGS
   dbg_t1 = __builtin_amdgcn_s_memtime();
 #endif

@@ -32,7 +32,8 @@ def main():
             out = subprocess.check_output(
                 [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "300",
                  "--no-cpu-baseline", "--envs", str(a.envs), "--gametype", a.gametype, "--obs-type", a.obs_type,
-                 "--rollout-k", "0", "--image-envs", "0", "--kernel-timing-launches", "1", "--repeats", "1"],
+                 "--rollout-k", "0", "--image-envs", "0", "--kernel-timing-launches", "1", "--repeats", "1", "--numpy-api", "0",
+                 "--no-configs", "--steady-seconds", "0.2"],
                 env=env, stderr=subprocess.DEVNULL, text=True)
             res[l].append(json.loads(out.strip().splitlines()[-1])["ms_per_step"] * 1e3)
     for l, v in res.items():

@@ -14,12 +14,12 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_${RND}_${VER}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="--steps 2000 --warmup 200 --no-cpu-baseline"
+B="--steps 2000 --warmup 200 --no-cpu-baseline --numpy-api 0 --no-configs --steady-seconds 0.5"
 python3 $R/bench.py --steps 12000 --warmup 200 > $OUT/${RND}_bench_${VER}.json 2> $OUT/bench.err
 echo "bench done"
 # the traced run launches its timed blocks as HIP graphs (512 launches per replay): launched one by one under the profiler the
 # kernels are no longer back to back (its per-dispatch work is on the host) and every one starts on an idle chip
-BT="--steps 512 --warmup 100 --repeats 8 --launch graph --no-cpu-baseline"
+BT="--steps 512 --warmup 100 --repeats 12 --launch graph --timed-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py $BT > $OUT/${RND}_bench_${VER}_under_rocprof.json 2>> $OUT/bench.err
 echo "kernel trace done"
 SF_PMC_CALIB=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pf -- python3 $R/bench.py $B --rollout-k 0 --image-envs 0 > /dev/null 2>> $OUT/bench.err
@@ -47,7 +47,7 @@ rep["note"] = ("per-dispatch durations (End - Start timestamps) from the same ro
                "kernel_stats csv, whose sf_step_kernel row mixes this workload's launches with those of bench.py's other legs; "
                "command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 512 --warmup 100 --repeats 8 --launch graph --no-cpu-baseline")
 json.dump(rep, open(os.path.join(out, "%s_kernel_trace_%s_step65536.json" % (rnd, ver)), "w"), indent=1)
-main = [k for k in rep if k.endswith("grid 65536") and ", false, 1>" in k]
+main = [k for k in rep if k.endswith("grid 65536") and ", false, 1, false>" in k]
 t = json.load(open(os.path.join(out, "%s_pmc_traffic_%s.json" % (rnd, ver))))
 latest = {"version": "%s_%s" % (rnd, ver), "workload": t["workload"], "kernel": "sf_step_kernel",
           "traffic_bytes_per_launch": t["traffic_bytes_per_launch"], "read_bytes_per_launch": t["read_bytes_per_launch"],
