@@ -342,7 +342,10 @@ struct Frame {
 #ifndef SF_LISTCAP
 #define SF_LISTCAP 128
 #endif
-  static constexpr int kChunk = 8, kListCap = SF_LISTCAP;
+#ifndef SF_CHUNK
+#define SF_CHUNK 8
+#endif
+  static constexpr int kChunk = SF_CHUNK, kListCap = SF_LISTCAP;
   static constexpr int kRecFloats = 24;  // [0,12) quad x, y, slopes; [12,20) nx, ny, cn, hn, ux, uy, cu, hu; [20,23) x0 | y0 << 8, w, offset (ints); [23] 1 / w
   __device__ __forceinline__ void flush_list(int cnt) const {
     for (int base = 0; base < cnt; base += 64) {
