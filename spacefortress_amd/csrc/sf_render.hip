@@ -513,17 +513,24 @@ struct Frame {
 
 // Stroke of the segment A-B (wireframe coordinates), butt caps, width SF_LINE_W, under
 // translate(pos) rotate(angle) (drawWireFrame, SRC/draw.cpp:112-129)
-struct Seg {  // a wireframe segment with its transform: everything line_quad reads from memory
+struct Seg {  // a wireframe segment with its transform: everything line_quad reads
   float ax, ay, bx, by, ca, sa, posx, posy;
+  float inv;  // half the line width over the segment's length: a constant of the stroke (stroke_inv)
 };
+// (float)(SF_LINE_W / 2) / sqrtf(ux * ux + uy * uy) for a segment (ux, uy) = B - A.  The segments are compile-time tables:
+// on constant arguments the compiler folds this -- with the IEEE square root and division the run-time form has, so the
+// same float -- and a stroke carries the value instead of twenty-odd instructions of correctly rounded sqrt and division.
+__device__ __forceinline__ float stroke_inv(float ux, float uy) {
+  return (float)(SF_LINE_W / 2) / __builtin_sqrtf(ux * ux + uy * uy);
+}
 __device__ __forceinline__ Quad line_quad(const Seg& g);
 __device__ __forceinline__ Quad line_quad(const float* ln, float ca, float sa, float posx, float posy) {
-  return line_quad(Seg{ln[0], ln[1], ln[2], ln[3], ca, sa, posx, posy});
+  return line_quad(Seg{ln[0], ln[1], ln[2], ln[3], ca, sa, posx, posy, stroke_inv(ln[2] - ln[0], ln[3] - ln[1])});
 }
 __device__ __forceinline__ Quad line_quad(const Seg& g) {
   const float ax = g.ax, ay = g.ay, bx = g.bx, by = g.by, ca = g.ca, sa = g.sa, posx = g.posx, posy = g.posy;
   const float ux = bx - ax, uy = by - ay;
-  const float inv = (float)(SF_LINE_W / 2) / sqrtf(ux * ux + uy * uy);
+  const float inv = g.inv;
   const float nx = -uy * inv, ny = ux * inv;
   const float lx[4] = {ax + nx, bx + nx, bx - nx, ax - nx};
   const float ly[4] = {ay + ny, by + ny, by - ny, ay - ny};
@@ -570,24 +577,28 @@ __device__ __forceinline__ void sincos_lanes(const SinCosLanes& t, int deg, floa
 // a table indexed by the lane is a vector load from .rodata, a dependent round trip in front of every object (small whole
 // numbers: the selects give the same floats).
 struct Line {
-  float ax, ay, bx, by;
+  float ax, ay, bx, by, inv;  // inv = stroke_inv(bx - ax, by - ay), folded at compile time
 };
 __device__ __forceinline__ Line ship_line(int k) {     // {-18, 0, 18, 0}, {-18, 18, 0, 0}, {0, 0, -18, -18}
-  return Line{k == 2 ? 0.f : -18.f, k == 1 ? 18.f : 0.f, k == 0 ? 18.f : (k == 1 ? 0.f : -18.f), k == 2 ? -18.f : 0.f};
+  return Line{k == 2 ? 0.f : -18.f, k == 1 ? 18.f : 0.f, k == 0 ? 18.f : (k == 1 ? 0.f : -18.f), k == 2 ? -18.f : 0.f,
+              k == 0 ? stroke_inv(36.f, 0.f) : (k == 1 ? stroke_inv(18.f, -18.f) : stroke_inv(-18.f, -18.f))};
 }
 __device__ __forceinline__ Line fort_line(int k) {     // {0, 0, 36, 0}, {0, -18, 18, -18}, {18, -18, 18, 18}, {18, 18, 0, 18}
   return Line{k >= 2 ? 18.f : 0.f, k == 0 ? 0.f : (k == 3 ? 18.f : -18.f), k == 0 ? 36.f : (k == 3 ? 0.f : 18.f),
-              k == 0 ? 0.f : (k == 1 ? -18.f : 18.f)};
+              k == 0 ? 0.f : (k == 1 ? -18.f : 18.f),
+              k == 0 ? stroke_inv(36.f, 0.f) : (k == 1 ? stroke_inv(18.f, 0.f) : (k == 2 ? stroke_inv(0.f, 36.f) : stroke_inv(-18.f, 0.f)))};
 }
 __device__ __forceinline__ Line missile_line(int k) {  // {0, 0, -25, 0}, {0, 0, -5, 5}, {0, 0, -5, -5}
-  return Line{0.f, 0.f, k == 0 ? -25.f : -5.f, k == 0 ? 0.f : (k == 1 ? 5.f : -5.f)};
+  return Line{0.f, 0.f, k == 0 ? -25.f : -5.f, k == 0 ? 0.f : (k == 1 ? 5.f : -5.f),
+              k == 0 ? stroke_inv(-25.f, 0.f) : (k == 1 ? stroke_inv(-5.f, 5.f) : stroke_inv(-5.f, -5.f))};
 }
 __device__ __forceinline__ Line shell_line(int k) {    // {-8, 0, 0, -6}, {0, -6, 16, 0}, {16, 0, 0, 6}, {0, 6, -8, 0}
   return Line{k == 0 ? -8.f : (k == 2 ? 16.f : 0.f), k == 1 ? -6.f : (k == 3 ? 6.f : 0.f), k == 1 ? 16.f : (k == 3 ? -8.f : 0.f),
-              k == 0 ? -6.f : (k == 2 ? 6.f : 0.f)};
+              k == 0 ? -6.f : (k == 2 ? 6.f : 0.f),
+              k == 0 ? stroke_inv(8.f, -6.f) : (k == 1 ? stroke_inv(16.f, 6.f) : (k == 2 ? stroke_inv(-16.f, 6.f) : stroke_inv(-8.f, -6.f)))};
 }
 __device__ __forceinline__ Quad line_quad(const Line& ln, float ca, float sa, float posx, float posy) {
-  return line_quad(Seg{ln.ax, ln.ay, ln.bx, ln.by, ca, sa, posx, posy});
+  return line_quad(Seg{ln.ax, ln.ay, ln.bx, ln.by, ca, sa, posx, posy, ln.inv});
 }
 
 // drawExplosion (SRC/draw.cpp:145-175): 7 rings (radius 15 + 8i) of twelve 10-degree arcs starting at
@@ -1157,7 +1168,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const int lane = threadIdx.x;
 #ifdef SF_DBG_FLAGS
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-  unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_pa = 0, dbg_pb = 0, dbg_pc = 0, dbg_pd = 0;
+  unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_pa = 0, dbg_pb = 0, dbg_pc = 0, dbg_pd = 0, dbg_pe = 0, dbg_pf = 0, dbg_pg = 0;
   unsigned long long dbg_ds[5] = {0, 0, 0, 0, 0};
 #define SF_DBG_STAMP(v) do { asm volatile("" ::: "memory"); v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #else
@@ -1239,8 +1250,8 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
 #pragma unroll
   for (int r = 0; r < kPoolRows; r++) {
     const unsigned e = 64u * r + (unsigned)lane;  // (always inside the tile's pool rows: SF_NSLOT rows of 64 entries)
-    pmeta[r] = R_LD(uint32_t, R_CHUNK(missile_meta, 0), e * 4u);
-    ppos[r] = R_LD(d2_t, R_CHUNK(missile_pos, 0), e * 16u);
+    pmeta[r] = (SF_RENDER_SKIP & 8192) ? 0u : R_LD(uint32_t, R_CHUNK(missile_meta, 0), e * 4u);
+    ppos[r] = (SF_RENDER_SKIP & 8192) ? d2_t{0.0, 0.0} : R_LD(d2_t, R_CHUNK(missile_pos, 0), e * 16u);
   }
   // shells: lane 4 s + k will draw stroke k of slot s (slots 0 .. 15; the last four slots -- seventeen live shells -- have a
   // late round of their own): position and velocity of its slot
@@ -1348,8 +1359,8 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // compiler does not know of these ten, so every wait it counts out for something issued before them stays a wait for
   // that alone.  Nothing in the prologue depends on a load that depends on a load any more (the headings' sines are looked
   // up across lanes, sincos_lanes): state -> everything else -> the barrier, two round trips where round 2 had six.
-  start_surface(variant0);
-
+  if (!(SF_RENDER_SKIP & 4096)) start_surface(variant0);  // (bits 11, 12: timing-only, no background loads / no surface)
+  SF_DBG_STAMP(dbg_pb);
 
   // ---- projectile strokes: one lane per wireframe segment (missiles: slot*3 + k; shells: two rounds of slot*4 + k)
   constexpr int kFirstMissileLane = 7;
@@ -1390,7 +1401,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     if (mvalid) {  // (heading in .ca for now: every stroke's sine is looked up in one go below)
       const float* t = mtab + 3 * slot;
       const Line ml = missile_line(k);
-      mg = Seg{ml.ax, ml.ay, ml.bx, ml.by, t[2], 0.f, t[0], t[1]};
+      mg = Seg{ml.ax, ml.ay, ml.bx, ml.by, t[2], 0.f, t[0], t[1], ml.inv};
     }
     if (mmask >> 19) {  // uniform, all but never: its strokes are built where they are drawn
       m19x = mtab[3 * 19];
@@ -1404,6 +1415,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // shells (14 % of the frames have one): their strokes, built here with the surface's loads in flight (round 2 built them
   // where they are drawn, behind two loads and a double-precision atan2 at the end of the frame: the slowest frames of a
   // launch)
+  SF_DBG_STAMP(dbg_pe);
   bool sh_t = false, sh_b = false, sh_t3 = false, sh_b3 = false;
   Quad sq0 = {};
   bool sq0_valid = false;
@@ -1449,7 +1461,9 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   }
   // the 84x84 background's seven stores, behind everything: stores count like loads, in the same order -- in front of the
   // surface's loads, the wait for the surface would be a wait for their acknowledgement from HBM as well
+  SF_DBG_STAMP(dbg_pf);
   if (RESIZE) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
+  SF_DBG_STAMP(dbg_pg);
   // the frame stack's older slots (independent of the variant)
   const bool stack_traffic = RESIZE && (a.stack_prev || fin_b != 0);  // more loads / stores behind the seven: see the wait below
   if (RESIZE && a.stack_prev) {
@@ -1479,8 +1493,8 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const bool fort_strokes = !(SF_RENDER_SKIP & (1 | 512)) && fort_alive && !fort_pic;
   {
     const Line sl = ship_line(lane), fl = fort_line(lane - 3);
-    if (lane < 3) mg = Seg{sl.ax, sl.ay, sl.bx, sl.by, (float)ship_angle, 0.f, ship_x, ship_y};
-    else if (lane < kFirstMissileLane) mg = Seg{fl.ax, fl.ay, fl.bx, fl.by, (float)fort_angle, 0.f, (float)sfc::fort_x, (float)sfc::fort_y};
+    if (lane < 3) mg = Seg{sl.ax, sl.ay, sl.bx, sl.by, (float)ship_angle, 0.f, ship_x, ship_y, sl.inv};
+    else if (lane < kFirstMissileLane) mg = Seg{fl.ax, fl.ay, fl.bx, fl.by, (float)fort_angle, 0.f, (float)sfc::fort_x, (float)sfc::fort_y, fl.inv};
     float s_, c_;
     sincos_lanes(sct, (int)mg.ca, &s_, &c_);
     mg.ca = c_;
@@ -1697,6 +1711,10 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       const unsigned v = (unsigned)(dbg_ds[k] - dbg_t0);
       __builtin_memcpy(frame_out + 36 + 4 * k, &v, 4);
     }
+    const unsigned pe = (unsigned)(dbg_pe - dbg_t0), pf = (unsigned)(dbg_pf - dbg_t0), pg = (unsigned)(dbg_pg - dbg_t0);
+    __builtin_memcpy(frame_out + 56, &pe, 4);
+    __builtin_memcpy(frame_out + 60, &pf, 4);
+    __builtin_memcpy(frame_out + 64, &pg, 4);
     frame_out[0] = (uint8_t)((baked_text ? 1 : 0) | (baked_bar ? 2 : 0) | (near_text ? 4 : 0) | (near_bar ? 8 : 0) | (close_text ? 16 : 0) |
                              (close_bar ? 32 : 0) | (ship_alive ? 64 : 0) | (explosion_done ? 128 : 0));
     frame_out[1] = (uint8_t)((variant != variant0 ? 1 : 0) | (fort_pic ? 2 : 0) | (fort_alive ? 4 : 0) | (smask ? 8 : 0) | (mmask ? 16 : 0) |

@@ -6,7 +6,7 @@ env = SFVecEnv(n, gametype="youturn", obs_type="image", spawn_stride=1, reuse_bu
 env.reset()
 acts = torch.randint(0, env.n_actions, (64, n), device=env.device, dtype=torch.uint8)
 for t in range(400): o,_,_,_ = env.step_tensors(acts[t % 64])
-raw = o.reshape(n, -1)[:, :56].cpu().numpy()
+raw = o.reshape(n, -1)[:, :68].cpu().numpy()
 f = raw[:, :2]
 T = raw[:, 4:20].copy().view(np.uint32).astype(np.float64)  # wave life, to barrier, to after strokes, to after shells
 names0 = ["baked_text","baked_bar","near_text","near_bar","close_text","close_bar","ship_alive","explosion_done"]
@@ -26,3 +26,7 @@ print("prologue stamps (clocks from wave start): state decoded %.0f | mtab+shell
 D = raw[:, 36:56].copy().view(np.uint32).astype(np.float64)
 ok = (D < 1e6).all(1) & (D[:, 4] > 0)
 print("draw_strokes (main call, frames that drew: %d): entry(after setup) %.0f | records written %.0f | cheap rounds done %.0f | list drawn %.0f | resampled %.0f   (barrier passed %.0f)" % ((ok.sum(),) + tuple(D[ok].mean(0)) + (T[ok,1].mean(),)))
+
+E = raw[:, 56:68].copy().view(np.uint32).astype(np.float64)
+print("prologue, finer: state decoded %.0f | round trip 2 issued (DMA last) %.0f | pool filed, missiles' segments %.0f | shells done %.0f | background stored %.0f | strokes built+tests %.0f | barrier %.0f"
+      % (P[:,0].mean(), P[:,1].mean(), E[:,0].mean(), E[:,1].mean(), E[:,2].mean(), P[:,2].mean(), T[:,1].mean()))
