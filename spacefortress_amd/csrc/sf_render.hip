@@ -227,49 +227,51 @@ struct Frame {
   __device__ __forceinline__ void resample(const Box& b) const { resample_into(b, obuf, SF_OUT, 0, 0); }
 
   // ... written to dst[(dy - y_off) * stride + (dx - x_off)]
+  // one destination pixel (dx, dy) of the 84x84 image from the surface as it is (OpenCV's resizeArea_ arithmetic)
+  __device__ __forceinline__ void resample_px(int dx, int dy, uint8_t* dst, int stride, int x_off, int y_off) const {
+    const float* tabf = reinterpret_cast<const float*>(tab);
+    int fx, fy;
+    float a0, a1, b0, b1, b2;
+    if (ptab) {  // uniform
+      // 90 / 84 = 15 / 14 and 92 / 84 = 23 / 21: the taps repeat exactly every 14 columns / 21 rows (checked entry by
+      // entry in sf_create), the first source cell moving on by 15 / 23.  One period sits in LDS: the frame kernel's
+      // resampling then has no load from global memory -- and a wave's loads are counted with its stores: behind every
+      // object's byte stores to the caller's frame, the next object's table reads waited for those stores to be
+      // acknowledged, a memory round trip per object.
+      const int qx = (dx * 37) >> 9, px_ = dx - 14 * qx;   // dx / 14, dx % 14 for dx < 84
+      const int qy = (dy * 49) >> 10, py_ = dy - 21 * qy;  // dy / 21, dy % 21 for dy < 84
+      const uint4 tc = *reinterpret_cast<const uint4*>(ptab + 4 * px_);
+      const uint4 tr = *reinterpret_cast<const uint4*>(ptab + 4 * (kTapColPeriod + py_));
+      fx = (int)tc.x + 15 * qx;
+      fy = (int)tr.x + 23 * qy;
+      a0 = __uint_as_float(tc.y); a1 = __uint_as_float(tc.z);
+      b0 = __uint_as_float(tr.y); b1 = __uint_as_float(tr.z); b2 = __uint_as_float(tr.w);
+    } else {
+      fx = (int)tab[4 * dx];
+      a0 = tabf[4 * dx + 1]; a1 = tabf[4 * dx + 2];
+      fy = (int)tab[4 * (SF_OUT + dy)];
+      b0 = tabf[4 * (SF_OUT + dy) + 1]; b1 = tabf[4 * (SF_OUT + dy) + 2]; b2 = tabf[4 * (SF_OUT + dy) + 3];
+    }
+    const uint8_t* r0 = fb + fy * SF_IMG_W + fx;
+    const uint8_t* r1 = r0 + SF_IMG_W;
+    const uint8_t* r2 = r1 + SF_IMG_W;
+    const float h0 = (float)r0[0] * a0 + (float)r0[1] * a1;
+    const float h1 = (float)r1[0] * a0 + (float)r1[1] * a1;
+    const float h2 = (float)r2[0] * a0 + (float)r2[1] * a1;
+    const float sum = (b0 * h0 + b1 * h1) + b2 * h2;  // a two-row entry has b2 = 0: adds +0
+    int v = (int)rintf(sum);                            // saturate_cast<uchar>: round half to even, clamp
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    dst[(dy - y_off) * stride + (dx - x_off)] = (uint8_t)v;
+  }
   __device__ __forceinline__ void resample_into(const Box& b, uint8_t* dst, int stride, int x_off, int y_off) const {
     if (!RESIZE || (SF_RENDER_SKIP & 16) || b.empty()) return;
     const Box o = out_box(b);
     const int ox0 = o.x0, oy0 = o.y0;
     const int ow = o.x1 - o.x0, n = ow * (o.y1 - o.y0);
-    const float* tabf = reinterpret_cast<const float*>(tab);
     const float r_ow = recip_i(ow);
     for (int i = lane; i < n; i += 64) {
       const DivMod dm = fast_divmod(i, ow, r_ow);
-      const int ry = dm.q, rx = dm.r;
-      const int dx = ox0 + rx, dy = oy0 + ry;
-      int fx, fy;
-      float a0, a1, b0, b1, b2;
-      if (ptab) {  // uniform
-        // 90 / 84 = 15 / 14 and 92 / 84 = 23 / 21: the taps repeat exactly every 14 columns / 21 rows (checked entry by
-        // entry in sf_create), the first source cell moving on by 15 / 23.  One period sits in LDS: the frame kernel's
-        // resampling then has no load from global memory -- and a wave's loads are counted with its stores: behind every
-        // object's byte stores to the caller's frame, the next object's table reads waited for those stores to be
-        // acknowledged, a memory round trip per object.
-        const int qx = (dx * 37) >> 9, px_ = dx - 14 * qx;   // dx / 14, dx % 14 for dx < 84
-        const int qy = (dy * 49) >> 10, py_ = dy - 21 * qy;  // dy / 21, dy % 21 for dy < 84
-        const uint4 tc = *reinterpret_cast<const uint4*>(ptab + 4 * px_);
-        const uint4 tr = *reinterpret_cast<const uint4*>(ptab + 4 * (kTapColPeriod + py_));
-        fx = (int)tc.x + 15 * qx;
-        fy = (int)tr.x + 23 * qy;
-        a0 = __uint_as_float(tc.y); a1 = __uint_as_float(tc.z);
-        b0 = __uint_as_float(tr.y); b1 = __uint_as_float(tr.z); b2 = __uint_as_float(tr.w);
-      } else {
-        fx = (int)tab[4 * dx];
-        a0 = tabf[4 * dx + 1]; a1 = tabf[4 * dx + 2];
-        fy = (int)tab[4 * (SF_OUT + dy)];
-        b0 = tabf[4 * (SF_OUT + dy) + 1]; b1 = tabf[4 * (SF_OUT + dy) + 2]; b2 = tabf[4 * (SF_OUT + dy) + 3];
-      }
-      const uint8_t* r0 = fb + fy * SF_IMG_W + fx;
-      const uint8_t* r1 = r0 + SF_IMG_W;
-      const uint8_t* r2 = r1 + SF_IMG_W;
-      const float h0 = (float)r0[0] * a0 + (float)r0[1] * a1;
-      const float h1 = (float)r1[0] * a0 + (float)r1[1] * a1;
-      const float h2 = (float)r2[0] * a0 + (float)r2[1] * a1;
-      const float sum = (b0 * h0 + b1 * h1) + b2 * h2;  // a two-row entry has b2 = 0: adds +0
-      int v = (int)rintf(sum);                            // saturate_cast<uchar>: round half to even, clamp
-      v = v < 0 ? 0 : (v > 255 ? 255 : v);
-      dst[(dy - y_off) * stride + (dx - x_off)] = (uint8_t)v;
+      resample_px(ox0 + dm.r, oy0 + dm.q, dst, stride, x_off, y_off);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -411,25 +413,25 @@ struct Frame {
       const bool own = ((live >> lane) & 1ull) && rank < kChunk;
       const unsigned long long chunk = __ballot(own);
       live &= ~chunk;
-      int off[kChunk + 1];
-      off[0] = 0;
-      {
-        unsigned long long mm = chunk;
-#pragma unroll
-        for (int r = 0; r < kChunk; r++) {
-          int n = 0;
-          if (mm) {  // uniform
-            n = __builtin_amdgcn_readlane(myn, __builtin_ctzll(mm));
-            mm &= mm - 1;
-          }
-          off[r + 1] = off[r] + n;
-        }
-      }
-      const int total = off[kChunk];
+      // where each stroke's box pixels start in the chunk's enumeration: an exclusive prefix sum over the owners, in lane
+      // (= rank) order -- six DPP adds across the wave instead of a scalar loop of readlanes with their wait states -- and
+      // the starts of strokes 1 .. kChunk-1 in LDS for the pixels' lanes to find their stroke by
+      int incl = own ? myn : 0;
+      const int mine_n = incl;
+#define SF_SCAN_STEP(ctrl, rmask) incl += __builtin_amdgcn_update_dpp(0, incl, (ctrl), (rmask), 0xf, false)
+      SF_SCAN_STEP(0x111, 0xf);  // row_shr:1
+      SF_SCAN_STEP(0x112, 0xf);  // row_shr:2
+      SF_SCAN_STEP(0x114, 0xf);  // row_shr:4
+      SF_SCAN_STEP(0x118, 0xf);  // row_shr:8
+      SF_SCAN_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+      SF_SCAN_STEP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef SF_SCAN_STEP
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      int* const otab = reinterpret_cast<int*>(srec + kChunk * kRecFloats);
+      if (lane < kChunk) otab[lane] = 0x7fffffff;  // (a chunk with fewer strokes: no pixel is behind their start)
       if (own) {
-        int myoff = 0;
-#pragma unroll
-        for (int r = 1; r < kChunk; r++) myoff = rank == r ? off[r] : myoff;
+        const int myoff = incl - mine_n;
+        otab[rank] = myoff;
         const Slopes ms = quad_slopes(mine);
         float* g = srec + rank * kRecFloats;
 #pragma unroll
@@ -449,6 +451,9 @@ struct Frame {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       SF_DS_STAMP(1);
       int cnt = 0;
+      int off[kChunk];
+#pragma unroll
+      for (int r = 1; r < kChunk; r++) off[r] = otab[r];
       for (int base = 0; base < total; base += 64) {
         const int i = base + lane;
         bool touched = false;
@@ -486,24 +491,78 @@ struct Frame {
       SF_DS_STAMP(3);
       // (the next chunk's records overwrite these: every listed pixel has been drawn)
     }
-    // the 84x84 pixels that read what was drawn, object by object (an object = the strokes that share `obj0`)
-    if (RESIZE && !(SF_RENDER_SKIP & 16)) {
-      unsigned long long todo = drawn;
-      while (todo) {
-        const int first = __builtin_ctzll(todo);
-        const int o = __builtin_amdgcn_readlane(obj0, first);
-        const unsigned long long mates = __ballot(obj0 == o) & drawn;
-        todo &= ~mates;
-        Box u;
-        u.clear();
-        unsigned long long mm = mates;
-        while (mm) {  // at most four strokes
-          const int src = __builtin_ctzll(mm);
-          mm &= mm - 1;
-          u.add(__builtin_amdgcn_readlane(myb.x0, src), __builtin_amdgcn_readlane(myb.y0, src),
-                __builtin_amdgcn_readlane(myb.x1, src), __builtin_amdgcn_readlane(myb.y1, src));
+    // ---- the 84x84 pixels that read what was drawn.  An object = the (at most four, consecutive) strokes that share
+    // `obj0`; its box = the union of their boxes, gathered at its first lane with three whole-wave DPP shifts (round 2 and the
+    // first form of this function walked the strokes with scalar readlanes, object by object, and resampled object by object:
+    // a round of lanes each, two thirds full).  Then ONE enumeration over the destination pixels of all the objects' boxes --
+    // the cheap rounds' machinery: prefix sum, starts in LDS, a lane per pixel finds its object --, everything being drawn
+    // by now (a destination pixel that reads a changed source pixel lies in some object's box).
+    if (RESIZE && !(SF_RENDER_SKIP & 16) && drawn) {
+      const bool me = (drawn >> lane) & 1ull;
+      int ux0 = me ? myb.x0 : (1 << 20), uy0 = me ? myb.y0 : (1 << 20), ux1 = me ? myb.x1 : -1, uy1 = me ? myb.y1 : -1;
+      {
+        int sx0 = ux0, sy0 = uy0, sx1 = ux1, sy1 = uy1, so = obj0;
+#pragma unroll
+        for (int d = 1; d < 4; d++) {  // lane l sees lane l + d: wave_shl:1, applied d times; lanes past the end read the identity
+          sx0 = __builtin_amdgcn_update_dpp(1 << 20, sx0, 0x130, 0xf, 0xf, false);
+          sy0 = __builtin_amdgcn_update_dpp(1 << 20, sy0, 0x130, 0xf, 0xf, false);
+          sx1 = __builtin_amdgcn_update_dpp(-1, sx1, 0x130, 0xf, 0xf, false);
+          sy1 = __builtin_amdgcn_update_dpp(-1, sy1, 0x130, 0xf, 0xf, false);
+          so = __builtin_amdgcn_update_dpp(-1, so, 0x130, 0xf, 0xf, false);
+          const bool same = so == obj0;
+          ux0 = same ? min(ux0, sx0) : ux0;
+          uy0 = same ? min(uy0, sy0) : uy0;
+          ux1 = same ? max(ux1, sx1) : ux1;
+          uy1 = same ? max(uy1, sy1) : uy1;
         }
-        resample(u);
+      }
+      const Box o = out_box(Box{ux0, uy0, ux1, uy1});
+      const int ow = o.x1 - o.x0;
+      const int on = (lane == obj0 && ux1 > ux0 && uy1 > uy0) ? ow * (o.y1 - o.y0) : 0;
+      unsigned long long todo = __ballot(on > 0);
+      while (todo) {
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo, 0u));
+        const bool own = ((todo >> lane) & 1ull) && rank < kChunk;
+        todo &= ~__ballot(own);
+        int incl = own ? on : 0;
+        const int mine_n = incl;
+#define SF_SCAN_STEP(ctrl, rmask) incl += __builtin_amdgcn_update_dpp(0, incl, (ctrl), (rmask), 0xf, false)
+        SF_SCAN_STEP(0x111, 0xf);
+        SF_SCAN_STEP(0x112, 0xf);
+        SF_SCAN_STEP(0x114, 0xf);
+        SF_SCAN_STEP(0x118, 0xf);
+        SF_SCAN_STEP(0x142, 0xa);
+        SF_SCAN_STEP(0x143, 0xc);
+#undef SF_SCAN_STEP
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        int* const otab = reinterpret_cast<int*>(srec + kChunk * kRecFloats);
+        int* const orec = reinterpret_cast<int*>(srec);  // (the strokes' records are done with) per object: x0 | y0 << 8, w, start, 1 / w
+        if (lane < kChunk) otab[lane] = 0x7fffffff;
+        if (own) {
+          otab[rank] = incl - mine_n;
+          orec[4 * rank] = o.x0 | (o.y0 << 8);
+          orec[4 * rank + 1] = ow;
+          orec[4 * rank + 2] = incl - mine_n;
+          reinterpret_cast<float*>(orec)[4 * rank + 3] = recip_i(ow);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int off[kChunk];
+#pragma unroll
+        for (int r = 1; r < kChunk; r++) off[r] = otab[r];
+        for (int base = 0; base < total; base += 64) {
+          const int i = base + lane;
+          if (i < total) {
+            int k = 0;
+#pragma unroll
+            for (int r = 1; r < kChunk; r++) k += (i >= off[r]) ? 1 : 0;
+            const int4 rec = *reinterpret_cast<const int4*>(orec + 4 * k);
+            const DivMod dm = fast_divmod(i - rec.z, rec.y, __int_as_float(rec.w));
+            resample_px((rec.x & 255) + dm.r, (rec.x >> 8) + dm.q, obuf, SF_OUT, 0, 0);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
     SF_DS_STAMP(4);
@@ -1161,7 +1220,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
 #else
   const uint32_t* const tabw = a.tabs;  // 2.7 KB read by every wave: L1/L2 resident; LDS is better spent on waves
 #endif
-  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats];
+  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats + Frame<RESIZE>::kChunk];  // records, then the strokes' starts
   __shared__ __attribute__((aligned(16))) uint32_t slist[Frame<RESIZE>::kListCap];
   __shared__ __attribute__((aligned(16))) uint32_t ptab[(RESIZE && SF_PTAB) ? 4 * (kTapColPeriod + kTapRowPeriod) : 4];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
