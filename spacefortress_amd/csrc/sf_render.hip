@@ -211,6 +211,18 @@ __device__ __forceinline__ Box out_box(const Box& b) {
 // is going anyway, in the caller's frame in HBM: it starts as a copy of the resampled background and only the few
 // dozen pixels an object touches are rewritten (byte stores that merge in L2).  Keeping it in LDS too cost 7 of
 // the 18 KB per env, i.e. waves per CU, on a kernel that needs them to hide its LDS round trips.
+// inclusive prefix sum across the wave: six DPP adds (row_shr 1, 2, 4, 8; row_bcast 15 into rows 1 and 3, 31 into rows 2 and 3)
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+#define SF_SCAN_STEP(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, (ctrl), (rmask), 0xf, false)
+  SF_SCAN_STEP(0x111, 0xf);
+  SF_SCAN_STEP(0x112, 0xf);
+  SF_SCAN_STEP(0x114, 0xf);
+  SF_SCAN_STEP(0x118, 0xf);
+  SF_SCAN_STEP(0x142, 0xa);
+  SF_SCAN_STEP(0x143, 0xc);
+#undef SF_SCAN_STEP
+  return v;
+}
 template <bool RESIZE>
 struct Frame {
   uint8_t* fb;
@@ -227,31 +239,32 @@ struct Frame {
   __device__ __forceinline__ void resample(const Box& b) const { resample_into(b, obuf, SF_OUT, 0, 0); }
 
   // ... written to dst[(dy - y_off) * stride + (dx - x_off)]
-  // one destination pixel (dx, dy) of the 84x84 image from the surface as it is (OpenCV's resizeArea_ arithmetic)
-  __device__ __forceinline__ void resample_px(int dx, int dy, uint8_t* dst, int stride, int x_off, int y_off) const {
-    const float* tabf = reinterpret_cast<const float*>(tab);
-    int fx, fy;
-    float a0, a1, b0, b1, b2;
+  // one destination pixel (dx, dy) of the 84x84 image from the surface as it is (OpenCV's resizeArea_ arithmetic): the taps, then the sums
+  struct Taps {
+    uint4 c, r;  // column: first source column, a0, a1, -; row: first source row, b0, b1, b2
+  };
+  __device__ __forceinline__ Taps taps_fetch(int dx, int dy) const {
+    Taps t;
     if (ptab) {  // uniform
       // 90 / 84 = 15 / 14 and 92 / 84 = 23 / 21: the taps repeat exactly every 14 columns / 21 rows (checked entry by
-      // entry in sf_create), the first source cell moving on by 15 / 23.  One period sits in LDS: the frame kernel's
-      // resampling then has no load from global memory -- and a wave's loads are counted with its stores: behind every
-      // object's byte stores to the caller's frame, the next object's table reads waited for those stores to be
-      // acknowledged, a memory round trip per object.
+      // entry in sf_create), the first source cell moving on by 15 / 23.  One period sits in LDS.
       const int qx = (dx * 37) >> 9, px_ = dx - 14 * qx;   // dx / 14, dx % 14 for dx < 84
       const int qy = (dy * 49) >> 10, py_ = dy - 21 * qy;  // dy / 21, dy % 21 for dy < 84
-      const uint4 tc = *reinterpret_cast<const uint4*>(ptab + 4 * px_);
-      const uint4 tr = *reinterpret_cast<const uint4*>(ptab + 4 * (kTapColPeriod + py_));
-      fx = (int)tc.x + 15 * qx;
-      fy = (int)tr.x + 23 * qy;
-      a0 = __uint_as_float(tc.y); a1 = __uint_as_float(tc.z);
-      b0 = __uint_as_float(tr.y); b1 = __uint_as_float(tr.z); b2 = __uint_as_float(tr.w);
+      t.c = *reinterpret_cast<const uint4*>(ptab + 4 * px_);
+      t.r = *reinterpret_cast<const uint4*>(ptab + 4 * (kTapColPeriod + py_));
+      t.c.x += 15u * (unsigned)qx;
+      t.r.x += 23u * (unsigned)qy;
     } else {
-      fx = (int)tab[4 * dx];
-      a0 = tabf[4 * dx + 1]; a1 = tabf[4 * dx + 2];
-      fy = (int)tab[4 * (SF_OUT + dy)];
-      b0 = tabf[4 * (SF_OUT + dy) + 1]; b1 = tabf[4 * (SF_OUT + dy) + 2]; b2 = tabf[4 * (SF_OUT + dy) + 3];
+      // (unsigned indices: base pointer in scalar registers + a 32-bit offset per lane, no 64-bit address arithmetic)
+      t.c = *reinterpret_cast<const uint4*>(tab + 4u * (unsigned)dx);
+      t.r = *reinterpret_cast<const uint4*>(tab + 4u * (unsigned)(SF_OUT + dy));
     }
+    return t;
+  }
+  __device__ __forceinline__ void resample_finish(const Taps& t, int dx, int dy, uint8_t* dst, int stride, int x_off, int y_off) const {
+    const int fx = (int)t.c.x, fy = (int)t.r.x;
+    const float a0 = __uint_as_float(t.c.y), a1 = __uint_as_float(t.c.z);
+    const float b0 = __uint_as_float(t.r.y), b1 = __uint_as_float(t.r.z), b2 = __uint_as_float(t.r.w);
     const uint8_t* r0 = fb + fy * SF_IMG_W + fx;
     const uint8_t* r1 = r0 + SF_IMG_W;
     const uint8_t* r2 = r1 + SF_IMG_W;
@@ -261,7 +274,10 @@ struct Frame {
     const float sum = (b0 * h0 + b1 * h1) + b2 * h2;  // a two-row entry has b2 = 0: adds +0
     int v = (int)rintf(sum);                            // saturate_cast<uchar>: round half to even, clamp
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    dst[(dy - y_off) * stride + (dx - x_off)] = (uint8_t)v;
+    if (!(SF_RENDER_SKIP & 16384) || v == 77) dst[(unsigned)((dy - y_off) * stride + (dx - x_off))] = (uint8_t)v;  // (16384: timing only)
+  }
+  __device__ __forceinline__ void resample_px(int dx, int dy, uint8_t* dst, int stride, int x_off, int y_off) const {
+    resample_finish(taps_fetch(dx, dy), dx, dy, dst, stride, x_off, y_off);
   }
   __device__ __forceinline__ void resample_into(const Box& b, uint8_t* dst, int stride, int x_off, int y_off) const {
     if (!RESIZE || (SF_RENDER_SKIP & 16) || b.empty()) return;
@@ -345,9 +361,13 @@ struct Frame {
 #define SF_LISTCAP 128
 #endif
 #ifndef SF_CHUNK
-#define SF_CHUNK 8
+#define SF_CHUNK 12  // (records: 96 B each; the workgroup's LDS stays under 10 240 B = 16 workgroups per CU: 14 strokes measured +3 us)
 #endif
   static constexpr int kChunk = SF_CHUNK, kListCap = SF_LISTCAP;
+  static_assert(kListCap >= 127, "a round appends up to 64 entries behind the 63 kept");
+  static constexpr int kMapBits = 512;      // the map of the strokes' starts (behind the records): 8 boxes of 8 x 8
+  static constexpr int kMapBitsOut = 1024;  // ... and of the objects' 84x84 boxes (in the records' space, behind the objects' own)
+  static_assert(4 * kChunk + kMapBitsOut / 32 <= kChunk * 24, "the resample pass's records and map fit in the strokes' records");
   static constexpr int kRecFloats = 24;  // [0,12) quad x, y, slopes; [12,20) nx, ny, cn, hn, ux, uy, cu, hu; [20,23) x0 | y0 << 8, w, offset (ints); [23] 1 / w
   __device__ __forceinline__ void flush_list(int cnt) const {
     for (int base = 0; base < cnt; base += 64) {
@@ -381,7 +401,9 @@ struct Frame {
     }
   }
   __device__ __forceinline__ void draw_strokes(const Quad& mine, bool valid, int obj0, unsigned long long* dbg = nullptr) const {
-#define SF_DS_STAMP(k) do { if (dbg) { asm volatile("" ::: "memory"); dbg[k] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
+#define SF_DS_STAMP(k) do { if (dbg) { asm volatile("" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    if ((k) == 0 || (k) == 4) dbg[k] = t_; else dbg[k] += t_ - dbg_last; dbg_last = t_; if ((k) == 1) dbg[5]++; } } while (0)
+    unsigned long long dbg_last = 0;  // (diagnostic builds: [0], [4] = entry and exit, [1..3] = clocks spent writing records / in cheap rounds / in dense rounds, [5] = chunks)
     const Box myb = quad_box(mine);
     const int mybw = myb.x1 - myb.x0, mybh = myb.y1 - myb.y0;
     const int myn = (valid && !myb.empty()) ? mybw * mybh : 0;
@@ -408,30 +430,27 @@ struct Frame {
     }
     SF_DS_STAMP(0);
     while (live) {
-      // this chunk: the lowest kChunk strokes still to draw
+      // this chunk: the lowest kChunk strokes still to draw -- fewer if their box pixels would start beyond what the map of
+      // starts below holds (never with this game's strokes: 8 boxes of at most 10 x 10)
       const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u));
-      const bool own = ((live >> lane) & 1ull) && rank < kChunk;
+      const bool cand = ((live >> lane) & 1ull) && rank < kChunk;
+      // where each stroke's box pixels start in the chunk's enumeration: an exclusive prefix sum over the owners, in lane
+      // (= rank) order -- six DPP adds across the wave instead of a scalar loop of readlanes with their wait states
+      int incl = cand ? myn : 0;
+      const int mine_n = incl;
+      incl = wave_inclusive_sum(incl);
+      const int myoff = incl - mine_n;
+      const bool own = cand && myoff <= kMapBits;
       const unsigned long long chunk = __ballot(own);
       live &= ~chunk;
-      // where each stroke's box pixels start in the chunk's enumeration: an exclusive prefix sum over the owners, in lane
-      // (= rank) order -- six DPP adds across the wave instead of a scalar loop of readlanes with their wait states -- and
-      // the starts of strokes 1 .. kChunk-1 in LDS for the pixels' lanes to find their stroke by
-      int incl = own ? myn : 0;
-      const int mine_n = incl;
-#define SF_SCAN_STEP(ctrl, rmask) incl += __builtin_amdgcn_update_dpp(0, incl, (ctrl), (rmask), 0xf, false)
-      SF_SCAN_STEP(0x111, 0xf);  // row_shr:1
-      SF_SCAN_STEP(0x112, 0xf);  // row_shr:2
-      SF_SCAN_STEP(0x114, 0xf);  // row_shr:4
-      SF_SCAN_STEP(0x118, 0xf);  // row_shr:8
-      SF_SCAN_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-      SF_SCAN_STEP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
-#undef SF_SCAN_STEP
-      const int total = __builtin_amdgcn_readlane(incl, 63);
-      int* const otab = reinterpret_cast<int*>(srec + kChunk * kRecFloats);
-      if (lane < kChunk) otab[lane] = 0x7fffffff;  // (a chunk with fewer strokes: no pixel is behind their start)
+      const int total = __builtin_amdgcn_readlane(incl, 63 - __builtin_clzll(chunk));
+      // ... and which stroke a box pixel belongs to: bit p - 1 of a map in LDS is set for every start p >= 1; pixel i of
+      // the enumeration then belongs to stroke #(set bits below i) -- per round of 64 pixels one 64-bit word of the map, a
+      // v_mbcnt pair and the running count, where a compare-and-add chain over the kChunk starts was fourteen instructions
+      uint32_t* const smap = reinterpret_cast<uint32_t*>(srec + kChunk * kRecFloats);
+      if (lane < kMapBits / 32) smap[lane] = 0u;
       if (own) {
-        const int myoff = incl - mine_n;
-        otab[rank] = myoff;
+        if (myoff > 0) atomicOr(&smap[(myoff - 1) >> 5], 1u << ((myoff - 1) & 31));
         const Slopes ms = quad_slopes(mine);
         float* g = srec + rank * kRecFloats;
 #pragma unroll
@@ -451,17 +470,15 @@ struct Frame {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       SF_DS_STAMP(1);
       int cnt = 0;
-      int off[kChunk];
-#pragma unroll
-      for (int r = 1; r < kChunk; r++) off[r] = otab[r];
+      int kb = 0;
       for (int base = 0; base < total; base += 64) {
         const int i = base + lane;
         bool touched = false;
         uint32_t ent = 0;
+        const uint2 mw = base < kMapBits ? *reinterpret_cast<const uint2*>(smap + (base >> 5)) : uint2{0u, 0u};  // (uniform)
+        const int k = kb + (int)__builtin_amdgcn_mbcnt_hi(mw.y, __builtin_amdgcn_mbcnt_lo(mw.x, 0u));
+        kb += __popc(mw.x) + __popc(mw.y);
         if (i < total) {
-          int k = 0;
-#pragma unroll
-          for (int r = 1; r < kChunk; r++) k += (i >= off[r]) ? 1 : 0;
           const float* g = srec + k * kRecFloats;
           const int* gi = reinterpret_cast<const int*>(g + 20);
           const int x0 = gi[0] & 255, y0 = gi[0] >> 8, w = gi[1], j = i - gi[2];
@@ -475,12 +492,15 @@ struct Frame {
         if (touched)
           slist[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tb, 0u))] = ent;
         cnt += (int)__popcll(tb);
-        if (cnt > kListCap - 64) {  // uniform: no room for another round's worth -- draw what is listed
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (cnt >= 64) {  // uniform: a full round's worth is listed -- draw exactly that, keep the rest for the next full round
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (drawing all of it was a second, nearly empty dense round)
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          flush_list(cnt);
-          cnt = 0;
+          flush_list(64);
+          cnt -= 64;
+          const uint32_t keep = lane < cnt ? slist[64 + lane] : 0u;
+          __builtin_amdgcn_wave_barrier();
+          if (lane < cnt) slist[lane] = keep;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -522,41 +542,35 @@ struct Frame {
       unsigned long long todo = __ballot(on > 0);
       while (todo) {
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo, 0u));
-        const bool own = ((todo >> lane) & 1ull) && rank < kChunk;
-        todo &= ~__ballot(own);
-        int incl = own ? on : 0;
+        const bool cand = ((todo >> lane) & 1ull) && rank < kChunk;
+        int incl = cand ? on : 0;
         const int mine_n = incl;
-#define SF_SCAN_STEP(ctrl, rmask) incl += __builtin_amdgcn_update_dpp(0, incl, (ctrl), (rmask), 0xf, false)
-        SF_SCAN_STEP(0x111, 0xf);
-        SF_SCAN_STEP(0x112, 0xf);
-        SF_SCAN_STEP(0x114, 0xf);
-        SF_SCAN_STEP(0x118, 0xf);
-        SF_SCAN_STEP(0x142, 0xa);
-        SF_SCAN_STEP(0x143, 0xc);
-#undef SF_SCAN_STEP
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        int* const otab = reinterpret_cast<int*>(srec + kChunk * kRecFloats);
+        incl = wave_inclusive_sum(incl);
+        const int myoff = incl - mine_n;
+        const bool own = cand && myoff <= kMapBitsOut;
+        const unsigned long long chunk = __ballot(own);
+        todo &= ~chunk;
+        const int total = __builtin_amdgcn_readlane(incl, 63 - __builtin_clzll(chunk));
         int* const orec = reinterpret_cast<int*>(srec);  // (the strokes' records are done with) per object: x0 | y0 << 8, w, start, 1 / w
-        if (lane < kChunk) otab[lane] = 0x7fffffff;
+        uint32_t* const omap = reinterpret_cast<uint32_t*>(srec + 4 * kChunk);
+        if (lane < kMapBitsOut / 32) omap[lane] = 0u;
         if (own) {
-          otab[rank] = incl - mine_n;
+          if (myoff > 0) atomicOr(&omap[(myoff - 1) >> 5], 1u << ((myoff - 1) & 31));
           orec[4 * rank] = o.x0 | (o.y0 << 8);
           orec[4 * rank + 1] = ow;
-          orec[4 * rank + 2] = incl - mine_n;
+          orec[4 * rank + 2] = myoff;
           reinterpret_cast<float*>(orec)[4 * rank + 3] = recip_i(ow);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int off[kChunk];
-#pragma unroll
-        for (int r = 1; r < kChunk; r++) off[r] = otab[r];
+        int kb = 0;
         for (int base = 0; base < total; base += 64) {
           const int i = base + lane;
+          const uint2 mw = base < kMapBitsOut ? *reinterpret_cast<const uint2*>(omap + (base >> 5)) : uint2{0u, 0u};
+          const int k = kb + (int)__builtin_amdgcn_mbcnt_hi(mw.y, __builtin_amdgcn_mbcnt_lo(mw.x, 0u));
+          kb += __popc(mw.x) + __popc(mw.y);
           if (i < total) {
-            int k = 0;
-#pragma unroll
-            for (int r = 1; r < kChunk; r++) k += (i >= off[r]) ? 1 : 0;
             const int4 rec = *reinterpret_cast<const int4*>(orec + 4 * k);
             const DivMod dm = fast_divmod(i - rec.z, rec.y, __int_as_float(rec.w));
             resample_px((rec.x & 255) + dm.r, (rec.x >> 8) + dm.q, obuf, SF_OUT, 0, 0);
@@ -1220,15 +1234,15 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
 #else
   const uint32_t* const tabw = a.tabs;  // 2.7 KB read by every wave: L1/L2 resident; LDS is better spent on waves
 #endif
-  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats + Frame<RESIZE>::kChunk];  // records, then the strokes' starts
+  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats + Frame<RESIZE>::kMapBits / 32];  // records, then the map of the strokes' starts
   __shared__ __attribute__((aligned(16))) uint32_t slist[Frame<RESIZE>::kListCap];
-  __shared__ __attribute__((aligned(16))) uint32_t ptab[(RESIZE && SF_PTAB) ? 4 * (kTapColPeriod + kTapRowPeriod) : 4];
+  __shared__ __attribute__((aligned(16))) uint32_t ptab[(RESIZE && SF_PTAB) ? 4 * (kTapColPeriod + kTapRowPeriod) : 1];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int lane = threadIdx.x;
 #ifdef SF_DBG_FLAGS
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
   unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_pa = 0, dbg_pb = 0, dbg_pc = 0, dbg_pd = 0, dbg_pe = 0, dbg_pf = 0, dbg_pg = 0;
-  unsigned long long dbg_ds[5] = {0, 0, 0, 0, 0};
+  unsigned long long dbg_ds[6] = {0, 0, 0, 0, 0, 0};
 #define SF_DBG_STAMP(v) do { asm volatile("" ::: "memory"); v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #else
 #define SF_DBG_STAMP(v)
@@ -1767,9 +1781,10 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     __builtin_memcpy(frame_out + 32, &pd, 4);
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      const unsigned v = (unsigned)(dbg_ds[k] - dbg_t0);
+      const unsigned v = (k == 0 || k == 4) ? (unsigned)(dbg_ds[k] - dbg_t0) : (unsigned)dbg_ds[k];
       __builtin_memcpy(frame_out + 36 + 4 * k, &v, 4);
     }
+    frame_out[2] = (uint8_t)dbg_ds[5];
     const unsigned pe = (unsigned)(dbg_pe - dbg_t0), pf = (unsigned)(dbg_pf - dbg_t0), pg = (unsigned)(dbg_pg - dbg_t0);
     __builtin_memcpy(frame_out + 56, &pe, 4);
     __builtin_memcpy(frame_out + 60, &pf, 4);

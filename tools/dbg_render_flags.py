@@ -25,7 +25,12 @@ print("prologue stamps (clocks from wave start): state decoded %.0f | mtab+shell
 
 D = raw[:, 36:56].copy().view(np.uint32).astype(np.float64)
 ok = (D < 1e6).all(1) & (D[:, 4] > 0)
-print("draw_strokes (main call, frames that drew: %d): entry(after setup) %.0f | records written %.0f | cheap rounds done %.0f | list drawn %.0f | resampled %.0f   (barrier passed %.0f)" % ((ok.sum(),) + tuple(D[ok].mean(0)) + (T[ok,1].mean(),)))
+nch = raw[:, 2]
+for c in sorted(set(nch[ok].tolist())):
+    m = ok & (nch == c)
+    d = D[m].mean(0)
+    print("draw_strokes, main call, %d chunk(s): n=%5d  entry %.0f | writing records %.0f | cheap rounds %.0f | dense rounds %.0f | resample %.0f | exit %.0f  (barrier passed %.0f, wave life %.0f)"
+          % (c, m.sum(), d[0], d[1], d[2], d[3], d[4] - d[0] - d[1] - d[2] - d[3], d[4], T[m, 1].mean(), T[m, 0].mean()))
 
 E = raw[:, 56:68].copy().view(np.uint32).astype(np.float64)
 print("prologue, finer: state decoded %.0f | round trip 2 issued (DMA last) %.0f | pool filed, missiles' segments %.0f | shells done %.0f | background stored %.0f | strokes built+tests %.0f | barrier %.0f"
