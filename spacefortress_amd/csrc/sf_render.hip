@@ -39,6 +39,9 @@
 // diagnostic builds only: the frame kernel returns behind phase N (1 the prologue up to the barrier, 2 the restored
 // pictures, 3 the fresh explosions, 4 the strokes of ship / fortress / missiles, 5 the shells) -- instruction counts of the
 // phases by difference (tools/pmc_render_variants.sh)
+#ifndef SF_MERGE_SHELLS
+#define SF_MERGE_SHELLS 1
+#endif
 #ifndef SF_RENDER_STOP
 #define SF_RENDER_STOP 0
 #endif
@@ -1328,8 +1331,16 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   }
   // shells: lane 4 s + k will draw stroke k of slot s (slots 0 .. 15; the last four slots -- seventeen live shells -- have a
   // late round of their own): position and velocity of its slot
-  d2_t shell_p = R_LD(d2_t, R_CHUNK(shell_pos, lane >> 2), o16);
-  d2_t shell_v = R_LD(d2_t, R_CHUNK(shell_vel, lane >> 2), o16);
+  // ... unless the top lanes of the missiles' range are free for them (1 + highest live slot <= 8, the missile slots whose
+  // lanes those are empty -- nearly always): then the shells' strokes sit there, behind the missiles' as in the draw order,
+  // and go through draw_strokes with everything else instead of a call, a chunk, a resample pass of their own
+  constexpr int kFirstMissileLane = 7;  // lanes 0 .. 2: the ship's strokes, 3 .. 6: the fortress's, 7 ..: three per missile slot
+  const int sh_hi = smask ? 32 - __builtin_clz(smask) : 0;  // 1 + highest live slot
+  const int sh_base = 64 - 4 * sh_hi;
+  const bool merge_shells = SF_MERGE_SHELLS && smask != 0u && sh_hi <= 8 && (mmask >> ((sh_base - kFirstMissileLane) / 3)) == 0u;
+  const int shl = merge_shells ? lane - sh_base : lane;  // 4 * slot + stroke, negative = not a shell's lane
+  d2_t shell_p = R_LD(d2_t, R_CHUNK(shell_pos, max(shl, 0) >> 2), o16);
+  d2_t shell_v = R_LD(d2_t, R_CHUNK(shell_vel, max(shl, 0) >> 2), o16);
 
   // what was drawn before the fortress: the ship (within 25.5 + 1.5 user units of its position) or its explosion
   Box sb = explosion_box(ship_x, ship_y);
@@ -1436,7 +1447,6 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   SF_DBG_STAMP(dbg_pb);
 
   // ---- projectile strokes: one lane per wireframe segment (missiles: slot*3 + k; shells: two rounds of slot*4 + k)
-  constexpr int kFirstMissileLane = 7;
   static_assert(kFirstMissileLane + 3 * 19 == 64, "slots 0 .. 18 fill the wave behind the ship's and the fortress's strokes");
   Seg mg = {};
   float m19x = 0.f, m19y = 0.f, m19a = 0.f;
@@ -1514,7 +1524,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     const Box tb3{SF_TXT_BOX_X0 - kReachX, SF_TXT_BOX_Y0 - kReachY, SF_TXT_BOX_X1 + kReachX, SF_TXT_BOX_Y1 + kReachY};
     const Box bb3{SF_BAR_BOX_X0 - kReachX, SF_BAR_BOX_Y0 - kReachY, SF_BAR_BOX_X1 + kReachX, SF_BAR_BOX_Y1 + kReachY};
     asm volatile("" : "+v"(shell_p.x), "+v"(shell_p.y), "+v"(shell_v.x), "+v"(shell_v.y));
-    sq0_valid = shell_quad(shell_p, shell_v, lane & 3, (smask >> (lane >> 2)) & 1u, &sq0);
+    sq0_valid = shell_quad(shell_p, shell_v, lane & 3, shl >= 0 && ((smask >> (shl >> 2)) & 1u), &sq0);
     if (sq0_valid) {
       const Box shb = quad_box(sq0);
       sh_t = shb.meets(tb0);
@@ -1577,6 +1587,13 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const int sobj = lane < 3 ? 0 : (lane < kFirstMissileLane ? 3 : kFirstMissileLane + 3 * ((lane - kFirstMissileLane) / 3));
   Quad mq = {};
   if (svalid) mq = line_quad(mg);
+  bool dvalid = svalid;  // what draw_strokes is given: with the shells' strokes in the top lanes when they fit there
+  int dobj = sobj;
+  if (merge_shells && shl >= 0) {
+    mq = sq0;
+    dvalid = sq0_valid;
+    dobj = lane & ~3;
+  }
 
   // ---- background variant.  The score and the bar are drawn LAST (SRC/draw.cpp:266-268); when they
   // show 0000000 / an empty bar and nothing drawn before them reaches their pixels, the result is the
@@ -1675,14 +1692,14 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // ---- the live ship, the fortress in place, the missiles (:233-247): all their strokes at once
   if (!fort_explodes_in_place) {
 #ifdef SF_DBG_FLAGS
-    F.draw_strokes(mq, svalid, sobj, dbg_ds);
+    F.draw_strokes(mq, dvalid, dobj, dbg_ds);
 #else
-    F.draw_strokes(mq, svalid, sobj);
+    F.draw_strokes(mq, dvalid, dobj);
 #endif
   } else {  // (rare: the ship, or its explosion, next to an exploding fortress)
-    F.draw_strokes(mq, svalid && lane < 3, sobj);
+    F.draw_strokes(mq, dvalid && lane < 3, dobj);
     draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);
-    F.draw_strokes(mq, svalid && lane >= kFirstMissileLane, sobj);
+    F.draw_strokes(mq, dvalid && lane >= kFirstMissileLane, dobj);
   }
   if (mmask >> 19) {  // (the twentieth missile)
     float s19, c19;
@@ -1694,7 +1711,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   dbg_t2 = __builtin_amdgcn_s_memtime();
 #endif
   // ---- shells (:248-253): slot order
-  if (smask) {
+  if (smask && !merge_shells) {
     F.draw_strokes(sq0, sq0_valid, lane & ~3);
     if (smask >> 16) {  // (slots 16 .. 19)
       const int slot = 16 + (lane >> 2);
