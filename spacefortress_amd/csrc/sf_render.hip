@@ -1758,6 +1758,9 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       }
     }
   }
+#ifdef SF_DBG_FLAGS
+  const unsigned long long dbg_h1 = __builtin_amdgcn_s_memtime();
+#endif
   if (!baked_bar && !(SF_RENDER_SKIP & 8)) {
     constexpr unsigned kBits = RESIZE ? 48u : 16u;
     const int state = bstate;
@@ -1802,6 +1805,9 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       __builtin_memcpy(frame_out + 36 + 4 * k, &v, 4);
     }
     frame_out[2] = (uint8_t)dbg_ds[5];
+    const unsigned h1 = (unsigned)(dbg_h1 - dbg_t0);
+    __builtin_memcpy(frame_out + 68, &h1, 4);
+    frame_out[3] = (uint8_t)((close_text ? 1 : 0) | (close_bar ? 2 : 0) | (score_pre ? 4 : 0) | (bar_pre ? 8 : 0) | (merge_shells ? 16 : 0));
     const unsigned pe = (unsigned)(dbg_pe - dbg_t0), pf = (unsigned)(dbg_pf - dbg_t0), pg = (unsigned)(dbg_pg - dbg_t0);
     __builtin_memcpy(frame_out + 56, &pe, 4);
     __builtin_memcpy(frame_out + 60, &pf, 4);

@@ -6,7 +6,7 @@ env = SFVecEnv(n, gametype="youturn", obs_type="image", spawn_stride=1, reuse_bu
 env.reset()
 acts = torch.randint(0, env.n_actions, (64, n), device=env.device, dtype=torch.uint8)
 for t in range(400): o,_,_,_ = env.step_tensors(acts[t % 64])
-raw = o.reshape(n, -1)[:, :68].cpu().numpy()
+raw = o.reshape(n, -1)[:, :72].cpu().numpy()
 f = raw[:, :2]
 T = raw[:, 4:20].copy().view(np.uint32).astype(np.float64)  # wave life, to barrier, to after strokes, to after shells
 names0 = ["baked_text","baked_bar","near_text","near_bar","close_text","close_bar","ship_alive","explosion_done"]
@@ -35,3 +35,10 @@ for c in sorted(set(nch[ok].tolist())):
 E = raw[:, 56:68].copy().view(np.uint32).astype(np.float64)
 print("prologue, finer: state decoded %.0f | round trip 2 issued (DMA last) %.0f | pool filed, missiles' segments %.0f | shells done %.0f | background stored %.0f | strokes built+tests %.0f | barrier %.0f"
       % (P[:,0].mean(), P[:,1].mean(), E[:,0].mean(), E[:,1].mean(), E[:,2].mean(), P[:,2].mean(), T[:,1].mean()))
+
+H = raw[:, 68:72].copy().view(np.uint32).astype(np.float64)[:, 0]
+f3 = raw[:, 3]
+for nm, m in (("text not baked", (f[:,0]&1)==0), ("text baked, bar not", ((f[:,0]&1)==1) & (((f[:,0]>>1)&1)==0)), ("both baked", (f[:,0]&3)==3)):
+    print("%-20s n=%5d: shells done %.0f | score block done %.0f | end %.0f   close_text %.2f close_bar %.2f score_pre %.2f bar_pre %.2f" % (
+        nm, m.sum(), T[m,3].mean(), H[m].mean(), T[m,0].mean(), (f3[m]&1).mean(), ((f3[m]>>1)&1).mean(), ((f3[m]>>2)&1).mean(), ((f3[m]>>3)&1).mean()))
+print("shells merged into the main call: %.3f of the frames with shells" % (((f3>>4)&1)[((f[:,1]>>3)&1)==1].mean()))
