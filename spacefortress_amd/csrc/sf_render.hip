@@ -1288,8 +1288,15 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const i4_t mi = R_LD(i4_t, R_CHUNK(misc, 0), o16);
   const i4_t sm = R_LD(i4_t, R_CHUNK(small, 0), o16);  // ship_angle, fort_angle (int16), .., flags (uint8 at byte 6): sf_layout.h
   // (a frame stack's done flag of this env: asked for here, read where the older slots are handled)
-  unsigned fin_b = 0;
-  if (RESIZE && a.stack_done) fin_b = a.stack_done[env];
+  // (through an index the compiler cannot see is the same in every lane: a byte it knows to be uniform it moves to a scalar
+  //  register at once -- v_readfirstlane behind a wait, i.e. a memory round trip in front of the state's loads, 7 % of the
+  //  step with a frame stack)
+  unsigned fin_v = 0;
+  if (RESIZE && a.stack_done) {
+    int idx = env;
+    asm volatile("" : "+v"(idx));
+    fin_v = a.stack_done[idx];
+  }
   if (recheck) {
     const unsigned long long w = a.hint[env >> 6];  // uniform: a scalar load, in flight beside the vector loads above
     if ((w >> (env & 63)) & 1ull)                    // a hinted env: one of the front workgroups may be drawing it
@@ -1548,6 +1555,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   if (RESIZE) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
   SF_DBG_STAMP(dbg_pg);
   // the frame stack's older slots (independent of the variant)
+  const unsigned fin_b = (RESIZE && a.stack_done) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fin_v) : 0u;
   const bool stack_traffic = RESIZE && (a.stack_prev || fin_b != 0);  // more loads / stores behind the seven: see the wait below
   if (RESIZE && a.stack_prev) {
     const bool fin = fin_b != 0;

@@ -11,7 +11,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 args = sys.argv[3:]
 hunter = "hunter" in args  # a firing pattern that destroys the fortress every few seconds (tools/soak.py), autoturn game
 args = [a for a in args if a != "hunter"]
-for mode in (args or ["image", "image-raw"]):
+for mode in ([a for a in args if a != "stack"] or ([] if args else ["image", "image-raw"])):
     env = SFVecEnv(n, gametype="autoturn" if hunter else "youturn", obs_type=mode, spawn_stride=1, reuse_buffers=True)
     env.reset()
     acts = torch.randint(0, env.n_actions, (64, n), device=env.device, dtype=torch.uint8)
@@ -42,4 +42,24 @@ for mode in (args or ["image", "image-raw"]):
     ms_r = e0.elapsed_time(e1) / steps
     print(("hunter " if hunter else "") + "%s n=%d: step+render %.1f us (%.3g frames/s), render alone %.1f us, output %.2f GB/s" %
           (mode, n, ms * 1e3, n / ms * 1e3, ms_r * 1e3, out.numel() / ms_r / 1e6))
+    env.close()
+
+if "stack" in sys.argv[3:] or not sys.argv[3:]:
+    # BASELINE configs[4] as bench.py times it: the 4-frame ring, sf_step + sf_render_stack per step
+    from spacefortress_amd import FrameStack
+    env = SFVecEnv(n, gametype="youturn", obs_type="image", spawn_stride=1, reuse_buffers=True)
+    st = FrameStack(env, 4)
+    st.reset()
+    acts = torch.randint(0, env.n_actions, (64, n), device=env.device, dtype=torch.uint8)
+    for t in range(400):
+        st.step(acts[t % 64])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for t in range(steps):
+        st.step(acts[t % 64])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    print("stack n=%d: step+render into the 4-frame ring %.1f us (%.3g frames/s)" % (n, ms * 1e3, n / ms * 1e3))
     env.close()
