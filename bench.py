@@ -543,8 +543,8 @@ def main():
                                   "note": "SURVEY 8(d)'s 7 448 B per env-step over the whole step (sf_step + sf_render_stack); "
                                           "the render kernel is issue-bound, not memory-bound (DESIGN.md 10)"},
                      "note": "BASELINE configs[4]: youturn image obs, 84x84 grey raster + 4-frame stack (device ring "
-                             "[N,4,84,84], one new frame per env and step), sf_step + sf_frame_stack_clear + sf_render "
-                             "per step; one wave per env rasterises the 90x92 frame in LDS (INTER_AREA to 84x84); HIP "
+                             "[N,4,84,84], one new frame per env and step, finished envs' older slots zeroed by the same launch), "
+                             "sf_step + sf_render_stack per step; one wave per env rasterises the 90x92 frame in LDS (INTER_AREA to 84x84); HIP "
                              "events; pixel model pinned to the numpy restatement, not to cairo/cv2 (DESIGN.md 10)"}
         ienv.close()
     configs = None
