@@ -200,6 +200,8 @@ __device__ __forceinline__ Box explosion_box(float cx, float cy) {
 // destination pixels that read `b` read nothing further than this outside it.  A picture saved with its 84x84 part is
 // good where nothing else is drawn within that reach of its box (kReachX, kReachY).
 constexpr int kReachX = 1, kReachY = 2;
+// a box that meets the score's or the bar's box, wider by the reach or not, has y0 < kHudTopRows or y1 > kHudBottomRows
+constexpr int kHudTopRows = SF_TXT_BOX_Y1 + kReachY, kHudBottomRows = SF_BAR_BOX_Y0 - kReachY;
 constexpr int kTapColPeriod = 14, kTapRowPeriod = 21;  // destination columns / rows after which the INTER_AREA taps repeat
 __device__ __forceinline__ Box out_box(const Box& b) {
   Box o;
@@ -368,8 +370,12 @@ struct Frame {
 #endif
   static constexpr int kChunk = SF_CHUNK, kListCap = SF_LISTCAP;
   static_assert(kListCap >= 127, "a round appends up to 64 entries behind the 63 kept");
-  static constexpr int kMapBits = 512;      // the map of the strokes' starts (behind the records): 8 boxes of 8 x 8
-  static constexpr int kMapBitsOut = 1024;  // ... and of the objects' 84x84 boxes (in the records' space, behind the objects' own)
+#ifndef SF_MAPBITS  /* (tests: tiny maps -- 64 / 128 -- send every frame through the "chunk ends where the map ends" path) */
+#define SF_MAPBITS 512
+#define SF_MAPBITS_OUT 1024
+#endif
+  static constexpr int kMapBits = SF_MAPBITS;      // the map of the strokes' starts (behind the records): 12 boxes of 6 x 7
+  static constexpr int kMapBitsOut = SF_MAPBITS_OUT;  // ... and of the objects' 84x84 boxes (in the records' space, behind the objects' own)
   static_assert(4 * kChunk + kMapBitsOut / 32 <= kChunk * 24, "the resample pass's records and map fit in the strokes' records");
   static constexpr int kRecFloats = 24;  // [0,12) quad x, y, slopes; [12,20) nx, ny, cn, hn, ux, uy, cu, hu; [20,23) x0 | y0 << 8, w, offset (ints); [23] 1 / w
   __device__ __forceinline__ void flush_list(int cnt) const {
@@ -1237,7 +1243,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
 #else
   const uint32_t* const tabw = a.tabs;  // 2.7 KB read by every wave: L1/L2 resident; LDS is better spent on waves
 #endif
-  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats + Frame<RESIZE>::kMapBits / 32];  // records, then the map of the strokes' starts
+  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats + (Frame<RESIZE>::kMapBits + 63) / 64 * 2];  // records, then the map of the strokes' starts
   __shared__ __attribute__((aligned(16))) uint32_t slist[Frame<RESIZE>::kListCap];
   __shared__ __attribute__((aligned(16))) uint32_t ptab[(RESIZE && SF_PTAB) ? 4 * (kTapColPeriod + kTapRowPeriod) : 1];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
@@ -1534,10 +1540,12 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     sq0_valid = shell_quad(shell_p, shell_v, lane & 3, shl >= 0 && ((smask >> (shl >> 2)) & 1u), &sq0);
     if (sq0_valid) {
       const Box shb = quad_box(sq0);
-      sh_t = shb.meets(tb0);
-      sh_b = shb.meets(bb0);
-      sh_t3 = shb.meets(tb3);
-      sh_b3 = shb.meets(bb3);
+      if (shb.y0 < kHudTopRows || shb.y1 > kHudBottomRows) {  // (in the rows of the score or of the bar, reach included: all but never)
+        sh_t = shb.meets(tb0);
+        sh_b = shb.meets(bb0);
+        sh_t3 = shb.meets(tb3);
+        sh_b3 = shb.meets(bb3);
+      }
     }
     if ((smask >> 16) && lane < 4 && ((smask >> (16 + lane)) & 1u)) {  // (slots 16 .. 19: within 16 + 1.5 user units of the position)
       const d2_t sp1 = R_LD(d2_t, R_CHUNK(shell_pos, 16 + lane), o16);
@@ -1627,21 +1635,33 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       t3 = qb.meets(tbox3);
       b3 = qb.meets(bbox3);
     }
+    // a missile's stroke in the rows of the score or of the bar (their reach included): the four box tests only then -- a
+    // frame in a few hundred; they were seventy instructions of every frame
+    bool rows = false;
+    Box qb;
+    qb.clear();
     if (mvalid) {
-      const Box qb = quad_box(mq);
-      t = t || qb.meets(tbox);
-      b = b || qb.meets(bbox);
-      t3 = t3 || qb.meets(tbox3);
-      b3 = b3 || qb.meets(bbox3);
+      qb = quad_box(mq);
+      rows = qb.y0 < kHudTopRows || qb.y1 > kHudBottomRows;
+    }
+    if (__any(rows)) {
+      if (rows) {
+        t = t || qb.meets(tbox);
+        b = b || qb.meets(bbox);
+        t3 = t3 || qb.meets(tbox3);
+        b3 = b3 || qb.meets(bbox3);
+      }
     }
     t = t || sh_t;
     b = b || sh_b;
     t3 = t3 || sh_t3;
     b3 = b3 || sh_b3;
-    near_text = near_text || __any(t);
-    near_bar = near_bar || __any(b);
-    other_text = other_text || __any(t3);
-    other_bar = other_bar || __any(b3);
+    if (__any(t || b || t3 || b3)) {
+      near_text = near_text || __any(t);
+      near_bar = near_bar || __any(b);
+      other_text = other_text || __any(t3);
+      other_bar = other_bar || __any(b3);
+    }
   }
   SF_DBG_STAMP(dbg_pc);
   const bool close_text = ex_text || other_text, close_bar = ex_bar || other_bar;

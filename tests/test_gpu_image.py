@@ -469,3 +469,24 @@ def test_config5_at_its_size_against_the_model(sfa, oracle_mod, model):
             frames_close(got[j, k], hist[k][j], ("slot", k, "lane", int(pick[j])))
     assert not bool(done.any())
     env.close()
+
+
+@pytest.mark.gpu
+def test_frames_reproduce_the_fingerprints_of_round_2s_kernel(sfa):
+    """tests/golden/render_fingerprints_youturn_1024x640_hunter.txt holds a 63-bit weighted sum of every byte of every frame
+    (84x84 each step, the raw 90x92 every eighth) of 1 024 envs over 640 steps of the fortress-hunting policy -- ships
+    exploding, missiles, shells, the fortress destroyed, scores and every state of the bar --, made by tools/render_hash.py
+    under ROUND 2's render kernel (the one the tests above and 460 M soaked frames pinned to the pixel model), before round 3
+    rebuilt the kernel.  Any later kernel has to reproduce every sum: a single changed byte in 655 360 frames shows."""
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from render_hash import fingerprints
+
+    want = open(os.path.join(GOLDEN, "render_fingerprints_youturn_1024x640_hunter.txt")).read().split("\n")[:-1]
+    got = fingerprints("youturn", 1024, 640, "hunter")
+    assert len(got) == len(want) == 640
+    bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+    assert not bad, "frames differ from round 2's at steps %s ..." % bad[:5]
