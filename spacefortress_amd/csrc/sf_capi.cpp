@@ -250,9 +250,10 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
         return SF_ERR_ARG;
       }
     }
-    HIP_TRY_FREE(hipMalloc((void**)&b->d_bg84, bg84.size()));
+    // (room for the backgrounds with the fortress in them, filled by the first frame: sf_launch_fort_patches)
+    HIP_TRY_FREE(hipMalloc((void**)&b->d_bg84, (size_t)SF_BG_COUNT * SF_OUT * SF_OUT));
     HIP_TRY_FREE(hipMemcpy(b->d_bg84, bg84.data(), bg84.size(), hipMemcpyHostToDevice));
-    HIP_TRY_FREE(hipMalloc((void**)&b->d_bg, bg.size()));
+    HIP_TRY_FREE(hipMalloc((void**)&b->d_bg, (size_t)SF_BG_COUNT * SF_BG_STRIDE));
     HIP_TRY_FREE(hipMalloc((void**)&b->d_tabs, tabs.size() * sizeof(uint32_t)));
     HIP_TRY_FREE(hipMemcpy(b->d_bg, bg.data(), bg.size(), hipMemcpyHostToDevice));
     HIP_TRY_FREE(hipMemcpy(b->d_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

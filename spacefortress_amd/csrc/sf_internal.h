@@ -36,7 +36,8 @@ hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32
 // the score / bar pictures (SF_HUD_BYTES, sf_raster.h)
 hipError_t sf_launch_hud_pictures(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* hud,
                                   hipStream_t stream);
-hipError_t sf_launch_fort_patches(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
+// ... and the 36 x 4 backgrounds with the fortress in them, behind the four plain ones (SF_BG_COUNT, sf_raster.h)
+hipError_t sf_launch_fort_patches(uint32_t* bg, uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
                                   hipStream_t stream);
 
 // sf_normalize.hip: reduce + apply (two launches); partials = SF_NORM_GROUPS x 2 (dim + 1) doubles; stats is the

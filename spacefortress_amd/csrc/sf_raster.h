@@ -42,6 +42,9 @@
 // Device copies of the static background: variant v (bit 0: score 0000000 baked in, bit 1: empty bar
 // baked in) at byte offset v * SF_BG_STRIDE (92x90) and v * 84*84 (resampled)
 #define SF_BG_STRIDE 8288
+// backgrounds on the device: the four variants, then the same four with the live fortress at 0, 10, ... 350 degrees in them
+// (sf_bg_fort_kernel: index 4 (1 + sector) + variant)
+#define SF_BG_COUNT (4 * 37)
 // per-env cache of the dead ship's explosion pixels (sf_render.hip: ship_explosion)
 // ... followed by the score box and the bar box as they end up when only that explosion is on them (keyed by the points /
 // the bar's state): SF_XC_BYTES = 1600 + 320 + 384

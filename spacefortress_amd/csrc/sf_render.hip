@@ -39,6 +39,9 @@
 // diagnostic builds only: the frame kernel returns behind phase N (1 the prologue up to the barrier, 2 the restored
 // pictures, 3 the fresh explosions, 4 the strokes of ship / fortress / missiles, 5 the shells) -- instruction counts of the
 // phases by difference (tools/pmc_render_variants.sh)
+#ifndef SF_BG_FORT
+#define SF_BG_FORT 1
+#endif
 #ifndef SF_MERGE_SHELLS
 #define SF_MERGE_SHELLS 1
 #endif
@@ -1441,14 +1444,17 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // ... and the 84x84 background's seven pieces, for the variant the score, the bar and the dead ship's explosion call for
   // (nearly always the final one: a projectile over the score or the bar starts again below)
   Pieces frame0 = {};
-  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant0 * (kOutBytes / 4)), kOutBytes / 16, lane);
+  // ... with the live fortress's picture already in it when that picture is good (fort_pic): backgrounds 4 (1 + sector) + variant
+  // (sf_bg_fort_kernel; SF_BG_FORT = 0: the picture is fetched here and put in behind the barrier, as until round 3)
+  const int bgsel = (SF_BG_FORT && fort_pic) ? 4 * (1 + sector) : 0;
+  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + (bgsel + variant0) * (kOutBytes / 4)), kOutBytes / 16, lane);
   // (in front of them, for what is restored right behind the barrier or at the very end: the dead ship's cached
   //  explosion -- key and pixels together, the pixels used if the key matches --, the fortress's picture, the score's and
   //  the bar's: not needed before the surface is, so not held in registers through the arithmetic above)
   XcFetch xf = {};
   if (dead_ship && xc_mine) xf = xc_fetch<RESIZE>(xc_mine, lane);
   FortPic fpic = {};
-  if (fort_pic) fpic = fort_patch_fetch<RESIZE>(a.fpatch + sector * SF_FP_BYTES, lane);
+  if (!SF_BG_FORT && fort_pic) fpic = fort_patch_fetch<RESIZE>(a.fpatch + sector * SF_FP_BYTES, lane);
   HudWords hscore = {}, hbar = {};
   if (score_pre) hscore = hud_fetch<RESIZE>(hud_score_picture(a.hud, pnts), SF_HUD_SCORE_ROW, tbox, lane);
   if (bar_pre) hbar = hud_fetch<RESIZE>(hud_bar_picture(a.hud, bstate), SF_HUD_BAR_ROW, bbox, lane);
@@ -1456,7 +1462,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // compiler does not know of these ten, so every wait it counts out for something issued before them stays a wait for
   // that alone.  Nothing in the prologue depends on a load that depends on a load any more (the headings' sines are looked
   // up across lanes, sincos_lanes): state -> everything else -> the barrier, two round trips where round 2 had six.
-  if (!(SF_RENDER_SKIP & 4096)) start_surface(variant0);  // (bits 11, 12: timing-only, no background loads / no surface)
+  if (!(SF_RENDER_SKIP & 4096)) start_surface(bgsel + variant0);  // (bits 11, 12: timing-only, no background loads / no surface)
   SF_DBG_STAMP(dbg_pb);
 
   // ---- projectile strokes: one lane per wireframe segment (missiles: slot*3 + k; shells: two rounds of slot*4 + k)
@@ -1670,9 +1676,9 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const int variant = (baked_text ? 1 : 0) | (baked_bar ? 2 : 0);
   if (variant != variant0) {  // a projectile over the score or the bar (rare): start again from the right picture
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    start_surface(variant);
+    start_surface(bgsel + variant);
     if (RESIZE)
-      copy_pieces(reinterpret_cast<const uint4*>(a.bg84 + variant * (kOutBytes / 4)), reinterpret_cast<uint4*>(frame_out),
+      copy_pieces(reinterpret_cast<const uint4*>(a.bg84 + (bgsel + variant) * (kOutBytes / 4)), reinterpret_cast<uint4*>(frame_out),
                   kOutBytes / 16, lane);
   }
   // The 84x84 background's seven stores are the LAST vector-memory instructions in front of this wait (but for a frame
@@ -1698,7 +1704,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   XcState xst{0u, 0, 0};
   bool explosion_done = false;
   if (dead_ship && xc_mine) explosion_done = xc_apply(F, xf, sp.x, sp.y, &xst);
-  if (fort_pic) fort_patch_put(F, fpic);
+  if (!SF_BG_FORT && fort_pic) fort_patch_put(F, fpic);
   if (SF_RENDER_STOP == 2) return;
 
   // ---- ship (SRC/draw.cpp:233-237): a dead ship's explosion that was not in the cache is the first thing drawn
@@ -1882,9 +1888,35 @@ __global__ __launch_bounds__(64) void sf_fort_patch_kernel(const uint32_t* bg, c
   fort_patch_copy(F, fpatch + sector * SF_FP_BYTES, true);
 }
 
-hipError_t sf_launch_fort_patches(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
+// The backgrounds with the live fortress in them: 36 headings x 4 variants behind the four plain ones (index 4 (1 + sector) +
+// variant, SF_BG_COUNT in all: 1.2 MB of surfaces, 1.0 MB of 84x84 images).  The fortress's picture is bytes of the surface
+// and of the 84x84 image (fort_patch_copy), the score and the bar are elsewhere: a frame whose fortress picture is good starts
+// from the background that already holds it -- the picture used to be three more loads in the prologue and three branchy
+// partial-word writes behind the barrier, 65 instructions of four frames in five.
+__global__ __launch_bounds__(256) void sf_bg_fort_kernel(uint32_t* bg, uint32_t* bg84, const unsigned char* fpatch) {
+  const int sector = blockIdx.x >> 2, v = blockIdx.x & 3, t = threadIdx.x;
+  const uint32_t* src = bg + v * (SF_BG_STRIDE / 4);
+  uint32_t* dst = bg + (4 * (1 + sector) + v) * (SF_BG_STRIDE / 4);
+  const uint32_t* src84 = bg84 + v * (kOutBytes / 4);
+  uint32_t* dst84 = bg84 + (4 * (1 + sector) + v) * (kOutBytes / 4);
+  for (int i = t; i < SF_BG_STRIDE / 4; i += 256) dst[i] = src[i];
+  for (int i = t; i < kOutBytes / 4; i += 256) dst84[i] = src84[i];
+  __syncthreads();
+  const unsigned char* gp = fpatch + sector * SF_FP_BYTES;
+  const Box b{kFpX0, kFpY0, kFpX1, kFpY1}, o = out_box(b);
+  uint8_t* d8 = reinterpret_cast<uint8_t*>(dst);
+  uint8_t* d84 = reinterpret_cast<uint8_t*>(dst84);
+  if (t < 256) d8[(kFpY0 + (t >> 4)) * SF_IMG_W + kFpX0 + (t & 15)] = gp[t];
+  const int ow = o.x1 - o.x0, oh = o.y1 - o.y0;
+  for (int i = t; i < kFpOutRow * oh; i += 256) {
+    const int r = i / kFpOutRow, c = i - r * kFpOutRow;
+    if (c < ow) d84[(o.y0 + r) * SF_OUT + o.x0 + c] = gp[kFpOutAt + i];
+  }
+}
+hipError_t sf_launch_fort_patches(uint32_t* bg, uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
                                   hipStream_t stream) {
   hipLaunchKernelGGL(sf_fort_patch_kernel, dim3(37), dim3(64), 0, stream, bg, bg84, tabs, fpatch);
+  hipLaunchKernelGGL(sf_bg_fort_kernel, dim3(36 * 4), dim3(256), 0, stream, bg, bg84, fpatch);
   return hipGetLastError();
 }
 
