@@ -42,3 +42,13 @@ print("step + render rotating slots (no done)             %.1f us" % timeit(a2))
 print("step + sf_render_stack rotating, done = zeros      %.1f us" % timeit(a3))
 print("step + sf_render_stack rotating, done of the step  %.1f us" % timeit(a4))
 print("step + sf_render_stack one slot, done of the step  %.1f us" % timeit(a5))
+ring2 = torch.empty((4, n, 1, 84, 84), dtype=torch.uint8, device=env.device)
+def b1(i): stp(i); env.render("image", out=ring2[i % 4])
+print("step + render rotating, SLOT-MAJOR ring [4][N]        %.1f us" % timeit(b1))
+print("render alone rotating, SLOT-MAJOR ring [4][N]         %.1f us" % timeit(lambda i: env.render("image", out=ring2[i % 4])))
+big = torch.empty((16, n, 1, 84, 84), dtype=torch.uint8, device=env.device)
+def b2(i): stp(i); env.render("image", out=big[i % 16])
+print("step + render rotating over 16 flat buffers (1.8 GB)  %.1f us" % timeit(b2))
+two = torch.empty((2, n, 1, 84, 84), dtype=torch.uint8, device=env.device)
+def b3(i): stp(i); env.render("image", out=two[i % 2])
+print("step + render rotating over 2 flat buffers (231 MB)   %.1f us" % timeit(b3))
