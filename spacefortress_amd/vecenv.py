@@ -97,10 +97,10 @@ class SFVecEnv:
         if self.reuse_buffers and self._bufs is not None:
             return self._bufs
         n = self.num_envs
+        # reward, done and info share one allocation (4 n + n + n bytes): the host API brings them over in ONE copy
+        rdi = torch.empty(6 * n, dtype=torch.uint8, device=self.device)
         bufs = (torch.empty((n,) + self.obs_shape, dtype=self.obs_dtype, device=self.device),
-                torch.empty(n, dtype=torch.int32, device=self.device),
-                torch.empty(n, dtype=torch.uint8, device=self.device),
-                torch.empty(n, dtype=torch.uint8, device=self.device))
+                rdi[:4 * n].view(torch.int32), rdi[4 * n:5 * n], rdi[5 * n:])
         if self.reuse_buffers:
             self._bufs = bufs
             self._buf_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in bufs)
@@ -224,6 +224,11 @@ class SFVecEnv:
         if not as_numpy:
             return obs, rew, done.view(torch.bool), info.view(torch.bool)  # 0 / 1 bytes: views, not kernels
         # np.stack of per-env python ints / bools, as the subprocess vec-env returns them
+        base, n = done._base, self.num_envs
+        if base is not None and info._base is base and base.numel() == 6 * n and rew.data_ptr() == base.data_ptr():
+            h = base.cpu().numpy()  # one transfer for the three small results (_alloc)
+            return (obs.cpu().numpy(), h[:4 * n].view(np.int32).astype(np.int64), h[4 * n:5 * n].astype(bool),
+                    h[5 * n:].astype(bool))
         return (obs.cpu().numpy(), rew.cpu().numpy().astype(np.int64), done.cpu().numpy().astype(bool),
                 info.cpu().numpy().astype(bool))
 
