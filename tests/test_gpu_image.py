@@ -490,3 +490,40 @@ def test_frames_reproduce_the_fingerprints_of_round_2s_kernel(sfa):
     assert len(got) == len(want) == 640
     bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
     assert not bad, "frames differ from round 2's at steps %s ..." % bad[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gametype,seed", [("youturn", 21), ("autoturn", 22)])
+def test_crowded_constructed_frames_vs_model(sfa, oracle_mod, model, monkeypatch, gametype, seed):
+    """Frames play never produces: up to 20 missiles and 20 shells anywhere on (and off) the screen, ships and explosions
+    anywhere, a dead or live fortress at any heading (test_gpu_parity._fuzz_base).  They take the render kernel's rare paths
+    -- the twentieth missile's own call, shells in slots 16..19, shells that do and do not fit the free top lanes of the
+    missiles' range, several chunks of strokes, a fortress drawn in place under a ship, projectiles over the score and the
+    bar (the restart from another background) -- against the numpy model, in both sizes; and with every shortcut switched
+    off (drawn in place, env order) the frames must be the same bytes."""
+    from test_gpu_parity import _fuzz_base, _load_both
+
+    R, hb, hs, bg = model
+    O = oracle_mod
+    n = 128
+    base, pv = _fuzz_base(O, gametype, n, np.random.default_rng(seed))
+    # a shell's heading is what its velocity says (set once, at launch: SRC/game.cpp:263); the device keeps the velocity only
+    ang = np.degrees(np.arctan2(base["shell_vy"], base["shell_vx"]))
+    base["shell_angle"] = np.where(ang < 0, ang + 360.0, ang)
+    env, orc = _load_both(sfa, O, gametype, base, prev_vlner=pv)
+    raw = env.render("image-raw").cpu().numpy()
+    small = env.render("image").cpu().numpy()
+    snaps = orc.snapshots()
+    assert (snaps["missile_alive"][:, 19] == 1).any() and (snaps["shell_alive"][:, 16:] == 1).any()
+    assert (snaps["missile_alive"].sum(1) >= 15).any() and (snaps["shell_alive"].sum(1) >= 15).any()
+    for i in range(n):
+        want = R.render_raw(snaps[i], hb, hs, bg=bg)
+        frames_close(raw[i], want, ("raw", gametype, i))
+        frames_close(small[i, 0], R.resize_area(want), ("84x84", gametype, i))
+    env.close()
+    monkeypatch.setenv("SFMI_NO_EXPLOSION_CACHE", "1")
+    monkeypatch.setenv("SFMI_NO_RENDER_ORDER", "1")
+    plain, _ = _load_both(sfa, O, gametype, base, prev_vlner=pv)
+    assert np.array_equal(plain.render("image-raw").cpu().numpy(), raw)
+    assert np.array_equal(plain.render("image").cpu().numpy(), small)
+    plain.close()
