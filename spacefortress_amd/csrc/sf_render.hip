@@ -42,6 +42,9 @@
 #ifndef SF_BG_FORT
 #define SF_BG_FORT 1
 #endif
+#ifndef SF_RESAMPLE_QUADS
+#define SF_RESAMPLE_QUADS 1
+#endif
 #ifndef SF_MERGE_SHELLS
 #define SF_MERGE_SHELLS 1
 #endif
@@ -244,7 +247,22 @@ struct Frame {
   // cv2.resize(..., INTER_AREA) restricted to the destination pixels that read source pixels of `b`
   // (OpenCV's resizeArea_ arithmetic: per source row buf = sum alpha * S, then sum += beta * buf in
   // table order, saturate_cast<uchar>).
-  __device__ __forceinline__ void resample(const Box& b) const { resample_into(b, obuf, SF_OUT, 0, 0); }
+  __device__ __forceinline__ void resample(const Box& b) const {
+    if (!SF_RESAMPLE_QUADS) {
+      resample_into(b, obuf, SF_OUT, 0, 0);
+      return;
+    }
+    if (!RESIZE || (SF_RENDER_SKIP & 16) || b.empty()) return;
+    // in groups of four pixels of a row (resample_quad): the box's columns widened to multiples of four
+    const Box o = out_box(b);
+    const int gx0 = o.x0 >> 2, gw = ((o.x1 + 3) >> 2) - gx0, n = gw * (o.y1 - o.y0);
+    const float r_gw = recip_i(gw);
+    for (int i = lane; i < n; i += 64) {
+      const DivMod dm = fast_divmod(i, gw, r_gw);
+      resample_quad(4 * (gx0 + dm.r), o.y0 + dm.q);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 
   // ... written to dst[(dy - y_off) * stride + (dx - x_off)]
   // one destination pixel (dx, dy) of the 84x84 image from the surface as it is (OpenCV's resizeArea_ arithmetic): the taps, then the sums
@@ -286,6 +304,36 @@ struct Frame {
   }
   __device__ __forceinline__ void resample_px(int dx, int dy, uint8_t* dst, int stride, int x_off, int y_off) const {
     resample_finish(taps_fetch(dx, dy), dx, dy, dst, stride, x_off, y_off);
+  }
+  // FOUR destination pixels (dx0 .. dx0 + 3, dx0 a multiple of 4, row dy) of the 84x84 image, one aligned 32-bit store: the
+  // per-pixel arithmetic of resample_px on the same operands -- every pixel the same byte -- at half the instructions a pixel:
+  // one row entry, three 8-byte reads of the surface (four destination columns read at most six source columns) instead of
+  // twelve 2-byte ones, one store instead of four.  A pixel beside an object's box that is swept along gets the value it has:
+  // the image is the resampled surface everywhere, at all times before the score's / bar's pictures go in.
+  __device__ __forceinline__ void resample_quad(int dx0, int dy) const {
+    const uint4* t4 = reinterpret_cast<const uint4*>(tab);
+    const uint4 tr = t4[(unsigned)(SF_OUT + dy)];
+    const uint4 c0 = t4[(unsigned)dx0], c1 = t4[(unsigned)dx0 + 1u], c2 = t4[(unsigned)dx0 + 2u], c3 = t4[(unsigned)dx0 + 3u];
+    const float b0 = __uint_as_float(tr.y), b1 = __uint_as_float(tr.z), b2 = __uint_as_float(tr.w);
+    const uint8_t* r0 = fb + (int)tr.x * SF_IMG_W + (int)c0.x;
+    unsigned long long w0, w1, w2;
+    __builtin_memcpy(&w0, r0, 8);
+    __builtin_memcpy(&w1, r0 + SF_IMG_W, 8);
+    __builtin_memcpy(&w2, r0 + 2 * SF_IMG_W, 8);
+    auto one = [&](const uint4& c) -> unsigned {
+      const unsigned sh = 8u * (c.x - c0.x);  // 0 .. 32: the pixel's two source columns are bytes sh / 8 and sh / 8 + 1
+      const unsigned p0 = (unsigned)(w0 >> sh), p1 = (unsigned)(w1 >> sh), p2 = (unsigned)(w2 >> sh);
+      const float a0 = __uint_as_float(c.y), a1 = __uint_as_float(c.z);
+      const float h0 = (float)(p0 & 255u) * a0 + (float)((p0 >> 8) & 255u) * a1;
+      const float h1 = (float)(p1 & 255u) * a0 + (float)((p1 >> 8) & 255u) * a1;
+      const float h2 = (float)(p2 & 255u) * a0 + (float)((p2 >> 8) & 255u) * a1;
+      const float sum = (b0 * h0 + b1 * h1) + b2 * h2;
+      int v = (int)rintf(sum);
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      return (unsigned)v;
+    };
+    const unsigned word = one(c0) | (one(c1) << 8) | (one(c2) << 16) | (one(c3) << 24);
+    *reinterpret_cast<uint32_t*>(obuf + (unsigned)(dy * SF_OUT + dx0)) = word;
   }
   __device__ __forceinline__ void resample_into(const Box& b, uint8_t* dst, int stride, int x_off, int y_off) const {
     if (!RESIZE || (SF_RENDER_SKIP & 16) || b.empty()) return;
@@ -549,7 +597,9 @@ struct Frame {
         }
       }
       const Box o = out_box(Box{ux0, uy0, ux1, uy1});
-      const int ow = o.x1 - o.x0;
+      // (SF_RESAMPLE_QUADS: the unit of the enumeration is four pixels of a row, at multiples of four: resample_quad)
+      const int ogx0 = SF_RESAMPLE_QUADS ? o.x0 >> 2 : o.x0;
+      const int ow = SF_RESAMPLE_QUADS ? ((o.x1 + 3) >> 2) - ogx0 : o.x1 - o.x0;
       const int on = (lane == obj0 && ux1 > ux0 && uy1 > uy0) ? ow * (o.y1 - o.y0) : 0;
       unsigned long long todo = __ballot(on > 0);
       while (todo) {
@@ -568,7 +618,7 @@ struct Frame {
         if (lane < kMapBitsOut / 32) omap[lane] = 0u;
         if (own) {
           if (myoff > 0) atomicOr(&omap[(myoff - 1) >> 5], 1u << ((myoff - 1) & 31));
-          orec[4 * rank] = o.x0 | (o.y0 << 8);
+          orec[4 * rank] = ogx0 | (o.y0 << 8);
           orec[4 * rank + 1] = ow;
           orec[4 * rank + 2] = myoff;
           reinterpret_cast<float*>(orec)[4 * rank + 3] = recip_i(ow);
@@ -585,7 +635,8 @@ struct Frame {
           if (i < total) {
             const int4 rec = *reinterpret_cast<const int4*>(orec + 4 * k);
             const DivMod dm = fast_divmod(i - rec.z, rec.y, __int_as_float(rec.w));
-            resample_px((rec.x & 255) + dm.r, (rec.x >> 8) + dm.q, obuf, SF_OUT, 0, 0);
+            if (SF_RESAMPLE_QUADS) resample_quad(4 * ((rec.x & 255) + dm.r), (rec.x >> 8) + dm.q);
+            else resample_px((rec.x & 255) + dm.r, (rec.x >> 8) + dm.q, obuf, SF_OUT, 0, 0);
           }
         }
         __builtin_amdgcn_wave_barrier();
