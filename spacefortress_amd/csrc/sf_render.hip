@@ -1053,16 +1053,22 @@ struct SfRenderArgs {
 // only WHEN a frame is drawn: any content of the words gives every env exactly one workgroup.
 // Order of the hinted envs: by (tile & 63), then tile >> 6, then lane of the tile.  Returns -1 for "nothing to draw".
 __device__ __forceinline__ int hinted_scan(const unsigned long long* hint, int n_tiles, int lane, int* mine) {
+  // (four words in flight per lane and trip -- 16 384 envs are four words a lane: one round trip, where a plain loop was
+  //  four, one behind the other --, and the scan by six DPP adds instead of six LDS permutes: every one of the n_front
+  //  workgroups comes through here, most of them to find nothing to draw)
   int c = 0;
-  for (int t = lane; t < n_tiles; t += 64) c += __popcll(hint[t]);
-  *mine = c;
-  int v = c;  // inclusive scan over the lanes
+  for (int t0 = 0; t0 < n_tiles; t0 += 256) {
+    unsigned long long w[4];
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int u = __shfl_up(v, d);
-    v += lane >= d ? u : 0;
+    for (int j = 0; j < 4; j++) {
+      const int t = t0 + 64 * j + lane;
+      w[j] = hint[t < n_tiles ? t : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) c += (t0 + 64 * j + lane < n_tiles) ? __popcll(w[j]) : 0;
   }
-  return v;
+  *mine = c;
+  return wave_inclusive_sum(c);  // inclusive scan over the lanes
 }
 
 __device__ __forceinline__ int pick_env(const SfRenderArgs& a, int p, int lane) {
