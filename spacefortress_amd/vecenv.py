@@ -152,18 +152,30 @@ class SFVecEnv:
             rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
             done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
             info = torch.empty((K, n), dtype=torch.uint8, device=self.device)
+        ev = self._rollout_events_begin(K)
+        try:
+            _lib.check(self._L.sf_rollout(self._h, C.c_void_p(actions.data_ptr()), at, int(K),
+                                          C.c_void_p(obs.data_ptr()) if obs is not None else None,
+                                          C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
+                                          C.c_void_p(info.data_ptr()), self._stream()))
+        finally:
+            self._rollout_events_end(ev)
+        return obs, rew, done, info
+
+    def _rollout_events_begin(self, K):
+        """A fused launch stores one row of event masks PER TICK (a.events[step * n_envs + i], sf_kernels.hip): with
+        events enabled it gets a [K, N] buffer of its own for the duration of the launch (`self.rollout_events`);
+        `self.events` holds one tick's row and would be overrun by K - 1 rows."""
         ev = None
-        if getattr(self, "events", None) is not None:  # the fused launch writes one row of event masks per tick
-            ev = torch.zeros((K, n), dtype=torch.int32, device=self.device)
+        if getattr(self, "events", None) is not None:
+            ev = torch.zeros((K, self.num_envs), dtype=torch.int32, device=self.device)
             _lib.check(self._L.sf_set_event_output(self._h, C.c_void_p(ev.data_ptr())))
         self.rollout_events = ev
-        _lib.check(self._L.sf_rollout(self._h, C.c_void_p(actions.data_ptr()), at, int(K),
-                                      C.c_void_p(obs.data_ptr()) if obs is not None else None,
-                                      C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
-                                      C.c_void_p(info.data_ptr()), self._stream()))
+        return ev
+
+    def _rollout_events_end(self, ev):
         if ev is not None:
             _lib.check(self._L.sf_set_event_output(self._h, C.c_void_p(self.events.data_ptr())))
-        return obs, rew, done, info
 
     def seed_actions(self, seed, first_lane=0):
         """Restart the on-device action sampler of `step_sampled` at tick 0 (sfmi.h: sf_seed_actions): lane i then plays
@@ -199,10 +211,14 @@ class SFVecEnv:
         done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
         info = torch.empty((K, n), dtype=torch.uint8, device=self.device)
         acts = torch.empty((K, n), dtype=torch.uint8, device=self.device) if want_actions else None
-        _lib.check(self._L.sf_rollout_sampled(self._h, K, C.c_void_p(acts.data_ptr()) if acts is not None else None,
-                                              C.c_void_p(obs.data_ptr()) if obs is not None else None,
-                                              C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
-                                              C.c_void_p(info.data_ptr()), self._stream()))
+        ev = self._rollout_events_begin(K)
+        try:
+            _lib.check(self._L.sf_rollout_sampled(self._h, K, C.c_void_p(acts.data_ptr()) if acts is not None else None,
+                                                  C.c_void_p(obs.data_ptr()) if obs is not None else None,
+                                                  C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
+                                                  C.c_void_p(info.data_ptr()), self._stream()))
+        finally:
+            self._rollout_events_end(ev)
         return obs, rew, done, info, acts
 
     def step_async(self, actions):

@@ -63,3 +63,36 @@ def test_event_masks_match_reference_event_strings(name):
         assert torch.equal(e2.rollout_events[k], ev3)
     for e in (env, e2, e3):
         e.close()
+
+
+@pytest.mark.gpu
+def test_sampled_rollout_with_events_enabled():
+    """enable_events() then rollout_sampled(K): the fused launch stores K rows of event masks, so it must get a [K, N]
+    buffer of its own (`rollout_events`) instead of overrunning the one-row `events` tensor; the rows equal what K
+    step_sampled() calls write, and a canary tensor allocated right behind `events` stays untouched."""
+    from spacefortress_amd import SFVecEnv
+
+    N, K = 256, 12
+    e1 = SFVecEnv(N, gametype="youturn", seed=3, spawn_stride=1)
+    e2 = SFVecEnv(N, gametype="youturn", seed=3, spawn_stride=1)
+    for e in (e1, e2):
+        e.reset()
+        e.seed_actions(99)
+    ev1 = e1.enable_events()
+    canary = torch.full((4 * K * N,), 0x5A5A5A5A, dtype=torch.int32, device=e1.device)
+    ev2 = e2.enable_events()
+    _, rew, done, info, acts = e1.rollout_sampled(K, want_obs=False)
+    torch.cuda.synchronize()
+    assert e1.rollout_events is not None and tuple(e1.rollout_events.shape) == (K, N)
+    assert bool((canary == 0x5A5A5A5A).all())
+    for k in range(K):
+        a = torch.empty(N, dtype=torch.uint8, device=e2.device)
+        _, r2, d2, i2 = e2.step_sampled(actions_out=a)
+        assert torch.equal(a, acts[k]) and torch.equal(r2, rew[k]) and torch.equal(d2, done[k]) and torch.equal(i2, info[k])
+        assert torch.equal(ev2, e1.rollout_events[k]), k
+    # the one-row buffer is back in place for the next single step
+    _, r1, _, _ = e1.step_sampled()
+    _, r2, _, _ = e2.step_sampled()
+    assert torch.equal(r1, r2) and torch.equal(ev1, ev2)
+    e1.close()
+    e2.close()

@@ -740,3 +740,63 @@ def test_full_size_properties(sfa, oracle_mod, gametype, n):
         snaps.append(out["snaps"][-1])
     bad = compare_state(sd, np.array(snaps), lanes=lanes)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("gametype", ["autoturn", "youturn"])
+def test_full_size_hunter_sample(sfa, oracle_mod, gametype):
+    """BASELINE.json's batch size under play that destroys the fortress (random actions never do): 65 536 lanes on the
+    hunter pattern (tests/sfscript.py), 192 lanes against the oracle step for step -- the lanes that scored a kill first,
+    random ones for the rest -- with every reward, info flag and observation compared and the final state bit-exact.
+    At least one kill must be in the sample, and the kills the wrapper reported (sum of info) must be the fortresses the
+    engines destroyed (stats row 5)."""
+    from sfscript import open_loop_actions
+
+    O = oracle_mod
+    n, T = 65536, 640
+    rng = np.random.default_rng(77 + len(gametype))
+    n_act = 5 if gametype == "youturn" else 3
+    acts = open_loop_actions("hunter", (T, n), n_act, rng, phase=rng.integers(0, 96, n))
+    a = torch.from_numpy(acts).cuda()
+    # pass 1: which lanes kill
+    env = sfa.SFVecEnv(n, gametype=gametype, spawn_stride=1)
+    env.reset()
+    kills = torch.zeros(n, dtype=torch.int32, device=env.device)
+    for t in range(T):
+        _, _, _, info = env.step_tensors(a[t])
+        kills += info
+    kills = kills.cpu().numpy()
+    sd = env.state_dict()
+    env.close()
+    assert int(kills.sum()) == int(sd["stats"][5].sum())  # no episode ends inside 640 steps: the counters are the run's
+    assert kills.sum() >= (1000 if gametype == "autoturn" else 1), kills.sum()
+    killers = np.flatnonzero(kills)
+    pick = killers[:96]
+    rest = np.setdiff1d(np.arange(n), pick)
+    lanes = np.sort(np.concatenate([pick, rng.choice(rest, 192 - len(pick), replace=False)]))
+    assert kills[lanes].sum() >= 1
+    # pass 2 (same seeds, same actions: the same games): the sampled lanes' outputs at every step
+    env = sfa.SFVecEnv(n, gametype=gametype, spawn_stride=1)
+    env.reset()
+    li = torch.from_numpy(lanes).to(env.device)
+    obs = torch.empty((T, len(lanes), env.obs_dim), dtype=torch.float32, device=env.device)
+    rew = torch.empty((T, len(lanes)), dtype=torch.int32, device=env.device)
+    inf = torch.empty((T, len(lanes)), dtype=torch.uint8, device=env.device)
+    for t in range(T):
+        o, r, _, i = env.step_tensors(a[t])
+        obs[t], rew[t], inf[t] = o[li], r[li], i[li]
+    obs, rew, inf = obs.cpu().numpy(), rew.cpu().numpy(), inf.cpu().numpy().astype(bool)
+    sd2 = env.state_dict()
+    env.close()
+    for k in sd:
+        assert np.array_equal(sd[k], sd2[k]), k
+    snaps = []
+    for j, lane in enumerate(lanes):
+        o = O.OracleEnv(gametype, spawn_skip=int(lane))
+        out = o.replay(acts[:, lane], want_obs=True)
+        assert np.array_equal(out["reward"], rew[:, j]), lane
+        assert np.array_equal(out["info"], inf[:, j]), lane
+        assert obs_close(obs[:, j], out["obs"], False).all(), lane
+        assert out["info"].sum() == kills[lane]
+        snaps.append(out["snaps"][-1])
+    bad = compare_state(sd, np.array(snaps), lanes=lanes)
+    assert not bad, bad

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden_names
+from sfscript import aimed_hunter_actions, open_loop_actions
 
 # extras are stale heap in the reference until the first tick (SRC/game.cpp:78, SURVEY 8a note 4)
 RESET_MASKED = ("vdir", "fdist", "ndist", "aim")
@@ -209,3 +210,41 @@ def test_oracle_vs_reference_live(oracle_mod, gametype):
     r = O.RefGame(gametype)
     assert o.rollout(500000, 11) == r.rollout(500000, 11)
     assert o.snapshot().tobytes() == r.snapshot().tobytes()
+
+
+@pytest.mark.parametrize("gametype", ["youturn", "autoturn", "test-youturn", "test-autoturn"])
+def test_oracle_vs_reference_live_kills(oracle_mod, gametype):
+    """The live check on the paths random play does not reach: the vlner state machine, destroy, the fortress's respawn,
+    shell and hexagon deaths -- 40 000 hunter + 40 000 charger steps per preset (7.5 episodes each, new Game at game over)
+    through the REAL engine (oracle/_ref) and through the C restatement, every snapshot field of every tick bit-identical,
+    wrapper rewards (ENV:233-244) included."""
+    O = oracle_mod
+    if not O.have_ref():
+        pytest.skip("oracle/_ref/libsfref.so not built here")
+    rng = np.random.default_rng(1000 + sum(map(ord, gametype)))
+    shaped = gametype in ("youturn", "autoturn")
+    T = 40000
+    for policy in ("hunter", "charger"):
+        o = O.OracleEnv(gametype, action_set=1)
+        r = O.RefGame(gametype)
+        keys = np.array(o.action_keys(), np.uint8)
+        if policy == "hunter":  # closed loop (nothing else aims the ship in a youturn game), played on a second oracle env
+            acts = aimed_hunter_actions(O.OracleEnv(gametype, action_set=1), T, rng)
+        else:
+            acts = open_loop_actions(policy, T, len(keys), rng, phase=int(rng.integers(0, 96)))
+        oo = o.replay(acts, want_obs=False, max_resets=16)
+        rr = r.replay(keys[acts])
+        assert not fields_differing(oo["snaps"], rr["snaps"]), (gametype, policy)
+        assert np.array_equal(oo["done"], rr["done"]) and oo["done"].sum() == T // 5295
+        assert np.array_equal(oo["reward"], shaped_reward(rr["eng_reward"], rr["snaps"]["vlner"], shaped))
+        st = rr["snaps"]["stats"]
+        ends = np.flatnonzero(rr["done"])
+        # per-episode counters (a new Game zeroes them): summed over the finished episodes, plus the running one
+        tot = st[ends].sum(axis=0) + st[-1]
+        if policy == "hunter":
+            # stats: 4 resets, 5 destroyed, 11 vlner increments, 12 max vlner (SRC/game.hh:29-43)
+            assert tot[5] >= 20 and tot[4] >= 20 and tot[11] >= 400 and st[:, 12].max() >= 11, (gametype, tot)
+            assert oo["info"].sum() == (np.asarray(rr["eng_reward"]) > 0).sum() >= 20
+        else:
+            # 0 big-hex, 1 small-hex, 2 shell deaths, 3 ship deaths (autoturn ships charge INTO the small hexagon)
+            assert tot[0] + tot[1] >= 100 and tot[0] >= 1 and tot[1] >= 1 and tot[2] >= 1 and tot[3] == tot[:3].sum(), (gametype, tot)
