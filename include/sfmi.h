@@ -368,6 +368,16 @@ int sf_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, 
  * batch without image observations. */
 int sf_set_render_order_hint(sf_batch* b, const uint64_t* words_host, int n_words);
 
+/* ---- diagnostics: the envs' DRAW RECORDS (spacefortress_amd/csrc/sf_drawrec.h), SF_DRAW_RECORD_BYTES per env: what the
+ *      frame kernel reads instead of the state -- a 32-byte header of finished decisions (which background, which cached
+ *      pictures apply) and 22 transforms (x, y, cos, sin as float32: ship, fortress, 20 missile slots).  The step launches
+ *      of an image batch leave them behind; any other change of the state marks them stale and the next frame rebuilds them
+ *      from the state.  from_state = 0: the records as they are (SF_ERR_ARG if the batch has none yet); 1: rebuilt from the
+ *      state into the batch's buffer first.  host: n_envs * SF_DRAW_RECORD_BYTES bytes.  Synchronous.  Tests compare the
+ *      two ways of making them byte for byte (live entries). ---- */
+#define SF_DRAW_RECORD_BYTES 384
+int sf_draw_records(sf_batch* b, void* host, size_t bytes, int from_state);
+
 const char* sf_last_error(void);
 int sf_version(void);
 /* hash of the sources and compiler flags this binary was built from (spacefortress_amd/build.py: source_hash) */

@@ -83,6 +83,7 @@ SYMBOLS = {
     "sf_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "sf_episode_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sf_calibration_copy": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
+    "sf_draw_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "sf_preset_get": (C.c_int, [C.c_char_p, C.POINTER(Preset)]),
     "sf_action_table": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p]),
     "sf_spawn_table": (C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
@@ -126,6 +127,8 @@ def lib():
                 "(there is no CPU fallback)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if not hasattr(L, name) and os.environ.get("SFMI_LIB_PATH"):
+                continue  # an older diagnostic build (A/B against an earlier round's library): entry points added since
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args

@@ -9,6 +9,7 @@
 
 #include <vector>
 
+#include "sf_drawrec.h"
 #include "sf_internal.h"
 #include "sf_raster.h"
 
@@ -39,6 +40,14 @@ struct sf_batch {
   int32_t* d_ms_ang;
   bool mslots_dirty;
   uint32_t* d_actrec;        // sf_step_sampled: one (tick, key0, key1, first lane) record per tile
+  // The envs' draw records (sf_drawrec.h), SF_DR_BYTES per lane: what the frame kernel reads.  Image batches have them from
+  // sf_create on and their step launches keep them current (args.draw); any other change of the state -- sf_reset,
+  // sf_set_field, the missile view -- clears `draw_current`, and the next frame rebuilds them from the state first
+  // (sf_drawrec_kernel).  Batches that step with a symbolic observation get the buffer with their first frame and rebuild
+  // before every frame.
+  unsigned char* d_draw;
+  bool draw_current;
+  bool render_ready;         // the render caches and pictures exist (or were declined: SFMI_NO_EXPLOSION_CACHE)
 };
 
 namespace {
@@ -69,6 +78,7 @@ int flush_missile_view(sf_batch* b, hipStream_t stream) {
   if (!b->mslots_dirty) return SF_OK;
   HIP_TRY(sf_launch_slots_to_mpool(b->d_state, b->args.lanes, b->n_envs, b->d_ms_pos, b->d_ms_ang, stream));
   b->mslots_dirty = false;
+  b->draw_current = false;
   return SF_OK;
 }
 #define SF_FLUSH_VIEW(b, stream)                                   \
@@ -97,6 +107,32 @@ int write_action_records(sf_batch* b, uint64_t seed, uint32_t first_lane, hipStr
 }
 
 bool is_pow2(long v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// What a batch needs to draw frames, made once: the per-env explosion cache followed by the 36 fortress pictures, the
+// destroyed fortress's explosion (in the layout of an env's cache entry) and the score / bar pictures -- all drawn here, on
+// `stream`, by the frame kernel's own code; the 36 x 4 backgrounds with the fortress in them; the envs' draw records.
+// Image batches call this from sf_create and wait for it (every later launch, on whatever stream, finds the pictures
+// finished: a first frame inside a HIP-graph capture allocates nothing); other batches with their first frame.
+// SFMI_NO_EXPLOSION_CACHE (diagnostics, tools/render_soak.py): no caches, no pictures -- every frame drawn in place.
+int ensure_render_resources(sf_batch* b, hipStream_t stream) {
+  if (b->render_ready) return SF_OK;
+  if (!b->d_draw) {
+    const size_t bytes = (size_t)b->args.lanes * SF_DR_BYTES;
+    HIP_TRY(hipMalloc((void**)&b->d_draw, bytes));
+    HIP_TRY(hipMemsetAsync(b->d_draw, 0, bytes, stream));
+  }
+  if (!b->d_xcache && !getenv("SFMI_NO_EXPLOSION_CACHE")) {
+    const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES, tail = 36 * SF_FP_BYTES + SF_XC_BYTES + SF_HUD_BYTES;
+    HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes + tail));
+    HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes + tail, stream));
+    HIP_TRY(sf_launch_hud_pictures(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes + 36 * SF_FP_BYTES + SF_XC_BYTES, stream));
+    HIP_TRY(sf_launch_fort_patches(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes, stream));
+  }
+  HIP_TRY(hipStreamSynchronize(stream));
+  b->render_ready = true;
+  b->draw_current = false;
+  return SF_OK;
+}
 
 }  // namespace
 
@@ -252,8 +288,10 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
     }
     // (room for the backgrounds with the fortress in them, filled by the first frame: sf_launch_fort_patches)
     HIP_TRY_FREE(hipMalloc((void**)&b->d_bg84, (size_t)SF_BG_COUNT * SF_OUT * SF_OUT));
+    HIP_TRY_FREE(hipMemset(b->d_bg84, 0, (size_t)SF_BG_COUNT * SF_OUT * SF_OUT));
     HIP_TRY_FREE(hipMemcpy(b->d_bg84, bg84.data(), bg84.size(), hipMemcpyHostToDevice));
     HIP_TRY_FREE(hipMalloc((void**)&b->d_bg, (size_t)SF_BG_COUNT * SF_BG_STRIDE));
+    HIP_TRY_FREE(hipMemset(b->d_bg, 0, (size_t)SF_BG_COUNT * SF_BG_STRIDE));
     HIP_TRY_FREE(hipMalloc((void**)&b->d_tabs, tabs.size() * sizeof(uint32_t)));
     HIP_TRY_FREE(hipMemcpy(b->d_bg, bg.data(), bg.size(), hipMemcpyHostToDevice));
     HIP_TRY_FREE(hipMemcpy(b->d_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -327,8 +365,18 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   HIP_TRY_FREE(hipMemset(a.dbg, 0, (size_t)(lanes / 64) * 16 * sizeof(unsigned long long)));
 #endif
 
+  a.draw = nullptr;
+  a.draw_pics = 0;
   HIP_TRY_FREE(sf_launch_reset(a, 1, (unsigned)p->spawn_skip, (unsigned)p->spawn_stride, nullptr, nullptr));
   HIP_TRY_FREE(hipStreamSynchronize(nullptr));
+  if (image) {  // the render caches and pictures, and the draw records the step launches of this batch keep current
+    if (ensure_render_resources(b, nullptr) != SF_OK) {
+      sf_destroy(b);
+      return SF_ERR_HIP;
+    }
+    a.draw = b->d_draw;
+    a.draw_pics = b->d_xcache ? 1 : 0;
+  }
 #undef HIP_TRY_FREE
   *out = b;
   return SF_OK;
@@ -349,6 +397,7 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_tabs) (void)hipFree(b->d_tabs);
   if (b->d_xcache) (void)hipFree(b->d_xcache);
   if (b->d_bg84) (void)hipFree(b->d_bg84);
+  if (b->d_draw) (void)hipFree(b->d_draw);
   if (b->args.dbg) (void)hipFree(b->args.dbg);
   if (b->args.hint) (void)hipFree(b->args.hint);
   delete b;
@@ -400,21 +449,48 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
     return SF_ERR_ARG;
   }
   SF_FLUSH_VIEW(b, stream);
-  if (!b->d_xcache && !getenv("SFMI_NO_EXPLOSION_CACHE")) {
-    // first frame of this batch: the per-env explosion cache (feature-only batches never pay for it)
-    // ... followed by the 36 fortress pictures, drawn here once
-    // ... and by the destroyed fortress's explosion, in the layout of an env's cache entry
-    // ... and by the score / bar pictures
-    const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES, tail = 36 * SF_FP_BYTES + SF_XC_BYTES + SF_HUD_BYTES;
-    HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes + tail));
-    HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes + tail, stream));
-    HIP_TRY(sf_launch_hud_pictures(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes + 36 * SF_FP_BYTES + SF_XC_BYTES, stream));
-    HIP_TRY(sf_launch_fort_patches(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes, stream));
+  {
+    // first frame of a batch that steps with a symbolic observation: the caches, pictures and draw records (feature-only
+    // batches never pay for them; image batches made them in sf_create)
+    const int rc = ensure_render_resources(b, stream);
+    if (rc != SF_OK) return rc;
+  }
+  if (!b->draw_current) {  // the state changed otherwise than through a step launch of an image batch: records from the state
+    SfKernelArgs da = b->args;
+    da.draw = b->d_draw;
+    da.draw_pics = b->d_xcache ? 1 : 0;
+    HIP_TRY(sf_launch_drawrec(da, stream));
+    b->draw_current = b->args.draw != nullptr;  // (only an image batch's step launches keep them current from here on)
   }
   const unsigned char* fpatch = b->d_xcache ? b->d_xcache + (size_t)b->n_envs * SF_XC_BYTES : nullptr;
-  HIP_TRY(sf_launch_render(b->d_state, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache, fpatch,
+  HIP_TRY(sf_launch_render(b->d_state, b->d_draw, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache, fpatch,
                            mode == SF_OBS_IMAGE ? 1 : 0, stack_done, stack_slot, stack_n, stack_prev, b->args.hint,
                            fpatch ? fpatch + 36 * SF_FP_BYTES + SF_XC_BYTES : nullptr, stream));
+  return SF_OK;
+}
+
+extern "C" int sf_draw_records(sf_batch* b, void* host, size_t bytes, int from_state) {
+  static_assert(SF_DRAW_RECORD_BYTES == SF_DR_BYTES, "sfmi.h vs sf_drawrec.h");
+  if (!b || !host || bytes != (size_t)b->n_envs * SF_DR_BYTES) {
+    sf_set_error("sf_draw_records: need a batch and n_envs * %d bytes", SF_DR_BYTES);
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  HIP_TRY(hipDeviceSynchronize());
+  if (from_state) {
+    SF_FLUSH_VIEW(b, nullptr);
+    const int rc = ensure_render_resources(b, nullptr);
+    if (rc != SF_OK) return rc;
+    SfKernelArgs da = b->args;
+    da.draw = b->d_draw;
+    da.draw_pics = b->d_xcache ? 1 : 0;
+    HIP_TRY(sf_launch_drawrec(da, nullptr));
+    b->draw_current = b->args.draw != nullptr;
+  } else if (!b->d_draw) {
+    sf_set_error("sf_draw_records: this batch has no draw records yet (they come with its first frame)");
+    return SF_ERR_ARG;
+  }
+  HIP_TRY(hipMemcpy(host, b->d_draw, bytes, hipMemcpyDeviceToHost));
   return SF_OK;
 }
 
@@ -472,6 +548,7 @@ extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
   DeviceGuard guard(b->device);
   const bool image = is_image(b);
   b->mslots_dirty = false;  // new games everywhere: no missiles, whatever a caller wrote into the slot view
+  b->draw_current = false;
   HIP_TRY(sf_launch_reset(b->args, 0, 0, 0, image ? nullptr : obs_dev, (hipStream_t)stream));
   if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
   return SF_OK;
@@ -492,6 +569,7 @@ extern "C" int sf_step(sf_batch* b, const void* actions_dev, int act_type, void*
   SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, image ? nullptr : obs_dev,
                          reward_dev, done_dev, info_dev, 1, false, (hipStream_t)stream));
+  b->draw_current = b->args.draw != nullptr;  // (an image batch's step launch leaves the draw records of the new state)
   if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
   return SF_OK;
 }
@@ -519,6 +597,7 @@ int sf_step_with_norm_partials(sf_batch* b, const void* actions_dev, int act_typ
   SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev,
                          info_dev, 1, false, (hipStream_t)stream));
+  b->draw_current = b->args.draw != nullptr;  // (an image batch's step launch leaves the draw records of the new state)
   *rows_out = (int)(b->args.lanes / 64);
   return SF_OK;
 }
@@ -550,6 +629,7 @@ extern "C" int sf_step_record(sf_batch* b, const void* actions_dev, int act_type
   SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, image ? nullptr : obs_dev,
                          reward_dev, done_dev, info_dev, 1, false, (hipStream_t)stream));
+  b->draw_current = b->args.draw != nullptr;  // (an image batch's step launch leaves the draw records of the new state)
   if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
   return SF_OK;
 }
@@ -577,6 +657,7 @@ extern "C" int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, in
   SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev,
                          n_steps, true, (hipStream_t)stream));
+  b->draw_current = b->args.draw != nullptr;  // (an image batch's step launch leaves the draw records of the new state)
   return SF_OK;
 }
 
@@ -602,6 +683,7 @@ extern "C" int sf_step_sampled(sf_batch* b, uint8_t* actions_out_dev, void* obs_
   SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, b->d_actrec, SF_ACT_SAMPLED, image ? nullptr : obs_dev,
                          reward_dev, done_dev, info_dev, 1, false, (hipStream_t)stream));
+  b->draw_current = b->args.draw != nullptr;  // (an image batch's step launch leaves the draw records of the new state)
   if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
   return SF_OK;
 }
@@ -626,6 +708,7 @@ extern "C" int sf_rollout_sampled(sf_batch* b, int n_steps, uint8_t* actions_out
   SF_FLUSH_VIEW(b, stream);
   HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, b->d_actrec, SF_ACT_SAMPLED, obs_dev, reward_dev, done_dev,
                          info_dev, n_steps, true, (hipStream_t)stream));
+  b->draw_current = b->args.draw != nullptr;  // (an image batch's step launch leaves the draw records of the new state)
   return SF_OK;
 }
 
@@ -765,7 +848,10 @@ static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host
     }
     if (!b->mslots_dirty) HIP_TRY(sf_launch_mpool_to_slots(b->d_state, b->n_envs, b->d_ms_pos, b->d_ms_ang, nullptr));
   }
-  if (!to_host) HIP_TRY(hipMemcpy(b->d_scratch, host, total, hipMemcpyHostToDevice));
+  if (!to_host) {
+    HIP_TRY(hipMemcpy(b->d_scratch, host, total, hipMemcpyHostToDevice));
+    b->draw_current = false;
+  }
   if (mview) {
     const int which = f == SF_F_missile_x ? 0 : (f == SF_F_missile_y ? 1 : 2);
     HIP_TRY(sf_launch_mslot_component(b->d_ms_pos, b->d_ms_ang, (long)b->n_envs * SF_NSLOT, which, b->d_scratch,

@@ -12,6 +12,9 @@ hipError_t sf_launch_reset(const SfKernelArgs& a, int first, unsigned cursor0, u
 hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, const void* actions, int act_type, void* obs,
                           int32_t* reward, uint8_t* done, uint8_t* info, int n_steps, bool fused, hipStream_t stream);
 
+// the envs' draw records (sf_drawrec.h) from the state as it is: a.draw / a.draw_pics say where and for which pictures
+hipError_t sf_launch_drawrec(const SfKernelArgs& a, hipStream_t stream);
+
 // gather (to_linear) / scatter one field between the tiled state and a linear [count][n_envs] buffer
 hipError_t sf_launch_field_copy(unsigned char* state, int n_envs, int field, unsigned char* linear, int to_linear,
                                 hipStream_t stream);
@@ -28,7 +31,7 @@ hipError_t sf_launch_group_copy(const unsigned char* state, int n_envs, int grou
                                 hipStream_t stream);
 
 // sf_render.hip: one wave per env; bg = 92*90 bytes, bg84 = its 84*84 INTER_AREA image, tabs = SF_TAB_WORDS
-hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
+hipError_t sf_launch_render(const unsigned char* state, const unsigned char* draw, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
                             const uint8_t* stack_prev, const unsigned long long* hint, const unsigned char* hud,

@@ -50,6 +50,7 @@
 #include "sf_internal.h"
 #include "sf_layout.h"
 #include "sf_deg_dd.h"
+#include "sf_drawrec.h"
 
 // Four waves per workgroup share one LDS copy of the cos/sin table (one barrier, early, while the
 // waves are still in step; a copy per wave was tried: 1024 waves pulling the same 45 cache lines
@@ -1058,6 +1059,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
   }
   const size_t so = (size_t)step * (size_t)a.n_envs;  // this tick's row of the output arrays
+  // image batches: this tick leaves the envs' draw records for the frame kernel (sf_drawrec.h) -- of a fused launch, the
+  // last tick does.  `dr_proj`: where this env's projectiles come near the score / the bar (sfd::hud_flags_near)
+  const bool draw_now = OBSK != 1 && a.draw != nullptr && (!FUSED || step + 1 == n_iter);  // uniform
+  unsigned dr_proj = 0u;
 
   const int act_raw = act;  // what rollouts.actions[step] records
   if (act < 0 || act >= a.n_actions) {
@@ -1301,6 +1306,9 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       for (int k = 0; k < SF_SGSZ; k++) {
         const int s = SF_SGSZ * g + k;
         pst16(SF_GOFF(shell_pos, s), (L.smask >> s) & 1u, d2_t{nx[k], ny[k]});
+        if (draw_now)
+          if (((L.smask >> s) & 1u) && sfd::hud_rows_near((float)ny[k], sfd::kShellExt))  // (all but never)
+            dr_proj |= sfd::hud_flags_near((float)nx[k], (float)ny[k], sfd::kShellExt);
       }
     }
     if (SF_ABL_PROJ < 2 && __ballot((L.smask >> SF_SPF) != 0u) != 0ull) {  // rare: more than SF_SPF shells in some lane
@@ -1340,6 +1348,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
             L.smask &= ~(1u << s);
           } else {
             SF_ST(d2_t, SF_CHUNK(shell_pos, s), o.o16, (d2_t{x, y}));
+            if (draw_now) dr_proj |= sfd::hud_flags_near((float)x, (float)y, sfd::kShellExt);
           }
         }
       }
@@ -1359,6 +1368,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   {
     unsigned wp = 0;  // write pointer of the compaction = entries kept so far (wave-uniform)
     unsigned* const evw32 = reinterpret_cast<unsigned*>(evw);
+    // (the draw records of this wave's 64 envs: one descriptor, like the tile's)
+    const __amdgpu_buffer_rsrc_t rs_draw = __builtin_amdgcn_make_buffer_rsrc(
+        draw_now ? a.draw + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * (size_t)(64 * SF_DR_BYTES) : (unsigned char*)nullptr, 0,
+        draw_now ? 64 * SF_DR_BYTES : 0, 0x00020000);
     auto m_row = [&](double x, double y, unsigned meta, d2_t cs, bool valid) __attribute__((always_inline)) {
       // velocity = missileSpeed * (cos, sin)(deg2rad(angle)) with an integer angle: table
       const double nx = x + kv_speed * cs.x, ny = y + kv_speed * cs.y;
@@ -1378,6 +1391,19 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, (d2_t{nx, ny})), rs, keep ? idx * 16u : SF_OOB,
                                              SF_GOFF(missile_pos, 0), kStAux);
       __builtin_amdgcn_raw_buffer_store_b32(meta, rs, keep ? idx * 4u : SF_OOB, SF_GOFF(missile_meta, 0), kStAux);
+      if (draw_now) {  // uniform.  The survivor's transform goes to its OWNER's draw record, at its slot (sf_drawrec.h)
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const unsigned doff = SF_MM_OWNER(meta) * (unsigned)SF_DR_BYTES +
+                              (unsigned)(SF_DR_HDR_BYTES + SF_DR_OBJ_MISSILE0 * SF_DR_OBJ_BYTES) + SF_MM_SLOT(meta) * (unsigned)SF_DR_OBJ_BYTES;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, (f4_t{(float)nx, (float)ny, (float)cs.x, (float)cs.y})), rs_draw,
+                                               keep ? doff : SF_OOB, 0, kStAux);
+        const bool rows = keep & sfd::hud_rows_near((float)ny, sfd::kMissileExt);
+        if (__ballot(rows) != 0ull) {  // (all but never) -> bits 24..27 of the owner's hit word
+          if (rows)
+            __hip_atomic_fetch_or(evw32 + 2 * SF_MM_OWNER(meta), sfd::hud_flags_near((float)nx, (float)ny, sfd::kMissileExt) << 24,
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
     };
     if (SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3) {
 #pragma unroll
@@ -1404,6 +1430,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     const unsigned long long evp = evw[lane];
     if (FUSED) evw[lane] = 0ull;  // ready for the next tick
     unsigned ev_hit = (unsigned)evp, ev_out = (unsigned)(evp >> 32);
+    dr_proj |= (ev_hit >> 24) & 0xFu;  // (draw records: this env's missiles near the score / the bar, sfd::hud_flags_near)
     ev_hit &= L.mmask;             // hit = live & collided
     ev_out &= L.mmask & ~ev_hit;   // out = live & !hit & outside
     unsigned ev = ev_hit | ev_out;
@@ -1551,6 +1578,23 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   }
 
   SF_STAMP(11, false);
+  if (draw_now) {  // uniform: the env's draw record (sf_drawrec.h) -- header, ship, fortress; the missiles' entries went out above
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const sfd::Header h = sfd::make_header(L.sx, L.sy, (L.fl & SF_FL_SHIP_ALIVE) != 0u, (L.fl & SF_FL_FORT_ALIVE) != 0u, L.fort_angle,
+                                           L.points, L.vlner, L.fort_vuln_t, L.mmask, L.smask,
+                                           (done && a.auto_reset) ? 0u : dr_proj /* a new game has no projectiles */, a.draw_pics != 0, L.time);
+    const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(
+        a.draw + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * (size_t)(64 * SF_DR_BYTES), 0, 64 * SF_DR_BYTES, 0x00020000);
+    const unsigned d0 = real ? lane * (unsigned)SF_DR_BYTES : SF_OOB;
+    __builtin_amdgcn_raw_buffer_store_b128(u4_t{h.w[0], h.w[1], h.w[2], h.w[3]}, rs_dr, d0, 0, kStAux);
+    __builtin_amdgcn_raw_buffer_store_b128(u4_t{h.w[4], h.w[5], h.w[6], h.w[7]}, rs_dr, d0, 16, kStAux);
+    __builtin_amdgcn_raw_buffer_store_b128(
+        __builtin_bit_cast(u4_t, (f4_t{(float)L.sx, (float)L.sy, (float)SF_COS(L.angle), (float)SF_SIN(L.angle)})), rs_dr, d0,
+        SF_DR_HDR_BYTES + SF_DR_OBJ_SHIP * SF_DR_OBJ_BYTES, kStAux);
+    __builtin_amdgcn_raw_buffer_store_b128(
+        __builtin_bit_cast(u4_t, (f4_t{(float)sfc::fort_x, (float)sfc::fort_y, (float)SF_COS(L.fort_angle), (float)SF_SIN(L.fort_angle)})),
+        rs_dr, d0, SF_DR_HDR_BYTES + SF_DR_OBJ_FORT * SF_DR_OBJ_BYTES, kStAux);
+  }
   if (!FUSED) store_lane_buf(rs, o, L);
   SF_STAMP(14, false);
 
@@ -1638,6 +1682,69 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     for (int k = 0; k < 16; k++) d[k] = stamp_[k];
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// The envs' draw records (sf_drawrec.h) from the state as it is in HBM: what the image instantiations of the step kernel
+// leave behind themselves, for a state that got there any other way -- a reset, sf_set_field, a batch that steps with a
+// symbolic observation and renders now and then.  One wave per tile, a lane per env; the pool's entries file their
+// transforms at [owner][slot] and tell their owners through LDS where they come near the score / the bar, exactly like the
+// step kernel's m_row.  Same functions, same values: tests/test_gpu_image.py compares the two byte for byte.
+__global__ __launch_bounds__(64) void sf_drawrec_kernel(const unsigned char* state, const double* consts, int n_envs,
+                                                       unsigned char* draw, int pics) {
+  __shared__ unsigned near[64];
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  const unsigned lane = threadIdx.x;
+  const long tile_i = blockIdx.x;
+  const unsigned char* tb = state + tile_i * sfl::kTileBytes;
+  unsigned char* const dr = draw + tile_i * (long)(64 * SF_DR_BYTES);
+  const unsigned o16 = lane * 16u;
+  const d2_t sp = SF_LD(d2_t, SF_CHUNK(ship_pos, 0), o16);
+  const i4_t tc = SF_LD(i4_t, SF_CHUNK(timers_b, 0), o16);
+  const i4_t sc = SF_LD(i4_t, SF_CHUNK(score, 0), o16);
+  const i4_t mi = SF_LD(i4_t, SF_CHUNK(misc, 0), o16);
+  const i4_t sm = SF_LD(i4_t, SF_CHUNK(small, 0), o16);
+  near[lane] = 0u;
+  __syncthreads();
+  const unsigned n_pool = (unsigned)__builtin_amdgcn_readfirstlane(mi.z) >> SF_MPOOL_SHIFT;  // (the same in every lane of the tile)
+  for (unsigned k = lane; k < n_pool; k += 64) {
+    const d2_t p = SF_LD(d2_t, SF_CHUNK(missile_pos, 0), k * 16u);
+    const unsigned m = SF_LD(unsigned, SF_CHUNK(missile_meta, 0), k * 4u);
+    const double* cs = consts + 2 * SF_MM_ANGLE(m);  // cos, sin of the heading (sf_host_fill_consts)
+    *reinterpret_cast<f4_t*>(dr + SF_MM_OWNER(m) * SF_DR_BYTES + SF_DR_HDR_BYTES + (SF_DR_OBJ_MISSILE0 + SF_MM_SLOT(m)) * SF_DR_OBJ_BYTES) =
+        f4_t{(float)p.x, (float)p.y, (float)cs[0], (float)cs[1]};
+    const unsigned f = sfd::hud_flags_near((float)p.x, (float)p.y, sfd::kMissileExt);
+    if (f) atomicOr(&near[SF_MM_OWNER(m)], f);
+  }
+  const unsigned smask = (unsigned)mi.w & SF_MASK_LOW, mmask = (unsigned)mi.z & SF_MASK_LOW;
+  unsigned proj = 0u;
+  for (unsigned rest = smask; rest; rest &= rest - 1u) {
+    const int s = __ffs(rest) - 1;
+    const d2_t q = SF_LD(d2_t, SF_CHUNK(shell_pos, s), o16);
+    proj |= sfd::hud_flags_near((float)q.x, (float)q.y, sfd::kShellExt);
+  }
+  __syncthreads();
+  proj |= near[lane];
+  if (tile_i * 64 + lane >= n_envs) return;
+  const int ship_angle = (int16_t)(sm.x & 0xFFFF), fort_angle = (int16_t)((unsigned)sm.x >> 16);
+  const unsigned fl = ((unsigned)sm.y >> 16) & 0xFFu;
+  const sfd::Header h = sfd::make_header(sp.x, sp.y, (fl & SF_FL_SHIP_ALIVE) != 0u, (fl & SF_FL_FORT_ALIVE) != 0u, fort_angle,
+                                         __int_as_float(sc.x), sc.z & 0xFFF, tc.w, mmask, smask, proj, pics != 0,
+                                         (int)((unsigned)sc.w & 0xFFFFFFu));
+  unsigned char* const me = dr + lane * SF_DR_BYTES;
+  reinterpret_cast<u4_t*>(me)[0] = u4_t{h.w[0], h.w[1], h.w[2], h.w[3]};
+  reinterpret_cast<u4_t*>(me)[1] = u4_t{h.w[4], h.w[5], h.w[6], h.w[7]};
+  const int sa = ship_angle < 0 ? 0 : (ship_angle > 359 ? 359 : ship_angle), fa = fort_angle < 0 ? 0 : (fort_angle > 359 ? 359 : fort_angle);
+  reinterpret_cast<f4_t*>(me + SF_DR_HDR_BYTES)[SF_DR_OBJ_SHIP] = f4_t{(float)sp.x, (float)sp.y, (float)consts[2 * sa], (float)consts[2 * sa + 1]};
+  reinterpret_cast<f4_t*>(me + SF_DR_HDR_BYTES)[SF_DR_OBJ_FORT] =
+      f4_t{(float)sfc::fort_x, (float)sfc::fort_y, (float)consts[2 * fa], (float)consts[2 * fa + 1]};
+}
+
+hipError_t sf_launch_drawrec(const SfKernelArgs& a, hipStream_t stream) {
+  if (!a.draw) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sf_drawrec_kernel, dim3((unsigned)(a.lanes / 64)), dim3(64), 0, stream, a.state, a.consts, a.n_envs, a.draw,
+                     a.draw_pics);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

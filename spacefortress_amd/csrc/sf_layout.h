@@ -305,6 +305,10 @@ struct SfKernelArgs {
   unsigned long long* hint;
   // optional: the action every env played this tick as uint8 [n_steps][n_envs] (the sampled ones of sf_step_sampled); else null
   unsigned char* act_out;
+  // image batches only: the envs' draw records (sf_drawrec.h), SF_DR_BYTES per lane, written by the step kernel for the frame
+  // kernel; else null.  draw_pics: the batch's render pictures exist (the records' decisions depend on it)
+  unsigned char* draw;
+  int draw_pics;
 };
 
 // words of SfKernelArgs::acc behind the SF_EPISODE_STATS_LEN (8) episode statistics

@@ -26,6 +26,7 @@
 // UNPINNED; tests pin this kernel to the numpy restatement of the same model (oracle/render_np.py).
 #include <hip/hip_runtime.h>
 
+#include "sf_drawrec.h"
 #include "sf_internal.h"
 #include "sf_raster.h"
 
@@ -39,9 +40,6 @@
 // diagnostic builds only: the frame kernel returns behind phase N (1 the prologue up to the barrier, 2 the restored
 // pictures, 3 the fresh explosions, 4 the strokes of ship / fortress / missiles, 5 the shells) -- instruction counts of the
 // phases by difference (tools/pmc_render_variants.sh)
-#ifndef SF_BG_FORT
-#define SF_BG_FORT 1
-#endif
 #ifndef SF_RESAMPLE_QUADS
 #define SF_RESAMPLE_QUADS 1
 #endif
@@ -50,12 +48,6 @@
 #endif
 #ifndef SF_RENDER_STOP
 #define SF_RENDER_STOP 0
-#endif
-#ifndef SF_PTAB
-#define SF_PTAB 0 /* 1: resample_into reads one period of the tap tables from LDS instead of the tables through L1 (measured: 73.7 against 72.0 us per step, the 560 bytes of LDS cost more than the loads) */
-#endif
-#ifndef SF_RENDER_TABS_IN_LDS
-#define SF_RENDER_TABS_IN_LDS 0
 #endif
 
 namespace {
@@ -159,15 +151,16 @@ __device__ __forceinline__ float bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-struct Box {  // pixel rectangle [x0, x1) x [y0, y1) of the 90x92 surface
-  int x0, y0, x1, y1;
-  __device__ __forceinline__ void clear() { x0 = y0 = 1 << 20; x1 = y1 = -1; }
-  __device__ __forceinline__ bool empty() const { return x1 <= x0 || y1 <= y0; }
-  __device__ __forceinline__ void add(int ax0, int ay0, int ax1, int ay1) {
-    x0 = min(x0, ax0); y0 = min(y0, ay0); x1 = max(x1, ax1); y1 = max(y1, ay1);
-  }
-  __device__ __forceinline__ bool meets(const Box& o) const { return x0 < o.x1 && o.x0 < x1 && y0 < o.y1 && o.y0 < y1; }
-};
+using sfd::Box;
+using sfd::explosion_box;
+using sfd::kReachX;
+using sfd::kReachY;
+using sfd::kHudTopRows;
+using sfd::kHudBottomRows;
+using sfd::kFpX0;
+using sfd::kFpX1;
+using sfd::kFpY0;
+using sfd::kFpY1;
 
 // pixel box of a quad, clipped to the surface (empty for NaN / far-away geometry)
 __device__ __forceinline__ Box quad_box(const Quad& q) {
@@ -186,17 +179,6 @@ __device__ __forceinline__ Box quad_box(const Quad& q) {
   return b;
 }
 
-// everything an explosion draws lies within 63 + 1.5 user units of its centre
-__device__ __forceinline__ Box explosion_box(float cx, float cy) {
-  const float gx = dev_x(cx), gy = dev_y(cy), ext = 64.5f * (float)SF_SCALE;
-  Box b;
-  b.x0 = max((int)floorf(gx - ext), 0);
-  b.y0 = max((int)floorf(gy - ext), 0);
-  b.x1 = min((int)ceilf(gx + ext), SF_IMG_W);
-  b.y1 = min((int)ceilf(gy + ext), SF_IMG_H);
-  return b;
-}
-
 // Destination pixels of the 84x84 image that read source pixels of `b`, exactly: INTER_AREA gives destination
 // column dx the source interval [dx * 15/14, (dx + 1) * 15/14), so source column s is read (with a weight that is
 // not zero) by the destination columns floor(14 s / 15) ... ceil(14 (s + 1) / 15) - 1, and likewise 21/23 for the rows
@@ -205,9 +187,7 @@ __device__ __forceinline__ Box explosion_box(float cx, float cy) {
 // ... and the other way round: a destination pixel reads two adjacent source columns and up to three adjacent rows, so the
 // destination pixels that read `b` read nothing further than this outside it.  A picture saved with its 84x84 part is
 // good where nothing else is drawn within that reach of its box (kReachX, kReachY).
-constexpr int kReachX = 1, kReachY = 2;
-// a box that meets the score's or the bar's box, wider by the reach or not, has y0 < kHudTopRows or y1 > kHudBottomRows
-constexpr int kHudTopRows = SF_TXT_BOX_Y1 + kReachY, kHudBottomRows = SF_BAR_BOX_Y0 - kReachY;
+// (kReachX, kReachY: sf_drawrec.h)
 constexpr int kTapColPeriod = 14, kTapRowPeriod = 21;  // destination columns / rows after which the INTER_AREA taps repeat
 __device__ __forceinline__ Box out_box(const Box& b) {
   Box o;
@@ -688,45 +668,16 @@ __device__ __forceinline__ void sincos_deg(int deg, float* s, float* c) {
   *c = sc.y;
 }
 
-// ... and without any load: the frame kernel keeps sin / cos of 0, 10, .. 350 degrees (lane a: kSinCos10[a]) and of 0 .. 9
-// degrees (lane b: kSinCos1[b]) as doubles across its lanes -- two loads per wave, asked for before the state is known --
-// and a lane looks its heading k = 10 a + b up with lane permutes: sin k = sin 10a cos b + cos 10a sin b in double, rounded
-// to float, is kSinCosDeg[k] bit for bit (all 360 asserted by tools/gen_render_tables.py; the double operations are IEEE on
-// both sides).  A table lookup per lane is a vector load, and a wave's vector loads come back in issue order: the missiles'
-// sines were a round trip behind the pool's, with the surface's ten loads queued in between.
-struct SinCosLanes {
-  double s10, c10, s1, c1;
-};
-__device__ __forceinline__ SinCosLanes sincos_lanes_load(int lane) {
-  const int a = lane < 36 ? lane : 35, b = lane < 10 ? lane : 9;
-  return SinCosLanes{kSinCos10[a][0], kSinCos10[a][1], kSinCos1[b][0], kSinCos1[b][1]};
-}
-__device__ __forceinline__ void sincos_lanes(const SinCosLanes& t, int deg, float* s, float* c) {
-  deg = deg < 0 ? 0 : (deg > 359 ? 359 : deg);
-  const int a = (deg * 205) >> 11, b = deg - 10 * a;  // deg / 10 for deg < 1029
-  const double sa = __shfl(t.s10, a), ca = __shfl(t.c10, a), sb = __shfl(t.s1, b), cb = __shfl(t.c1, b);
-  *s = (float)(sa * cb + ca * sb);
-  *c = (float)(ca * cb - sa * sb);
-}
-
 // wireframe segments (ax, ay, bx, by), SRC/wireframe.cpp:11-67.  As functions of the stroke index, not tables in memory:
 // a table indexed by the lane is a vector load from .rodata, a dependent round trip in front of every object (small whole
 // numbers: the selects give the same floats).
 struct Line {
   float ax, ay, bx, by, inv;  // inv = stroke_inv(bx - ax, by - ay), folded at compile time
 };
-__device__ __forceinline__ Line ship_line(int k) {     // {-18, 0, 18, 0}, {-18, 18, 0, 0}, {0, 0, -18, -18}
-  return Line{k == 2 ? 0.f : -18.f, k == 1 ? 18.f : 0.f, k == 0 ? 18.f : (k == 1 ? 0.f : -18.f), k == 2 ? -18.f : 0.f,
-              k == 0 ? stroke_inv(36.f, 0.f) : (k == 1 ? stroke_inv(18.f, -18.f) : stroke_inv(-18.f, -18.f))};
-}
 __device__ __forceinline__ Line fort_line(int k) {     // {0, 0, 36, 0}, {0, -18, 18, -18}, {18, -18, 18, 18}, {18, 18, 0, 18}
   return Line{k >= 2 ? 18.f : 0.f, k == 0 ? 0.f : (k == 3 ? 18.f : -18.f), k == 0 ? 36.f : (k == 3 ? 0.f : 18.f),
               k == 0 ? 0.f : (k == 1 ? -18.f : 18.f),
               k == 0 ? stroke_inv(36.f, 0.f) : (k == 1 ? stroke_inv(18.f, 0.f) : (k == 2 ? stroke_inv(0.f, 36.f) : stroke_inv(-18.f, 0.f)))};
-}
-__device__ __forceinline__ Line missile_line(int k) {  // {0, 0, -25, 0}, {0, 0, -5, 5}, {0, 0, -5, -5}
-  return Line{0.f, 0.f, k == 0 ? -25.f : -5.f, k == 0 ? 0.f : (k == 1 ? 5.f : -5.f),
-              k == 0 ? stroke_inv(-25.f, 0.f) : (k == 1 ? stroke_inv(-5.f, 5.f) : stroke_inv(-5.f, -5.f))};
 }
 __device__ __forceinline__ Line shell_line(int k) {    // {-8, 0, 0, -6}, {0, -6, 16, 0}, {16, 0, 0, 6}, {0, 6, -8, 0}
   return Line{k == 0 ? -8.f : (k == 2 ? 16.f : 0.f), k == 1 ? -6.f : (k == 3 ? 6.f : 0.f), k == 1 ? 16.f : (k == 3 ? -8.f : 0.f),
@@ -1020,7 +971,8 @@ __device__ __forceinline__ void copy_pieces(const uint4* src, uint4* dst, int n,
 }
 
 struct SfRenderArgs {
-  const unsigned char* state;
+  const unsigned char* state;   // the tiled state: the shells' positions and velocities (everything else comes from `draw`)
+  const unsigned char* draw;    // the envs' draw records (sf_drawrec.h), SF_DR_BYTES each, current for `state`
   int n_envs;
   const uint32_t* bg;    // four variants of the static 92x90 background, SF_BG_STRIDE bytes apart:
                          // bit 0 = with the score 0000000, bit 1 = with the empty vulnerability bar
@@ -1107,10 +1059,7 @@ __device__ __forceinline__ int pick_env(const SfRenderArgs& a, int p, int lane) 
 // 36 pictures.  sf_fort_patch_kernel draws them once per batch with the frame code below (so they are
 // bit-identical to drawing in place); a frame whose ship / explosion pixels stay clear of the fortress's
 // box then copies 256 + 306 bytes instead of rasterising four strokes.
-constexpr int kFpX0 = 37, kFpX1 = 53, kFpY0 = 39, kFpY1 = 55;  // 355 +- 37.5, 315 +- 37.5 user units, in pixels
-constexpr int kFpOutRow = 20, kFpOutAt = 256;
-static_assert(kFpX0 <= (355 - 37.5 - SF_VP_X) * SF_SCALE && kFpX1 >= (355 + 37.5 - SF_VP_X) * SF_SCALE &&
-              kFpY0 <= (315 - 37.5 - SF_VP_Y) * SF_SCALE && kFpY1 >= (315 + 37.5 - SF_VP_Y) * SF_SCALE, "fortress box");
+constexpr int kFpOutRow = 20, kFpOutAt = 256;  // (the picture's box kFpX0 .. kFpY1: sf_drawrec.h)
 
 template <bool RESIZE>
 __device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned char* gp, bool store) {
@@ -1155,36 +1104,6 @@ __device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned
 }
 
 
-// fort_patch_copy's restore in two halves (the frame kernel asks for the picture in its prologue's round trip)
-struct FortPic {
-  uint32_t w, v0, v1;
-};
-template <bool RESIZE>
-__device__ __forceinline__ FortPic fort_patch_fetch(const unsigned char* gp, int lane) {
-  constexpr int oh = (kFpY1 * 21 + 22) / 23 - (kFpY0 * 21) / 23;  // rows of out_box of the picture's box
-  const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gp);
-  FortPic f;
-  f.w = g32[lane];
-  f.v0 = RESIZE ? g32[kFpOutAt / 4 + lane] : 0u;
-  f.v1 = (RESIZE && 64 + lane < (kFpOutRow / 4) * oh) ? g32[kFpOutAt / 4 + 64 + lane] : 0u;
-  return f;
-}
-template <bool RESIZE>
-__device__ __forceinline__ void fort_patch_put(const Frame<RESIZE>& F, const FortPic& f) {
-  const Box b{kFpX0, kFpY0, kFpX1, kFpY1}, o = out_box(b);
-  const int lane = F.lane, ow = o.x1 - o.x0, oh = o.y1 - o.y0;
-  put_bytes(F.fb + (kFpY0 + (lane >> 2)) * SF_IMG_W + kFpX0 + (lane & 3) * 4, f.w, 4);
-  if (RESIZE) {
-    const uint32_t v[2] = {f.v0, f.v1};
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int d = lane + 64 * j, r = d / (kFpOutRow / 4), c4 = (d - r * (kFpOutRow / 4)) * 4;
-      if (r < oh) put_bytes(F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4, v[j], ow - c4);
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
 // ---- score (drawScore, SRC/draw.cpp:190-203): "%07d", grey .5, seven-segment digits; a lane per pixel of the box
 template <bool RESIZE>
 __device__ __forceinline__ void draw_score(const Frame<RESIZE>& F, int pnts) {
@@ -1204,10 +1123,7 @@ __device__ __forceinline__ void draw_score(const Frame<RESIZE>& F, int pnts) {
 }
 // ---- vulnerability bar (drawVlner, :205-225): two filled rectangles, a lane per pixel of the box.  `state`: 0..10
 // tenths in grey .66, 11 = full and white (kill-ready, :268)
-__device__ __forceinline__ int bar_state(int vlner, int fort_vuln_timer) {
-  const bool kill = vlner > 10 && fort_vuln_timer < sfc::vuln_time;
-  return kill ? 11 : (vlner > 10 ? 10 : vlner);
-}
+// (the state: sfd::bar_state, sf_drawrec.h)
 template <bool RESIZE>
 __device__ __forceinline__ void draw_bar(const Frame<RESIZE>& F, int state) {
   const int v = state > 10 ? 10 : state, vg = state > 10 ? 255 : 168;
@@ -1298,31 +1214,20 @@ template <bool RESIZE>
 #endif
 __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
-#if SF_RENDER_TABS_IN_LDS
-  __shared__ __attribute__((aligned(16))) uint32_t tabw[RESIZE ? SF_TAB_WORDS : 4];
-#else
   const uint32_t* const tabw = a.tabs;  // 2.7 KB read by every wave: L1/L2 resident; LDS is better spent on waves
-#endif
   __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats + (Frame<RESIZE>::kMapBits + 63) / 64 * 2];  // records, then the map of the strokes' starts
   __shared__ __attribute__((aligned(16))) uint32_t slist[Frame<RESIZE>::kListCap];
-  __shared__ __attribute__((aligned(16))) uint32_t ptab[(RESIZE && SF_PTAB) ? 4 * (kTapColPeriod + kTapRowPeriod) : 1];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int lane = threadIdx.x;
-#ifdef SF_DBG_FLAGS
-  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-  unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_pa = 0, dbg_pb = 0, dbg_pc = 0, dbg_pd = 0, dbg_pe = 0, dbg_pf = 0, dbg_pg = 0;
-  unsigned long long dbg_ds[6] = {0, 0, 0, 0, 0, 0};
-#define SF_DBG_STAMP(v) do { asm volatile("" ::: "memory"); v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
-#else
-#define SF_DBG_STAMP(v)
-#endif
-  // one period of the tap tables into LDS (resample_into): 35 entries of 16 bytes, asked for before anything else
-  uint4 ptab_e = {0u, 0u, 0u, 0u};
-  if (RESIZE && SF_PTAB && lane < kTapColPeriod + kTapRowPeriod)
-    ptab_e = reinterpret_cast<const uint4*>(a.tabs)[lane < kTapColPeriod ? lane : SF_OUT + (lane - kTapColPeriod)];
-  const SinCosLanes sct = sincos_lanes_load(lane);  // (sincos_lanes: the headings' sines, looked up without a load)
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  typedef unsigned u8_t __attribute__((ext_vector_type(8)));
+  // ---- this lane's stroke of the frame's draw order (lanes 0..2 the ship's three, 3..6 the fortress's four, 7..63 those of
+  // missile slots 0..18): its four corners in the wireframe's own coordinates depend on the lane alone -- two loads, asked
+  // for before anything is known, where round 3 selected segment constants and built the rectangle per frame
+  const f4_t lsx = *reinterpret_cast<const f4_t*>(kLaneStroke[lane].x);
+  const f4_t lsy = *reinterpret_cast<const f4_t*>(kLaneStroke[lane].y);
   // ---- which env (pick_env).  Nearly every workgroup behind the front draws env = its index - n_front, and learns that
-  // from one word of the hint: the state loads go out for that env at once, next to the word's load, instead of behind it.
+  // from one word of the hint: the record's loads go out for that env at once, next to the word's load, instead of behind it.
   int env = blockIdx.x;
   bool recheck = false;
   if (a.hint) {
@@ -1334,28 +1239,25 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       if (env < 0) return;  // uniform, before any barrier
     }
   }
+  env = __builtin_amdgcn_readfirstlane(env);
   uint8_t* const frame_out = a.out + (size_t)env * a.out_stride;
 
-#if SF_RENDER_TABS_IN_LDS
-  if (RESIZE) {
-    const uint4* tsrc = reinterpret_cast<const uint4*>(a.tabs);
-    uint4* tdst = reinterpret_cast<uint4*>(tabw);
-    for (int i = lane; i < SF_TAB_WORDS / 4; i += 64) tdst[i] = tsrc[i];
-  }
-#endif
-
-  // this env's lane of its wave tile
-  const unsigned char* tile = a.state + (long)(env >> 6) * sfl::kTileBytes;
-  const int l = env & 63;
-  const int o16 = l * 16, o8 = l * 8, o2 = l * 2;
-  const d2_t sp = R_LD(d2_t, R_CHUNK(ship_pos, 0), o16);
-  const i4_t tb = R_LD(i4_t, R_CHUNK(timers_b, 0), o16);
-  const i4_t sc = R_LD(i4_t, R_CHUNK(score, 0), o16);
-  const i4_t mi = R_LD(i4_t, R_CHUNK(misc, 0), o16);
-  const i4_t sm = R_LD(i4_t, R_CHUNK(small, 0), o16);  // ship_angle, fort_angle (int16), .., flags (uint8 at byte 6): sf_layout.h
+  // ---- ROUND TRIP 1: the env's draw record (sf_drawrec.h), left by the step kernel: 32 bytes of finished decisions through
+  // ONE scalar load -- uniform by construction, in SGPRs without a v_readfirstlane, and every test of them below is a scalar
+  // bit test -- and, per lane, the transform (x, y, cos, sin) of the object its stroke belongs to.  Round 3 read five chunks
+  // of the state and three rows of the tile's missile pool here, every one of a tile's 64 frames filtering the same rows for
+  // its own entries, and decided in all 64 lanes what one lane of the step kernel decides now.
+  const unsigned char* const rec = a.draw + (size_t)env * SF_DR_BYTES;
+  const u8_t hd = *reinterpret_cast<const __attribute__((address_space(4))) u8_t*>(
+      reinterpret_cast<const __attribute__((address_space(4))) void*>((unsigned long long)rec));
+  constexpr int kFirstMissileLane = 7;
+  static_assert(kFirstMissileLane + 3 * 19 == 64, "slots 0 .. 18 fill the wave behind the ship's and the fortress's strokes");
+  const int mslot = ((lane - kFirstMissileLane) * 171) >> 9;  // (lane - 7) / 3 for lanes 7 .. 63
+  const int obj = lane < 3 ? SF_DR_OBJ_SHIP : (lane < kFirstMissileLane ? SF_DR_OBJ_FORT : SF_DR_OBJ_MISSILE0 + mslot);
+  const f4_t tf = *reinterpret_cast<const f4_t*>(rec + (unsigned)(SF_DR_HDR_BYTES + obj * SF_DR_OBJ_BYTES));
   // (a frame stack's done flag of this env: asked for here, read where the older slots are handled)
   // (through an index the compiler cannot see is the same in every lane: a byte it knows to be uniform it moves to a scalar
-  //  register at once -- v_readfirstlane behind a wait, i.e. a memory round trip in front of the state's loads, 7 % of the
+  //  register at once -- v_readfirstlane behind a wait, i.e. a memory round trip in front of everything else, 7 % of the
   //  step with a frame stack)
   unsigned fin_v = 0;
   if (RESIZE && a.stack_done) {
@@ -1364,75 +1266,40 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     fin_v = a.stack_done[idx];
   }
   if (recheck) {
-    const unsigned long long w = a.hint[env >> 6];  // uniform: a scalar load, in flight beside the vector loads above
+    const unsigned long long w = a.hint[env >> 6];  // uniform: a scalar load, in flight beside the loads above
     if ((w >> (env & 63)) & 1ull)                    // a hinted env: one of the front workgroups may be drawing it
       if (pick_env(a, (int)blockIdx.x, lane) < 0) return;
   }
-  if (RESIZE && SF_PTAB && lane < kTapColPeriod + kTapRowPeriod) reinterpret_cast<uint4*>(ptab)[lane] = ptab_e;
-  const int ship_angle = (int)(int16_t)(sm.x & 0xFFFF);
-  const int fort_angle = (int)(int16_t)((unsigned)sm.x >> 16);
-  const unsigned flags = ((unsigned)sm.y >> 16) & 0xFFu;
-  const unsigned mmask = (SF_RENDER_SKIP & 2) ? 0u : ((unsigned)mi.z & SF_MASK_LOW),
-                 smask = (SF_RENDER_SKIP & 2) ? 0u : ((unsigned)mi.w & SF_MASK_LOW);
-  const int pnts = (int)__int_as_float(sc.x);  // drawScore takes mScore.mPoints as an int (SRC/draw.cpp:190,266)
-  const int vlner = sc.z & 0xFFF;  // the low 12 bits of the packed word (sf_layout.h: SF_W_VLNER)
-  const int fort_vuln_timer = tb.w;
-  const float ship_x = (float)sp.x, ship_y = (float)sp.y;
-  const bool ship_alive = flags & SF_FL_SHIP_ALIVE;
+  const float ship_x = __uint_as_float(hd[SF_DRW_SHIP_X]), ship_y = __uint_as_float(hd[SF_DRW_SHIP_Y]);
+  const int pnts = (int)hd[SF_DRW_POINTS];
+  const unsigned objmask = (SF_RENDER_SKIP & 2) ? (hd[SF_DRW_OBJMASK] & 3u) : hd[SF_DRW_OBJMASK];
+  const unsigned mmask = objmask >> SF_DR_OBJ_MISSILE0;
+  const unsigned shw = hd[SF_DRW_SHELLS], smask = (SF_RENDER_SKIP & 2) ? 0u : (shw & SF_MASK_LOW);
+  const unsigned fl = hd[SF_DRW_FLAGS];
+  const int bgi = (int)SF_DRF_BG(fl), bstate = (int)SF_DRF_BAR(fl);
+  const bool dead_ship = !(fl & SF_DRF_SHIP_ALIVE);
 
-  SF_DBG_STAMP(dbg_pa);
-  // ---- ROUND TRIP 2: everything else this frame reads from memory, asked for at once now that the state says what that
-  // is -- a wave's loads come back in the order they were issued, so what is needed first goes first: (1) the tile's
-  // missile pool, meta AND position of up to three rows whether or not an entry turns out to be this env's (an env's
-  // missiles used to cost two dependent trips: the meta words, then the positions of the matches); the shells' positions;
-  // the sines of the two headings; (2) what is restored right after the surface is in: the dead ship's cached explosion
-  // -- key and pixels together, the pixels used if the key matches -- and the fortress's picture; (3) the 84x84
-  // background's seven pieces; (4) LAST, the surface's direct-to-LDS loads.  Until round 2 each of these was a round trip
-  // of its own, one behind the other: 30 % of a wave's life was this skeleton (profiles/r02_pmc_render_variants_v22.txt,
-  // `only_copy`).
-  constexpr int kPoolRows = 3;
-  // (unconditional instructions: under `if (mmask)` the compiler merges the loaded registers with their defaults right
-  //  behind the loads, i.e. waits for them there; a frame without missiles -- one in five -- reads six rows for nothing)
-  unsigned pmeta[kPoolRows];
-  d2_t ppos[kPoolRows];
-  const unsigned n_pool = (unsigned)mi.z >> SF_MPOOL_SHIFT;
-#pragma unroll
-  for (int r = 0; r < kPoolRows; r++) {
-    const unsigned e = 64u * r + (unsigned)lane;  // (always inside the tile's pool rows: SF_NSLOT rows of 64 entries)
-    pmeta[r] = (SF_RENDER_SKIP & 8192) ? 0u : R_LD(uint32_t, R_CHUNK(missile_meta, 0), e * 4u);
-    ppos[r] = (SF_RENDER_SKIP & 8192) ? d2_t{0.0, 0.0} : R_LD(d2_t, R_CHUNK(missile_pos, 0), e * 16u);
+  // ---- ROUND TRIP 2: everything else this frame reads from memory, asked for at once now that the record says what that
+  // is -- a wave's loads come back in the order they were issued, so what is needed first goes first: (1) the shells'
+  // positions, for the frames that have one; (2) what is restored right after the surface is in: the dead ship's cached
+  // explosion -- key and pixels together, the pixels used if the key matches; (3) the 84x84 background's seven pieces;
+  // (4) LAST, the surface's direct-to-LDS loads.
+  // shells (14 % of the frames have one): lane 4 s + k draws stroke k of slot s (slots 0 .. 15; the last four slots --
+  // seventeen live shells -- have a late round of their own) -- unless the top lanes of the missiles' range are free for
+  // them (the record's SF_DRF_MERGE_SHELLS: nearly always): then their strokes sit there, behind the missiles' as in the draw
+  // order, and go through draw_strokes with everything else instead of a call, a chunk, a resample pass of their own
+  const bool merge_shells = SF_MERGE_SHELLS && (fl & SF_DRF_MERGE_SHELLS);
+  const int shl = merge_shells ? lane - (int)(shw >> 24) : lane;  // 4 * slot + stroke, negative = not a shell's lane
+  const unsigned char* const tile = a.state + (long)(env >> 6) * sfl::kTileBytes;  // (the shells' positions live in the state)
+  const int o16 = (env & 63) * 16;
+  d2_t shell_p = {0.0, 0.0}, shell_v = {0.0, 0.0};
+  if (smask) {  // uniform
+    shell_p = R_LD(d2_t, R_CHUNK(shell_pos, max(shl, 0) >> 2), o16);
+    shell_v = R_LD(d2_t, R_CHUNK(shell_vel, max(shl, 0) >> 2), o16);
   }
-  // shells: lane 4 s + k will draw stroke k of slot s (slots 0 .. 15; the last four slots -- seventeen live shells -- have a
-  // late round of their own): position and velocity of its slot
-  // ... unless the top lanes of the missiles' range are free for them (1 + highest live slot <= 8, the missile slots whose
-  // lanes those are empty -- nearly always): then the shells' strokes sit there, behind the missiles' as in the draw order,
-  // and go through draw_strokes with everything else instead of a call, a chunk, a resample pass of their own
-  constexpr int kFirstMissileLane = 7;  // lanes 0 .. 2: the ship's strokes, 3 .. 6: the fortress's, 7 ..: three per missile slot
-  const int sh_hi = smask ? 32 - __builtin_clz(smask) : 0;  // 1 + highest live slot
-  const int sh_base = 64 - 4 * sh_hi;
-  const bool merge_shells = SF_MERGE_SHELLS && smask != 0u && sh_hi <= 8 && (mmask >> ((sh_base - kFirstMissileLane) / 3)) == 0u;
-  const int shl = merge_shells ? lane - sh_base : lane;  // 4 * slot + stroke, negative = not a shell's lane
-  d2_t shell_p = R_LD(d2_t, R_CHUNK(shell_pos, max(shl, 0) >> 2), o16);
-  d2_t shell_v = R_LD(d2_t, R_CHUNK(shell_vel, max(shl, 0) >> 2), o16);
-
-  // what was drawn before the fortress: the ship (within 25.5 + 1.5 user units of its position) or its explosion
-  Box sb = explosion_box(ship_x, ship_y);
-  if (ship_alive) {
-    const float gx = dev_x(ship_x), gy = dev_y(ship_y), ext = 27.f * (float)SF_SCALE;
-    sb = Box{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
-  }
-  const bool fort_alive = flags & SF_FL_FORT_ALIVE;
-  const int sector = fort_angle / 10;
-  // the fortress's picture is good when nothing the ship drew comes within reach of its box (+ what its 84x84 pixels read);
-  // the two then touch no pixel in common, in either size, so the picture may go in BEFORE the ship is drawn
-  const bool fort_pic = !(SF_RENDER_SKIP & (1 | 512)) && fort_alive && a.fpatch && fort_angle >= 0 && fort_angle < 360 &&
-                        sector * 10 == fort_angle && !sb.meets(Box{kFpX0 - kReachX, kFpY0 - kReachY, kFpX1 + kReachX, kFpY1 + kReachY});
   unsigned char* const xc_mine = a.xcache ? a.xcache + (size_t)env * SF_XC_BYTES : nullptr;
-  const bool dead_ship = !ship_alive && !(SF_RENDER_SKIP & (1 | 256));
   // ---- The frame starts as a copy of the static background: the 92x90 surface into LDS, its 84x84 image into the
-  // caller's frame.  Which variant (score / bar baked in) depends on what the projectiles touch, known only after their
-  // strokes are built -- but nearly always it is what the score, the bar and the dead ship's explosion say, and the
-  // copies are made for that guess.
+  // caller's frame.  Which one -- score / bar baked in, the live fortress's picture baked in -- the record says.
   auto start_surface = [&](int variant) {
     // Ten loads that write LDS directly (global_load_lds: lane i's 16 bytes land at M0 + offset + 16 i; the offset
     // moves both addresses), all in flight at once and without registers: 8 x 1 KiB, the 5 whole pieces behind them,
@@ -1481,101 +1348,27 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // the score's and the bar's pictures, when they will not be the baked-in 0000000 / empty ones: used last, asked for now
   const Box tbox{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1};
   const Box bbox{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
-  const int bstate = bar_state(vlner, fort_vuln_timer);
 #ifndef SF_HUD_PREFETCH
 #define SF_HUD_PREFETCH 1
 #endif
   const bool score_pre = SF_HUD_PREFETCH && a.hud && pnts != 0 && pnts >= -SF_HUD_SCORE_HALF && pnts < SF_HUD_SCORE_HALF && !(SF_RENDER_SKIP & 4);
-  const bool bar_pre = SF_HUD_PREFETCH && a.hud && vlner != 0 && !(SF_RENDER_SKIP & 8);
-  bool near_text = false, near_bar = false;
-  if (!ship_alive && !(SF_RENDER_SKIP & 1)) {
-    // wider by the reach (kReachX, kReachY) than what the explosion paints: the 84x84 pixels recomputed (or restored from the
-    // cache) for it read that far, and must not depend on whether the score / bar were baked in
-    Box eb = explosion_box(ship_x, ship_y);
-    eb.x0 -= kReachX; eb.y0 -= kReachY; eb.x1 += kReachX; eb.y1 += kReachY;
-    near_text = eb.meets(tbox);
-    near_bar = eb.meets(bbox);
-  }
-  const int variant0 = ((pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4)) ? 1 : 0) |
-                       ((vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8)) ? 2 : 0);
-  // ... and the 84x84 background's seven pieces, for the variant the score, the bar and the dead ship's explosion call for
-  // (nearly always the final one: a projectile over the score or the bar starts again below)
-  Pieces frame0 = {};
-  // ... with the live fortress's picture already in it when that picture is good (fort_pic): backgrounds 4 (1 + sector) + variant
-  // (sf_bg_fort_kernel; SF_BG_FORT = 0: the picture is fetched here and put in behind the barrier, as until round 3)
-  const int bgsel = (SF_BG_FORT && fort_pic) ? 4 * (1 + sector) : 0;
-  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + (bgsel + variant0) * (kOutBytes / 4)), kOutBytes / 16, lane);
-  // (in front of them, for what is restored right behind the barrier or at the very end: the dead ship's cached
-  //  explosion -- key and pixels together, the pixels used if the key matches --, the fortress's picture, the score's and
-  //  the bar's: not needed before the surface is, so not held in registers through the arithmetic above)
+  const bool bar_pre = SF_HUD_PREFETCH && a.hud && bstate != 0 && !(SF_RENDER_SKIP & 8);
+  // (in front of the background's pieces, for what is restored right behind the barrier or at the very end: the dead ship's
+  //  cached explosion -- key and pixels together, the pixels used if the key matches --, the score's and the bar's pictures)
   XcFetch xf = {};
   if (dead_ship && xc_mine) xf = xc_fetch<RESIZE>(xc_mine, lane);
-  FortPic fpic = {};
-  if (!SF_BG_FORT && fort_pic) fpic = fort_patch_fetch<RESIZE>(a.fpatch + sector * SF_FP_BYTES, lane);
   HudWords hscore = {}, hbar = {};
   if (score_pre) hscore = hud_fetch<RESIZE>(hud_score_picture(a.hud, pnts), SF_HUD_SCORE_ROW, tbox, lane);
   if (bar_pre) hbar = hud_fetch<RESIZE>(hud_bar_picture(a.hud, bstate), SF_HUD_BAR_ROW, bbox, lane);
+  // the 84x84 background's seven pieces
+  Pieces frame0 = {};
+  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + bgi * (kOutBytes / 4)), kOutBytes / 16, lane);
   // ... and LAST of the round trip, the surface's ten direct-to-LDS loads: a wave's loads come back in issue order and the
   // compiler does not know of these ten, so every wait it counts out for something issued before them stays a wait for
-  // that alone.  Nothing in the prologue depends on a load that depends on a load any more (the headings' sines are looked
-  // up across lanes, sincos_lanes): state -> everything else -> the barrier, two round trips where round 2 had six.
-  if (!(SF_RENDER_SKIP & 4096)) start_surface(bgsel + variant0);  // (bits 11, 12: timing-only, no background loads / no surface)
-  SF_DBG_STAMP(dbg_pb);
+  // that alone.
+  if (!(SF_RENDER_SKIP & 4096)) start_surface(bgi);  // (bit 12: timing-only, no surface)
 
-  // ---- projectile strokes: one lane per wireframe segment (missiles: slot*3 + k; shells: two rounds of slot*4 + k)
-  static_assert(kFirstMissileLane + 3 * 19 == 64, "slots 0 .. 18 fill the wave behind the ship's and the fortress's strokes");
-  Seg mg = {};
-  float m19x = 0.f, m19y = 0.f, m19a = 0.f;
-  bool mvalid = false;
-  if (mmask) {
-    // The tile keeps its live missiles as one dense pool (sf_layout.h); this env's are the entries whose owner is its
-    // lane.  The wave looks at the pool's entries, 64 at a time, and files its own by slot -- the reference draws in
-    // slot order (SRC/draw.cpp:243-247) -- in the scratch area.
-    float* const mtab = reinterpret_cast<float*>(slist);  // [slot] (x, y, heading): the stroke list's LDS, not yet in use
-    static_assert(SF_NSLOT * 3 * sizeof(float) <= sizeof(slist), "slot table fits the scratch");
-    auto file_entry = [&](unsigned e, unsigned meta, const d2_t& m) {
-      if (e < n_pool && SF_MM_OWNER(meta) == (unsigned)l) {
-        float* t = mtab + 3 * SF_MM_SLOT(meta);
-        t[0] = (float)m.x;
-        t[1] = (float)m.y;
-        t[2] = (float)SF_MM_ANGLE(meta);
-      }
-    };
-    // (opaque to the optimiser up to here: it would otherwise convert the positions where they are loaded -- and wait for
-    //  them there, in front of the loads that follow)
-    asm volatile("" : "+v"(pmeta[0]), "+v"(pmeta[1]), "+v"(pmeta[2]));
-#pragma unroll
-    for (int r = 0; r < kPoolRows; r++) asm volatile("" : "+v"(ppos[r].x), "+v"(ppos[r].y));
-#pragma unroll
-    for (int r = 0; r < kPoolRows; r++) file_entry(64u * r + (unsigned)lane, pmeta[r], ppos[r]);
-    for (unsigned e = 64u * kPoolRows + lane; e < n_pool; e += 64)  // (more than 192 live missiles in the tile: rare)
-      file_entry(e, R_LD(uint32_t, R_CHUNK(missile_meta, 0), e * 4u), R_LD(d2_t, R_CHUNK(missile_pos, 0), e * 16u));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // lanes 7 .. 63 take the strokes of slots 0 .. 18 (lanes 0 .. 6 are the ship's and the fortress's: draw order);
-    // slot 19 -- twenty live missiles -- has a round of its own at the end of the list
-    const int pl = lane - kFirstMissileLane, slot = pl / 3, k = pl - slot * 3;
-    mvalid = pl >= 0 && ((mmask >> slot) & 1u);
-    if (mvalid) {  // (heading in .ca for now: every stroke's sine is looked up in one go below)
-      const float* t = mtab + 3 * slot;
-      const Line ml = missile_line(k);
-      mg = Seg{ml.ax, ml.ay, ml.bx, ml.by, t[2], 0.f, t[0], t[1], ml.inv};
-    }
-    if (mmask >> 19) {  // uniform, all but never: its strokes are built where they are drawn
-      m19x = mtab[3 * 19];
-      m19y = mtab[3 * 19 + 1];
-      m19a = mtab[3 * 19 + 2];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  // shells (14 % of the frames have one): their strokes, built here with the surface's loads in flight (round 2 built them
-  // where they are drawn, behind two loads and a double-precision atan2 at the end of the frame: the slowest frames of a
-  // launch)
-  SF_DBG_STAMP(dbg_pe);
-  bool sh_t = false, sh_b = false, sh_t3 = false, sh_b3 = false;
+  // ---- the shells' strokes, built here with the surface's loads in flight
   Quad sq0 = {};
   bool sq0_valid = false;
   auto shell_quad = [&](d2_t s, d2_t v, int k, bool have, Quad* q) -> bool {
@@ -1589,43 +1382,19 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       if (ang < 0) ang += 360.0;
       ideg = (int)ang;
     }
-    // (the lookup permutes lanes: every lane of the wave takes part, whatever it holds)
     float sn, cs;
-    sincos_lanes(sct, ideg, &sn, &cs);
+    sincos_deg(ideg, &sn, &cs);
     if (valid) *q = line_quad(shell_line(k), cs, sn, (float)s.x, (float)s.y);
     return valid;
   };
-  if (smask) {
-    const Box tb0{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1}, bb0{SF_BAR_BOX_X0, SF_BAR_BOX_Y0, SF_BAR_BOX_X1, SF_BAR_BOX_Y1};
-    const Box tb3{SF_TXT_BOX_X0 - kReachX, SF_TXT_BOX_Y0 - kReachY, SF_TXT_BOX_X1 + kReachX, SF_TXT_BOX_Y1 + kReachY};
-    const Box bb3{SF_BAR_BOX_X0 - kReachX, SF_BAR_BOX_Y0 - kReachY, SF_BAR_BOX_X1 + kReachX, SF_BAR_BOX_Y1 + kReachY};
+  if (smask) {  // uniform
     asm volatile("" : "+v"(shell_p.x), "+v"(shell_p.y), "+v"(shell_v.x), "+v"(shell_v.y));
     sq0_valid = shell_quad(shell_p, shell_v, lane & 3, shl >= 0 && ((smask >> (shl >> 2)) & 1u), &sq0);
-    if (sq0_valid) {
-      const Box shb = quad_box(sq0);
-      if (shb.y0 < kHudTopRows || shb.y1 > kHudBottomRows) {  // (in the rows of the score or of the bar, reach included: all but never)
-        sh_t = shb.meets(tb0);
-        sh_b = shb.meets(bb0);
-        sh_t3 = shb.meets(tb3);
-        sh_b3 = shb.meets(bb3);
-      }
-    }
-    if ((smask >> 16) && lane < 4 && ((smask >> (16 + lane)) & 1u)) {  // (slots 16 .. 19: within 16 + 1.5 user units of the position)
-      const d2_t sp1 = R_LD(d2_t, R_CHUNK(shell_pos, 16 + lane), o16);
-      const float gx = dev_x((float)sp1.x), gy = dev_y((float)sp1.y), ext = 17.5f * (float)SF_SCALE + 0.01f;
-      const Box shb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
-      sh_t = sh_t || shb.meets(tb0);
-      sh_b = sh_b || shb.meets(bb0);
-      sh_t3 = sh_t3 || shb.meets(tb3);
-      sh_b3 = sh_b3 || shb.meets(bb3);
-    }
   }
   // the 84x84 background's seven stores, behind everything: stores count like loads, in the same order -- in front of the
   // surface's loads, the wait for the surface would be a wait for their acknowledgement from HBM as well
-  SF_DBG_STAMP(dbg_pf);
   if (RESIZE) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
-  SF_DBG_STAMP(dbg_pg);
-  // the frame stack's older slots (independent of the variant)
+  // the frame stack's older slots
   const unsigned fin_b = (RESIZE && a.stack_done) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fin_v) : 0u;
   const bool stack_traffic = RESIZE && (a.stack_prev || fin_b != 0);  // more loads / stores behind the seven: see the wait below
   if (RESIZE && a.stack_prev) {
@@ -1649,23 +1418,19 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     }
   }
 
-  // the frame's strokes in draw order, one per lane: the live ship's three, the fortress's four when it has to be drawn
-  // in place, the missiles' (SRC/draw.cpp:233-247); one line_quad for all of them
-  const bool ship_strokes = ship_alive && !(SF_RENDER_SKIP & (1 | 128));
-  const bool fort_strokes = !(SF_RENDER_SKIP & (1 | 512)) && fort_alive && !fort_pic;
-  {
-    const Line sl = ship_line(lane), fl = fort_line(lane - 3);
-    if (lane < 3) mg = Seg{sl.ax, sl.ay, sl.bx, sl.by, (float)ship_angle, 0.f, ship_x, ship_y, sl.inv};
-    else if (lane < kFirstMissileLane) mg = Seg{fl.ax, fl.ay, fl.bx, fl.by, (float)fort_angle, 0.f, (float)sfc::fort_x, (float)sfc::fort_y, fl.inv};
-    float s_, c_;
-    sincos_lanes(sct, (int)mg.ca, &s_, &c_);
-    mg.ca = c_;
-    mg.sa = s_;
-  }
-  const bool svalid = lane < 3 ? ship_strokes : (lane < kFirstMissileLane ? fort_strokes : mvalid);
-  const int sobj = lane < 3 ? 0 : (lane < kFirstMissileLane ? 3 : kFirstMissileLane + 3 * ((lane - kFirstMissileLane) / 3));
+  // ---- the frame's strokes in draw order, one per lane: the live ship's three, the fortress's four when it has to be
+  // drawn in place, the missiles' (SRC/draw.cpp:233-247) -- the lane's corners under the object's transform, translate(pos)
+  // rotate(angle) (drawWireFrame, SRC/draw.cpp:112-129), in device pixels
+  const bool svalid = ((objmask >> obj) & 1u) && !((SF_RENDER_SKIP & 1) && lane < kFirstMissileLane);
+  const int sobj = lane < 3 ? 0 : (lane < kFirstMissileLane ? 3 : kFirstMissileLane + 3 * mslot);
   Quad mq = {};
-  if (svalid) mq = line_quad(mg);
+  if (svalid) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      mq.x[k] = dev_x(tf.x + tf.z * lsx[k] - tf.w * lsy[k]);
+      mq.y[k] = dev_y(tf.y + tf.w * lsx[k] + tf.z * lsy[k]);
+    }
+  }
   bool dvalid = svalid;  // what draw_strokes is given: with the shells' strokes in the top lanes when they fit there
   int dobj = sobj;
   if (merge_shells && shl >= 0) {
@@ -1674,133 +1439,59 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     dobj = lane & ~3;
   }
 
-  // ---- background variant.  The score and the bar are drawn LAST (SRC/draw.cpp:266-268); when they
-  // show 0000000 / an empty bar and nothing drawn before them reaches their pixels, the result is the
-  // static picture the host baked (same arithmetic, sf_raster.h).  A live ship and the fortress never
-  // reach them (the ship is inside the big hexagon, rows 12.2 .. 81.6 +- 5.4 px).
-  // A score / bar that is not baked in is one of the pictures (hud_picture) unless something comes within reach (kReachX, kReachY)
-  // of its box: the picture's 84x84 pixels read that far, and it is restored after everything else was resampled.
-  const Box tbox3{SF_TXT_BOX_X0 - kReachX, SF_TXT_BOX_Y0 - kReachY, SF_TXT_BOX_X1 + kReachX, SF_TXT_BOX_Y1 + kReachY};
-  const Box bbox3{SF_BAR_BOX_X0 - kReachX, SF_BAR_BOX_Y0 - kReachY, SF_BAR_BOX_X1 + kReachX, SF_BAR_BOX_Y1 + kReachY};
-  const bool ex_text = near_text, ex_bar = near_bar;  // the explosion's share (its box above is already wider by the reach)
-  bool other_text = false, other_bar = false;          // anything else within reach: the live ship, projectiles
-  if (ship_alive) {  // (the ship stays inside the big hexagon: rows 12.2 .. 81.6 +- 5.4 px -- never on the bar, but close)
-    other_text = sb.meets(tbox3);
-    other_bar = sb.meets(bbox3);
-  }
-  {
-    bool t = false, b = false, t3 = false, b3 = false;
-    if ((mmask >> 19) && lane == 0) {  // (the twentieth missile: within 25 + 1.5 user units of its position)
-      const float gx = dev_x(m19x), gy = dev_y(m19y), ext = 26.5f * (float)SF_SCALE + 0.01f;
-      const Box qb{(int)floorf(gx - ext), (int)floorf(gy - ext), (int)ceilf(gx + ext), (int)ceilf(gy + ext)};
-      t = qb.meets(tbox);
-      b = qb.meets(bbox);
-      t3 = qb.meets(tbox3);
-      b3 = qb.meets(bbox3);
-    }
-    // a missile's stroke in the rows of the score or of the bar (their reach included): the four box tests only then -- a
-    // frame in a few hundred; they were seventy instructions of every frame
-    bool rows = false;
-    Box qb;
-    qb.clear();
-    if (mvalid) {
-      qb = quad_box(mq);
-      rows = qb.y0 < kHudTopRows || qb.y1 > kHudBottomRows;
-    }
-    if (__any(rows)) {
-      if (rows) {
-        t = t || qb.meets(tbox);
-        b = b || qb.meets(bbox);
-        t3 = t3 || qb.meets(tbox3);
-        b3 = b3 || qb.meets(bbox3);
-      }
-    }
-    t = t || sh_t;
-    b = b || sh_b;
-    t3 = t3 || sh_t3;
-    b3 = b3 || sh_b3;
-    if (__any(t || b || t3 || b3)) {
-      near_text = near_text || __any(t);
-      near_bar = near_bar || __any(b);
-      other_text = other_text || __any(t3);
-      other_bar = other_bar || __any(b3);
-    }
-  }
-  SF_DBG_STAMP(dbg_pc);
-  const bool close_text = ex_text || other_text, close_bar = ex_bar || other_bar;
-  const bool baked_text = pnts == 0 && !near_text && !(SF_RENDER_SKIP & 4);
-  const bool baked_bar = vlner == 0 && !near_bar && !(SF_RENDER_SKIP & 8);
-  const int variant = (baked_text ? 1 : 0) | (baked_bar ? 2 : 0);
-  if (variant != variant0) {  // a projectile over the score or the bar (rare): start again from the right picture
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    start_surface(bgsel + variant);
-    if (RESIZE)
-      copy_pieces(reinterpret_cast<const uint4*>(a.bg84 + (bgsel + variant) * (kOutBytes / 4)), reinterpret_cast<uint4*>(frame_out),
-                  kOutBytes / 16, lane);
-  }
   // The 84x84 background's seven stores are the LAST vector-memory instructions in front of this wait (but for a frame
   // stack's shifted / cleared slots): vmcnt counts loads, stores and LDS-DMA together in issue order, so `vmcnt(7)` =
   // everything but these stores is done -- the surface is in LDS -- without waiting for the stores to be acknowledged.  The
   // byte stores that follow land on top of them anyway: one wave's stores to one address are performed in program order.
   static_assert(kFrameRounds == 7 && 6 * 64 < kOutBytes / 16, "all seven stores have lanes to do");
-  SF_DBG_STAMP(dbg_pd);
   if (RESIZE && !stack_traffic) {
     asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  const Frame<RESIZE> F{fb, frame_out, tabw, (RESIZE && SF_PTAB) ? ptab : nullptr, lane, srec, slist};
-#ifdef SF_DBG_FLAGS
-  dbg_t1 = __builtin_amdgcn_s_memtime();
-#endif
+  const Frame<RESIZE> F{fb, frame_out, tabw, nullptr, lane, srec, slist};
   if (SF_RENDER_STOP == 1) return;
 
-  // ---- what is restored from round trip 2's registers: the dead ship's explosion if its cache entry is this one, and
-  // the fortress's picture
+  // ---- what is restored from round trip 2's registers: the dead ship's explosion if its cache entry is this one
+  // (the entry is keyed by where the ship died as the picture sees it: the float32 position)
   XcState xst{0u, 0, 0};
   bool explosion_done = false;
-  if (dead_ship && xc_mine) explosion_done = xc_apply(F, xf, sp.x, sp.y, &xst);
-  if (!SF_BG_FORT && fort_pic) fort_patch_put(F, fpic);
-  if (SF_RENDER_STOP == 2) return;
-
-  // ---- ship (SRC/draw.cpp:233-237): a dead ship's explosion that was not in the cache is the first thing drawn
-  if (dead_ship && !explosion_done) xst = ship_explosion(F, xc_mine, sp.x, sp.y, true, /*skip_lookup=*/true);
+  if (dead_ship && !(SF_RENDER_SKIP & (1 | 256))) {
+    if (xc_mine) explosion_done = xc_apply(F, xf, (double)ship_x, (double)ship_y, &xst);
+    if (SF_RENDER_STOP == 2) return;
+    // ---- ship (SRC/draw.cpp:233-237): a dead ship's explosion that was not in the cache is the first thing drawn
+    if (!explosion_done) xst = ship_explosion(F, xc_mine, (double)ship_x, (double)ship_y, true, /*skip_lookup=*/true);
+  }
   // ---- fortress (:238-242), destroyed: it explodes for 1000 ms where it stands: one more picture drawn once per batch, in
   // the layout of the per-env explosion cache (a trained agent destroys it every few seconds -- 30 frames each time).
   // Restored when what the ship drew stays clear of it (wider by the reach: what its 84x84 pixels read) -- the two touch no
   // pixel in common then, so it may go in before the ship --; else drawn in place between the ship and the missiles.
-  bool fort_explodes_in_place = false;
-  if (!fort_alive && !(SF_RENDER_SKIP & (1 | 512))) {
-    Box fe = explosion_box((float)sfc::fort_x, (float)sfc::fort_y);
-    fe.x0 -= kReachX; fe.y0 -= kReachY; fe.x1 += kReachX; fe.y1 += kReachY;
-    if (a.fpatch && !sb.meets(fe))
-      ship_explosion(F, const_cast<unsigned char*>(a.fpatch) + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y, false);
-    else
-      fort_explodes_in_place = true;
-  }
+  if ((fl & SF_DRF_FORT_EX_PATCH) && !(SF_RENDER_SKIP & (1 | 512)))
+    ship_explosion(F, const_cast<unsigned char*>(a.fpatch) + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y, false);
+  const bool fort_explodes_in_place = (fl & SF_DRF_FORT_EX_PLACE) && !(SF_RENDER_SKIP & (1 | 512));
   if (SF_RENDER_STOP == 3) return;
   // ---- the live ship, the fortress in place, the missiles (:233-247): all their strokes at once
   if (!fort_explodes_in_place) {
-#ifdef SF_DBG_FLAGS
-    F.draw_strokes(mq, dvalid, dobj, dbg_ds);
-#else
     F.draw_strokes(mq, dvalid, dobj);
-#endif
   } else {  // (rare: the ship, or its explosion, next to an exploding fortress)
     F.draw_strokes(mq, dvalid && lane < 3, dobj);
     draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);
     F.draw_strokes(mq, dvalid && lane >= kFirstMissileLane, dobj);
   }
-  if (mmask >> 19) {  // (the twentieth missile)
-    float s19, c19;
-    sincos_lanes(sct, (int)m19a, &s19, &c19);
-    F.draw_strokes(line_quad(missile_line(lane < 3 ? lane : 0), c19, s19, m19x, m19y), lane < 3, 0);
+  if ((fl & SF_DRF_MISSILE19) && !(SF_RENDER_SKIP & 2)) {  // (the twentieth missile: its strokes have no lanes of their own)
+    const f4_t t19 = *reinterpret_cast<const f4_t*>(rec + (SF_DR_HDR_BYTES + (SF_DR_OBJ_MISSILE0 + 19) * SF_DR_OBJ_BYTES));
+    const int ml = kFirstMissileLane + (lane < 3 ? lane : 0);  // a missile's three strokes: the corners of lanes 7 .. 9
+    const f4_t mx = *reinterpret_cast<const f4_t*>(kLaneStroke[ml].x), my = *reinterpret_cast<const f4_t*>(kLaneStroke[ml].y);
+    Quad q19;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      q19.x[k] = dev_x(t19.x + t19.z * mx[k] - t19.w * my[k]);
+      q19.y[k] = dev_y(t19.y + t19.w * mx[k] + t19.z * my[k]);
+    }
+    F.draw_strokes(q19, lane < 3, 0);
   }
   if (SF_RENDER_STOP == 4) return;
-#ifdef SF_DBG_FLAGS
-  dbg_t2 = __builtin_amdgcn_s_memtime();
-#endif
   // ---- shells (:248-253): slot order
   if (smask && !merge_shells) {
     F.draw_strokes(sq0, sq0_valid, lane & ~3);
@@ -1815,25 +1506,25 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     }
   }
   if (SF_RENDER_STOP == 5) return;
-#ifdef SF_DBG_FLAGS
-  dbg_t3 = __builtin_amdgcn_s_memtime();
-#endif
   // ---- score and bar, last (SRC/draw.cpp:266-268): baked into the background already (0000000 / empty), or one of
-  // the pictures, or -- something else touches their pixels, or the points are off the table -- in place
+  // the pictures, or -- something else touches their pixels, or the points are off the table -- in place.
+  // A score / bar that is not baked in is one of the pictures (hud_picture) unless something comes within reach (kReachX,
+  // kReachY) of its box: the picture's 84x84 pixels read that far, and it is restored after everything else was resampled.
   // When the only thing on them is the dead ship's explosion (a ship lost through the upper or lower edge of the big
   // hexagon, right under the score / over the bar: a sixth of the losses each, 30 frames a time), what the box ends up as
   // belongs to (where the ship died, the points / the bar's state): drawn in place once, kept in the env's explosion
   // cache entry, restored for the other frames.
   // (one call site each for drawing and for the picture copy: what to do is decided first)
-  if (!baked_text && !(SF_RENDER_SKIP & 4)) {
+  if (!(fl & SF_DRF_BAKED_TEXT) && !(SF_RENDER_SKIP & 4)) {
     constexpr unsigned kBits = RESIZE ? 12u : 4u;
+    const bool near_text = fl & SF_DRF_NEAR_TEXT, ex_text = fl & SF_DRF_EX_TEXT, other_text = fl & SF_DRF_OTHER_TEXT;
     unsigned char* pic = nullptr;
     bool draw = true, save = false, with_out = true;
     bool pre = false;
     if (a.hud && !near_text && pnts >= -SF_HUD_SCORE_HALF && pnts < SF_HUD_SCORE_HALF) {
       pic = hud_score_picture(a.hud, pnts);
       draw = false;
-      with_out = !close_text;
+      with_out = !(ex_text || other_text);
       pre = score_pre;
     } else if (xst.flags && ex_text && !other_text) {
       pic = xc_mine + kXcScore;
@@ -1849,18 +1540,16 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       }
     }
   }
-#ifdef SF_DBG_FLAGS
-  const unsigned long long dbg_h1 = __builtin_amdgcn_s_memtime();
-#endif
-  if (!baked_bar && !(SF_RENDER_SKIP & 8)) {
+  if (!(fl & SF_DRF_BAKED_BAR) && !(SF_RENDER_SKIP & 8)) {
     constexpr unsigned kBits = RESIZE ? 48u : 16u;
+    const bool near_bar = fl & SF_DRF_NEAR_BAR, ex_bar = fl & SF_DRF_EX_BAR, other_bar = fl & SF_DRF_OTHER_BAR;
     const int state = bstate;
     unsigned char* pic = nullptr;
     bool draw = true, save = false, with_out = true, pre = false;
     if (a.hud && !near_bar) {
       pic = hud_bar_picture(a.hud, state);
       draw = false;
-      with_out = !close_bar;
+      with_out = !(ex_bar || other_bar);
       pre = bar_pre;
     } else if (xst.flags && ex_bar && !other_bar) {
       pic = xc_mine + kXcBar;
@@ -1877,38 +1566,6 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     }
   }
   __syncthreads();
-#ifdef SF_DBG_FLAGS  // diagnostic builds only: the frame's decisions in its first bytes, its wave's life (shader clocks) behind
-  if (lane == 0) {
-    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-    const unsigned dt = (unsigned)(t_end - dbg_t0), d1 = (unsigned)(dbg_t1 - dbg_t0), d2 = (unsigned)(dbg_t2 - dbg_t0), d3 = (unsigned)(dbg_t3 - dbg_t0);
-    __builtin_memcpy(frame_out + 4, &dt, 4);
-    __builtin_memcpy(frame_out + 8, &d1, 4);
-    __builtin_memcpy(frame_out + 12, &d2, 4);
-    __builtin_memcpy(frame_out + 16, &d3, 4);
-    const unsigned pa = (unsigned)(dbg_pa - dbg_t0), pb = (unsigned)(dbg_pb - dbg_t0), pc = (unsigned)(dbg_pc - dbg_t0), pd = (unsigned)(dbg_pd - dbg_t0);
-    __builtin_memcpy(frame_out + 20, &pa, 4);
-    __builtin_memcpy(frame_out + 24, &pb, 4);
-    __builtin_memcpy(frame_out + 28, &pc, 4);
-    __builtin_memcpy(frame_out + 32, &pd, 4);
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-      const unsigned v = (k == 0 || k == 4) ? (unsigned)(dbg_ds[k] - dbg_t0) : (unsigned)dbg_ds[k];
-      __builtin_memcpy(frame_out + 36 + 4 * k, &v, 4);
-    }
-    frame_out[2] = (uint8_t)dbg_ds[5];
-    const unsigned h1 = (unsigned)(dbg_h1 - dbg_t0);
-    __builtin_memcpy(frame_out + 68, &h1, 4);
-    frame_out[3] = (uint8_t)((close_text ? 1 : 0) | (close_bar ? 2 : 0) | (score_pre ? 4 : 0) | (bar_pre ? 8 : 0) | (merge_shells ? 16 : 0));
-    const unsigned pe = (unsigned)(dbg_pe - dbg_t0), pf = (unsigned)(dbg_pf - dbg_t0), pg = (unsigned)(dbg_pg - dbg_t0);
-    __builtin_memcpy(frame_out + 56, &pe, 4);
-    __builtin_memcpy(frame_out + 60, &pf, 4);
-    __builtin_memcpy(frame_out + 64, &pg, 4);
-    frame_out[0] = (uint8_t)((baked_text ? 1 : 0) | (baked_bar ? 2 : 0) | (near_text ? 4 : 0) | (near_bar ? 8 : 0) | (close_text ? 16 : 0) |
-                             (close_bar ? 32 : 0) | (ship_alive ? 64 : 0) | (explosion_done ? 128 : 0));
-    frame_out[1] = (uint8_t)((variant != variant0 ? 1 : 0) | (fort_pic ? 2 : 0) | (fort_alive ? 4 : 0) | (smask ? 8 : 0) | (mmask ? 16 : 0) |
-                             (pnts != 0 ? 32 : 0) | (vlner != 0 ? 64 : 0) | (xst.flags ? 128 : 0));
-  }
-#endif
 
   // ---- epilogue: the 84x84 frame is already where it belongs; the raw one leaves LDS (8280 = 1035 * 8)
   if (!RESIZE) {
@@ -2024,7 +1681,7 @@ hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uin
   return hipGetLastError();
 }
 
-hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32_t* bg, const uint32_t* bg84,
+hipError_t sf_launch_render(const unsigned char* state, const unsigned char* draw, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
                             const uint8_t* stack_prev, const unsigned long long* hint, const unsigned char* hud,
@@ -2033,7 +1690,7 @@ hipError_t sf_launch_render(const unsigned char* state, int n_envs, const uint32
   // the front of the grid: a sixteenth of the batch (ships die in about 1.3 % of the ticks of random play); batches
   // whose hint words no longer fit a short scan (> 32 per lane) are drawn in env order
   const int n_front = hint && n_envs <= 64 * 64 * 32 ? (n_envs / 16 > 64 ? n_envs / 16 : 64) : 0;
-  SfRenderArgs a{state, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n, stack_prev,
+  SfRenderArgs a{state, draw, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n, stack_prev,
                  n_front ? hint : nullptr, n_front, hud};
   const unsigned grid = (unsigned)(n_envs + n_front);
   if (resize)

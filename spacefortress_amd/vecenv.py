@@ -278,6 +278,14 @@ class SFVecEnv:
         _lib.check(self._L.sf_render(self._h, _lib.OBS_TYPES[mode], C.c_void_p(out.data_ptr()), stride, self._stream()))
         return out
 
+    def draw_records(self, from_state=False):
+        """Diagnostics: the envs' draw records (sfmi.h: sf_draw_records) as uint8 [N, 384] -- what the frame kernel reads
+        instead of the state.  from_state=True rebuilds them from the state first (what a frame does after reset() /
+        set_field()); False returns what the last step launch of an image batch left."""
+        out = np.empty((self.num_envs, 384), np.uint8)
+        _lib.check(self._L.sf_draw_records(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes, int(bool(from_state))))
+        return out
+
     def enable_events(self, on=True):
         """Per-tick event bitmasks (sfmi.h SF_EV_*; `_lib.EVENT_NAMES`): after every step `self.events` holds
         uint32 [N] for that tick.  Off by default: it is one more 4-byte store per env and step."""

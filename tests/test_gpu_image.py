@@ -527,3 +527,45 @@ def test_crowded_constructed_frames_vs_model(sfa, oracle_mod, model, monkeypatch
     assert np.array_equal(plain.render("image-raw").cpu().numpy(), raw)
     assert np.array_equal(plain.render("image").cpu().numpy(), small)
     plain.close()
+
+
+def _live_record_bytes(rec):
+    """The bytes of draw records [N, 384] that mean something: the header, the ship's and the fortress's transforms, the
+    transforms of the LIVE missile slots (a dead slot's entry keeps whatever was there)."""
+    n = rec.shape[0]
+    live = np.zeros((n, 384), bool)
+    live[:, :64] = True
+    objmask = rec[:, 12:16].copy().view(np.uint32)[:, 0]
+    for s in range(20):
+        live[:, 64 + 16 * s:80 + 16 * s] = ((objmask >> (2 + s)) & 1).astype(bool)[:, None]
+    return np.where(live, rec, 0)
+
+
+@pytest.mark.parametrize("gametype,policy", [("youturn", "random"), ("autoturn", "hunter"), ("youturn", "charger")])
+def test_draw_records_of_the_step_equal_records_from_the_state(sfa, gametype, policy):
+    """The frame kernel reads the envs' DRAW RECORDS (sf_drawrec.h), which an image batch's step launches leave behind
+    (sf_step_kernel, with the state in registers) and which a frame rebuilds from the state in HBM after any other change
+    (sf_drawrec_kernel).  Two pieces of code, one set of functions: after every few steps of three kinds of play both ways
+    give the same bytes (header, ship, fortress, live missiles) -- and the same frames."""
+    from sfscript import open_loop_actions
+
+    N, T = 1024, 900
+    rng = np.random.default_rng(5)
+    env = sfa.SFVecEnv(N, gametype=gametype, obs_type="image", spawn_stride=1)
+    env.reset()
+    acts = torch.from_numpy(open_loop_actions(policy, (T, N), env.n_actions, rng, phase=rng.integers(0, 96, N))).to(env.device)
+    seen_flags = 0
+    for t in range(T):
+        obs, *_ = env.step_tensors(acts[t])
+        if t % 37 == 0 or t > T - 30:
+            a = env.draw_records(False)
+            frame_a = obs.clone()
+            b = env.draw_records(True)
+            assert np.array_equal(_live_record_bytes(a), _live_record_bytes(b)), (t, np.argwhere(_live_record_bytes(a) != _live_record_bytes(b))[:8])
+            assert torch.equal(env.render("image"), frame_a), t
+            seen_flags |= int(np.bitwise_or.reduce(a[:, 20:24].copy().view(np.uint32)[:, 0]))
+    # the play reached the decisions the records exist for: dead ships, a picture-less fortress, score / bar off the baked path
+    assert seen_flags & (1 << 12) and seen_flags & (1 << 13)
+    if policy == "hunter":
+        assert seen_flags & (3 << 20), hex(seen_flags)  # a destroyed fortress's explosion
+    env.close()
