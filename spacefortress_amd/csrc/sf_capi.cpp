@@ -490,7 +490,13 @@ extern "C" int sf_draw_records(sf_batch* b, void* host, size_t bytes, int from_s
     sf_set_error("sf_draw_records: this batch has no draw records yet (they come with its first frame)");
     return SF_ERR_ARG;
   }
-  HIP_TRY(hipMemcpy(host, b->d_draw, bytes, hipMemcpyDeviceToHost));
+  // (the caller gets them env by env, whatever the device layout: sf_drawrec.h SF_DR_LAYOUT)
+  std::vector<unsigned char> raw((size_t)b->args.lanes * SF_DR_BYTES);
+  HIP_TRY(hipMemcpy(raw.data(), b->d_draw, raw.size(), hipMemcpyDeviceToHost));
+  for (long e = 0; e < b->n_envs; e++)
+    for (int r = 0; r < SF_DR_PIECES; r++)
+      memcpy((unsigned char*)host + (size_t)e * SF_DR_BYTES + 16 * r,
+             raw.data() + (size_t)(e >> 6) * SF_DR_TILE_BYTES + (size_t)r * SF_DR_PIECE_STRIDE + (size_t)(e & 63) * SF_DR_LANE_STRIDE, 16);
   return SF_OK;
 }
 

@@ -32,6 +32,32 @@
 #define SF_DR_OBJ_MISSILE0 2
 #define SF_DR_OBJS (2 + SF_NSLOT)
 #define SF_DR_BYTES (SF_DR_HDR_BYTES + SF_DR_OBJS * SF_DR_OBJ_BYTES) /* 384 */
+// In HBM the records of a wave tile (64 envs, sf_layout.h) form one block of SF_DR_TILE_BYTES; env lane l's 16-byte piece p
+// (pieces 0, 1 = header words 0..3, 4..7; piece 2 + k = object k's transform) sits at l * SF_DR_LANE_STRIDE + p *
+// SF_DR_PIECE_STRIDE.  SF_DR_LAYOUT 0: env by env (384 contiguous bytes per env).  The frame kernel is a wave per env: its
+// two scalar loads and its lanes' transform loads then touch three or four 128-byte lines, 0.5 KB per frame.
+// SF_DR_LAYOUT 1: rows of 64 x 16 bytes like the state's chunks -- every store of the step kernel (a lane per env) a
+// coalesced 1 KiB row, but a frame then pulls up to 23 different lines, 2.9 KB: measured 45.5 against 42.9 us per 16 384
+// frames, for 0 us on the step kernel (profiles/r04_render_versions.md).
+#ifndef SF_DR_LAYOUT
+#define SF_DR_LAYOUT 0
+#endif
+#define SF_DR_PIECES (2 + SF_DR_OBJS)
+#define SF_DR_TILE_BYTES (64 * SF_DR_BYTES)
+#if SF_DR_LAYOUT == 0
+#define SF_DR_LANE_STRIDE SF_DR_BYTES
+#define SF_DR_PIECE_STRIDE 16
+#else
+#define SF_DR_LANE_STRIDE 16
+#define SF_DR_PIECE_STRIDE 1024
+#endif
+#define SF_DR_PIECE_OBJ0 2
+// the cache bits of the step kernel's record stores (aux of the buffer-store builtins): 0 = plain -- the header's two pieces
+// and the ship's and the fortress's transforms are 64 contiguous bytes per env and merge in L2; 16 = sc1, write-through
+// like the state's chunks: each piece then leaves as a partial line of its own (step launch 8.45 against 7.74 us)
+#ifndef SF_DR_AUX
+#define SF_DR_AUX 0
+#endif
 
 // header words
 #define SF_DRW_SHIP_X 0  /* (float)ship_x, bits */
@@ -145,6 +171,17 @@ struct Header {
   unsigned w[8];
 };
 
+// A box by its float edges, before floor / ceil: for a pixel box o = [x0, x1) x [y0, y1) with integer corners,
+//   Box{floor(a.x0), floor(a.y0), ceil(a.x1), ceil(a.y1)}.meets(o)  ==  a.x0 < o.x1 && o.x0 < a.x1 && a.y0 < o.y1 && o.y0 < a.y1
+// (floor(a) < n <=> a < n and n < ceil(b) <=> n < b for an integer n), and clamping the left side to the surface changes
+// nothing for an o that lies on it (max(., 0) < o.x1 with o.x1 > 0, o.x0 < min(., W) with o.x0 < W).  Eight float
+// compares against constants where the boxes cost eight floor / ceil, conversions and clamps per test: the step kernel runs
+// this once per env and tick, with one wave per SIMD and nothing to hide an instruction behind.
+struct FBox {
+  float x0, y0, x1, y1;
+  SFD_FN bool meets(const Box& o) const { return x0 < (float)o.x1 && (float)o.x0 < x1 && y0 < (float)o.y1 && (float)o.y0 < y1; }
+};
+
 // The decisions of a frame (sf_render.hip, round 3: between "round trip 2" and the barrier), from the env's state.
 //   proj  = OR of hud_flags_near over the env's live missiles and shells
 //   pics  = the batch has its pictures (the 36 fortress headings baked into backgrounds, the destroyed fortress's
@@ -153,39 +190,30 @@ SFD_FN Header make_header(double sx, double sy, bool ship_alive, bool fort_alive
                           int fort_vuln_timer, unsigned mmask, unsigned smask, unsigned proj, bool pics, int time_ms) {
   Header h;
   const float ship_x = (float)sx, ship_y = (float)sy;
-  const Box tbox = text_box(), bbox = bar_box();
-  // what was drawn before the fortress: the ship (within 25.5 + 1.5 user units of its position) or its explosion
-  const Box sb = ship_alive ? around(ship_x, ship_y, kShipExt) : explosion_box(ship_x, ship_y);
+  // what was drawn before the fortress: the live ship (within 25.5 + 1.5 user units of its position) or the dead one's
+  // explosion (63 + 1.5) -- sfd::around / sfd::explosion_box, as float edges
+  const float gx = sfr::dev_x(ship_x), gy = sfr::dev_y(ship_y), ext = ship_alive ? kShipExt : 64.5f * (float)SF_SCALE;
+  const FBox sb{gx - ext, gy - ext, gx + ext, gy + ext};
   const int sector = fort_angle / 10;
   // the fortress's picture is good when nothing the ship drew comes within reach of its box (+ what its 84x84 pixels read)
   const bool fort_pic = pics && fort_alive && fort_angle >= 0 && fort_angle < 360 && sector * 10 == fort_angle &&
                         !sb.meets(widened(Box{kFpX0, kFpY0, kFpX1, kFpY1}));
-  bool ex_text = false, ex_bar = false, other_text = false, other_bar = false;
-  if (!ship_alive) {
-    // wider by the reach than what the explosion paints: the 84x84 pixels recomputed (or restored from the cache) for it
-    // read that far, and must not depend on whether the score / bar were baked in
-    const Box eb = widened(sb);
-    ex_text = eb.meets(tbox);
-    ex_bar = eb.meets(bbox);
-  } else {  // (the ship stays inside the big hexagon: rows 12.2 .. 81.6 +- 5.4 px -- never on the bar, but close)
-    other_text = sb.meets(widened(tbox));
-    other_bar = sb.meets(widened(bbox));
-  }
+  // within reach of the score's / the bar's box.  The dead ship's explosion: its 84x84 pixels, recomputed or restored from
+  // the cache, read that far and must not depend on whether the score / bar were baked in (round 3 widened the explosion's
+  // box instead of the score's: the same test).  The live ship stays inside the big hexagon, rows 12.2 .. 81.6 +- 5.4 px:
+  // never on the bar, but close.
+  const bool mt = sb.meets(widened(text_box())), mb = sb.meets(widened(bar_box()));
+  const bool ex_text = !ship_alive && mt, ex_bar = !ship_alive && mb;
+  const bool other_text = (ship_alive && mt) || (proj & 4u), other_bar = (ship_alive && mb) || (proj & 8u);
   const bool near_text = ex_text || (proj & 1u), near_bar = ex_bar || (proj & 2u);
-  other_text = other_text || (proj & 4u);
-  other_bar = other_bar || (proj & 8u);
   const int pnts = (int)points;
   const bool baked_text = pnts == 0 && !near_text, baked_bar = vlner == 0 && !near_bar;
   const unsigned variant = (baked_text ? 1u : 0u) | (baked_bar ? 2u : 0u);
   const unsigned bg = (fort_pic ? 4u * (1u + (unsigned)sector) : 0u) + variant;
   // the destroyed fortress explodes for 1000 ms where it stands: restored from its picture when what the ship drew stays
   // clear of it (wider by the reach), else drawn in place between the ship and the missiles
-  bool fe_patch = false, fe_place = false;
-  if (!fort_alive) {
-    const Box fe = widened(explosion_box((float)sfc::fort_x, (float)sfc::fort_y));
-    fe_patch = pics && !sb.meets(fe);
-    fe_place = !fe_patch;
-  }
+  const bool fe_clear = !sb.meets(widened(explosion_box((float)sfc::fort_x, (float)sfc::fort_y)));
+  const bool fe_patch = !fort_alive && pics && fe_clear, fe_place = !fort_alive && !fe_patch;
   // shells: lane 4 s + k of the frame kernel draws stroke k of slot s -- unless the top lanes of the missiles' range are
   // free for them (1 + highest live slot <= 8, and the missile slots whose lanes those are empty: nearly always): then the
   // shells' strokes sit there, behind the missiles' as in the draw order, and go through draw_strokes with everything else

@@ -1370,8 +1370,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     unsigned* const evw32 = reinterpret_cast<unsigned*>(evw);
     // (the draw records of this wave's 64 envs: one descriptor, like the tile's)
     const __amdgpu_buffer_rsrc_t rs_draw = __builtin_amdgcn_make_buffer_rsrc(
-        draw_now ? a.draw + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * (size_t)(64 * SF_DR_BYTES) : (unsigned char*)nullptr, 0,
-        draw_now ? 64 * SF_DR_BYTES : 0, 0x00020000);
+        draw_now ? a.draw + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * (size_t)SF_DR_TILE_BYTES : (unsigned char*)nullptr, 0,
+        draw_now ? SF_DR_TILE_BYTES : 0, 0x00020000);
     auto m_row = [&](double x, double y, unsigned meta, d2_t cs, bool valid) __attribute__((always_inline)) {
       // velocity = missileSpeed * (cos, sin)(deg2rad(angle)) with an integer angle: table
       const double nx = x + kv_speed * cs.x, ny = y + kv_speed * cs.y;
@@ -1393,10 +1393,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
       __builtin_amdgcn_raw_buffer_store_b32(meta, rs, keep ? idx * 4u : SF_OOB, SF_GOFF(missile_meta, 0), kStAux);
       if (draw_now) {  // uniform.  The survivor's transform goes to its OWNER's draw record, at its slot (sf_drawrec.h)
         typedef float f4_t __attribute__((ext_vector_type(4)));
-        const unsigned doff = SF_MM_OWNER(meta) * (unsigned)SF_DR_BYTES +
-                              (unsigned)(SF_DR_HDR_BYTES + SF_DR_OBJ_MISSILE0 * SF_DR_OBJ_BYTES) + SF_MM_SLOT(meta) * (unsigned)SF_DR_OBJ_BYTES;
+        const unsigned doff = (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_MISSILE0 + SF_MM_SLOT(meta)) * (unsigned)SF_DR_PIECE_STRIDE +
+                              SF_MM_OWNER(meta) * (unsigned)SF_DR_LANE_STRIDE;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, (f4_t{(float)nx, (float)ny, (float)cs.x, (float)cs.y})), rs_draw,
-                                               keep ? doff : SF_OOB, 0, kStAux);
+                                               keep ? doff : SF_OOB, 0, SF_DR_AUX);
         const bool rows = keep & sfd::hud_rows_near((float)ny, sfd::kMissileExt);
         if (__ballot(rows) != 0ull) {  // (all but never) -> bits 24..27 of the owner's hit word
           if (rows)
@@ -1584,16 +1584,16 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
                                            L.points, L.vlner, L.fort_vuln_t, L.mmask, L.smask,
                                            (done && a.auto_reset) ? 0u : dr_proj /* a new game has no projectiles */, a.draw_pics != 0, L.time);
     const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(
-        a.draw + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * (size_t)(64 * SF_DR_BYTES), 0, 64 * SF_DR_BYTES, 0x00020000);
-    const unsigned d0 = real ? lane * (unsigned)SF_DR_BYTES : SF_OOB;
-    __builtin_amdgcn_raw_buffer_store_b128(u4_t{h.w[0], h.w[1], h.w[2], h.w[3]}, rs_dr, d0, 0, kStAux);
-    __builtin_amdgcn_raw_buffer_store_b128(u4_t{h.w[4], h.w[5], h.w[6], h.w[7]}, rs_dr, d0, 16, kStAux);
+        a.draw + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * (size_t)SF_DR_TILE_BYTES, 0, SF_DR_TILE_BYTES, 0x00020000);
+    const unsigned d0 = real ? lane * (unsigned)SF_DR_LANE_STRIDE : SF_OOB;
+    __builtin_amdgcn_raw_buffer_store_b128(u4_t{h.w[0], h.w[1], h.w[2], h.w[3]}, rs_dr, d0, 0, SF_DR_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(u4_t{h.w[4], h.w[5], h.w[6], h.w[7]}, rs_dr, d0, SF_DR_PIECE_STRIDE, SF_DR_AUX);
     __builtin_amdgcn_raw_buffer_store_b128(
         __builtin_bit_cast(u4_t, (f4_t{(float)L.sx, (float)L.sy, (float)SF_COS(L.angle), (float)SF_SIN(L.angle)})), rs_dr, d0,
-        SF_DR_HDR_BYTES + SF_DR_OBJ_SHIP * SF_DR_OBJ_BYTES, kStAux);
+        (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE, SF_DR_AUX);
     __builtin_amdgcn_raw_buffer_store_b128(
         __builtin_bit_cast(u4_t, (f4_t{(float)sfc::fort_x, (float)sfc::fort_y, (float)SF_COS(L.fort_angle), (float)SF_SIN(L.fort_angle)})),
-        rs_dr, d0, SF_DR_HDR_BYTES + SF_DR_OBJ_FORT * SF_DR_OBJ_BYTES, kStAux);
+        rs_dr, d0, (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_FORT) * SF_DR_PIECE_STRIDE, SF_DR_AUX);
   }
   if (!FUSED) store_lane_buf(rs, o, L);
   SF_STAMP(14, false);
@@ -1697,7 +1697,7 @@ __global__ __launch_bounds__(64) void sf_drawrec_kernel(const unsigned char* sta
   const unsigned lane = threadIdx.x;
   const long tile_i = blockIdx.x;
   const unsigned char* tb = state + tile_i * sfl::kTileBytes;
-  unsigned char* const dr = draw + tile_i * (long)(64 * SF_DR_BYTES);
+  unsigned char* const dr = draw + tile_i * (long)SF_DR_TILE_BYTES;
   const unsigned o16 = lane * 16u;
   const d2_t sp = SF_LD(d2_t, SF_CHUNK(ship_pos, 0), o16);
   const i4_t tc = SF_LD(i4_t, SF_CHUNK(timers_b, 0), o16);
@@ -1711,7 +1711,7 @@ __global__ __launch_bounds__(64) void sf_drawrec_kernel(const unsigned char* sta
     const d2_t p = SF_LD(d2_t, SF_CHUNK(missile_pos, 0), k * 16u);
     const unsigned m = SF_LD(unsigned, SF_CHUNK(missile_meta, 0), k * 4u);
     const double* cs = consts + 2 * SF_MM_ANGLE(m);  // cos, sin of the heading (sf_host_fill_consts)
-    *reinterpret_cast<f4_t*>(dr + SF_MM_OWNER(m) * SF_DR_BYTES + SF_DR_HDR_BYTES + (SF_DR_OBJ_MISSILE0 + SF_MM_SLOT(m)) * SF_DR_OBJ_BYTES) =
+    *reinterpret_cast<f4_t*>(dr + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_MISSILE0 + SF_MM_SLOT(m)) * SF_DR_PIECE_STRIDE + SF_MM_OWNER(m) * SF_DR_LANE_STRIDE) =
         f4_t{(float)p.x, (float)p.y, (float)cs[0], (float)cs[1]};
     const unsigned f = sfd::hud_flags_near((float)p.x, (float)p.y, sfd::kMissileExt);
     if (f) atomicOr(&near[SF_MM_OWNER(m)], f);
@@ -1731,12 +1731,13 @@ __global__ __launch_bounds__(64) void sf_drawrec_kernel(const unsigned char* sta
   const sfd::Header h = sfd::make_header(sp.x, sp.y, (fl & SF_FL_SHIP_ALIVE) != 0u, (fl & SF_FL_FORT_ALIVE) != 0u, fort_angle,
                                          __int_as_float(sc.x), sc.z & 0xFFF, tc.w, mmask, smask, proj, pics != 0,
                                          (int)((unsigned)sc.w & 0xFFFFFFu));
-  unsigned char* const me = dr + lane * SF_DR_BYTES;
-  reinterpret_cast<u4_t*>(me)[0] = u4_t{h.w[0], h.w[1], h.w[2], h.w[3]};
-  reinterpret_cast<u4_t*>(me)[1] = u4_t{h.w[4], h.w[5], h.w[6], h.w[7]};
+  unsigned char* const me = dr + lane * SF_DR_LANE_STRIDE;
+  *reinterpret_cast<u4_t*>(me) = u4_t{h.w[0], h.w[1], h.w[2], h.w[3]};
+  *reinterpret_cast<u4_t*>(me + SF_DR_PIECE_STRIDE) = u4_t{h.w[4], h.w[5], h.w[6], h.w[7]};
   const int sa = ship_angle < 0 ? 0 : (ship_angle > 359 ? 359 : ship_angle), fa = fort_angle < 0 ? 0 : (fort_angle > 359 ? 359 : fort_angle);
-  reinterpret_cast<f4_t*>(me + SF_DR_HDR_BYTES)[SF_DR_OBJ_SHIP] = f4_t{(float)sp.x, (float)sp.y, (float)consts[2 * sa], (float)consts[2 * sa + 1]};
-  reinterpret_cast<f4_t*>(me + SF_DR_HDR_BYTES)[SF_DR_OBJ_FORT] =
+  *reinterpret_cast<f4_t*>(me + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE) =
+      f4_t{(float)sp.x, (float)sp.y, (float)consts[2 * sa], (float)consts[2 * sa + 1]};
+  *reinterpret_cast<f4_t*>(me + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_FORT) * SF_DR_PIECE_STRIDE) =
       f4_t{(float)sfc::fort_x, (float)sfc::fort_y, (float)consts[2 * fa], (float)consts[2 * fa + 1]};
 }
 

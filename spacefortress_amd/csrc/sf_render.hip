@@ -129,9 +129,49 @@ __device__ __forceinline__ Slopes quad_slopes(const Quad& q) {
   return sl;
 }
 
+// ... and for TWO edges at once, on pairs of floats: gfx950 has packed float32 multiply / add / subtract (v_pk_mul_f32,
+// v_pk_add_f32: two IEEE operations per instruction, each rounded exactly as its scalar form -- nothing is contracted or
+// reordered), and a pixel's four edge terms are the same two dozen operations on different operands.  The kernel's bound
+// is the NUMBER of instructions issued: the products, sums and differences of a pair of edges issue once instead of
+// twice (min / max / clamp / reciprocal have no packed form and stay per edge) -- a third of the 150 vector instructions
+// a pixel cost.  Same operations on the same operands in the same order per edge: the same coverage, bit for bit.
+#ifndef SF_PK_COVER
+#define SF_PK_COVER 1
+#endif
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2_t clamp01(f2_t v) { return f2_t{clamp01(v.x), clamp01(v.y)}; }
+__device__ __forceinline__ f2_t ramp_mean(f2_t ya, f2_t yb) {
+  const f2_t lo = f2_t{fminf(ya.x, yb.x), fminf(ya.y, yb.y)};
+  const f2_t dd = yb - ya;
+  const f2_t d = f2_t{fabsf(dd.x), fabsf(dd.y)};
+  const f2_t flat = clamp01(lo + 0.5f * d);
+  const f2_t inv = f2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f2_t ta = clamp01(-lo * inv), tb = clamp01((1.0f - lo) * inv);
+  const f2_t ramp = (1.0f - tb) + (tb - ta) * (lo + 0.5f * d * (ta + tb));
+  return f2_t{d.x < 1e-6f ? flat.x : ramp.x, d.y < 1e-6f ? flat.y : ramp.y};
+}
+__device__ __forceinline__ f2_t edge_term(f2_t x0, f2_t y0, f2_t x1, f2_t slope) {
+  const f2_t xa = clamp01(x0), xb = clamp01(x1);
+  const f2_t w = xb - xa;
+  const f2_t t = w * ramp_mean(y0 + (xa - x0) * slope, y0 + (xb - x0) * slope);
+  return f2_t{w.x == 0.f ? 0.f : t.x, w.y == 0.f ? 0.f : t.y};
+}
+
 // area of quad /\ pixel [px,px+1]x[py,py+1]:  | sum over edges of the integral of clamp(y,0,1) dx |
 __device__ __forceinline__ float quad_cover(const Quad& q, const Slopes& sl, float px, float py) {
   float s = 0.f;
+  if (SF_PK_COVER) {
+    const f2_t pp = {px, px}, qq = {py, py};
+    const f2_t x01 = f2_t{q.x[0], q.x[1]} - pp, x23 = f2_t{q.x[2], q.x[3]} - pp;
+    const f2_t y01 = f2_t{q.y[0], q.y[1]} - qq, y23 = f2_t{q.y[2], q.y[3]} - qq;
+    const f2_t t01 = edge_term(x01, y01, f2_t{x01.y, x23.x}, f2_t{sl.s[0], sl.s[1]});
+    const f2_t t23 = edge_term(x23, y23, f2_t{x23.y, x01.x}, f2_t{sl.s[2], sl.s[3]});
+    s += t01.x;
+    s += t01.y;
+    s += t23.x;
+    s += t23.y;
+    return fabsf(s);
+  }
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const int f = (e + 1) & 3;
@@ -1220,7 +1260,6 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int lane = threadIdx.x;
   typedef float f4_t __attribute__((ext_vector_type(4)));
-  typedef unsigned u8_t __attribute__((ext_vector_type(8)));
   // ---- this lane's stroke of the frame's draw order (lanes 0..2 the ship's three, 3..6 the fortress's four, 7..63 those of
   // missile slots 0..18): its four corners in the wireframe's own coordinates depend on the lane alone -- two loads, asked
   // for before anything is known, where round 3 selected segment constants and built the rectangle per frame
@@ -1247,14 +1286,18 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // bit test -- and, per lane, the transform (x, y, cos, sin) of the object its stroke belongs to.  Round 3 read five chunks
   // of the state and three rows of the tile's missile pool here, every one of a tile's 64 frames filtering the same rows for
   // its own entries, and decided in all 64 lanes what one lane of the step kernel decides now.
-  const unsigned char* const rec = a.draw + (size_t)env * SF_DR_BYTES;
-  const u8_t hd = *reinterpret_cast<const __attribute__((address_space(4))) u8_t*>(
+  const unsigned char* const rec = a.draw + (size_t)(env >> 6) * SF_DR_TILE_BYTES + (size_t)(env & 63) * SF_DR_LANE_STRIDE;
+  typedef unsigned u4s_t __attribute__((ext_vector_type(4)));
+  const u4s_t hd0 = *reinterpret_cast<const __attribute__((address_space(4))) u4s_t*>(
       reinterpret_cast<const __attribute__((address_space(4))) void*>((unsigned long long)rec));
+  const u4s_t hd1 = *reinterpret_cast<const __attribute__((address_space(4))) u4s_t*>(
+      reinterpret_cast<const __attribute__((address_space(4))) void*>((unsigned long long)(rec + SF_DR_PIECE_STRIDE)));
+  const unsigned hd[8] = {hd0.x, hd0.y, hd0.z, hd0.w, hd1.x, hd1.y, hd1.z, hd1.w};
   constexpr int kFirstMissileLane = 7;
   static_assert(kFirstMissileLane + 3 * 19 == 64, "slots 0 .. 18 fill the wave behind the ship's and the fortress's strokes");
   const int mslot = ((lane - kFirstMissileLane) * 171) >> 9;  // (lane - 7) / 3 for lanes 7 .. 63
   const int obj = lane < 3 ? SF_DR_OBJ_SHIP : (lane < kFirstMissileLane ? SF_DR_OBJ_FORT : SF_DR_OBJ_MISSILE0 + mslot);
-  const f4_t tf = *reinterpret_cast<const f4_t*>(rec + (unsigned)(SF_DR_HDR_BYTES + obj * SF_DR_OBJ_BYTES));
+  const f4_t tf = *reinterpret_cast<const f4_t*>(rec + (unsigned)((SF_DR_PIECE_OBJ0 + obj) * SF_DR_PIECE_STRIDE));
   // (a frame stack's done flag of this env: asked for here, read where the older slots are handled)
   // (through an index the compiler cannot see is the same in every lane: a byte it knows to be uniform it moves to a scalar
   //  register at once -- v_readfirstlane behind a wait, i.e. a memory round trip in front of everything else, 7 % of the
@@ -1480,7 +1523,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     F.draw_strokes(mq, dvalid && lane >= kFirstMissileLane, dobj);
   }
   if ((fl & SF_DRF_MISSILE19) && !(SF_RENDER_SKIP & 2)) {  // (the twentieth missile: its strokes have no lanes of their own)
-    const f4_t t19 = *reinterpret_cast<const f4_t*>(rec + (SF_DR_HDR_BYTES + (SF_DR_OBJ_MISSILE0 + 19) * SF_DR_OBJ_BYTES));
+    const f4_t t19 = *reinterpret_cast<const f4_t*>(rec + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_MISSILE0 + 19) * SF_DR_PIECE_STRIDE);
     const int ml = kFirstMissileLane + (lane < 3 ? lane : 0);  // a missile's three strokes: the corners of lanes 7 .. 9
     const f4_t mx = *reinterpret_cast<const f4_t*>(kLaneStroke[ml].x), my = *reinterpret_cast<const f4_t*>(kLaneStroke[ml].y);
     Quad q19;

@@ -18,9 +18,9 @@ for r in range(a.rounds):
         env = dict(os.environ, SFMI_LIB_PATH=os.path.abspath(l))
         out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "image_probe.py"), str(a.envs), str(a.steps)] + a.mode.split(),
                                       env=env, stderr=subprocess.DEVNULL, text=True)
-        m = re.search(r"step\+render ([0-9.]+) us .*render alone ([0-9.]+) us", out)
-        res[l].append((float(m.group(1)), float(m.group(2))))
+        m = re.search(r"step\+render ([0-9.]+) us .*render alone ([0-9.]+) us.*?(?:step alone ([0-9.]+) us)?$", out, re.M)
+        res[l].append((float(m.group(1)), float(m.group(2)), float(m.group(3) or 0)))
 for l, v in res.items():
-    sr = sorted(x[0] for x in v); ra = sorted(x[1] for x in v)
-    print("%-36s step+render median %.1f min %.1f | render alone median %.1f min %.1f  (%s)" % (
-        os.path.basename(l), sr[len(sr) // 2], sr[0], ra[len(ra) // 2], ra[0], " ".join("%.1f/%.1f" % x for x in v)), flush=True)
+    sr = sorted(x[0] for x in v); ra = sorted(x[1] for x in v); sa = sorted(x[2] for x in v)
+    print("%-36s step+render median %.1f min %.1f | render alone median %.1f min %.1f | step alone median %.2f  (%s)" % (
+        os.path.basename(l), sr[len(sr) // 2], sr[0], ra[len(ra) // 2], ra[0], sa[len(sa) // 2], " ".join("%.1f/%.1f/%.2f" % x for x in v)), flush=True)

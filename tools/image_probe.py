@@ -40,8 +40,20 @@ for mode in ([a for a in args if a != "stack"] or ([] if args else ["image", "im
     e1.record()
     torch.cuda.synchronize()
     ms_r = e0.elapsed_time(e1) / steps
-    print(("hunter " if hunter else "") + "%s n=%d: step+render %.1f us (%.3g frames/s), render alone %.1f us, output %.2f GB/s" %
-          (mode, n, ms * 1e3, n / ms * 1e3, ms_r * 1e3, out.numel() / ms_r / 1e6))
+    # ... and the step launch of an image batch alone (no frame): sf_step with obs_dev = NULL
+    import ctypes as C
+    from spacefortress_amd import _lib
+    _, rew, done, info = env._alloc()
+    e0.record()
+    for t in range(steps):
+        a = acts[t % ring]
+        _lib.check(env._L.sf_step(env._h, C.c_void_p(a.data_ptr()), 1, None, C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
+                                  C.c_void_p(info.data_ptr()), env._stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    ms_s = e0.elapsed_time(e1) / steps
+    print(("hunter " if hunter else "") + "%s n=%d: step+render %.1f us (%.3g frames/s), render alone %.1f us, output %.2f GB/s, step alone %.2f us" %
+          (mode, n, ms * 1e3, n / ms * 1e3, ms_r * 1e3, out.numel() / ms_r / 1e6, ms_s * 1e3))
     env.close()
 
 if "stack" in sys.argv[3:] or not sys.argv[3:]:
