@@ -758,8 +758,7 @@ def test_full_size_hunter_sample(sfa, oracle_mod, gametype):
     acts = open_loop_actions("hunter", (T, n), n_act, rng, phase=rng.integers(0, 96, n))
     a = torch.from_numpy(acts).cuda()
     # pass 1: which lanes kill
-    env = sfa.SFVecEnv(n, gametype=gametype, spawn_stride=1)
-    env.reset()
+    env = sfa.SFVecEnv(n, gametype=gametype, spawn_stride=1)  # (a new batch is reset: lane i plays spawn i first)
     kills = torch.zeros(n, dtype=torch.int32, device=env.device)
     for t in range(T):
         _, _, _, info = env.step_tensors(a[t])
@@ -767,7 +766,11 @@ def test_full_size_hunter_sample(sfa, oracle_mod, gametype):
     kills = kills.cpu().numpy()
     sd = env.state_dict()
     env.close()
-    assert int(kills.sum()) == int(sd["stats"][5].sum())  # no episode ends inside 640 steps: the counters are the run's
+    # no episode ends inside 640 steps, so the counters are the run's: every kill the wrapper reported is a destroyed fortress;
+    # the other way round a FIRE press on the kill tick hides the kill from the wrapper ((int)(-0.05 + 1) = 0, ENV:233:
+    # the `autoturn_destroy_truncated` golden)
+    destroyed = int(sd["stats"][5].sum())
+    assert destroyed // 2 <= int(kills.sum()) <= destroyed, (int(kills.sum()), destroyed)
     assert kills.sum() >= (1000 if gametype == "autoturn" else 1), kills.sum()
     killers = np.flatnonzero(kills)
     pick = killers[:96]
@@ -775,8 +778,7 @@ def test_full_size_hunter_sample(sfa, oracle_mod, gametype):
     lanes = np.sort(np.concatenate([pick, rng.choice(rest, 192 - len(pick), replace=False)]))
     assert kills[lanes].sum() >= 1
     # pass 2 (same seeds, same actions: the same games): the sampled lanes' outputs at every step
-    env = sfa.SFVecEnv(n, gametype=gametype, spawn_stride=1)
-    env.reset()
+    env = sfa.SFVecEnv(n, gametype=gametype, spawn_stride=1)  # (a new batch is reset: lane i plays spawn i first)
     li = torch.from_numpy(lanes).to(env.device)
     obs = torch.empty((T, len(lanes), env.obs_dim), dtype=torch.float32, device=env.device)
     rew = torch.empty((T, len(lanes)), dtype=torch.int32, device=env.device)
@@ -793,10 +795,14 @@ def test_full_size_hunter_sample(sfa, oracle_mod, gametype):
     for j, lane in enumerate(lanes):
         o = O.OracleEnv(gametype, spawn_skip=int(lane))
         out = o.replay(acts[:, lane], want_obs=True)
-        assert np.array_equal(out["reward"], rew[:, j]), lane
+        if not np.array_equal(out["reward"], rew[:, j]):
+            t0 = int(np.flatnonzero(out["reward"] != rew[:, j])[0])
+            raise AssertionError("lane %d: first reward mismatch at step %d: device %d oracle %d; actions %s; oracle obs %s; device obs %s; device obs before %s" % (
+                lane, t0, rew[t0, j], out["reward"][t0], acts[max(0, t0 - 6):t0 + 1, lane].tolist(), np.array2string(out["obs"][t0], precision=6),
+                np.array2string(obs[t0, j], precision=6), np.array2string(obs[t0 - 1, j], precision=6)))
         assert np.array_equal(out["info"], inf[:, j]), lane
         assert obs_close(obs[:, j], out["obs"], False).all(), lane
-        assert out["info"].sum() == kills[lane]
+        assert out["info"].sum() == kills[lane] and out["snaps"][-1]["stats"][5] == sd["stats"][5][lane]
         snaps.append(out["snaps"][-1])
     bad = compare_state(sd, np.array(snaps), lanes=lanes)
     assert not bad, bad
