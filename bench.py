@@ -71,18 +71,50 @@ def cpu_baseline(gametype, seconds, cores):
     out = {"value": total, "unit": "env-steps/s", "cores": cores, "kind": kind,
            "sample": "%s, %s, uniform random actions, one process per core x %d, %.1f s each; "
                      "bare engine only (no Python wrapper, no IPC)" % (what, gametype, cores, seconds)}
-    # the reference's actual shape: SubprocVecEnv (one process per env, Pipe IPC, Python wrapper, rl/train.py:30-32)
+    # the bare engine on ONE core as well
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "subproc_bench.py"), "--procs", str(cores),
-                            "--gametype", gametype, "--seconds", str(max(0.5, seconds / 2))],
-                           stdout=subprocess.PIPE, text=True, timeout=120)
+        r = subprocess.run(cmd + ["--seed", "99", "--seconds", str(min(3.0, seconds))], stdout=subprocess.PIPE, text=True, timeout=120)
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        out["subproc_vecenv"] = {"value": j["steps"] / j["seconds"], "unit": "env-steps/s", "procs": j["procs"],
-                                 "sample": "SubprocVecEnv-shaped harness (oracle/subproc_bench.py): one process per env, "
-                                           "multiprocessing.Pipe, per-env wrapper step + features obs, reset on done; "
-                                           "the C restatement inside each worker"}
+        out["single_core"] = {"value": j["steps"] / j["seconds"], "unit": "env-steps/s", "cores": 1, "kind": j["kind"],
+                              "sample": "the same loop in ONE process, %.1f s" % j["seconds"]}
     except Exception as e:  # the baseline is informative, never fatal
-        out["subproc_vecenv"] = {"error": str(e)}
+        out["single_core"] = {"error": str(e)}
+    # the reference's actual shape: SubprocVecEnv (one process per env, Pipe IPC, Python wrapper, rl/train.py:30-32) with its
+    # default 16 processes (rl/arguments.py:21-22) -- capped at this box's share -- and with one process per available core
+    def subproc(procs, secs):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "subproc_bench.py"), "--procs", str(procs),
+                                "--gametype", gametype, "--seconds", str(secs)], stdout=subprocess.PIPE, text=True, timeout=120)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            return {"value": j["steps"] / j["seconds"], "unit": "env-steps/s", "procs": j["procs"],
+                    "sample": "SubprocVecEnv-shaped harness (oracle/subproc_bench.py): one process per env, "
+                              "multiprocessing.Pipe, per-env wrapper step + features obs, reset on done; "
+                              "the C restatement inside each worker"}
+        except Exception as e:
+            return {"error": str(e)}
+    out["subproc_vecenv"] = subproc(min(16, cores), max(0.5, seconds / 2))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    avail = min(avail, 64)  # (a GPU box allows a job a bounded number of processes)
+    if avail != min(16, cores):
+        out["subproc_vecenv_all_cores"] = dict(subproc(avail, max(0.5, seconds / 4)), host_cores=avail,
+                                               note="num_processes = the cores this job may use (os.sched_getaffinity, at most 64)")
+    # BASELINE.json configs[0]: youturn, 1 env on the CPU through the engine's per-call entry points, 1000-step random rollout
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--kind", kind, "--gametype", gametype,
+                            "--rollout-steps", "1000"], stdout=subprocess.PIPE, text=True, timeout=120)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        out["config0"] = {"name": "configs[0]: %s, 1 env on the CPU, 1000-step random rollout" % gametype,
+                          "value": j["steps"] / j["seconds"], "unit": "env-steps/s", "steps": j["steps"], "ms_total": j["seconds"] * 1e3,
+                          "kind": j["kind"],
+                          "sample": "ONE env stepped from Python one call at a time -- press_key / release_key x 4, step_one_tick(34), "
+                                    "is_game_over, as SSF_Env.step does (ENV:208-253) -- through ctypes on the %s; actions "
+                                    "numpy RandomState(0).randint; best of 5 runs" %
+                                    ("reference C++ engine (oracle/_ref)" if j["kind"] == "reference" else "C restatement")}
+    except Exception as e:
+        out["config0"] = {"error": str(e)}
     return out
 
 
@@ -284,10 +316,16 @@ def main():
         stats = reduce_episode_stats(local)
         tt = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ranks = gather_ranks({"rank": rank, "device_index": None, "pci_bus_id": None, "block_ms_median": 1.0 + rank,
-                              "lanes": [lane0, lane1]})
+        # (dry run: a stand-in device id per rank; SF_BENCH_TEST_SAME_DEVICE makes two ranks claim the same one)
+        fake = 0 if os.environ.get("SF_BENCH_TEST_SAME_DEVICE") else rank
+        ranks = gather_ranks({"rank": rank, "device_index": None, "pci_bus_id": "dry:%02x" % fake, "uuid": "dry-%d" % fake,
+                              "block_ms_median": 1.0 + rank, "lanes": [lane0, lane1]})
+        if len({(r["pci_bus_id"], r["uuid"]) for r in ranks}) != world or dist.get_world_size() != world:
+            sys.stderr.write("bench.py: %d ranks but not %d distinct devices\n" % (world, world))
+            sys.exit(4)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "dry_run": True, "value": None, "n_gpus": world, "steps": args.steps,
+                              "rccl_world": dist.get_world_size(),
                               "warmup": args.warmup, "repeats": repeats, "lanes_rank0": [lane0, lane1],
                               "max_over_ranks": float(tt.item()), "ranks": ranks, "cpu_baseline": base,
                               "episode_stats": summarize(stats)}))
@@ -456,6 +494,14 @@ def main():
     mine = dict(device_identity(torch, local_rank), rank=rank, lanes=[lane0, lane1],
                 block_ms_median=sorted(own_blocks)[len(own_blocks) // 2] * 1e3, launch_period_steady_ms=steady_ms)
     ranks = gather_ranks(mine)
+    # an N-GPU line is evidence of N GPUs: every rank on a device of its own, or the job fails (two ranks on one device would
+    # still print a line -- at half the speed, or worse, looking like a scaling problem)
+    rccl_world = dist.get_world_size() if dist is not None else 1
+    if world > 1:
+        ids = [(r.get("pci_bus_id"), r.get("uuid")) for r in ranks]
+        if len(set(ids)) != world or rccl_world != world:
+            sys.stderr.write("bench.py: %d ranks on %d distinct devices (process group of %d): %r\n" % (world, len(set(ids)), rccl_world, ids))
+            sys.exit(4)
 
     # ---- each launch bracketed by its own event pair (the events themselves add about 2 us, so this reads high)
     k = min(args.kernel_timing_launches, max(1, args.steps))
@@ -584,10 +630,42 @@ def main():
             cenv.check_actions()
             del cg
             cenv.close()
+        # the reference's observation dtype: _get_features returns float64 (ENV:134-157); the headline times float32 rows
+        # (SURVEY a14 / 8d).  Same batch, same kernel family, 8 bytes per feature: 464 + 4 * 19 algorithmic bytes per env-step
+        if True:
+            cenv = SFVecEnv(n, gametype=args.gametype, obs_type="features", device=dev, spawn_stride=1, reuse_buffers=True,
+                            obs_dtype=torch.float64)
+            cacts = torch.randint(0, cenv.n_actions, (ring, n), device=dev, dtype=torch.uint8, generator=g)
+            crows = [cacts[k] for k in range(ring)]
+            cenv.reset()
+            for t in range(64):
+                cenv.step_tensors(crows[t % ring])
+            cg = capture(lambda k: cenv.step_tensors(crows[k % ring]), KC)
+            ms = []
+            for _ in range(reps):
+                ev0.record()
+                cg.replay()
+                ev1.record()
+                sync()
+                ms.append(ev0.elapsed_time(ev1) / KC)
+            ms.sort()
+            m = ms[len(ms) // 2]
+            b64 = ALGO_BYTES[args.gametype] + 4 * cenv.obs_dim
+            ach = b64 * n / (m * 1e-3) / 1e9
+            configs.append({"name": "%s, %d envs, float64 observations (SF_FLAG_OBS_F64: the reference's dtype, ENV:134-157)" % (args.gametype, n),
+                            "gametype": args.gametype, "envs": n, "obs_dtype": "float64", "ms_per_step": m, "value": n / m * 1e3,
+                            "unit": "env-steps/s", "launches_per_block": KC, "blocks": reps,
+                            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                         "algorithmic_bytes_per_env_step": b64, "algorithmic_bytes_per_launch": b64 * n,
+                                         "note": "SURVEY 8(d)'s B with 8 * D observation bytes instead of 4 * D"}})
+            del cg
+            cenv.close()
         if image_obs is not None:
             configs.append({"name": "configs[4]: youturn image obs, 84x84 grey raster + 4-frame stack, %d envs" % image_obs["envs"],
                             "gametype": args.gametype, "envs": image_obs["envs"], "ms_per_step": image_obs["us_per_step"] * 1e-3,
                             "value": image_obs["value"], "unit": "env-steps/s", "roofline": image_obs["roofline"]})
+    if configs is not None and base and isinstance(base.get("config0"), dict) and "value" in base["config0"]:
+        configs.insert(0, base["config0"])
     # (last of the extras: its per-step synchronise leaves the GPU idle most of the time and the clocks drop -- whatever ran
     #  right behind it measured the ramp-up, e.g. a 1 GiB copy at 0.7 TB/s)
     host_api = None
@@ -668,12 +746,14 @@ def main():
                                         "`frac` use the timed region's period, which for a block of a few launches includes its "
                                         "start on an idle GPU" % (n_steady, steady_total_ms * 1e-3),
                          "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
+                         "kernel_ms_rocprof_median": prof.get("kernel_ms_rocprof_median"),
                          "kernel_ms_rocprof_source": ("rocprofv3 --kernel-trace mean of kernel version %s (profiles/%s)"
                                                       % (prof.get("version"), prof.get("trace_file"))) if prof else None,
                          "kernel_ms_event_pair_mean": kern_ms, "kernel_ms_event_pair_median": kern_ms_med,
                          "algorithmic_bytes_per_launch": algo, "launches_timed": K},
             "cpu_baseline": base,
             "ranks": ranks,
+            "rccl_world": rccl_world,
             "rollout_fused": fused,
             "host_api": host_api,
             "image_obs": image_obs,

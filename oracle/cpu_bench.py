@@ -26,7 +26,33 @@ def main():
     ap.add_argument("--gametype", default="youturn")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--rollout-steps", type=int, default=0,
+                    help="BASELINE.json configs[0]: ONE env, a rollout of exactly this many steps with actions from "
+                         "numpy RandomState(0).randint(0, n_actions) through the engine's press / release / step_one_tick "
+                         "entry points one call at a time (what SSF_Env.step does, ENV:208-253), timed")
     a = ap.parse_args()
+    if a.rollout_steps:
+        import numpy as np
+        ref = a.kind == "reference" and O.have_ref()
+        env = O.OracleEnv(a.gametype)  # the action table + wrapper logic; the engine under it is the restatement ...
+        g = O.RefGame(a.gametype) if ref else env  # ... or the real reference engine
+        keys = env.action_keys()
+        acts = np.random.RandomState(0).randint(0, len(keys), a.rollout_steps)
+        best = None
+        for rep in range(5):
+            g.new_game()
+            ret = 0
+            t0 = time.perf_counter()
+            for act in acts:
+                g.apply_keys(keys[act], env.youturn)
+                ret += g.step_one_tick(34)
+                if g.is_game_over():
+                    g.new_game()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        print(json.dumps({"steps": int(a.rollout_steps), "seconds": best, "kind": "reference" if ref else "port",
+                          "engine_return": int(ret)}))
+        return
     if a.kind == "reference" and O.have_ref():
         g = O.RefGame(a.gametype)
         kind = "reference"

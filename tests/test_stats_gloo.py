@@ -156,3 +156,64 @@ def test_a_rank_that_dies_takes_the_job_down_at_once():
     assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
     assert time.time() - t0 < 60  # not a rendezvous timeout
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # and no line from a half-run job
+
+
+def _bench_env(**extra):
+    env = dict(os.environ, SF_BENCH_FORCE_DIST="gloo", **extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "SF_BENCH_CPU_BASELINE_FILE"):
+        env.pop(k, None)
+    return env
+
+
+def test_world_of_eight_dry_run():
+    """The driver's 8-GPU command rehearsed on CPU tensors (gloo): bench.py starts eight fresh ranks, polls them, hands the
+    CPU baseline from the launcher to rank 0 through a file; the line carries eight `ranks` entries gathered from the ranks
+    themselves -- eight contiguous shards of one 524 288-lane batch, eight distinct device ids -- and the size of the
+    process group the collective ran in."""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+                        "--cpu-seconds", "0.3", "--cpu-cores", "2"],
+                       env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["dry_run"] is True and j["n_gpus"] == 8 and j["rccl_world"] == 8
+    assert [x["rank"] for x in j["ranks"]] == list(range(8))
+    assert [x["lanes"] for x in j["ranks"]] == [[65536 * k, 65536 * (k + 1)] for k in range(8)]
+    assert len({(x["pci_bus_id"], x["uuid"]) for x in j["ranks"]}) == 8
+    assert j["max_over_ranks"] == 8.0
+    es = j["episode_stats"]  # sums over ranks of (rank + 1, ...); min of -5 - rank, max of 7 + rank
+    assert es["episodes"] == 36 and es["min_return"] == -12 and es["max_return"] == 14
+    cb = j["cpu_baseline"]
+    assert cb is not None and cb["cores"] == 2 and cb["single_core"]["value"] > 1e4
+    assert cb["config0"]["steps"] == 1000 and cb["config0"]["value"] > 1e3
+    assert cb["subproc_vecenv"]["procs"] == 2 and cb["subproc_vecenv"]["value"] > 100
+
+
+def test_dead_rank_five_of_eight_takes_the_job_down():
+    import subprocess
+    import time
+
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline"], env=_bench_env(SF_BENCH_TEST_FAIL_RANK="5"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 90
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_two_ranks_on_one_device_fail_the_job():
+    """An N-GPU line must be evidence of N GPUs: ranks that report the same device id end the job with a non-zero code
+    instead of a line that looks like bad scaling."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline"], env=_bench_env(SF_BENCH_TEST_SAME_DEVICE="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 4, (r.returncode, r.stderr[-1000:])
+    assert "distinct devices" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
