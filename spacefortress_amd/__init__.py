@@ -7,7 +7,7 @@ environment does, and fails loudly if the extension or the device is missing.
 """
 from ._lib import SfmiError, lib  # noqa: F401
 
-__all__ = ["SFVecEnv", "SSF_Env", "FrameStack", "SFVecNormalize", "DeviceRollout", "SfmiError", "lib"]
+__all__ = ["SFVecEnv", "SSF_Env", "FrameStack", "SFVecNormalize", "DeviceRollout", "Replay", "SfmiError", "lib"]
 
 
 def __getattr__(name):
@@ -26,4 +26,7 @@ def __getattr__(name):
     if name == "DeviceRollout":
         from .rollout import DeviceRollout
         return DeviceRollout
+    if name == "Replay":
+        from .replay import Replay
+        return Replay
     raise AttributeError(name)

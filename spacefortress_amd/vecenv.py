@@ -62,6 +62,11 @@ class SFVecEnv:
         h = C.c_void_p()
         _lib.check(self._L.sf_create(C.byref(p), C.byref(h)))
         self._h = h
+        # what a replay file needs to make this batch again (spacefortress_amd/replay.py)
+        self._create = {"action_set": int(action_set), "seed": int(seed) & 0xFFFFFFFF, "spawn_skip": int(spawn_skip),
+                        "spawn_stride": int(spawn_stride), "auto_reset": bool(auto_reset)}
+        self._fresh = True  # nothing has changed the state sf_create left: a recording may start here
+        self._rec = None
         self.num_envs = int(num_envs)
         self.gametype = gametype
         self.obs_type = obs_type
@@ -110,6 +115,7 @@ class SFVecEnv:
     def reset(self, numpy=False):
         """env.reset() in every lane (ENV:163-178): new games; returns obs [N, obs_dim]."""
         obs = self._alloc()[0]
+        self._touch()
         _lib.check(self._L.sf_reset(self._h, C.c_void_p(obs.data_ptr()), self._stream()))
         return obs.cpu().numpy() if numpy else obs
 
@@ -128,6 +134,9 @@ class SFVecEnv:
             ptrs = tuple(C.c_void_p(t.data_ptr()) for t in bufs)
         _lib.check(self._L.sf_step(self._h, C.c_void_p(actions.data_ptr()), at, ptrs[0], ptrs[1], ptrs[2], ptrs[3],
                                    self._stream()))
+        self._fresh = False
+        if self._rec is not None:
+            self._rec.add(actions.to(torch.uint8), bufs[1], bufs[2], bufs[3])
         return bufs
 
     def rollout(self, actions, out=None, want_obs=True):
@@ -160,7 +169,45 @@ class SFVecEnv:
                                           C.c_void_p(info.data_ptr()), self._stream()))
         finally:
             self._rollout_events_end(ev)
+        self._fresh = False
+        if self._rec is not None:
+            self._rec.add(actions.to(torch.uint8), rew, done, info)
         return obs, rew, done, info
+
+    # ------------------------------------------------------------------ replay files (spacefortress_amd/replay.py)
+    def _touch(self):
+        """The state is about to change otherwise than by a recorded step: a recording cannot go on."""
+        self._fresh = False
+        if self._rec is not None:
+            self._rec = None
+            raise RuntimeError("reset() / set_field() during a recording: a replay file is the game from a NEW batch on; "
+                               "the recording was dropped")
+
+    def start_recording(self):
+        """From here on every action played is kept (device tensors, no synchronisation); save_replay() writes them out with
+        what they produced.  Only on a batch nothing has stepped or reset since it was made: a replay starts from the state
+        sf_create leaves (the reference has no way to put a Game into a given state either)."""
+        from .replay import Recorder
+
+        if not self._fresh:
+            raise RuntimeError("start_recording() needs a new batch (nothing stepped, reset or edited since SFVecEnv(...))")
+        self._rec = Recorder(self)
+
+    def save_replay(self, path):
+        """Write the recording so far (gametype, action set, seed, spawn offsets, build id, uint8 [T, N] actions, per-env
+        returns / kills / episode ends, digest of the state now) to `path`; the recording goes on."""
+        if self._rec is None:
+            raise RuntimeError("save_replay(): no recording (start_recording() on a new batch first)")
+        rp = self._rec.replay(self)
+        rp.save(path)
+        return rp
+
+    @staticmethod
+    def load_replay(path):
+        """The file as a spacefortress_amd.replay.Replay: `.run()` plays it on the device and verifies it."""
+        from .replay import Replay
+
+        return Replay.load(path)
 
     def _rollout_events_begin(self, K):
         """A fused launch stores one row of event masks PER TICK (a.events[step * n_envs + i], sf_kernels.hip): with
@@ -193,12 +240,17 @@ class SFVecEnv:
             bufs = out if out is not None else self._alloc()
             ptrs = tuple(C.c_void_p(t.data_ptr()) for t in bufs)
         ao = None
+        if actions_out is None and self._rec is not None:  # a recording wants to know what was drawn
+            actions_out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
         if actions_out is not None:
             if actions_out.device != self.device or actions_out.dtype != torch.uint8 or not actions_out.is_contiguous() \
                     or actions_out.numel() != self.num_envs:
                 raise ValueError("actions_out must be a contiguous uint8 tensor of %d elements on %s" % (self.num_envs, self.device))
             ao = C.c_void_p(actions_out.data_ptr())
         _lib.check(self._L.sf_step_sampled(self._h, ao, ptrs[0], ptrs[1], ptrs[2], ptrs[3], self._stream()))
+        self._fresh = False
+        if self._rec is not None:
+            self._rec.add(actions_out, bufs[1], bufs[2], bufs[3])
         return bufs
 
     def rollout_sampled(self, n_steps, want_obs=True, want_actions=True):
@@ -210,7 +262,7 @@ class SFVecEnv:
         rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
         done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
         info = torch.empty((K, n), dtype=torch.uint8, device=self.device)
-        acts = torch.empty((K, n), dtype=torch.uint8, device=self.device) if want_actions else None
+        acts = torch.empty((K, n), dtype=torch.uint8, device=self.device) if (want_actions or self._rec is not None) else None
         ev = self._rollout_events_begin(K)
         try:
             _lib.check(self._L.sf_rollout_sampled(self._h, K, C.c_void_p(acts.data_ptr()) if acts is not None else None,
@@ -219,6 +271,9 @@ class SFVecEnv:
                                                   C.c_void_p(info.data_ptr()), self._stream()))
         finally:
             self._rollout_events_end(ev)
+        self._fresh = False
+        if self._rec is not None:
+            self._rec.add(acts, rew, done, info)
         return obs, rew, done, info, acts
 
     def step_async(self, actions):
@@ -341,6 +396,7 @@ class SFVecEnv:
             raise KeyError(name)
         f, dt, count = self._fields[name]
         arr = np.ascontiguousarray(np.asarray(value, dt).reshape(count, self.num_envs))
+        self._touch()
         _lib.check(self._L.sf_set_field(self._h, f, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
 
     def state_dict(self):
