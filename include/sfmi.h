@@ -166,6 +166,18 @@ int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, 
  *      DESIGN.md "image observation". ---- */
 int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, void* stream);
 
+/* ---- SSF_Env(scale, viewport, ls) (ENV:50-60 -> sf.Game(width = int(vw * scale), height = int(vh * scale), viewport, lw),
+ *      SRC/pymodule.cpp:319-354, SRC/draw.cpp:256-270): the geometry of this batch's frames.  The default -- scale .2,
+ *      viewport (130, 80, 450, 460), line width 3: every registered gym id and the trainer use it -- has the fast frame
+ *      kernel (92x90 surface, caches, draw records); any other geometry switches the batch to the general renderer (one
+ *      workgroup per env, every stroke in place): surface width, height in [84, 251] with width * height <= 49 152, i.e.
+ *      cv2's INTER_AREA shrink to 84x84 stays below threefold.  SF_OBS_IMAGE_RAW frames are then uint8 [h][w]
+ *      (sf_image_size; sf_obs_dim follows), sf_render_shift is not available, sf_render_stack clears a finished env's
+ *      slots with a launch of its own.  May be called any time between frames; synchronous.  SF_ERR_ARG for a geometry
+ *      outside those bounds (the batch keeps the one it had). ---- */
+int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, double vp_y, double vp_w, double vp_h, double line_width);
+int sf_image_size(const sf_batch* b, int32_t* width, int32_t* height); /* of SF_OBS_IMAGE_RAW frames: 90 x 92 by default */
+
 /* One step of the trainer's frame stack in one launch (rl/train.py:51-56,92-97): the 84x84 frame of every env
  * goes to slot `slot` of stack_dev uint8 [n_envs][num_stack][84][84] (16-byte aligned), and an env whose
  * done_dev flag is set (may be NULL) first gets its other slots zeroed. */
@@ -348,16 +360,19 @@ int sf_hex_points(int radius, double* out);
 /* the part of every frame that never changes: both hexagons stroked on black (SRC/draw.cpp:131-143,
  * 230-231, 262-263) as 8-bit grey: out is uint8[92][90] */
 int sf_image_background(uint8_t* out);
+/* ... for any geometry (sf_set_image_geometry): a w x h surface under scale(scale) translate(-vx, -vy), line width lw user
+ * units; out is uint8[h][w] */
+int sf_image_background_geom(double scale, double vx, double vy, int w, int h, double lw, uint8_t* out);
 /* the background plus the overlays the render kernel starts from when they are static: variant bit 0 =
  * the score text "0000000", bit 1 = the vulnerability bar at 0 (drawScore / drawVlner, SRC/draw.cpp:
  * 190-225); out is uint8[92][90] */
 int sf_image_static(int variant, uint8_t* out);
-/* cv2.resize(..., INTER_AREA) taps for one axis, ssize -> dsize with dsize <= ssize < 2*dsize
- * (rl/envs.py:29: 90 -> 84 and 92 -> 84): destination i reads source cells first[i] .. first[i] +
- * count[i] - 1 with weights alpha[4*i ..]; alpha is float[dsize][4] */
+/* cv2.resize(..., INTER_AREA) taps for one axis, ssize -> dsize with dsize <= ssize < 3*dsize
+ * (rl/envs.py:29: 90 -> 84 and 92 -> 84 in the default geometry): destination i reads source cells first[i] ..
+ * first[i] + count[i] - 1 (count <= 4) with weights alpha[4*i ..]; alpha is float[dsize][4] */
 int sf_resize_area_tab(int ssize, int dsize, int32_t* first, int32_t* count, float* alpha);
-/* cv2.resize(src, (dw, dh), interpolation=INTER_AREA) for 8-bit grey frames and a shrink below 2x per
- * axis, with OpenCV's float arithmetic and rounding: the library's own resampling of the static
+/* cv2.resize(src, (dw, dh), interpolation=INTER_AREA) for 8-bit grey frames and a shrink below 3x per
+ * axis (below 3x: sf_resize_area_tab), with OpenCV's float arithmetic and rounding: the library's own resampling of the static
  * background; host memory, row-major */
 int sf_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
 

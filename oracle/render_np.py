@@ -32,6 +32,17 @@ W, H, OUT = 90, 92, 84
 VP_X, VP_Y, SCALE, LINE_W = 130.0, 80.0, 0.2, 3.0
 FORT = (355.0, 315.0)
 
+
+def set_geometry(scale=.2, viewport=(130, 80, 450, 460), ls=3):
+    """The geometry SSF_Env(scale, viewport, ls) asks for (ENV:50-60): surface int(vw * scale) x int(vh * scale), device =
+    (user - (vx, vy)) * scale, line width ls user units.  Module-wide (the functions below read the globals); returns the
+    previous (scale, viewport, ls) so that a test can put it back."""
+    global W, H, VP_X, VP_Y, SCALE, LINE_W
+    prev = (SCALE, (VP_X, VP_Y, W / SCALE, H / SCALE), LINE_W)
+    VP_X, VP_Y, SCALE, LINE_W = float(viewport[0]), float(viewport[1]), float(scale), float(ls)
+    W, H = int(viewport[2] * scale), int(viewport[3] * scale)
+    return prev
+
 SHIP_LINES = [(-18, 0, 18, 0), (-18, 18, 0, 0), (0, 0, -18, -18)]
 FORT_LINES = [(0, 0, 36, 0), (0, -18, 18, -18), (18, -18, 18, 18), (18, 18, 0, 18)]
 MISSILE_LINES = [(0, 0, -25, 0), (0, 0, -5, 5), (0, 0, -5, -5)]
@@ -263,7 +274,7 @@ def area_tab(ssize, dsize):
 
 
 def resize_area(frame, dsize=(OUT, OUT)):
-    """cv2.resize(frame, dsize, interpolation=INTER_AREA) for a non-integer shrink < 2 (resizeArea_)."""
+    """cv2.resize(frame, dsize, interpolation=INTER_AREA) for a non-integer shrink (resizeArea_)."""
     sh, sw = frame.shape
     xtab, ytab = area_tab(sw, dsize[0]), area_tab(sh, dsize[1])
     src = frame.astype(np.float32)

@@ -84,6 +84,8 @@ SYMBOLS = {
     "sf_episode_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sf_calibration_copy": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "sf_draw_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "sf_set_image_geometry": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
+    "sf_image_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sf_preset_get": (C.c_int, [C.c_char_p, C.POINTER(Preset)]),
     "sf_action_table": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p]),
     "sf_spawn_table": (C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
@@ -105,6 +107,7 @@ SYMBOLS = {
     "sf_set_event_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sf_render": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sf_image_background": (C.c_int, [C.c_void_p]),
+    "sf_image_background_geom": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "sf_image_static": (C.c_int, [C.c_int, C.c_void_p]),
     "sf_resize_area_tab": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_resize_area_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),

@@ -47,6 +47,11 @@ struct sf_batch {
   // before every frame.
   unsigned char* d_draw;
   bool draw_current;
+  // sf_set_image_geometry: a geometry other than the default one (sf_render_generic.hip); g_w == 0: the default
+  int g_w, g_h;
+  double g_scale, g_vx, g_vy, g_lw;
+  uint8_t* d_gbg;            // g_w * g_h bytes: the hexagons
+  uint32_t* d_gtabs;         // the INTER_AREA taps g_w -> 84, g_h -> 84
   bool render_ready;         // the render caches and pictures exist (or were declined: SFMI_NO_EXPLOSION_CACHE)
 };
 
@@ -398,6 +403,8 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_xcache) (void)hipFree(b->d_xcache);
   if (b->d_bg84) (void)hipFree(b->d_bg84);
   if (b->d_draw) (void)hipFree(b->d_draw);
+  if (b->d_gbg) (void)hipFree(b->d_gbg);
+  if (b->d_gtabs) (void)hipFree(b->d_gtabs);
   if (b->args.dbg) (void)hipFree(b->args.dbg);
   if (b->args.hint) (void)hipFree(b->args.hint);
   delete b;
@@ -429,7 +436,7 @@ extern "C" int sf_n_envs(const sf_batch* b) { return b ? b->n_envs : SF_ERR_ARG;
 extern "C" int sf_obs_dim(const sf_batch* b) {
   if (!b) return SF_ERR_ARG;
   if (b->obs_mode == SF_OBS_IMAGE) return SF_OUT * SF_OUT;
-  if (b->obs_mode == SF_OBS_IMAGE_RAW) return SF_IMG_W * SF_IMG_H;
+  if (b->obs_mode == SF_OBS_IMAGE_RAW) return b->g_w ? b->g_w * b->g_h : SF_IMG_W * SF_IMG_H;
   return b->args.obs_dim;
 }
 extern "C" int sf_n_actions(const sf_batch* b) { return b ? b->act_count : SF_ERR_ARG; }
@@ -438,10 +445,97 @@ extern "C" int sf_max_ticks(const sf_batch* b) { return b ? (int)sfc::max_ticks 
 
 static bool is_image(const sf_batch* b) { return b->obs_mode == SF_OBS_IMAGE || b->obs_mode == SF_OBS_IMAGE_RAW; }
 
+extern "C" int sf_image_size(const sf_batch* b, int32_t* width, int32_t* height) {
+  if (!b || !width || !height) return SF_ERR_ARG;
+  *width = b->g_w ? b->g_w : SF_IMG_W;
+  *height = b->g_w ? b->g_h : SF_IMG_H;
+  return SF_OK;
+}
+
+extern "C" int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, double vp_y, double vp_w, double vp_h, double line_width) {
+  if (!b) {
+    sf_set_error("sf_set_image_geometry: null batch");
+    return SF_ERR_ARG;
+  }
+  if (!(scale > 0) || !(vp_w > 0) || !(vp_h > 0) || !(line_width > 0) || !(vp_w * scale < 1e6) || !(vp_h * scale < 1e6)) {
+    sf_set_error("sf_set_image_geometry: scale, viewport size and line width must be positive");
+    return SF_ERR_ARG;
+  }
+  const int w = (int)(vp_w * scale), h = (int)(vp_h * scale);  // ENV:57-58
+  DeviceGuard guard(b->device);
+  HIP_TRY(hipDeviceSynchronize());
+  if (scale == SF_SCALE && vp_x == SF_VP_X && vp_y == SF_VP_Y && w == SF_IMG_W && h == SF_IMG_H && line_width == SF_LINE_W) {
+    b->g_w = b->g_h = 0;  // the default geometry: the fast frame kernel
+    return SF_OK;
+  }
+  if (w < SF_OUT || h < SF_OUT || w >= 3 * SF_OUT || h >= 3 * SF_OUT || (long)w * h > 49152) {
+    sf_set_error("sf_set_image_geometry: a %d x %d surface (scale %g, viewport %g x %g): width and height must lie in [%d, %d] "
+                 "with width * height <= 49152 (the 84x84 INTER_AREA image of the trainer is a shrink below threefold)",
+                 w, h, scale, vp_w, vp_h, SF_OUT, 3 * SF_OUT - 1);
+    return SF_ERR_ARG;
+  }
+  std::vector<uint8_t> bg((size_t)w * h);
+  int rc = sf_image_background_geom(scale, vp_x, vp_y, w, h, line_width, bg.data());
+  if (rc != SF_OK) return rc;
+  std::vector<uint32_t> tabs(16 * SF_OUT, 0u);
+  const int ssize[2] = {w, h};
+  for (int ax = 0; ax < 2; ax++) {
+    int32_t first[SF_OUT], count[SF_OUT];
+    float alpha[SF_OUT * 4];
+    rc = sf_resize_area_tab(ssize[ax], SF_OUT, first, count, alpha);
+    if (rc != SF_OK) return rc;
+    for (int i = 0; i < SF_OUT; i++) {
+      uint32_t* t = &tabs[8 * (ax * SF_OUT + i)];
+      t[0] = (uint32_t)first[i];
+      t[1] = (uint32_t)count[i];
+      memcpy(t + 2, alpha + 4 * i, 4 * sizeof(float));
+      if (first[i] < 0 || count[i] < 1 || count[i] > 4 || first[i] + count[i] > ssize[ax]) {
+        sf_set_error("sf_set_image_geometry: INTER_AREA table out of range");
+        return SF_ERR_ARG;
+      }
+    }
+  }
+  uint8_t* nbg = nullptr;
+  uint32_t* ntabs = nullptr;
+  HIP_TRY(hipMalloc((void**)&nbg, bg.size()));
+  HIP_TRY(hipMalloc((void**)&ntabs, tabs.size() * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(nbg, bg.data(), bg.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ntabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (b->d_gbg) (void)hipFree(b->d_gbg);
+  if (b->d_gtabs) (void)hipFree(b->d_gtabs);
+  b->d_gbg = nbg;
+  b->d_gtabs = ntabs;
+  b->g_w = w;
+  b->g_h = h;
+  b->g_scale = scale;
+  b->g_vx = vp_x;
+  b->g_vy = vp_y;
+  b->g_lw = line_width;
+  return SF_OK;
+}
+
 static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, hipStream_t stream,
                   const uint8_t* stack_done = nullptr, int stack_slot = 0, int stack_n = 1,
                   const uint8_t* stack_prev = nullptr) {
-  const size_t frame = mode == SF_OBS_IMAGE ? (size_t)SF_OUT * SF_OUT : (size_t)SF_IMG_W * SF_IMG_H;
+  const size_t frame = mode == SF_OBS_IMAGE ? (size_t)SF_OUT * SF_OUT
+                                            : (b->g_w ? (size_t)b->g_w * b->g_h : (size_t)SF_IMG_W * SF_IMG_H);
+  if (b->g_w) {  // another geometry than the default: the general renderer (sf_render_generic.hip), from the state
+    if (env_stride == 0) env_stride = frame;
+    if (env_stride < frame) {
+      sf_set_error("image frames: env_stride %zu below the frame size %zu", env_stride, frame);
+      return SF_ERR_ARG;
+    }
+    if (stack_prev) {
+      sf_set_error("sf_render_shift is built for the default image geometry; use sf_render_stack with this one");
+      return SF_ERR_ARG;
+    }
+    SF_FLUSH_VIEW(b, stream);
+    if (stack_done)  // `current_obs *= masks` for the finished envs, then the new frame into its slot
+      HIP_TRY(sf_launch_stack_clear(frames_dev - (size_t)stack_slot * frame, (size_t)stack_n * frame, stack_done, b->n_envs, stream));
+    HIP_TRY(sf_launch_render_generic(b->d_state, b->n_envs, b->g_w, b->g_h, b->g_scale, b->g_vx, b->g_vy, b->g_lw, b->d_gbg,
+                                     b->d_gtabs, frames_dev, env_stride, mode == SF_OBS_IMAGE ? 1 : 0, stream));
+    return SF_OK;
+  }
   if (env_stride == 0) env_stride = frame;
   if (((uintptr_t)frames_dev & 15) != 0 || env_stride < frame || (env_stride & (mode == SF_OBS_IMAGE ? 15 : 7)) != 0) {
     sf_set_error("image frames must be 16-byte aligned, env_stride >= the frame size and a multiple of %d",

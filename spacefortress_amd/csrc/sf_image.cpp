@@ -16,10 +16,6 @@
 
 namespace {
 
-// user space -> device space: cairo_scale(.2) then cairo_translate(-130, -80), SRC/draw.cpp:259-260
-inline double dev_x(double x) { return (x - SF_VP_X) * SF_SCALE; }
-inline double dev_y(double y) { return (y - SF_VP_Y) * SF_SCALE; }
-
 // vertices of the polygon whose edges are the hexagon's edges moved by `off` along their outward
 // normals: the outline (off > 0) / inline (off < 0) of a closed stroke with miter joins
 void offset_polygon(const double* p /* [6][2] */, double off, double* qx, double* qy) {
@@ -50,41 +46,54 @@ void offset_polygon(const double* p /* [6][2] */, double off, double* qx, double
 
 }  // namespace
 
-extern "C" int sf_image_background(uint8_t* out) {
-  if (!out) {
-    sf_set_error("sf_image_background: null output");
+// the two hexagons stroked on black for a surface of w x h pixels under scale(s) translate(-vx, -vy), line width lw user units
+// (drawGameStateScaled, SRC/draw.cpp:256-263; Game(width, height, viewport, lw), SRC/pymodule.cpp:319-354)
+extern "C" int sf_image_background_geom(double scale, double vx, double vy, int w, int h, double lw, uint8_t* out) {
+  if (!out || w <= 0 || h <= 0 || !(scale > 0) || !(lw > 0)) {
+    sf_set_error("sf_image_background_geom: bad argument");
     return SF_ERR_ARG;
   }
-  memset(out, 0, SF_IMG_W * SF_IMG_H);  // cairo_paint of black, SRC/draw.cpp:262-263
-  const int radii[2] = {200, 40};       // bigHex, smallHex (SRC/configs.cpp:34-35), drawn in this order
-  for (int h = 0; h < 2; h++) {
+  memset(out, 0, (size_t)w * h);   // cairo_paint of black, SRC/draw.cpp:262-263
+  const int radii[2] = {200, 40};  // bigHex, smallHex (SRC/configs.cpp:34-35), drawn in this order
+  for (int k = 0; k < 2; k++) {
     double p[12], ox[6], oy[6], ix[6], iy[6];
-    sf_hex_points(radii[h], p);
-    offset_polygon(p, SF_LINE_W / 2, ox, oy);
-    offset_polygon(p, -SF_LINE_W / 2, ix, iy);
+    sf_hex_points(radii[k], p);
+    offset_polygon(p, lw / 2, ox, oy);
+    offset_polygon(p, -lw / 2, ix, iy);
     for (int i = 0; i < 6; i++) {
-      ox[i] = dev_x(ox[i]);
-      oy[i] = dev_y(oy[i]);
-      ix[i] = dev_x(ix[i]);
-      iy[i] = dev_y(iy[i]);
+      ox[i] = (ox[i] - vx) * scale;
+      oy[i] = (oy[i] - vy) * scale;
+      ix[i] = (ix[i] - vx) * scale;
+      iy[i] = (iy[i] - vy) * scale;
     }
-    for (int y = 0; y < SF_IMG_H; y++)
-      for (int x = 0; x < SF_IMG_W; x++) {
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
         // ring = outline minus inline; both convex, the inline inside the outline
         double a = sfr::clip_area<double>(ox, oy, 6, (double)x, (double)y) -
                    sfr::clip_area<double>(ix, iy, 6, (double)x, (double)y);
         if (a <= 0) continue;
         if (a > 1) a = 1;
         const int m = (int)(a * 255.0 + 0.5);
-        out[y * SF_IMG_W + x] = (uint8_t)sfr::over_un8(out[y * SF_IMG_W + x], 255, m);  // white, :133-136
+        out[(size_t)y * w + x] = (uint8_t)sfr::over_un8(out[(size_t)y * w + x], 255, m);  // white, :133-136
       }
   }
   return SF_OK;
 }
 
+extern "C" int sf_image_background(uint8_t* out) {
+  if (!out) {
+    sf_set_error("sf_image_background: null output");
+    return SF_ERR_ARG;
+  }
+  // (user space -> device space: cairo_scale(.2) then cairo_translate(-130, -80), SRC/draw.cpp:259-260)
+  return sf_image_background_geom(SF_SCALE, SF_VP_X, SF_VP_Y, SF_IMG_W, SF_IMG_H, SF_LINE_W, out);
+}
+
 extern "C" int sf_resize_area_tab(int ssize, int dsize, int32_t* first, int32_t* count, float* alpha) {
-  if (ssize <= 0 || dsize <= 0 || dsize > ssize || ssize >= 2 * dsize || !first || !count || !alpha) {
-    sf_set_error("sf_resize_area_tab: need dsize <= ssize < 2*dsize and non-null outputs");
+  // (the default geometry shrinks by 15/14 and 23/21: two or three taps; any geometry below a threefold shrink has at most
+  //  four: floor(scale) + 2)
+  if (ssize <= 0 || dsize <= 0 || dsize > ssize || ssize >= 3 * dsize || !first || !count || !alpha) {
+    sf_set_error("sf_resize_area_tab: need dsize <= ssize < 3*dsize and non-null outputs");
     return SF_ERR_ARG;
   }
   const double inv_scale = (double)dsize / (double)ssize;
@@ -105,7 +114,7 @@ extern "C" int sf_resize_area_tab(int ssize, int dsize, int32_t* first, int32_t*
     for (int sx = sx1; sx < sx2; sx++) a[k++] = (float)(1.0 / cell);
     if (fsx2 - sx2 > 1e-3) a[k++] = (float)(fmin(fmin(fsx2 - sx2, 1.0), cell) / cell);
     first[dx] = f;
-    count[dx] = k;  // <= 3 because ssize < 2*dsize
+    count[dx] = k;  // <= 3 for ssize < 2*dsize, <= 4 for ssize < 3*dsize
   }
   return SF_OK;
 }

@@ -51,6 +51,12 @@ hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, cons
                                int do_ret, double* partials, const double* stats, double* stats_next,
                                hipStream_t stream);
 
+// sf_render_generic.hip: the image observation in any geometry (sf_set_image_geometry): one workgroup per env, the W x H
+// surface in dynamic LDS, bg = W * H bytes (the hexagons), tabs = the INTER_AREA taps (8 words per destination column, then
+// per row: first, count, 4 weights, 2 pad)
+hipError_t sf_launch_render_generic(const unsigned char* state, int n_envs, int W, int H, double scale, double vp_x, double vp_y,
+                                    double line_w, const uint8_t* bg, const uint32_t* tabs, uint8_t* out, size_t out_stride,
+                                    int resize, hipStream_t stream);
 hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n, hipStream_t stream);
 
 hipError_t sf_launch_normalize_after_step(const void* obs, void* obs_out, int obs_f64, const int32_t* rew, float* rew_out, int n,

@@ -21,12 +21,13 @@ class SSF_Env(_Base):
     def __init__(self, gametype="youturn", scale=.2, viewport=(130, 80, 450, 460), ls=3, action_set=1,
                  obs_type="image", device=None, seed=1):
         assert obs_type in ("image", "features", "normalized-features", "monitors")  # ENV:51
-        # scale / viewport / ls only shape the picture (ENV:56-60 -> sf.Game(width, height, viewport, lw)); the
-        # renderer's geometry (90x92 surface, 0.6-pixel strokes) is compiled into the kernel, so any other geometry is
-        # accepted for the symbolic observations and refused where a frame would have to be drawn with it
-        self._default_geometry = (float(scale), tuple(viewport), float(ls)) == (.2, (130, 80, 450, 460), 3.0)
-        if obs_type == "image" and not self._default_geometry:
-            raise ValueError("image observations are built for the default scale=.2, viewport=(130,80,450,460), ls=3 only")
+        # scale / viewport / ls only shape the picture (ENV:56-60 -> sf.Game(width, height, viewport, lw)).  The default
+        # geometry has the fast frame kernel (90x92 surface, 0.6-pixel strokes compiled in); any other one is drawn by the
+        # general renderer (sfmi.h: sf_set_image_geometry) as long as the surface is 84 .. 251 pixels wide and high -- the
+        # trainer's 84x84 INTER_AREA image must be a shrink.  A geometry outside that is accepted for the symbolic
+        # observations and refused (ValueError) where a frame would have to be drawn with it.
+        self._geometry = (float(scale), tuple(float(v) for v in viewport), float(ls))
+        self._default_geometry = self._geometry == (.2, (130., 80., 450., 460.), 3.0)
         self.obs_type = obs_type
         self.gametype = gametype
         self.viewport = viewport
@@ -39,6 +40,15 @@ class SSF_Env(_Base):
         self._vec = SFVecEnv(1, gametype=gametype, obs_type="image-raw" if obs_type == "image" else obs_type,
                              action_set=action_set, device=device,
                              seed=seed, obs_dtype=__import__("torch").float64, auto_reset=False)
+        self._drawable = True
+        if not self._default_geometry:
+            try:
+                self._vec.set_image_geometry(scale, viewport, ls)
+            except ValueError:
+                self._drawable = False
+                if obs_type == "image":
+                    self._vec.close()
+                    raise
         self.tickdur = self._vec.tickdur
         self.max_ticks = float(self._vec.max_ticks)
         self.action_space = self._vec.action_space
@@ -66,8 +76,8 @@ class SSF_Env(_Base):
         the pyglet window of mode 'human' is not part of this library."""
         if close:
             return None
-        if not self._default_geometry:
-            raise ValueError("render() draws the default scale=.2, viewport=(130,80,450,460), ls=3 only")
+        if not self._drawable:
+            raise ValueError("render(): a %d x %d surface is outside what the renderer draws (84 .. 251 pixels each way)" % (self.w, self.h))
         if mode != "rgb_array":
             raise NotImplementedError("render(mode='human') opens a pyglet window in the reference; "
                                       "use mode='rgb_array'")

@@ -35,7 +35,7 @@ _UNSIGNED_FIELDS = {"spawn_cursor", "missile_mask", "shell_mask", "flags"}
 class SFVecEnv:
     def __init__(self, num_envs, gametype="youturn", obs_type="features", action_set=1, device=None,
                  seed=1, spawn_skip=0, spawn_stride=0, obs_dtype=torch.float32, faithful_bugs=True,
-                 auto_reset=True, spawn_table_len=0, reuse_buffers=False):
+                 auto_reset=True, spawn_table_len=0, reuse_buffers=False, image_geometry=None):
         if obs_type not in _lib.OBS_TYPES:
             raise AssertionError("obs_type %r" % (obs_type,))  # ENV:51
         self._L = _lib.lib()
@@ -75,8 +75,9 @@ class SFVecEnv:
         # 'image': what the trainer's VecEnv yields, WrapPyTorch's [1, 84, 84] uint8 (rl/envs.py:19-30);
         # 'image-raw': SSF_Env's own [92, 90] grey frame (ENV:171)
         self.is_image = obs_type in ("image", "image-raw")
+        self.image_w, self.image_h = _lib.IMAGE_W, _lib.IMAGE_H
         self.obs_shape = {"image": (1, _lib.IMAGE_OUT, _lib.IMAGE_OUT),
-                          "image-raw": (_lib.IMAGE_H, _lib.IMAGE_W)}.get(obs_type, (self.obs_dim,))
+                          "image-raw": (self.image_h, self.image_w)}.get(obs_type, (self.obs_dim,))
         self.n_actions = self._L.sf_n_actions(h)
         self.tickdur = self._L.sf_tick_ms(h)      # ENV:61
         self.max_ticks = self._L.sf_max_ticks(h)  # ENV:165
@@ -93,6 +94,13 @@ class SFVecEnv:
         self._buf_ptrs = None
         self._pending = None
         self._fields = None
+        # SSF_Env(scale, viewport, ls) (ENV:50-60): the frames' geometry; None = the reference's default (.2, (130, 80, 450, 460), 3)
+        if image_geometry is not None:
+            try:
+                self.set_image_geometry(*image_geometry)
+            except Exception:
+                self.close()
+                raise
 
     # ------------------------------------------------------------------ buffers
     def _stream(self):
@@ -318,12 +326,26 @@ class SFVecEnv:
         except Exception:
             pass
 
+    def set_image_geometry(self, scale=.2, viewport=(130, 80, 450, 460), ls=3):
+        """The geometry of this batch's frames, as SSF_Env's constructor takes it (ENV:50-60; sfmi.h: sf_set_image_geometry).
+        The default has the fast frame kernel; any other one the general renderer (surface width and height in [84, 251])."""
+        vx, vy, vw, vh = (float(v) for v in viewport)
+        _lib.check(self._L.sf_set_image_geometry(self._h, float(scale), vx, vy, vw, vh, float(ls)))
+        w, h = C.c_int32(), C.c_int32()
+        _lib.check(self._L.sf_image_size(self._h, C.byref(w), C.byref(h)))
+        self.image_w, self.image_h = int(w.value), int(h.value)
+        if self.obs_type == "image-raw":
+            self.obs_shape = (self.image_h, self.image_w)
+            self.obs_dim = self._L.sf_obs_dim(self._h)
+            self.observation_space = Box(0, 255, self.obs_shape, np.uint8)
+            self._bufs = self._buf_ptrs = None
+
     def render(self, mode="image-raw", out=None):
         """Frames of the CURRENT state of every env, whatever obs_type the batch steps with (the
         reference's `render()`, ENV:180-198): uint8 [N, 92, 90] ('image-raw') or [N, 1, 84, 84] ('image')."""
         if mode not in ("image", "image-raw"):
             raise ValueError("mode must be 'image' or 'image-raw'")
-        shape = (1, _lib.IMAGE_OUT, _lib.IMAGE_OUT) if mode == "image" else (_lib.IMAGE_H, _lib.IMAGE_W)
+        shape = (1, _lib.IMAGE_OUT, _lib.IMAGE_OUT) if mode == "image" else (self.image_h, self.image_w)
         if out is None:
             out = torch.empty((self.num_envs,) + shape, dtype=torch.uint8, device=self.device)
         # `out` may be a view whose env stride is larger than a frame (one slot of a frame stack)

@@ -569,3 +569,61 @@ def test_draw_records_of_the_step_equal_records_from_the_state(sfa, gametype, po
     if policy == "hunter":
         assert seen_flags & (3 << 20), hex(seen_flags)  # a destroyed fortress's explosion
     env.close()
+
+
+@pytest.mark.parametrize("scale,viewport,ls", [(.25, (100, 60, 500, 520), 2), (.3, (130, 80, 450, 460), 4.5)])
+def test_frames_in_another_geometry_vs_model(sfa, oracle_mod, scale, viewport, ls):
+    """SSF_Env(scale, viewport, ls) (ENV:50-60): any geometry but the default one goes through the general renderer
+    (sf_render_generic.hip).  Frames of both sizes -- the raw [h][w] surface and the trainer's 84x84 INTER_AREA image --
+    against the numpy model parametrised the same way, on oracle lock-step states with everything on screen (explosions,
+    missiles, shells, a score, a filling bar); and the SSF_Env surface: shapes follow the geometry, the default still
+    takes the fast kernel, a surface the trainer's resize cannot shrink is refused."""
+    from oracle import render_np as R
+    from sfscript import open_loop_actions
+
+    O = oracle_mod
+    z = np.load(os.path.join(GOLDEN, "tables.npz"))
+    hb, hs = z["hex_points"][:12], z["hex_points"][12:]
+    w, h = int(viewport[2] * scale), int(viewport[3] * scale)
+    N, T = 6, 420
+    rng = np.random.default_rng(8)
+    env = sfa.SFVecEnv(N, gametype="autoturn", obs_type="image-raw", spawn_stride=1, image_geometry=(scale, viewport, ls))
+    assert env.obs_shape == (h, w) and env.observation_space.shape == (h, w)
+    orc = O.OracleVecEnv("autoturn", N, spawn_stride=1)
+    acts = open_loop_actions("hunter", (T, N), env.n_actions, rng, phase=rng.integers(0, 96, N))
+    prev = R.set_geometry(scale, viewport, ls)
+    try:
+        bg = R.background(hb, hs)
+        checked = 0
+        for t in range(T):
+            raw, *_ = env.step_tensors(torch.from_numpy(acts[t]).to(env.device))
+            orc.step(acts[t].astype(np.int32))
+            if t % 30 == 29 or t > T - 4:
+                small = env.render("image").cpu().numpy()
+                raw = raw.cpu().numpy()
+                snaps = orc.snapshots()
+                for lane in range(0, N, 2):
+                    want = R.render_raw(snaps[lane], hb, hs, bg=bg)
+                    frames_close(raw[lane], want, ("raw", t, lane))
+                    frames_close(small[lane, 0], R.resize_area(want), ("84x84", t, lane))
+                    assert np.array_equal(small[lane, 0], R.resize_area(raw[lane]))  # the device's resize of the device's frame: exact
+                    checked += 1
+        assert checked >= 40
+    finally:
+        R.set_geometry(*prev)
+    # back to the default geometry on the same batch: the fast kernel's 92 x 90 frames again
+    env.set_image_geometry()
+    assert env.obs_shape == (92, 90) and env.render("image-raw").shape == (N, 92, 90)
+    env.close()
+    e1 = sfa.SSF_Env("youturn", scale=scale, viewport=viewport, ls=ls, obs_type="image")
+    o = e1.reset()
+    assert o.shape == (h, w) and e1.observation_space.shape == (h, w, 3) and e1.render("rgb_array").shape == (h, w, 3)
+    o2, r, d, i = e1.step(1)
+    assert o2.shape == (h, w) and o2.max() == 255 or o2.max() > 100
+    e1.close()
+    with pytest.raises(ValueError):
+        sfa.SSF_Env("youturn", scale=.1, obs_type="image")  # a 45 x 46 surface: nothing to shrink to 84 x 84
+    e2 = sfa.SSF_Env("youturn", scale=.1, obs_type="features")  # ... but fine where no frame is drawn
+    with pytest.raises(ValueError):
+        e2.render("rgb_array")
+    e2.close()

@@ -40,7 +40,7 @@ def test_background_matches_model_and_reference_hexagons():
 def test_resize_tables_follow_opencv_area():
     from oracle import render_np as R
     L = _lib()
-    for ss, ds in ((90, 84), (92, 84)):
+    for ss, ds in ((90, 84), (92, 84), (125, 84), (137, 84), (168, 84), (200, 84), (251, 84), (84, 84)):
         f, c, a = np.zeros(ds, np.int32), np.zeros(ds, np.int32), np.zeros((ds, 4), np.float32)
         assert L.sf_resize_area_tab(ss, ds, f.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
                                     a.ctypes.data_as(C.c_void_p)) == 0
@@ -51,12 +51,12 @@ def test_resize_tables_follow_opencv_area():
                 assert tab[k] == (d, f[d] + j, a[d, j])
                 k += 1
             assert (a[d, c[d]:] == 0).all()
-        assert k == len(tab) and c.max() <= 3
+        assert k == len(tab) and c.max() <= (3 if ss < 2 * ds else 4)
         assert np.allclose(a.sum(1), 1.0, atol=1e-6)
         assert f[0] == 0 and f[-1] + c[-1] == ss  # covers the source exactly
     i32 = np.zeros(4, np.int32)
-    assert L.sf_resize_area_tab(200, 84, i32.ctypes.data_as(C.c_void_p), i32.ctypes.data_as(C.c_void_p),
-                                i32.ctypes.data_as(C.c_void_p)) < 0  # scale >= 2: not this table's path
+    assert L.sf_resize_area_tab(252, 84, i32.ctypes.data_as(C.c_void_p), i32.ctypes.data_as(C.c_void_p),
+                                i32.ctypes.data_as(C.c_void_p)) < 0  # a threefold shrink or more: five taps, not this table's layout
 
 
 def test_dirty_boxes_of_the_resampling_are_exact():
@@ -101,6 +101,30 @@ def test_host_resize_matches_model():
         out = np.zeros((84, 84), np.uint8)
         assert L.sf_resize_area_u8(img.ctypes.data_as(C.c_void_p), 90, 92, out.ctypes.data_as(C.c_void_p), 84, 84) == 0
         assert np.array_equal(out, R.resize_area(img))
+
+
+def test_host_tables_of_another_geometry_match_model():
+    """sf_set_image_geometry's host tables -- the hexagons under scale(s) translate(-vx, -vy) with another line width, and
+    INTER_AREA from a surface that is not 90 x 92 -- against the numpy model parametrised the same way."""
+    from oracle import render_np as R
+    L = _lib()
+    hb, hs = _hex()
+    rng = np.random.default_rng(4)
+    for scale, vp, ls in ((.25, (100, 60, 500, 520), 2), (.3, (130, 80, 450, 460), 4.5)):
+        prev = R.set_geometry(scale, vp, ls)
+        try:
+            w, h = int(vp[2] * scale), int(vp[3] * scale)
+            assert (R.W, R.H) == (w, h)
+            bg = np.zeros((h, w), np.uint8)
+            assert L.sf_image_background_geom(scale, vp[0], vp[1], w, h, ls, bg.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(bg, R.background(hb, hs)) and bg.max() > 100
+            for img in (bg, rng.integers(0, 256, (h, w)).astype(np.uint8)):
+                out = np.zeros((84, 84), np.uint8)
+                assert L.sf_resize_area_u8(img.ctypes.data_as(C.c_void_p), w, h, out.ctypes.data_as(C.c_void_p), 84, 84) == 0
+                assert np.array_equal(out, R.resize_area(img))
+        finally:
+            R.set_geometry(*prev)
+    assert (R.W, R.H, R.SCALE, R.LINE_W) == (90, 92, .2, 3.0)
 
 
 def test_resize_area_properties():
