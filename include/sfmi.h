@@ -132,8 +132,9 @@ int sf_step(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, i
  *      sample (rl/train.py:76-80), without an action array to generate, store and load.  Lane l of tile t plays
  *      floor(x * n_actions / 2^32), x = the first word of Philox4x32-10 with key = the 64-bit seed and counter
  *      (first_lane + 64 t + l, tick, 0, 0); `tick` counts this batch's sampled steps since sf_seed_actions (kept per
- *      tile on the device, so the call is a pure stream operation: capturable in a HIP graph, every replay draws new
- *      actions).  actions_out_dev, uint8 [n_envs] (may be NULL), receives what was played -- replaying those through
+ *      tile on the device as a uint32, so the call is a pure stream operation: capturable in a HIP graph, every replay
+ *      draws new actions; after 2^32 sampled steps -- five days at a microsecond each -- the counter wraps and the stream of
+ *      actions repeats).  actions_out_dev, uint8 [n_envs] (may be NULL), receives what was played -- replaying those through
  *      sf_step from the same state gives the same results (tests/test_gpu_sampled.py).  sf_create seeds with
  *      (params.seed, first_lane 0); sf_seed_actions restarts the sequence at tick 0 (synchronises `stream`).
  *      sf_rollout_sampled: the fused n_steps form, actions_out_dev uint8 [n_steps][n_envs]. ---- */
@@ -229,11 +230,12 @@ int sf_check_actions(sf_batch* b, void* stream);
 /* The per-episode statistics and the key timers live in bit fields sized for one episode (5 295 ticks).  A batch created
  * with SF_FLAG_NO_AUTO_RESET keeps ticking past game over like the bare SSF_Env (ENV:246) until sf_reset; if it is stepped
  * for several episodes' worth of ticks a field can outgrow its bits (deaths / kills: 255 per game; resets, misses, key
- * presses: 65 535; vlner: 4 095; a key timer: +-32 767 ticks without an edge; time: 2^24 ms).  Every env-tick on which
- * that is the case is counted on the device; this reads and clears the count (synchronises `stream`) and returns
- * SF_ERR_STATE if any were seen -- the values sf_get_field returns for those envs have wrapped.  Auto-resetting batches
- * start every field over at each episode end and cannot get there.  sf_set_field refuses (SF_ERR_ARG) values that do
- * not fit a field, and a `stats` row 3 (ship deaths) that is not the sum of rows 0-2. */
+ * presses: 65 535; vlner: 4 095; a key timer: +-32 767 ticks without an edge; time: 2^24 ms).  Every time a field of
+ * some env leaves its range (the tick on which it wraps) is counted on the device; this reads the count (synchronises
+ * `stream`) and returns SF_ERR_STATE while it is not zero -- the values sf_get_field returns for those envs have wrapped,
+ * and stay wrapped: the count is STICKY until sf_reset starts new games everywhere.  Auto-resetting batches start every
+ * field over at each episode end and cannot get there.  sf_set_field refuses (SF_ERR_ARG) values that do not fit a
+ * field, and a `stats` row 3 (ship deaths) that is not the sum of rows 0-2. */
 int sf_check_state(sf_batch* b, void* stream);
 
 /* ---- state access: the 37 read-only attributes of `Game` (SRC/pymodule.cpp:372-411) in batched

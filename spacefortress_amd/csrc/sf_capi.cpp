@@ -649,6 +649,7 @@ extern "C" int sf_reset(sf_batch* b, void* obs_dev, void* stream) {
   const bool image = is_image(b);
   b->mslots_dirty = false;  // new games everywhere: no missiles, whatever a caller wrote into the slot view
   b->draw_current = false;
+  HIP_TRY(hipMemsetAsync(b->d_acc + SF_ACC_OVERFLOW, 0, sizeof(unsigned long long), (hipStream_t)stream));  // new games: nothing is wrapped
   HIP_TRY(sf_launch_reset(b->args, 0, 0, 0, image ? nullptr : obs_dev, (hipStream_t)stream));
   if (image && obs_dev) return render(b, b->obs_mode, (uint8_t*)obs_dev, 0, (hipStream_t)stream);
   return SF_OK;
@@ -798,8 +799,8 @@ extern "C" int sf_rollout_sampled(sf_batch* b, int n_steps, uint8_t* actions_out
     sf_set_error("sf_rollout_sampled: image observations are rendered one frame per sf_step; pass obs_dev = NULL");
     return SF_ERR_ARG;
   }
-  if (n_steps <= 0 || (double)n_steps * b->n_envs * 8.0 >= 4294967296.0) {
-    sf_set_error("sf_rollout_sampled: n_steps must be positive and n_steps * n_envs * 8 < 2^32 (got %d)", n_steps);
+  if (n_steps <= 0 || (double)n_steps * b->n_envs >= 4294967296.0) {  // (no action array here: the outputs' 32-bit row offsets bound it)
+    sf_set_error("sf_rollout_sampled: n_steps must be positive and n_steps * n_envs < 2^32 (got %d)", n_steps);
     return SF_ERR_ARG;
   }
   DeviceGuard guard(b->device);
@@ -818,9 +819,8 @@ extern "C" int sf_check_state(sf_batch* b, void* stream) {
   unsigned long long bad = 0;
   HIP_TRY(hipMemcpyAsync(&bad, b->d_acc + SF_ACC_OVERFLOW, sizeof(bad), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  if (bad) {
-    HIP_TRY(hipMemsetAsync(b->d_acc + SF_ACC_OVERFLOW, 0, sizeof(bad), (hipStream_t)stream));
-    sf_set_error("%llu env-ticks ran with a per-episode counter or timer beyond its packed width (a batch without "
+  if (bad) {  // sticky: the fields stay wrapped until new games start (sf_reset clears the count)
+    sf_set_error("%llu times since the last sf_reset a per-episode counter or timer left its packed width (a batch without "
                  "auto-reset stepped for several episodes without sf_reset): stats / timers of those envs have wrapped", bad);
     return SF_ERR_STATE;
   }

@@ -62,10 +62,11 @@ def test_four_episodes_without_reset_equal_the_oracle_or_raise_the_flag(sfa, ora
         if over.any():
             with pytest.raises(OverflowError):
                 env.check_state()
+            with pytest.raises(OverflowError):
+                env.check_state()  # sticky: the fields stay wrapped, every look says so (until reset(), below)
             flagged = True
         else:
             env.check_state()  # nothing outgrew its field: no flag
-        env.check_state()      # reading clears the count
         ok = np.flatnonzero(~over)
         assert ok.size > 0
         bad = compare_state(env.state_dict(), snaps[ok], lanes=ok)
@@ -75,6 +76,8 @@ def test_four_episodes_without_reset_equal_the_oracle_or_raise_the_flag(sfa, ora
         else:
             assert 0 < over.sum() < n
     assert flagged, "the test is meant to reach the 8-bit death counters"
+    env.reset()
+    env.check_state()  # new games everywhere: nothing is wrapped any more
     env.close()
 
 

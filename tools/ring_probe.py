@@ -1,5 +1,7 @@
-import sys, torch
-sys.path.insert(0, "/root/repo")
+"""The image step taken apart: render alone / with sf_step, flat output / one slot / rotating slots of the 4-frame ring, with and
+without the done flags.   python tools/ring_probe.py   (GPU box)"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spacefortress_amd import SFVecEnv, FrameStack
 n=16384; steps=500
 env = SFVecEnv(n, gametype="youturn", obs_type="image", spawn_stride=1, reuse_buffers=True)
