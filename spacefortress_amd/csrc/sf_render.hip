@@ -381,16 +381,20 @@ struct Frame {
       const int klo = __builtin_amdgcn_readfirstlane(k);
       const int last = min(cnt - base, 64) - 1;
       const int khi = __builtin_amdgcn_readlane(k, last);
+      // (every stroke of draw_strokes is white: over_un8(d, 255, m) = mul_un8(255, m) + mul_un8(d, 255 - m), and pixman's
+      //  mul_un8(255, m) is m for every m in 0 .. 255 -- asserted by tests/test_image_host.py -- so the turn of a stroke is
+      //  one multiply-round instead of two; a lane whose stroke leaves its pixel alone takes no turn)
+      const int kx = m > 0 ? k : -1, im = 255 - m;
       for (int kk = klo; kk <= khi; kk++) {
-        if (!(SF_RENDER_SKIP & 64) && k == kk && m > 0) *p = (uint8_t)sfr::over_un8(*p, 255, m);
+        if (!(SF_RENDER_SKIP & 64) && kx == kk) *p = (uint8_t)(m + sfr::mul_un8((int)*p, im));
         __builtin_amdgcn_wave_barrier();
       }
     }
   }
-  __device__ __forceinline__ void draw_strokes(const Quad& mine, bool valid, int obj0, unsigned long long* dbg = nullptr) const {
-#define SF_DS_STAMP(k) do { if (dbg) { asm volatile("" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    if ((k) == 0 || (k) == 4) dbg[k] = t_; else dbg[k] += t_ - dbg_last; dbg_last = t_; if ((k) == 1) dbg[5]++; } } while (0)
-    unsigned long long dbg_last = 0;  // (diagnostic builds: [0], [4] = entry and exit, [1..3] = clocks spent writing records / in cheap rounds / in dense rounds, [5] = chunks)
+  __device__ __forceinline__ void draw_strokes(const Quad& mine, bool valid, int obj0) const {
+// diagnostic builds (SF_RENDER_STOP 41 .. 44, tools/pmc_render_stops.sh): leave behind the set-up / the records / the cheap and dense
+    // rounds of the first chunk / everything but the resample pass -- instruction counts of the parts by difference
+#define SF_DS_STAMP(k) do { if (SF_RENDER_STOP == 41 + (k)) return; } while (0)
     const Box myb = quad_box(mine);
     const int mybw = myb.x1 - myb.x0, mybh = myb.y1 - myb.y0;
     const int myn = (valid && !myb.empty()) ? mybw * mybh : 0;
@@ -493,9 +497,8 @@ struct Frame {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      SF_DS_STAMP(2);
       flush_list(cnt);
-      SF_DS_STAMP(3);
+      SF_DS_STAMP(2);
       // (the next chunk's records overwrite these: every listed pixel has been drawn)
     }
     // ---- the 84x84 pixels that read what was drawn.  An object = the (at most four, consecutive) strokes that share
@@ -504,6 +507,7 @@ struct Frame {
     // a round of lanes each, two thirds full).  Then ONE enumeration over the destination pixels of all the objects' boxes --
     // the cheap rounds' machinery: prefix sum, starts in LDS, a lane per pixel finds its object --, everything being drawn
     // by now (a destination pixel that reads a changed source pixel lies in some object's box).
+    SF_DS_STAMP(3);
     if (RESIZE && !(SF_RENDER_SKIP & 16) && drawn) {
       const bool me = (drawn >> lane) & 1ull;
       int ux0 = me ? myb.x0 : (1 << 20), uy0 = me ? myb.y0 : (1 << 20), ux1 = me ? myb.x1 : -1, uy1 = me ? myb.y1 : -1;
@@ -569,7 +573,6 @@ struct Frame {
         __builtin_amdgcn_wave_barrier();
       }
     }
-    SF_DS_STAMP(4);
 #undef SF_DS_STAMP
   }
 };
@@ -752,6 +755,20 @@ __device__ __forceinline__ void put_bytes(uint8_t* p, uint32_t w, int n) {
       if (k < n) p[k] = (uint8_t)(w >> (8 * k));
   }
 }
+// The same for a rectangle whose rows are held a word per LANE, consecutive lanes consecutive words of a row at least four
+// bytes wide: the word that straddles the row's end (n = 1 .. 3 of its bytes belong to the row) is stored four bytes wide
+// all the same, ENDING at the row's end -- its front filled with the tail of the previous word, which the lane below holds
+// and has just written to those very bytes.  One store per lane and no branch on n, where put_bytes is a branch and up to
+// three byte stores under three more: a cached explosion is seven such words per lane, every frame of a dead ship.
+// (`lo` = the previous word of the row; n <= 0: the lane has nothing in this row.)
+__device__ __forceinline__ uint32_t lane_below(uint32_t w) {  // lane l gets lane l - 1's value (wave_shr:1; lane 0: its own)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)w, (int)w, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void put_row_word(uint8_t* p, uint32_t w, uint32_t lo, int n) {
+  const uint32_t v = n >= 4 ? w : __builtin_amdgcn_alignbyte(w, lo, (unsigned)n);  // bytes n .. 3 of lo, then 0 .. n - 1 of w
+  uint8_t* q = p + (n >= 4 ? 0 : n - 4);
+  if (n > 0) __builtin_memcpy(q, &v, 4);
+}
 
 // ---- A dead ship stays where it died for the 1000 ms of its explosion (30 frames), and the
 // explosion is the first thing drawn on the static background: its pixels -- and the 84x84 pixels
@@ -788,7 +805,10 @@ __device__ __forceinline__ XcState ship_explosion(const Frame<RESIZE>& F, unsign
     hit = (kx == x && ky == y && (fl & need) == need) || (SF_RENDER_SKIP & 1024);  // (bit 10: a miss costs what a hit does)
     st = XcState{fl, keys.x, keys.y};
   }
-  const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows;
+  // (put_row_word: rows of sixteen bytes or more, see kXcRowW -- a ship dies inside the big hexagon, 5 pixels or more from the
+  //  surface's edges: its explosion's box is never cut below 17)
+  const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows &&
+                    b.x1 - b.x0 >= 16 && o.x1 - o.x0 >= 16;
   if (hit && fits) {
     // every load first (3 + 4 dwords per lane), then the byte writes: one memory round trip instead of 25
     constexpr int kRowW = kXcRow / 4;  // 7 dwords a row
@@ -805,13 +825,13 @@ __device__ __forceinline__ XcState ship_explosion(const Frame<RESIZE>& F, unsign
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int d = lane + 64 * j, r = d / kRowW, c4 = (d - r * kRowW) * 4;
-      if (r < bh) put_bytes(F.fb + (b.y0 + r) * SF_IMG_W + b.x0 + c4, wf[j], bw - c4);
+      put_row_word(F.fb + (b.y0 + r) * SF_IMG_W + b.x0 + c4, wf[j], lane_below(wf[j]), r < bh ? bw - c4 : 0);
     }
     if (RESIZE) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int d = lane + 64 * j, r = d / kRowW, c4 = (d - r * kRowW) * 4;
-        if (r < oh) put_bytes(F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4, wo[j], ow - c4);
+        put_row_word(F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4, wo[j], lane_below(wo[j]), r < oh ? ow - c4 : 0);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -845,6 +865,10 @@ struct XcFetch {
   uint32_t wf[3], wo[4];
 };
 constexpr int kXcRowW = kXcRow / 4;  // 7 dwords a row
+// (put_row_word takes the previous word of a row from the lane below.  Lane 0's word is dword 64 j of the rectangle, column
+//  4 (64 j % 7) = 4, 8, 12 for j = 1, 2, 3: it is a full word -- never a row's cut last one -- in every row of 16 bytes or
+//  more, which is what `fits` lets through)
+static_assert((64 % kXcRowW) * 4 + 4 <= 16 && (128 % kXcRowW) * 4 + 4 <= 16 && (192 % kXcRowW) * 4 + 4 <= 16, "lane 0 of a later round");
 template <bool RESIZE>
 __device__ __forceinline__ XcFetch xc_fetch(const unsigned char* xc, int lane) {
   XcFetch f;
@@ -868,19 +892,20 @@ __device__ __forceinline__ bool xc_apply(const Frame<RESIZE>& F, const XcFetch& 
   const int lane = F.lane;
   const unsigned need = RESIZE ? 3u : 1u;
   const bool hit = (f.kx == x && f.ky == y && (f.fl & need) == need) || (SF_RENDER_SKIP & 1024);
-  const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows;
+  const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows &&
+                    b.x1 - b.x0 >= 16 && o.x1 - o.x0 >= 16;
   if (!(hit && fits)) return false;
   const int bw = b.x1 - b.x0, bh = b.y1 - b.y0, ow = o.x1 - o.x0, oh = o.y1 - o.y0;
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     const int d = lane + 64 * j, r = d / kXcRowW, c4 = (d - r * kXcRowW) * 4;
-    if (r < bh) put_bytes(F.fb + (b.y0 + r) * SF_IMG_W + b.x0 + c4, f.wf[j], bw - c4);
+    put_row_word(F.fb + (b.y0 + r) * SF_IMG_W + b.x0 + c4, f.wf[j], lane_below(f.wf[j]), r < bh ? bw - c4 : 0);
   }
   if (RESIZE) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int d = lane + 64 * j, r = d / kXcRowW, c4 = (d - r * kXcRowW) * 4;
-      if (r < oh) put_bytes(F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4, f.wo[j], ow - c4);
+      put_row_word(F.obuf + (o.y0 + r) * SF_OUT + o.x0 + c4, f.wo[j], lane_below(f.wo[j]), r < oh ? ow - c4 : 0);
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -1128,8 +1153,9 @@ __device__ __forceinline__ void hud_picture(const Frame<RESIZE>& F, unsigned cha
     wf = r < bh ? *gf : 0u;
     wo = (RESIZE && with_out && r < oh) ? *go : 0u;
   }
-  if (r < bh && c4 < bw) put_bytes(pf, wf, bw - c4);
-  if (RESIZE && with_out && r < oh && c4 < ow) put_bytes(po, wo, ow - c4);
+  // (rows of 26 .. 40 bytes, a word per lane: lane 0 holds a row's first word)
+  put_row_word(pf, wf, lane_below(wf), r < bh ? bw - c4 : 0);
+  if (RESIZE && with_out) put_row_word(po, wo, lane_below(wo), r < oh ? ow - c4 : 0);
   __builtin_amdgcn_wave_barrier();
   // (something within that reach, not on the box: the surface part of the picture still holds, the 84x84 pixels are taken
   //  from the surface as it is now)
@@ -1407,12 +1433,11 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // (the entry is keyed by where the ship died as the picture sees it: the float32 position)
   XcState xst{0u, 0, 0};
   bool explosion_done = false;
-  if (dead_ship && !(SF_RENDER_SKIP & (1 | 256))) {
-    if (xc_mine) explosion_done = xc_apply(F, xf, (double)ship_x, (double)ship_y, &xst);
-    if (SF_RENDER_STOP == 2) return;
-    // ---- ship (SRC/draw.cpp:233-237): a dead ship's explosion that was not in the cache is the first thing drawn
-    if (!explosion_done) xst = ship_explosion(F, xc_mine, (double)ship_x, (double)ship_y, true, /*skip_lookup=*/true);
-  }
+  const bool explosion = dead_ship && !(SF_RENDER_SKIP & (1 | 256));
+  if (explosion && xc_mine) explosion_done = xc_apply(F, xf, (double)ship_x, (double)ship_y, &xst);
+  if (SF_RENDER_STOP == 2) return;
+  // ---- ship (SRC/draw.cpp:233-237): a dead ship's explosion that was not in the cache is the first thing drawn
+  if (explosion && !explosion_done) xst = ship_explosion(F, xc_mine, (double)ship_x, (double)ship_y, true, /*skip_lookup=*/true);
   // ---- fortress (:238-242), destroyed: it explodes for 1000 ms where it stands: one more picture drawn once per batch, in
   // the layout of the per-env explosion cache (a trained agent destroys it every few seconds -- 30 frames each time).
   // Restored when what the ship drew stays clear of it (wider by the reach: what its 84x84 pixels read) -- the two touch no
@@ -1424,6 +1449,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // ---- the live ship, the fortress in place, the missiles (:233-247): all their strokes at once
   if (!fort_explodes_in_place) {
     F.draw_strokes(mq, dvalid, dobj);
+    if (SF_RENDER_STOP > 40) return;
   } else {  // (rare: the ship, or its explosion, next to an exploding fortress)
     F.draw_strokes(mq, dvalid && lane < 3, dobj);
     draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);

@@ -348,3 +348,12 @@ def test_fast_divmod_of_the_pixel_loops_is_exact():
         for rw in (r0, np.nextafter(r0, np.float32(0)), np.nextafter(r0, np.float32(2))):
             q = (fi * np.float32(rw)).astype(np.int64)  # float32 product, truncation
             assert np.array_equal(q, i // w), (w, rw)
+
+
+def test_white_over_is_one_multiply():
+    """sf_render.hip composites the wireframes' strokes (all white) as m + mul_un8(d, 255 - m): pixman's mul_un8(255, m) is m."""
+    mul = lambda a, b: ((a * b + 128) + ((a * b + 128) >> 8)) >> 8
+    for m in range(256):
+        assert mul(255, m) == m
+        for d in range(256):
+            assert m + mul(d, 255 - m) == mul(255, m) + mul(d, 255 - m) <= 255
