@@ -58,12 +58,10 @@
 #ifndef SF_BLOCK
 #define SF_BLOCK 256
 #endif
-#define SF_TRIG_PIECES ((SF_LDS_DOUBLES / 2 + SF_BLOCK - 1) / SF_BLOCK)
 // LDS map (doubles): [0, SF_LDS_DOUBLES) the cos/sin table; then one (hit, out) pair of 32-bit event words per lane,
 // through which the missile pool's entries tell their owner lanes what happened to them; then the observation staging
 #define SF_LDS_EV SF_LDS_DOUBLES
-#define SF_LDS_ATAB (SF_LDS_DOUBLES + SF_BLOCK) /* atan(k / 16), k = 0..16: sf_atan2_core */
-#define SF_LDS_STAGE (SF_LDS_ATAB + SF_ATAB_DOUBLES)
+/* then (sf_step_kernel: kLdsAtab, kLdsStage) behind the BLK event words: atan(k / 16), k = 0..16 (sf_atan2_core), and the staging rows */
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #ifndef SF_MROWS
 #define SF_MROWS 3 /* rows of the tile's missile pool (64 entries each) loaded up front with the lane's chunks; more live
@@ -841,8 +839,13 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 // XTRA = the launch may need what the plain VecEnv.step never does -- actions drawn in the kernel (SF_ACT_SAMPLED), the
 // played actions written out (a.act_out), the packed counters' overflow test of batches without auto-reset: three uniform
 // tests and their code, 0.07 us of a 6.5 us launch when they sit in the one kernel everybody runs (A/B, tools/ab.py)
-template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK, bool XTRA>
-__global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
+// BLK = threads per workgroup (64, 128 or 256: one to four tiles).  256 is what the metric's batch wants (65 536 envs = 256
+// workgroups, one per CU, the cos/sin table staged once per four waves); a batch of 16 384 envs is 256 waves all the same, and
+// as 64 workgroups of four it leaves three CUs in four idle while the four waves of a CU share its address unit and LDS:
+// launched as 256 workgroups of ONE wave the same step takes 7.0 instead of 8.0 us (image batch, draw records included;
+// sf_launch_step picks the smallest BLK that still fills every CU).
+template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK, bool XTRA, int BLK>
+__global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
                                                           const void* actions, int n_envs_p, int act_type,
                                                           int32_t* reward_out, uint8_t* done_out, uint8_t* info_out,
                                                           SfKernelArgs a, void* obs, int obs_vec_ok, int n_steps) {
@@ -851,9 +854,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   // SGPRs at wave launch and the state loads issue without a scalar-load round trip to the kernel-argument
   // segment first (on a firmware without the feature the compiler's compatibility preamble loads them).  The
   // three output pointers ride along: the epilogue then stores without a scalar load and its wait.
+  constexpr int kTrigPieces = (SF_LDS_DOUBLES / 2 + BLK - 1) / BLK;
+  constexpr int kLdsAtab = SF_LDS_DOUBLES + BLK, kLdsStage = kLdsAtab + SF_ATAB_DOUBLES;  // (the LDS map above, for BLK threads)
   extern __shared__ double lds[];  // [SF_LDS_DOUBLES] cos/sin table, the event words, then the obs staging rows (SF_LDS_*)
   const unsigned tid = threadIdx.x;
-  const unsigned i = blockIdx.x * SF_BLOCK + tid;  // env index: actions and outputs
+  const unsigned i = blockIdx.x * BLK + tid;  // env index: actions and outputs
   const unsigned lane = tid & 63u;
   // this wave's tile: wave-uniform by construction, made scalar for the compiler
   unsigned char* const tb = state_p + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * sfl::kTileBytes;
@@ -924,11 +929,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   const unsigned char* cb = (const unsigned char*)consts_p;
   // (threads past the end re-load and re-store the last piece: straight-line code, no exec-masked
   // branches for the compiler's wait-count insertion to be conservative about)
-  d2_t cst[SF_TRIG_PIECES];
-  unsigned cpi[SF_TRIG_PIECES];
+  d2_t cst[kTrigPieces];
+  unsigned cpi[kTrigPieces];
 #pragma unroll
-  for (int k = 0; k < SF_TRIG_PIECES; k++) {
-    cpi[k] = min(tid + k * SF_BLOCK, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
+  for (int k = 0; k < kTrigPieces; k++) {
+    cpi[k] = min(tid + k * BLK, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
     cst[k] = SF_LD(d2_t, cb, cpi[k] * 16u);
   }
   // (behind the last load of the early set: the ten rounds run while those are in flight)
@@ -965,13 +970,13 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   __builtin_amdgcn_s_waitcnt(0x0F70);
 #if SF_ABL_TRIG != 2
 #pragma unroll
-  for (int k = 0; k < SF_TRIG_PIECES; k++) reinterpret_cast<d2_t*>(lds)[cpi[k]] = cst[k];
+  for (int k = 0; k < kTrigPieces; k++) reinterpret_cast<d2_t*>(lds)[cpi[k]] = cst[k];
 #endif
   // this lane's (hit, out) event words start at zero; the missile pool's entries OR their slot bit into their
   // OWNER's words (wave-private: only lanes of this wave own entries of this tile; LDS is in order per wave)
   unsigned long long* const evw = reinterpret_cast<unsigned long long*>(lds + SF_LDS_EV) + (tid & ~63u);
   evw[lane] = 0ull;
-  reinterpret_cast<d2_t*>(lds + SF_LDS_ATAB)[atab_pi] = atab_piece;  // (every lane the same nine pieces: no branch)
+  reinterpret_cast<d2_t*>(lds + kLdsAtab)[atab_pi] = atab_piece;  // (every lane the same nine pieces: no branch)
 
   // ================= round trip 2: live shell slots, predicated by the alive mask ======
   // Slot groups (pairs): a wave ballot skips a group no lane uses.  The kernel lasts as long as its slowest wave, so
@@ -1127,7 +1132,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   if (L.fl & SF_FL_SHIP_ALIVE) {
     if (AUTOTURN) {
       // stdAngle(ceil(angleTo(ship, fortress)))  (SRC/vector.cpp:42-52)
-      double t = sf_atan2<true>(sfc::fort_y - L.sy, sfc::fort_x - L.sx, lds + SF_LDS_ATAB);
+      double t = sf_atan2<true>(sfc::fort_y - L.sy, sfc::fort_x - L.sx, lds + kLdsAtab);
       if (t < 0) t += M_PI * 2;
       double c = ceil(rad2deg(t));  // in [0, 360]
       int ia = (int)c;
@@ -1166,14 +1171,14 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
 #if SF_ABL_ATAN == 2
   double a_pos = (L.sy - sfc::fort_y) * 0.001 + (L.sx - sfc::fort_x) * 0.002;
 #else
-  double a_pos = sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x, lds + SF_LDS_ATAB);
+  double a_pos = sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x, lds + kLdsAtab);
 #endif
 #if SF_ABL_ATAN
   double a_vel = L.vy * 0.5 + L.vx;
 #elif SF_AXIS_VEL
   double a_vel = sf_atan2<false>(L.vy, L.vx);
 #else
-  double a_vel = SF_FAST_ATAN ? sf_atan2_core(L.vy, L.vx, lds + SF_LDS_ATAB) : atan2(L.vy, L.vx);
+  double a_vel = SF_FAST_ATAN ? sf_atan2_core(L.vy, L.vx, lds + kLdsAtab) : atan2(L.vy, L.vx);
 #endif
 
   // ---- updateFortress (SRC/game.cpp:194-216)
@@ -1625,7 +1630,7 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   if constexpr (SF_ABL_OBS == 1) {  // timing-only: no observation at all
   } else if constexpr (OBSK == 1) {  // the host guarantees: features, float32, n_envs % 64 == 0, aligned output (sf_launch_step)
     constexpr int DIM = AUTOTURN ? 17 : 19;
-    float* stage = reinterpret_cast<float*>(lds + SF_LDS_STAGE);
+    float* stage = reinterpret_cast<float*>(lds + kLdsStage);
     if (SF_ABL_OBS != 3) {  // SF_ABL_OBS 3 (timing-only): the stores alone, of whatever the staging rows hold
       const Extras e = compute_extras(a, L, a_pos, a_vel);
       write_features_f32<DIM>(stage + tid * DIM, L, e, a.real_shell_count);
@@ -1635,12 +1640,12 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
   } else if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid
     const Extras e = compute_extras(a, L, a_pos, a_vel);
     if (a.obs_f64) {
-      double* stage = lds + SF_LDS_STAGE;
+      double* stage = lds + kLdsStage;
       write_obs<double>(a, stage + tid * a.obs_dim, L, e);
       flush_obs_wave<double>(a, stage + (tid & ~63u) * a.obs_dim, (double*)obs + so * a.obs_dim, i & ~63u, lane,
                              obs_vec_ok);
     } else {
-      float* stage = reinterpret_cast<float*>(lds + SF_LDS_STAGE);
+      float* stage = reinterpret_cast<float*>(lds + kLdsStage);
       write_obs<float>(a, stage + tid * a.obs_dim, L, e);
       flush_obs_wave<float>(a, stage + (tid & ~63u) * a.obs_dim, (float*)obs + so * a.obs_dim, i & ~63u, lane,
                             obs_vec_ok);
@@ -1662,9 +1667,9 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_step_kernel(unsigned char* state_
     }
     const bool has_obs = obs != nullptr && a.obs_type != 3;
     if (a.obs_f64)
-      norm_partials_wave<double>(a, lds + SF_LDS_STAGE + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u, lane, my_ret, has_obs);
+      norm_partials_wave<double>(a, lds + kLdsStage + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u, lane, my_ret, has_obs);
     else
-      norm_partials_wave<float>(a, reinterpret_cast<float*>(lds + SF_LDS_STAGE) + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u,
+      norm_partials_wave<float>(a, reinterpret_cast<float*>(lds + kLdsStage) + (size_t)(tid & ~63u) * a.obs_dim, i & ~63u,
                                 lane, my_ret, has_obs);
   }
   }  // tick loop
@@ -2000,14 +2005,22 @@ hipError_t sf_launch_reset(const SfKernelArgs& a, int first, unsigned cursor0, u
 
 hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, const void* actions, int act_type, void* obs,
                           int32_t* reward, uint8_t* done, uint8_t* info, int n_steps, bool fused, hipStream_t stream) {
-  const unsigned grid = (unsigned)(a.lanes / SF_BLOCK);
+  // threads per workgroup: the smallest of 64 / 128 / 256 that still makes a workgroup per CU (256 of them) -- see sf_step_kernel
+  const int blk = fused ? SF_BLOCK : (a.lanes <= 64 * 256 ? 64 : (a.lanes <= 128 * 256 ? 128 : SF_BLOCK));
+  const unsigned grid = (unsigned)(a.lanes / blk);
   const size_t elem = a.obs_f64 ? sizeof(double) : sizeof(float);
-  const size_t lds_bytes = SF_LDS_STAGE * sizeof(double) + (size_t)SF_BLOCK * a.obs_dim * elem;
+  const size_t lds_bytes = (size_t)(SF_LDS_DOUBLES + blk + SF_ATAB_DOUBLES) * sizeof(double) + (size_t)blk * a.obs_dim * elem;
   // 16-byte obs stores need every tick's row of the output to start 16-byte aligned
   const int vec_ok = ((uintptr_t)obs & 15u) == 0 && (!fused || ((size_t)a.n_envs * a.obs_dim * elem) % 16 == 0);
-#define SF_GO1(AT, SH, FU, OK, XT)                                                                                 \
-  hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, OK, XT>), dim3(grid), dim3(SF_BLOCK), lds_bytes, stream, a.state,  \
+#define SF_GO2(AT, SH, FU, OK, XT, BL)                                                                             \
+  hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, OK, XT, BL>), dim3(grid), dim3(BL), lds_bytes, stream, a.state,    \
                      a.consts, actions, a.n_envs, act_type, reward, done, info, a, obs, vec_ok, n_steps)
+#define SF_GO1(AT, SH, FU, OK, XT)                                                                                 \
+  do {                                                                                                             \
+    if (FU || blk == SF_BLOCK) SF_GO2(AT, SH, FU, OK, XT, SF_BLOCK);                                               \
+    else if (blk == 128) SF_GO2(AT, SH, false, OK, XT, 128);                                                       \
+    else SF_GO2(AT, SH, false, OK, XT, 64);                                                                        \
+  } while (0)
 #define SF_GO(AT, SH, FU)                                                                                          \
   if (fast_obs) {                                                                                                  \
     if (xtra) SF_GO1(AT, SH, FU, 1, true); else SF_GO1(AT, SH, FU, 1, false);                                      \
@@ -2032,5 +2045,6 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
   }
 #undef SF_GO
 #undef SF_GO1
+#undef SF_GO2
   return hipGetLastError();
 }
