@@ -170,6 +170,25 @@ struct Frame {
   int lane;
   float* srec;          // LDS: kChunk stroke records of kRecFloats floats (draw_strokes)
   uint32_t* slist;      // LDS: kListCap touched (stroke, x, y) entries (draw_strokes)
+  // One PERIOD of the tap tables for resample_quad, in LDS behind the resample pass's own records (the strokes' records are
+  // dead by then): 90 / 84 = 15 / 14 and 92 / 84 = 23 / 21, so the column taps repeat every 14 destination columns -- every 28
+  // = 7 quads of four -- with the first source column moving on by 30, the row taps every 21 rows with the first source row
+  // moving on by 23 (checked entry by entry in sf_create).  kLtabEntries entries of 16 bytes: columns 0 .. 27, then rows
+  // 0 .. 20.  A lane holds its entry in registers from the prologue on (lt_e: ONE 16-byte load per lane and frame) and the
+  // wave drops the 784 bytes into LDS whenever a resample pass is about to run (fill_ltab) -- where every round of
+  // resample_quad used to pull five table entries per lane, 5 KB per round, through the vector cache: the frame kernel's L1
+  // moves 33 KB per frame, and what two more 16-byte loads per lane cost it was measured (+1.2 us per 16 384 frames).
+  uint32_t* ltab;       // or null: the tables are read where `tab` points (the picture kernels' LDS copy)
+  uint4 lt_e;
+  static constexpr int kLtabCols = 28, kLtabEntries = kLtabCols + 21;
+  __device__ __forceinline__ void fill_ltab() const {
+    if (ltab) {  // (uniform, known at compile time per kernel)
+      if (lane < kLtabEntries) reinterpret_cast<uint4*>(ltab)[lane] = lt_e;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
 
   // cv2.resize(..., INTER_AREA) restricted to the destination pixels that read source pixels of `b`
   // (OpenCV's resizeArea_ arithmetic: per source row buf = sum alpha * S, then sum += beta * buf in
@@ -180,6 +199,7 @@ struct Frame {
       return;
     }
     if (!RESIZE || (SF_RENDER_SKIP & 16) || b.empty()) return;
+    fill_ltab();
     // in groups of four pixels of a row (resample_quad): the box's columns widened to multiples of four
     const Box o = out_box(b);
     const int gx0 = o.x0 >> 2, gw = ((o.x1 + 3) >> 2) - gx0, n = gw * (o.y1 - o.y0);
@@ -238,11 +258,28 @@ struct Frame {
   // twelve 2-byte ones, one store instead of four.  A pixel beside an object's box that is swept along gets the value it has:
   // the image is the resampled surface everywhere, at all times before the score's / bar's pictures go in.
   __device__ __forceinline__ void resample_quad(int dx0, int dy) const {
-    const uint4* t4 = reinterpret_cast<const uint4*>(tab);
-    const uint4 tr = t4[(unsigned)(SF_OUT + dy)];
-    const uint4 c0 = t4[(unsigned)dx0], c1 = t4[(unsigned)dx0 + 1u], c2 = t4[(unsigned)dx0 + 2u], c3 = t4[(unsigned)dx0 + 3u];
+    uint4 tr, c0, c1, c2, c3;
+    int first = 0;  // what the period's entries leave out of the first source cell: 23 rows per 21, 30 columns per 28
+    if (ltab) {  // (uniform)
+      const uint4* lt = reinterpret_cast<const uint4*>(ltab);
+      const unsigned q = (unsigned)dx0 >> 2, qq = (q * 37u) >> 8, q7 = q - 7u * qq;  // q / 7, q % 7 for q < 21
+      const unsigned qy = ((unsigned)dy * 49u) >> 10, ry = (unsigned)dy - 21u * qy;  // dy / 21, dy % 21 for dy < 84
+      tr = lt[kLtabCols + ry];
+      c0 = lt[4u * q7];
+      c1 = lt[4u * q7 + 1u];
+      c2 = lt[4u * q7 + 2u];
+      c3 = lt[4u * q7 + 3u];
+      first = (int)(23u * qy) * SF_IMG_W + (int)(30u * qq);
+    } else {
+      const uint4* t4 = reinterpret_cast<const uint4*>(tab);
+      tr = t4[(unsigned)(SF_OUT + dy)];
+      c0 = t4[(unsigned)dx0];
+      c1 = t4[(unsigned)dx0 + 1u];
+      c2 = t4[(unsigned)dx0 + 2u];
+      c3 = t4[(unsigned)dx0 + 3u];
+    }
     const float b0 = __uint_as_float(tr.y), b1 = __uint_as_float(tr.z), b2 = __uint_as_float(tr.w);
-    const uint8_t* r0 = fb + (int)tr.x * SF_IMG_W + (int)c0.x;
+    const uint8_t* r0 = fb + first + (int)tr.x * SF_IMG_W + (int)c0.x;
     unsigned long long w0, w1, w2;
     __builtin_memcpy(&w0, r0, 8);
     __builtin_memcpy(&w1, r0 + SF_IMG_W, 8);
@@ -355,6 +392,8 @@ struct Frame {
   static constexpr int kMapBits = SF_MAPBITS;      // the map of the strokes' starts (behind the records): 12 boxes of 6 x 7
   static constexpr int kMapBitsOut = SF_MAPBITS_OUT;  // ... and of the objects' 84x84 boxes (in the records' space, behind the objects' own)
   static_assert(4 * kChunk + kMapBitsOut / 32 <= kChunk * 24, "the resample pass's records and map fit in the strokes' records");
+  static constexpr int kLtabAt = 4 * kChunk + kMapBitsOut / 32;  // words into srec: behind that pass's records and map
+  static_assert(kLtabAt + 4 * kLtabEntries <= kChunk * 24 && kLtabAt % 4 == 0, "the period of the tap tables fits behind them, 16-byte aligned");
   static constexpr int kRecFloats = 24;  // [0,12) quad x, y, slopes; [12,20) nx, ny, cn, hn, ux, uy, cu, hu; [20,23) x0 | y0 << 8, w, offset (ints); [23] 1 / w
   __device__ __forceinline__ void flush_list(int cnt) const {
     for (int base = 0; base < cnt; base += 64) {
@@ -509,6 +548,7 @@ struct Frame {
     // by now (a destination pixel that reads a changed source pixel lies in some object's box).
     SF_DS_STAMP(3);
     if (RESIZE && !(SF_RENDER_SKIP & 16) && drawn) {
+      fill_ltab();  // (behind the objects' records and map of this pass: nothing below writes there)
       const bool me = (drawn >> lane) & 1ull;
       int ux0 = me ? myb.x0 : (1 << 20), uy0 = me ? myb.y0 : (1 << 20), ux1 = me ? myb.x1 : -1, uy1 = me ? myb.y1 : -1;
       {
@@ -1198,6 +1238,12 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // for before anything is known, where round 3 selected segment constants and built the rectangle per frame
   const f4_t lsx = *reinterpret_cast<const f4_t*>(kLaneStroke[lane].x);
   const f4_t lsy = *reinterpret_cast<const f4_t*>(kLaneStroke[lane].y);
+  // ... and this lane's entry of the tap tables' period (Frame::ltab): columns 0 .. 27, then rows 0 .. 20
+  uint4 lt_e = {0u, 0u, 0u, 0u};
+  if (RESIZE) {
+    const int ti = lane < Frame<RESIZE>::kLtabCols ? lane : min(SF_OUT + lane - Frame<RESIZE>::kLtabCols, SF_OUT + 20);
+    lt_e = reinterpret_cast<const uint4*>(a.tabs)[ti];
+  }
   // ---- which env (pick_env).  Nearly every workgroup behind the front draws env = its index - n_front, and learns that
   // from one word of the hint: the record's loads go out for that env at once, next to the word's load, instead of behind it.
   int env = blockIdx.x;
@@ -1426,7 +1472,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  const Frame<RESIZE> F{fb, frame_out, tabw, nullptr, lane, srec, slist};
+  const Frame<RESIZE> F{fb, frame_out, tabw, nullptr, lane, srec, slist, reinterpret_cast<uint32_t*>(srec) + Frame<RESIZE>::kLtabAt, lt_e};
   if (SF_RENDER_STOP == 1) return;
 
   // ---- what is restored from round trip 2's registers: the dead ship's explosion if its cache entry is this one
@@ -1563,7 +1609,7 @@ __global__ __launch_bounds__(64) void sf_fort_patch_kernel(const uint32_t* bg, c
   for (int i = lane; i < kOutBytes / 4; i += 64) obufw[i] = bg84[i];
   for (int i = lane; i < SF_TAB_WORDS; i += 64) tabw[i] = tabs[i];
   __syncthreads();
-  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr};
+  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr, nullptr, uint4{0u, 0u, 0u, 0u}};
   if (sector == 36) {  // the destroyed fortress's explosion, behind the 36 headings
     ship_explosion(F, fpatch + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y);  // (a zeroed entry: draws and fills it)
     return;
@@ -1622,7 +1668,7 @@ __global__ __launch_bounds__(64) void sf_hud_kernel(const uint32_t* bg, const ui
   for (int i = lane; i < kOutBytes / 4; i += 64) obufw[i] = bg84[i];
   for (int i = lane; i < SF_TAB_WORDS; i += 64) tabw[i] = tabs[i];
   __syncthreads();
-  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr};
+  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr, nullptr, uint4{0u, 0u, 0u, 0u}};
   if (pic < 2 * SF_HUD_SCORE_HALF) {
     const int pnts = pic - SF_HUD_SCORE_HALF;
     draw_score(F, pnts);
