@@ -587,11 +587,11 @@ def main():
                      "roofline": {"bound": "hbm", "achieved": i_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": i_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": IMAGE_ALGO_BYTES,
                                   "note": "SURVEY 8(d)'s 7 448 B per env-step over the whole step (sf_step + sf_render_stack); "
-                                          "the render kernel is issue-bound, not memory-bound (DESIGN.md 10)"},
+                                          "the render kernel is issue-bound, not memory-bound (DESIGN.md 5)"},
                      "note": "BASELINE configs[4]: youturn image obs, 84x84 grey raster + 4-frame stack (device ring "
                              "[N,4,84,84], one new frame per env and step, finished envs' older slots zeroed by the same launch), "
                              "sf_step + sf_render_stack per step; one wave per env rasterises the 90x92 frame in LDS (INTER_AREA to 84x84); HIP "
-                             "events; pixel model pinned to the numpy restatement, not to cairo/cv2 (DESIGN.md 10)"}
+                             "events; pixel model pinned to the numpy restatement, not to cairo/cv2 (DESIGN.md 5)"}
         ienv.close()
     configs = None
     if solo and not args.no_configs:

@@ -16,7 +16,7 @@
 //     row at a time, every lane busy, and compacts in place with a ballot + prefix count as entries leave
 //     (per env and slot, two lanes in ten had a missile in a slot the wave had to walk anyway);
 //   * a wave's working set is one 72 KB block: page- and channel-local.
-// History: batch-wide [field][N] arrays -> a quarter of the instructions
+// History (see HISTORY.md §5): batch-wide [field][N] arrays -> a quarter of the instructions
 // were per-field 64-bit address math and SGPR spills; per-tile [field][64] rows -> 24 loads and
 // 23 stores of 1-8 bytes per lane and step; this layout -> 7 + 7.
 // The batch is padded to a multiple of 256 envs (4 tiles = one workgroup).  The reference keeps
