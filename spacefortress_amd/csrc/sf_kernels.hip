@@ -892,7 +892,19 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
   // late: a launch is a chip-wide load burst, then arithmetic with the fabric idle, then a store burst; staggered, one
   // half's bursts meet the other half's arithmetic.
   // (a batch that leaves CUs idle has no burst to split; the batch size is a preloaded kernel argument, gridDim is a load)
+#ifndef SF_STAGGER_PHASES
+#define SF_STAGGER_PHASES 2 /* A/B (tools/ab.py, round 4): 3 or 4 phases of SF_STAGGER x 64 cycles each, see NOTES.md */
+#endif
+#if SF_STAGGER_PHASES == 2
   if (n_envs_p > 65536 - 256 && ((blockIdx.x >> 3) & 1u)) __builtin_amdgcn_s_sleep(SF_STAGGER);
+#else
+  if (n_envs_p > 65536 - 256) {
+    const unsigned ph = (blockIdx.x >> 3) % SF_STAGGER_PHASES;  // uniform
+    if (ph == 1) __builtin_amdgcn_s_sleep(SF_STAGGER);
+    if (ph == 2) __builtin_amdgcn_s_sleep(2 * SF_STAGGER);
+    if (ph == 3) __builtin_amdgcn_s_sleep(3 * SF_STAGGER);
+  }
+#endif
 #endif
   // ================= round trip 1: every unconditional load =================
   // act_type SF_ACT_SAMPLED: no action array -- `actions` is this batch's sampler records (SfActRec, one per tile) and the

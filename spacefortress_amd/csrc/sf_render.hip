@@ -391,10 +391,13 @@ struct Frame {
 #endif
   static constexpr int kMapBits = SF_MAPBITS;      // the map of the strokes' starts (behind the records): 12 boxes of 6 x 7
   static constexpr int kMapBitsOut = SF_MAPBITS_OUT;  // ... and of the objects' 84x84 boxes (in the records' space, behind the objects' own)
-  static_assert(4 * kChunk + kMapBitsOut / 32 <= kChunk * 24, "the resample pass's records and map fit in the strokes' records");
+  // (LDS words of `srec`: the strokes' records and the map of their starts; the resample pass reuses the space -- its own records
+  //  and map, then one period of the tap tables)
   static constexpr int kLtabAt = 4 * kChunk + kMapBitsOut / 32;  // words into srec: behind that pass's records and map
-  static_assert(kLtabAt + 4 * kLtabEntries <= kChunk * 24 && kLtabAt % 4 == 0, "the period of the tap tables fits behind them, 16-byte aligned");
-  static constexpr int kRecFloats = 24;  // [0,12) quad x, y, slopes; [12,20) nx, ny, cn, hn, ux, uy, cu, hu; [20,23) x0 | y0 << 8, w, offset (ints); [23] 1 / w
+  static constexpr int kRecFloats = 20;  // [0,12) quad x, y, slopes; [12,16) nx, ny, cn, hn; [16,19) x0 | y0 << 8, w, offset (ints); [19] 1 / w
+  static constexpr int kStrokeWords = kChunk * kRecFloats + (kMapBits + 63) / 64 * 2, kResampleWords = kLtabAt + 4 * kLtabEntries;
+  static constexpr int kSrecWords = kStrokeWords > kResampleWords ? kStrokeWords : kResampleWords;
+  static_assert(kLtabAt % 4 == 0, "the period of the tap tables is 16-byte aligned");
   __device__ __forceinline__ void flush_list(int cnt) const {
     for (int base = 0; base < cnt; base += 64) {
       const int i = base + lane;
@@ -440,22 +443,21 @@ struct Frame {
     unsigned long long live = __ballot(myn > 0);
     const unsigned long long drawn = live;
     // the stroke's frame: edge 0 -> 1 runs along the stroke, edge 1 -> 2 across it (line_quad's vertex order)
-    float nx, ny, cn, hn, ux, uy, cu, hu;
+    // (the cheap rounds test the ACROSS axis only: a stroke's bounding box already cuts the strip |n . (c - m)| <= hn down to the
+    //  stroke but for a sliver at its two ends -- a pixel or two per stroke that get coverage 0 in the dense round --, and the
+    //  along-axis test cost more than that: a reciprocal square root, a reciprocal and a dozen instructions per stroke, five per
+    //  box pixel, four words per record: 50.5 -> 49.7 us per image step)
+    float nx, ny, cn, hn;
     {
-      const float ex = mine.x[1] - mine.x[0], ey = mine.y[1] - mine.y[0];
       const float fx = mine.x[2] - mine.x[1], fy = mine.y[2] - mine.y[1];
       // (v_rsq / v_rcp: an ulp or two, far inside the margin below; the IEEE forms are ten instructions each)
-      const float ie = __builtin_amdgcn_rsqf(ex * ex + ey * ey), jf = __builtin_amdgcn_rsqf(fx * fx + fy * fy);
-      const float le = __builtin_amdgcn_rcpf(ie), lf = __builtin_amdgcn_rcpf(jf);
-      ux = ex * ie; uy = ey * ie;
+      const float jf = __builtin_amdgcn_rsqf(fx * fx + fy * fy), lf = __builtin_amdgcn_rcpf(jf);
       nx = fx * jf; ny = fy * jf;
       const float mx = 0.25f * ((mine.x[0] + mine.x[1]) + (mine.x[2] + mine.x[3]));
       const float my = 0.25f * ((mine.y[0] + mine.y[1]) + (mine.y[2] + mine.y[3]));
-      // |u . (c - m)| <= len / 2 + the pixel square's half extent along u (and likewise across); c = pixel centre.  The
-      // margin makes float rounding err on the side of keeping a pixel: a kept pixel outside the stroke gets coverage 0.
-      cu = -(ux * mx + uy * my);
+      // |n . (c - m)| <= width / 2 + the pixel square's half extent along n; c = pixel centre.  The margin makes float
+      // rounding err on the side of keeping a pixel: a kept pixel outside the stroke gets coverage 0.
       cn = -(nx * mx + ny * my);
-      hu = 0.5f * le + 0.5f * (fabsf(ux) + fabsf(uy)) + 1e-3f;
       hn = 0.5f * lf + 0.5f * (fabsf(nx) + fabsf(ny)) + 1e-3f;
     }
     SF_DS_STAMP(0);
@@ -490,10 +492,9 @@ struct Frame {
           g[8 + v] = ms.s[v];
         }
         g[12] = nx; g[13] = ny; g[14] = cn; g[15] = hn;
-        g[16] = ux; g[17] = uy; g[18] = cu; g[19] = hu;
-        int* gi = reinterpret_cast<int*>(g + 20);
+        int* gi = reinterpret_cast<int*>(g + 16);
         gi[0] = myb.x0 | (myb.y0 << 8); gi[1] = mybw; gi[2] = myoff;
-        g[23] = recip_i(mybw);  // (per stroke, not per box pixel: a quarter-rate instruction)
+        g[19] = recip_i(mybw);  // (per stroke, not per box pixel: a quarter-rate instruction)
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -510,12 +511,12 @@ struct Frame {
         kb += __popc(mw.x) + __popc(mw.y);
         if (i < total) {
           const float* g = srec + k * kRecFloats;
-          const int* gi = reinterpret_cast<const int*>(g + 20);
+          const int* gi = reinterpret_cast<const int*>(g + 16);
           const int x0 = gi[0] & 255, y0 = gi[0] >> 8, w = gi[1], j = i - gi[2];
-          const DivMod dm = fast_divmod(j, w, g[23]);
+          const DivMod dm = fast_divmod(j, w, g[19]);
           const int px = x0 + dm.r, py = y0 + dm.q;
           const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
-          touched = (fabsf(g[12] * cx + g[13] * cy + g[14]) <= g[15]) & (fabsf(g[16] * cx + g[17] * cy + g[18]) <= g[19]);
+          touched = fabsf(g[12] * cx + g[13] * cy + g[14]) <= g[15];
           ent = ((uint32_t)k << 16) | ((uint32_t)py << 8) | (uint32_t)px;
         }
         const unsigned long long tb = __ballot(touched);
@@ -1228,7 +1229,7 @@ template <bool RESIZE>
 __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
   const uint32_t* const tabw = a.tabs;  // 2.7 KB read by every wave: L1/L2 resident; LDS is better spent on waves
-  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kChunk * Frame<RESIZE>::kRecFloats + (Frame<RESIZE>::kMapBits + 63) / 64 * 2];  // records, then the map of the strokes' starts
+  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kSrecWords];  // records, then the map of the strokes' starts (Frame::kSrecWords)
   __shared__ __attribute__((aligned(16))) uint32_t slist[Frame<RESIZE>::kListCap];
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int lane = threadIdx.x;
