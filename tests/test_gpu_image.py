@@ -627,3 +627,57 @@ def test_frames_in_another_geometry_vs_model(sfa, oracle_mod, scale, viewport, l
     with pytest.raises(ValueError):
         e2.render("rgb_array")
     e2.close()
+
+
+def test_frames_after_every_way_of_stepping(sfa):
+    """The draw records the frame kernel reads are left by the step launch that produced the state -- whichever entry point that
+    was: one step, a fused rollout (the LAST tick's records), sampled actions, the trainer's recorded step, a state edited
+    through set_field, a reset.  After each, the frame of an image batch equals the frame of a twin batch that was stepped
+    one tick at a time with the same actions, and the records equal records rebuilt from the state."""
+    N = 320
+    rng = np.random.default_rng(12)
+    a = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=1)
+    b = sfa.SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=1)
+    acts = torch.from_numpy(rng.integers(0, 5, (400, N)).astype(np.uint8)).to(a.device)
+
+    def same(what):
+        fa, fb = a.render("image"), b.render("image")
+        assert torch.equal(fa, fb), what
+        ra = a.draw_records(False)
+        assert np.array_equal(_live_record_bytes(ra), _live_record_bytes(a.draw_records(True))), what
+        assert torch.equal(a.render("image-raw"), b.render("image-raw")), what
+
+    t = 0
+    for _ in range(150):  # into mid-game states
+        a.step_tensors(acts[t]); b.step_tensors(acts[t]); t += 1
+    same("single steps")
+    a.rollout(acts[t:t + 37], want_obs=False)  # fused: 37 ticks in one launch
+    for k in range(37):
+        b.step_tensors(acts[t + k])
+    t += 37
+    same("fused rollout")
+    a.seed_actions(5); b.seed_actions(5)
+    played = torch.empty(N, dtype=torch.uint8, device=a.device)
+    for _ in range(9):
+        a.step_sampled(actions_out=played)
+        b.step_sampled()
+    same("sampled steps")
+    _, _, _, _, pa = a.rollout_sampled(11, want_obs=False)
+    for k in range(11):
+        b.step_tensors(pa[k])
+    b.seed_actions(5)  # (keep the two samplers in step: b did not draw those 11 ticks)
+    a.seed_actions(5)
+    same("fused sampled rollout")
+    # an edited state: the records are rebuilt from the state by the next frame
+    for e in (a, b):
+        x = e.get_field("ship_x")
+        x[::7] += 3.25
+        e.set_field("ship_x", x)
+    same("set_field")
+    a.step_tensors(acts[t]); b.step_tensors(acts[t]); t += 1
+    same("a step after set_field")
+    ra, rb = a.reset(), b.reset()
+    assert torch.equal(ra, rb)
+    same("reset")
+    a.close()
+    b.close()
