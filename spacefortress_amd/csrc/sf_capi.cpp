@@ -474,7 +474,7 @@ extern "C" int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, dou
                  w, h, scale, vp_w, vp_h, SF_OUT, 3 * SF_OUT - 1);
     return SF_ERR_ARG;
   }
-  std::vector<uint8_t> bg((size_t)w * h);
+  std::vector<uint8_t> bg(((size_t)w * h + 15) & ~(size_t)15, 0);  // (whole 16-byte pieces: the kernel copies it that way)
   int rc = sf_image_background_geom(scale, vp_x, vp_y, w, h, line_width, bg.data());
   if (rc != SF_OK) return rc;
   std::vector<uint32_t> tabs(16 * SF_OUT, 0u);

@@ -7,9 +7,14 @@
 // dynamic LDS, every stroke of the reference's draw order (SRC/draw.cpp:227-254,266-268) composited in place one after the
 // other with the same coverage model (sf_cover.h) and 8-bit OVER arithmetic (sf_raster.h), no caches, no shortcuts; then
 // cv2.resize(.., (84, 84), INTER_AREA) with per-batch tap tables for W, H < 3 * 84 (OpenCV's resizeArea_ arithmetic,
-// sf_image.cpp).  It reads the state, not the draw records.  A few hundred microseconds per 16 384 frames, not fifty:
-// correctness in every geometry, speed in the one the benchmark names.  tests/test_gpu_image.py compares it with
-// oracle/render_np.py parametrised the same way.
+// sf_image.cpp).  It reads the state, not the draw records.  Phases: all four waves copy the background in (16-byte pieces);
+// wave 0 alone composites the strokes, one after the other, wave-synchronously (no workgroup barrier per stroke) and the
+// score's glyphs with a lane per pixel of their box; all four waves resample, four pixels and one 32-bit store per thread.
+// Measured (tools/geometry_probe.py, 16 384 envs, 125 x 130 surface): 0.96 ms per launch for the raw frame, 1.24 ms with the
+// 84x84 image -- 14.8 k vector instructions per frame (tools/pmc_generic.sh) against 0.95 k in the default geometry's kernel,
+// most of them the 85 strokes of a dead ship's explosion drawn afresh in every frame of its 30 (no cache here).  Correctness
+// in every geometry; speed in the one the benchmark names.  tests/test_gpu_image.py compares it with oracle/render_np.py
+// parametrised the same way.
 #include <hip/hip_runtime.h>
 
 #include "sf_cover.h"
@@ -41,7 +46,7 @@ struct Ctx {
   __device__ __forceinline__ float dx(float x) const { return (x - vx) * sc; }
   __device__ __forceinline__ float dy(float y) const { return (y - vy) * sc; }
 
-  // one stroke, composited OVER the surface by the whole workgroup (a thread per pixel of its bounding box)
+  // one stroke, composited OVER the surface by wave 0 (a lane per pixel of its bounding box)
   __device__ void stroke(const Quad& q, int grey) const {
     const float fx0 = fminf(fminf(q.x[0], q.x[1]), fminf(q.x[2], q.x[3])), fx1 = fmaxf(fmaxf(q.x[0], q.x[1]), fmaxf(q.x[2], q.x[3]));
     const float fy0 = fminf(fminf(q.y[0], q.y[1]), fminf(q.y[2], q.y[3])), fy1 = fmaxf(fmaxf(q.y[0], q.y[1]), fmaxf(q.y[2], q.y[3]));
@@ -50,7 +55,7 @@ struct Ctx {
       const int x1 = (int)ceilf(fminf(fx1, (float)W)), y1 = (int)ceilf(fminf(fy1, (float)H));
       const int bw = x1 - x0, n = bw * (y1 - y0);
       const Slopes sl = quad_slopes(q);
-      for (int i = tid; i < n; i += kThreads) {
+      for (int i = tid; i < n; i += 64) {
         const int ry = i / bw, px = x0 + (i - ry * bw), py = y0 + ry;
         const int m = cover_to_mask(quad_cover(q, sl, (float)px, (float)py));
         if (m > 0) {
@@ -59,7 +64,13 @@ struct Ctx {
         }
       }
     }
-    __syncthreads();
+    order();
+  }
+  // the strokes are composited by ONE wave (tid = its lane): LDS is in order per wave, the fences pin the compiler
+  __device__ __forceinline__ static void order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   // a wireframe segment (ax, ay) - (bx, by) under translate(pos) rotate(angle): a rectangle, butt caps
   __device__ void line(float ax, float ay, float bx, float by, float ca, float sa, float px, float py, int grey) const {
@@ -109,7 +120,7 @@ struct Ctx {
     const int x0 = max((int)floorf(gx - ro), 0), y0 = max((int)floorf(gy - ro), 0);
     const int x1 = min((int)ceilf(gx + ro), W), y1 = min((int)ceilf(gy + ro), H);
     const int bw = x1 - x0, n = bw > 0 && y1 > y0 ? bw * (y1 - y0) : 0;
-    for (int i = tid; i < n; i += kThreads) {
+    for (int i = tid; i < n; i += 64) {
       const int ry = i / bw, px = x0 + (i - ry * bw), py = y0 + ry;
       const float area = gon(gx, gy, ro, (float)px, (float)py) - (ri > 0.f ? gon(gx, gy, ri, (float)px, (float)py) : 0.f);
       const int m = cover_to_mask(fmaxf(area, 0.f));
@@ -118,7 +129,43 @@ struct Ctx {
         *p = (uint8_t)sfr::over_un8(*p, 191, m);
       }
     }
-    __syncthreads();
+    order();
+  }
+  // the score (drawScore, SRC/draw.cpp:190-203): "%07d", grey .5, seven-segment glyphs (sf_raster.h) -- a lane per pixel of the
+  // text's box composites the segments that touch it in the strokes' order (cell by cell, A..G): what one stroke after the
+  // other gives, without 42 strokes.  A segment is an axis-aligned rectangle: its coverage of a pixel is the overlap's area.
+  __device__ void score(int pnts) const {
+    const unsigned long long masks = sfr::score_masks(pnts);
+    const float Wg = SF_TXT_W, Hg = SF_TXT_H, T = SF_TXT_T, m0 = 0.5f * (SF_TXT_H - SF_TXT_T), m1 = 0.5f * (SF_TXT_H + SF_TXT_T);
+    const float sx0[7] = {0, Wg - T, Wg - T, 0, 0, 0, 0}, sx1[7] = {Wg, Wg, Wg, Wg, T, T, Wg};
+    const float sy0[7] = {0, T, m1, Hg - T, m1, T, m0}, sy1[7] = {T, m0, Hg - T, Hg, Hg - T, m0, m1};
+    const float tx0 = dx(SF_TXT_X0 + SF_TXT_PAD), tx1 = dx(SF_TXT_X0 + 6.f * SF_TXT_ADV + SF_TXT_PAD + SF_TXT_W);
+    const float ty0 = dy(SF_TXT_TOP), ty1 = dy(SF_TXT_TOP + SF_TXT_H);
+    const int bx0 = max((int)floorf(tx0), 0), by0 = max((int)floorf(ty0), 0), bx1 = min((int)ceilf(tx1), W), by1 = min((int)ceilf(ty1), H);
+    const int bw = bx1 - bx0, n = bw > 0 && by1 > by0 ? bw * (by1 - by0) : 0;
+    for (int i = tid; i < n; i += 64) {
+      const int ry = i / bw, px = bx0 + (i - ry * bw), py = by0 + ry;
+      const float fpx = (float)px, fpy = (float)py;
+      uint8_t* p = fb + py * W + px;
+      int d = *p;
+      for (int cell = 0; cell < 7; cell++) {
+        const float gx = SF_TXT_X0 + SF_TXT_ADV * (float)cell + SF_TXT_PAD, gy = SF_TXT_TOP;
+        if (dx(gx + Wg) <= fpx || dx(gx) >= fpx + 1.f) continue;
+        const unsigned bits = (unsigned)(masks >> (7 * cell)) & 0x7Fu;
+#pragma unroll
+        for (int seg = 0; seg < 7; seg++) {
+          if (!((bits >> seg) & 1u)) continue;
+          const float ox = fminf(dx(gx + sx1[seg]), fpx + 1.f) - fmaxf(dx(gx + sx0[seg]), fpx);
+          const float oy = fminf(dy(gy + sy1[seg]), fpy + 1.f) - fmaxf(dy(gy + sy0[seg]), fpy);
+          if (ox > 0.f && oy > 0.f) {
+            const int m = cover_to_mask(ox * oy);
+            if (m > 0) d = sfr::over_un8(d, 128, m);
+          }
+        }
+      }
+      *p = (uint8_t)d;
+    }
+    order();
   }
   // area of the regular 12-gon (centre (gx, gy), circumradius r, device pixels) inside the pixel at (px, py)
   __device__ static float gon(float gx, float gy, float r, float px, float py) {
@@ -171,7 +218,21 @@ __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericAr
   const unsigned mmask = (unsigned)mi.z & SF_MASK_LOW, smask = (unsigned)mi.w & SF_MASK_LOW, n_pool = (unsigned)mi.z >> SF_MPOOL_SHIFT;
   const int pnts = (int)__int_as_float(sc.x), vlner = sc.z & 0xFFF;
   // the background: both hexagons stroked on black (SRC/draw.cpp:230-231,262-263)
-  for (int i = tid; i < W * H; i += kThreads) g_fb[i] = a.bg[i];
+  // (16 bytes per thread and piece, four pieces in flight: left byte by byte, every iteration waits out its own L2 round
+  //  trip -- 64 of them, a hundred microseconds per frame.  The host pads the background to whole pieces.)
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.bg);
+    uint4* dst = reinterpret_cast<uint4*>(g_fb);
+    const int n16 = (W * H + 15) >> 4;
+    for (int base = 0; base < n16; base += 4 * kThreads) {
+      uint4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = src[min(base + k * kThreads + tid, n16 - 1)];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (base + k * kThreads + tid < n16) dst[base + k * kThreads + tid] = v[k];
+    }
+  }
   // this env's missiles, out of the tile's pool, filed by slot (the reference draws in slot order, SRC/draw.cpp:243-247)
   for (unsigned e = tid; e < n_pool; e += kThreads) {
     const unsigned meta = G_LD(uint32_t, G_CHUNK(missile_meta, 0), e * 4u);
@@ -184,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericAr
     }
   }
   __syncthreads();
-  // ship (:233-237), fortress (:238-242)
+  if (tid < 64) {  // ---- wave 0 composites: ship (:233-237), fortress (:238-242)
   if (flags & SF_FL_SHIP_ALIVE) C.wireframe(kShipLines, 3, ship_angle, (float)sp.x, (float)sp.y);
   else C.explosion((float)sp.x, (float)sp.y);
   if (flags & SF_FL_FORT_ALIVE) C.wireframe(kFortLines, 4, fort_angle, (float)sfc::fort_x, (float)sfc::fort_y);
@@ -202,48 +263,65 @@ __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericAr
         C.wireframe(kShellLines, 4, (int)ang, (float)p.x, (float)p.y);
       }
     }
-  // score (drawScore, :190-203): "%07d", grey .5, seven-segment glyphs (sf_raster.h), segments in A..G order
-  {
-    const unsigned long long masks = sfr::score_masks(pnts);
-    const float Wg = SF_TXT_W, Hg = SF_TXT_H, T = SF_TXT_T, m0 = 0.5f * (SF_TXT_H - SF_TXT_T), m1 = 0.5f * (SF_TXT_H + SF_TXT_T);
-    const float sx0[7] = {0, Wg - T, Wg - T, 0, 0, 0, 0}, sx1[7] = {Wg, Wg, Wg, Wg, T, T, Wg};
-    const float sy0[7] = {0, T, m1, Hg - T, m1, T, m0}, sy1[7] = {T, m0, Hg - T, Hg, Hg - T, m0, m1};
-    for (int cell = 0; cell < 7; cell++) {
-      const unsigned bits = (unsigned)(masks >> (7 * cell)) & 0x7Fu;
-      const float gx = SF_TXT_X0 + SF_TXT_ADV * (float)cell + SF_TXT_PAD, gy = SF_TXT_TOP;
-      for (int seg = 0; seg < 7; seg++)
-        if ((bits >> seg) & 1u) C.rect(gx + sx0[seg], gy + sy0[seg], gx + sx1[seg], gy + sy1[seg], 128);
-    }
-  }
+  C.score(pnts);
   // vulnerability bar (drawVlner, :205-225,268)
   {
     const bool kill = vlner > 10 && tb.w < sfc::vuln_time;
     C.rect(255.f, 522.f, 455.f, 532.f, 84);
     if (vlner > 0) C.rect(255.f, 522.f, 255.f + 20.f * (float)(vlner > 10 ? 10 : vlner), 532.f, kill ? 255 : 168);
   }
+  }  // (wave 0)
+  __syncthreads();
   uint8_t* const frame_out = a.out + (size_t)env * a.out_stride;
   if (!a.resize) {
-    for (int i = tid; i < W * H; i += kThreads) frame_out[i] = g_fb[i];
+    // the raw frame leaves in 4-byte words at 4-byte aligned addresses (a frame of W * H bytes need not start on one: a few
+    // bytes first): byte stores are one 64-byte write per wave instruction and were half of the launch
+    const int head = (int)((0u - (unsigned)(uintptr_t)frame_out) & 3u), nw = (W * H - head) >> 2, tail = head + 4 * nw;
+    if (tid < head) frame_out[tid] = g_fb[tid];
+    for (int j = tid; j < nw; j += kThreads) {
+      uint32_t v;
+      __builtin_memcpy(&v, g_fb + head + 4 * j, 4);
+      *reinterpret_cast<uint32_t*>(frame_out + head + 4 * j) = v;
+    }
+    if (tail + tid < W * H) frame_out[tail + tid] = g_fb[tail + tid];
     return;
   }
   // cv2.resize(frame, (84, 84), INTER_AREA): per source row buf = sum alpha * S in table order, sum (+)= beta * buf in table
-  // order, saturate_cast<uchar> (round half to even) -- resizeArea_<uchar, float>
-  const uint32_t* ct = a.tabs;
-  const uint32_t* rt = a.tabs + 8 * SF_OUT;
-  for (int i = tid; i < SF_OUT * SF_OUT; i += kThreads) {
-    const int oy = i / SF_OUT, ox = i - oy * SF_OUT;
-    const int cf = (int)ct[8 * ox], cc = (int)ct[8 * ox + 1], rf = (int)rt[8 * oy], rc = (int)rt[8 * oy + 1];
-    float sum = 0.f;
-    for (int k = 0; k < rc; k++) {
-      const uint8_t* S = g_fb + (rf + k) * W + cf;
-      float b = 0.f;
-      for (int j = 0; j < cc; j++) b += (float)S[j] * __uint_as_float(ct[8 * ox + 2 + j]);
-      const float beta = __uint_as_float(rt[8 * oy + 2 + k]);
-      sum = k == 0 ? beta * b : sum + beta * b;
+  // order, saturate_cast<uchar> (round half to even) -- resizeArea_<uchar, float>.  Four destination pixels of a row per
+  // thread, one aligned 32-bit store (the 84x84 frames are 16-byte aligned); the taps are loaded before the sums start.
+  const uint4* ct4 = reinterpret_cast<const uint4*>(a.tabs);
+  const uint4* rt4 = reinterpret_cast<const uint4*>(a.tabs + 8 * SF_OUT);
+  for (int i = tid; i < SF_OUT * (SF_OUT / 4); i += kThreads) {
+    const int oy = i / (SF_OUT / 4), ox0 = 4 * (i - oy * (SF_OUT / 4));
+    const uint4 ra = rt4[2 * oy], rb = rt4[2 * oy + 1];  // first, count, b0, b1 | b2, b3, -, -
+    uint4 ca[4], cb[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      ca[p] = ct4[2 * (ox0 + p)];
+      cb[p] = ct4[2 * (ox0 + p) + 1];
     }
-    int v = (int)rintf(sum);
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    frame_out[i] = (uint8_t)v;
+    const int rf = (int)ra.x, rc = (int)ra.y;
+    const float beta[4] = {__uint_as_float(ra.z), __uint_as_float(ra.w), __uint_as_float(rb.x), __uint_as_float(rb.y)};
+    unsigned word = 0u;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int cf = (int)ca[p].x, cc = (int)ca[p].y;
+      const float al[4] = {__uint_as_float(ca[p].z), __uint_as_float(ca[p].w), __uint_as_float(cb[p].x), __uint_as_float(cb[p].y)};
+      float sum = 0.f;
+      for (int k = 0; k < rc; k++) {
+        const uint8_t* S = g_fb + (rf + k) * W + cf;
+        float bsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < cc) bsum += (float)S[j] * al[j];
+        const float bk = k == 0 ? beta[0] : (k == 1 ? beta[1] : (k == 2 ? beta[2] : beta[3]));
+        sum = k == 0 ? bk * bsum : sum + bk * bsum;
+      }
+      int v = (int)rintf(sum);
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      word |= (unsigned)v << (8 * p);
+    }
+    *reinterpret_cast<uint32_t*>(frame_out + oy * SF_OUT + ox0) = word;
   }
 }
 
