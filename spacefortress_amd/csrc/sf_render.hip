@@ -5,21 +5,27 @@
 // 3 user units = 0.6 px, SRC/draw.cpp:257-270), takes the grey channel (cv2.cvtColor, an identity
 // on R=G=B) and the trainer's wrapper shrinks the frame to 84x84 with cv2.INTER_AREA.
 //
-// Here: ONE WAVEFRONT PER ENV.  The 90x92 frame lives in LDS as bytes (8.3 KB: 18 waves per CU), starts
-// as a copy of the static background (hexagons; score 0000000 / empty bar baked in when nothing can
-// reach them; ten direct-to-LDS loads), and every stroke of the reference's draw order is a convex quad (a line
-// with butt caps, an arc chord, a filled rectangle) composited OVER it with 8-bit arithmetic, like the image
-// backend does.  Quads are built one per lane.  The small objects -- ship, missiles, shells, the fortress when
-// it has to be drawn in place -- are drawn one object at a time with the lanes on all its (stroke, pixel) pairs:
-// exact area coverage from an edge integral, kept in a register, then the strokes composite one after the
-// other (draw_objects); explosions go ring by ring, twelve arcs at once.  Whatever is a function of little is
-// drawn once and copied afterwards: a dead ship's explosion (per env, keyed by where the ship died; with the
-// score / bar box under it), and once per batch the live fortress at its 36 headings, the destroyed fortress's
-// explosion, 1 024 scores and the bar's 12 states.  The 84x84 frame is built IN PLACE in the caller's buffer in
-// HBM: it starts as the resampled background (host-made) and after every object the wave re-evaluates INTER_AREA
-// for exactly the output pixels that read the object's box (out_box) -- a frame is a few dozen changed pixels on
-// a static picture.  The frames whose ship just died (the expensive ones) are started first (pick_env).
-// Issue-bound (1.35 k vector instructions per frame), not memory-bound.
+// Here: ONE WAVEFRONT PER ENV, fed by the env's DRAW RECORD (sf_drawrec.h): what a frame decides from its env's state alone --
+// which of the 148 backgrounds it starts from, whether the cached pictures apply, where the ship's box lies relative to the
+// fortress's, the score's and the bar's -- was decided by the step kernel, where it costs a lane instead of a wave, and arrives
+// as a 32-byte header through scalar loads; the objects' transforms (x, y, cos, sin) arrive one per lane.  The kernel reads the
+// state only for the shells (14 % of the frames have one).
+// The 90x92 frame lives in LDS as bytes (10 240 B per workgroup with the stroke records: 16 workgroups per CU), starts as a
+// copy of the background the record names (hexagons; score 0000000 / empty bar / the live fortress at its heading baked in;
+// ten direct-to-LDS loads), and every stroke of the reference's draw order is a convex quad (a line with butt caps, an arc
+// chord, a filled rectangle) composited OVER it with 8-bit arithmetic, like the image backend does.  Quads are built one per
+// lane from a table of the lane's corners (kLaneStroke) and the object's transform.  The small objects -- ship, missiles,
+// shells, the fortress when it has to be drawn in place -- go through draw_strokes all at once: stroke records in LDS, cheap
+// rounds (a lane per box pixel, an across-axis test) list the touched pixels, dense rounds evaluate the exact area coverage
+// (edge integrals, sf_cover.h) and composite stroke after stroke, ONE pass resamples the objects' 84x84 boxes; explosions go
+// ring by ring, twelve arcs at once.  Whatever is a function of little is drawn once and copied afterwards: a dead ship's
+// explosion (per env, keyed by where the ship died; with the score / bar box under it), and once per batch the live fortress
+// at its 36 headings (baked into backgrounds), the destroyed fortress's explosion, 1 024 scores and the bar's 12 states.  The
+// 84x84 frame is built IN PLACE in the caller's buffer in HBM: it starts as the resampled background (host-made) and the wave
+// re-evaluates INTER_AREA for exactly the output pixels that read a drawn object's box (out_box) -- a frame is a few dozen
+// changed pixels on a static picture.  The frames whose ship just died (the expensive ones) are started first (pick_env).
+// Issue-bound (1 488 instructions per frame, 949 of them vector; VALU busy 64 % of the launch), not memory-bound.
+// profiles/r04_render_versions.md has the version table; DESIGN.md section 5 the design.
 //
 // Pixel values: what is drawn where, in which order and grey follows the reference; the
 // anti-aliasing model is ours (cairo is not in this image).  Pixel parity with cairo + cv2 is
@@ -31,16 +37,16 @@
 #include "sf_internal.h"
 #include "sf_raster.h"
 
-// diagnostic builds only (tools/render_ablate.py): bit 0 ship+fortress, 1 missiles+shells, 2 score,
-// 3 bar, 4 the resampling, 5 the coverage pass of draw_objects, 6 its composite pass, 7 the live ship, 8 the dead ship's
-// explosion, 9 the fortress -- each bit removes that phase so its cost can be read off; 10 = explosion-cache misses
-// take the hit path (wrong pixels: what the first frame of an explosion costs the launch)
+// diagnostic builds only (tools/variant.py NAME -DSF_RENDER_SKIP=bits): bit 0 ship + fortress strokes, 1 missiles + shells,
+// 2 score, 3 bar, 4 the resampling, 5 the coverage of the dense rounds, 6 their compositing, 8 the dead ship's explosion,
+// 9 the fortress's explosion, 10 = explosion-cache misses take the hit path, 12 = no surface loads -- each bit removes that
+// part (wrong pixels) so that its cost can be read off
 #ifndef SF_RENDER_SKIP
 #define SF_RENDER_SKIP 0
 #endif
-// diagnostic builds only: the frame kernel returns behind phase N (1 the prologue up to the barrier, 2 the restored
-// pictures, 3 the fresh explosions, 4 the strokes of ship / fortress / missiles, 5 the shells) -- instruction counts of the
-// phases by difference (tools/pmc_render_variants.sh)
+// diagnostic builds only: the frame kernel returns behind phase N (1 the prologue up to the barrier, 2 the cached explosion,
+// 3 the fresh explosions, 41 .. 44 inside draw_strokes, 4 the strokes of ship / fortress / missiles, 5 the shells) --
+// instruction counts of the phases by difference (tools/pmc_render_stops.sh)
 #ifndef SF_RESAMPLE_QUADS
 #define SF_RESAMPLE_QUADS 1
 #endif
