@@ -681,3 +681,36 @@ def test_frames_after_every_way_of_stepping(sfa):
     same("reset")
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("gametype", ["autoturn", "youturn"])
+def test_an_image_batch_plays_the_same_game_as_a_features_batch(sfa, gametype):
+    """The step launches of an image batch run another instantiation of the step kernel than a features batch -- no
+    observation epilogue, but the draw records for the frame kernel, with projectile-near-the-HUD flags riding on the missile
+    pool's event words -- and (16 384 envs and fewer) 64-thread workgroups.  Whatever they add must not touch the game: after
+    hundreds of steps of fortress-killing play the two batches hold the same state bit for bit and have paid out the same
+    rewards."""
+    from sfscript import open_loop_actions
+
+    N, T = 4096, 700
+    rng = np.random.default_rng(31)
+    img = sfa.SFVecEnv(N, gametype=gametype, obs_type="image", spawn_stride=1)
+    fea = sfa.SFVecEnv(N, gametype=gametype, obs_type="features", spawn_stride=1)
+    acts = torch.from_numpy(open_loop_actions("hunter", (T, N), img.n_actions, rng, phase=rng.integers(0, 96, N))).to(img.device)
+    ri = torch.zeros(N, dtype=torch.int64, device=img.device)
+    rf = torch.zeros_like(ri)
+    ki = torch.zeros_like(ri)
+    for t in range(T):
+        _, r1, d1, i1 = img.step_tensors(acts[t])
+        _, r2, d2, i2 = fea.step_tensors(acts[t])
+        ri += r1
+        rf += r2
+        ki += i1
+        if t % 97 == 0:
+            assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(i1, i2), t
+    assert torch.equal(ri, rf) and int(ki.sum()) > (200 if gametype == "autoturn" else 0)
+    a, b = img.state_dict(), fea.state_dict()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    img.close()
+    fea.close()
