@@ -38,9 +38,10 @@
 //    through buffer instructions on a per-wave descriptor (constant part of the address in the
 //    scalar offset, idle lanes out of range instead of branched around), what is written once
 //    per projectile is one store with the slot in the lane offset;
-//  * the nine rare statistics counters are never loaded: events add to them with no-return
-//    atomics (executed at the memory side); the four key-press counters ride in a chunk the
-//    lane loads and stores anyway;
+//  * the per-episode statistics ride in spare bits of words the lane loads and stores anyway (sf_layout.h: SF_W_*): no
+//    counter rows, no atomics on the tick; only an episode's END adds its totals to the batch's accumulators with atomics
+//    (once per env and 5 295 ticks);
+//  * image batches: the tick also leaves the env's draw record for the frame kernel (sf_drawrec.h);
 //  * observations are transposed through LDS and leave as 16-byte coalesced stores; every 16-byte
 //    store is write-through (sc1), so the end-of-kernel write-back has little left to flush;
 //  * no dense contraction anywhere on this path: no MFMA.  The bound is HBM traffic.
