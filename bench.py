@@ -398,27 +398,35 @@ def main():
 
     def timed_blocks(graph_, launch, reps):
         """reps timed blocks of EXACTLY K launches, barrier + synchronize on both sides, nothing else inside; returns
-        (block seconds -- max over ranks --, this rank's own block seconds, launch periods from HIP events)."""
-        blocks, own, periods = [], [], []
+        (block seconds -- max over ranks --, this rank's own block seconds, launch periods from HIP events, which blocks
+        carried the events).  Every OTHER block (the odd ones; the only one, if there is one) carries a pair of HIP events
+        around its launches: they measure the launch period on the GPU's clock for `roofline`, and they cost the block 7 us
+        of its own (two barrier packets on the stream and their completion: tools/block_probe.py, 155.5 against 148.0 us at
+        K = 20) -- so `value` comes from the blocks WITHOUT them, which hold the K launches between the brackets and nothing
+        else, and the event blocks' own median is reported beside it (block_ms.with_events_median)."""
+        blocks, own, periods, with_ev = [], [], [], []
         for rep in range(reps):
+            evs = reps == 1 or rep % 2 == 1
             barrier()
             t0 = time.perf_counter()
             if graph_ is not None:
-                ev0.record()  # HIP events around the replay: K launch periods + the graph's own launch latency
+                if evs:
+                    ev0.record()  # HIP events around the replay: K launch periods + the graph's own launch latency
                 graph_.replay()
-                ev1.record()
+                if evs:
+                    ev1.record()
             else:
                 launch(0)
                 # HIP events on the launch stream: the first one BEHIND the first launch (it completes when that kernel
                 # does), the second behind the last, so that K - 1 launch periods are measured on the GPU's clock and the
                 # host's latency in front of an idle GPU is not counted as kernel time (the wall clock counts everything)
-                ev0.record()
+                if evs:
+                    ev0.record()
                 for t in range(1, K):
                     launch(t)
-                ev1.record()
-            while not ev1.query():  # busy-wait for the last launch (a sleeping wait adds its wake-up time to a 160 us block) ...
-                pass
-            sync()                  # ... then the contract's synchronize: this rank's K launches are done, its clock stops
+                if evs:
+                    ev1.record()
+            sync()  # the contract's synchronize: this rank's K launches are done, its clock stops
             elapsed = time.perf_counter() - t0
             own.append(elapsed)
             if dist is not None:
@@ -430,35 +438,44 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 elapsed = float(tt.item())
             blocks.append(elapsed)
-            periods.append(ev0.elapsed_time(ev1) / (K if graph_ is not None else max(1, K - 1)))
-        return blocks, own, periods
+            with_ev.append(evs)
+            if evs:
+                periods.append(ev0.elapsed_time(ev1) / (K if graph_ is not None else max(1, K - 1)))
+        return blocks, own, periods, with_ev
+
+    def pick(blocks, with_ev):
+        """(index of the median block among those without events -- all of them if every block carried events --, sorted indices)"""
+        idx = [r for r in range(len(blocks)) if not with_ev[r]] or list(range(len(blocks)))
+        idx.sort(key=lambda r: blocks[r])
+        return idx[len(idx) // 2], idx
 
     tpos = [args.warmup]
 
     def launch_ring(t):
         step(act_rows[(tpos[0] + t) % ring])
 
-    blocks, own_blocks, periods = timed_blocks(graph, launch_ring, repeats)
+    blocks, own_blocks, periods, with_ev = timed_blocks(graph, launch_ring, repeats)
     tpos[0] += K * repeats
-    order = sorted(range(repeats), key=lambda r: blocks[r])
-    med = order[repeats // 2]
+    med, order = pick(blocks, with_ev)
     elapsed = blocks[med]
-    # mean launch-to-launch time of sf_step_kernel over the median block (HIP events, end of the first launch to end
-    # of the last): the launches are back to back on one stream, so this is the kernel duration plus the
+    ev_blocks = sorted(blocks[r] for r in range(repeats) if with_ev[r])
+    # mean launch-to-launch time of sf_step_kernel over the blocks that carried the HIP events (their median; end of the first
+    # launch to end of the last): the launches are back to back on one stream, so this is the kernel duration plus the
     # dependent-launch gap -- a launch PERIOD
-    region_ms = periods[med]
+    region_ms = sorted(periods)[len(periods) // 2]
 
     # ---- the same blocks with the actions drawn inside the launch (sf_step_sampled)
     s_reps = 1 if args.timed_only else repeats
-    s_blocks, _, s_periods = timed_blocks(graph_sampled, lambda t: step_sampled(), s_reps)
-    s_med = sorted(range(s_reps), key=lambda r: s_blocks[r])[s_reps // 2]
+    s_blocks, _, s_periods, s_ev = timed_blocks(graph_sampled, lambda t: step_sampled(), s_reps)
+    s_med, _ = pick(s_blocks, s_ev)
+    s_period = sorted(s_periods)[len(s_periods) // 2]
     # ---- ... and, when the blocks above were HIP graphs, a few blocks issued one by one from Python: the per-call host path
     loop_issue = None
     if graph is not None and not args.timed_only:
-        l_blocks, _, l_periods = timed_blocks(None, launch_ring, max(3, repeats // 8))
-        l_med = sorted(range(len(l_blocks)), key=lambda r: l_blocks[r])[len(l_blocks) // 2]
+        l_blocks, _, l_periods, l_ev = timed_blocks(None, launch_ring, max(4, repeats // 8))
+        l_med, _ = pick(l_blocks, l_ev)
         loop_issue = {"value": float(n) * K * world / l_blocks[l_med], "ms_per_step": l_blocks[l_med] / K * 1e3,
-                      "launch_period_ms": l_periods[l_med], "blocks": len(l_blocks),
+                      "launch_period_ms": sorted(l_periods)[len(l_periods) // 2], "blocks": len(l_blocks),
                       "note": "the same K-launch blocks issued one by one from Python (one env.step_tensors call per launch) "
                               "instead of one graph replay: what a caller's per-step loop pays at this block length"}
 
@@ -492,7 +509,7 @@ def main():
 
     # ---- who ran: one all-gather of (rank, device, PCI bus id, this rank's own median block)
     mine = dict(device_identity(torch, local_rank), rank=rank, lanes=[lane0, lane1],
-                block_ms_median=sorted(own_blocks)[len(own_blocks) // 2] * 1e3, launch_period_steady_ms=steady_ms)
+                block_ms_median=sorted(own_blocks[r] for r in order)[len(order) // 2] * 1e3, launch_period_steady_ms=steady_ms)
     ranks = gather_ranks(mine)
     # an N-GPU line is evidence of N GPUs: every rank on a device of its own, or the job fails (two ranks on one device would
     # still print a line -- at half the speed, or worse, looking like a scaling problem)
@@ -713,12 +730,17 @@ def main():
             "launch": "hip_graph (K sf_step launches captured once, one replay per block)" if use_graph else "loop (one Python call per launch)",
             "loop_issue": loop_issue,
             "block_ms": {"median": elapsed * 1e3, "min": blocks[order[0]] * 1e3, "max": blocks[order[-1]] * 1e3,
-                         "first": blocks[0] * 1e3,
+                         "first": blocks[0] * 1e3, "blocks_without_events": len(order),
+                         "with_events_median": ev_blocks[len(ev_blocks) // 2] * 1e3 if ev_blocks else None,
+                         "blocks_with_events": len(ev_blocks),
                          "note": "each block = exactly `steps` launches between barrier + synchronize brackets (max over "
-                                 "ranks); value and ms_per_step come from the median block"},
+                                 "ranks).  Every other block also carries the pair of HIP events that measures "
+                                 "roofline.launch_period_ms; the two event packets cost such a block about 7 us of its own "
+                                 "(tools/block_probe.py), so value and ms_per_step come from the median of the blocks WITHOUT "
+                                 "them, and the event blocks' median stands beside it"},
             "value_with_action_gen": total_steps / s_blocks[s_med],
             "action_gen": {"value": total_steps / s_blocks[s_med], "unit": "env-steps/s", "ms_per_step": s_blocks[s_med] / K * 1e3,
-                           "launch_period_ms": s_periods[s_med],
+                           "launch_period_ms": s_period,
                            "note": "the same timed blocks through sf_step_sampled: every lane draws its action inside the "
                                    "launch (Philox4x32-10 keyed by seed, counter (lane of the job, tick); the tick counter "
                                    "lives on the device, so every graph replay plays new actions); no action tensor is "
