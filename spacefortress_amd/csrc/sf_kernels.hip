@@ -65,6 +65,9 @@
 /* then (sf_step_kernel: kLdsAtab, kLdsStage) behind the BLK event words: atan(k / 16), k = 0..16 (sf_atan2_core), and the staging rows */
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #ifndef SF_MROWS
+#ifndef SF_SPLIT
+#define SF_SPLIT 0 /* 1: batches of 65 536 envs and more step by split launches (sf_step_kernel, BLKP = 512) */
+#endif
 #define SF_MROWS 3 /* rows of the tile's missile pool (64 entries each) loaded up front with the lane's chunks; more live
                       missiles than that (> 192 in 64 envs; random play averages 104) take the dependent-load loop */
 #endif
@@ -186,6 +189,28 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 typedef int i2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+
+// A 128-bit buffer store with the wait state its data registers need ATTACHED.  A store of more than 64 bits reads its data
+// VGPRs over several cycles, and a VALU write of one of them in the next issue slot changes what lanes 12-15 of every 16
+// store.  The compiler inserts the s_nop for global / flat stores and for buffer stores with an immediate soffset, but takes a
+// buffer store whose soffset is an SGPR to be safe (LLVM GCNHazardRecognizer::createsVALUHazard).  On MI355X that holds
+// while the wave is alone on its SIMD -- every batch up to 65 536 envs, every test of rounds 1-3 -- and does not with two or
+// more: a batch of 262 144 envs played different games than the same envs in four batches, in exactly those lanes (round 4;
+// tests/test_gpu_parity.py::test_batches_beyond_one_wave_per_simd).  So the store goes out as inline assembly with its s_nop
+// (the compiler cannot place anything in between), like sf_store's global one; tools/store_hazard_scan.py checks a build's
+// assembly for wide buffer stores the compiler emitted bare.  AUX as the builtin's: 0 plain, 16 write-through (sc1).
+template <int AUX>
+__device__ __forceinline__ void sf_buf_st128(u4_t v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  static_assert(AUX == 0 || AUX == 16 || AUX == 1 || AUX == 17, "cache bits of the store");
+  if constexpr (AUX == 16)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  else if constexpr (AUX == 1)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  else if constexpr (AUX == 17)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  else
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
 
 namespace {
 
@@ -504,7 +529,7 @@ __device__ __forceinline__ void unpack_lane_late(const LaneLate& t, Lane& L) {
 __device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const Off& o, const Lane& L) {
   constexpr int aux = SF_STORE_MODE == 2 ? SF_SC_AUX : 0;
 #define SF_BST16(group, v) \
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, o.o16, SF_GOFF(group, 0), aux)
+  sf_buf_st128<aux>(__builtin_bit_cast(u4_t, v), rs, o.o16, SF_GOFF(group, 0))
   SF_BST16(ship_pos, (d2_t{L.sx, L.sy}));
   SF_BST16(ship_vel, (d2_t{L.vx, L.vy}));
   // the packed words of sf_layout.h (SF_W_*): a value below, a per-episode counter above
@@ -520,10 +545,10 @@ __device__ __forceinline__ void store_lane_buf(__amdgpu_buffer_rsrc_t rs, const 
   SF_BST16(misc, (i4_t{L.death_t, (int)((L.cursor & 0xFFFFFFu) | (L.c_destroyed << 24)), (int)(L.mmask | (L.mpool << SF_MPOOL_SHIFT)),
                        (int)(L.smask | (L.ep_kills << SF_KILLS_SHIFT))}));
 #undef SF_BST16
-  __builtin_amdgcn_raw_buffer_store_b128(
+  sf_buf_st128<aux>(
       u4_t{(unsigned)(L.angle & 0xFFFF) | ((unsigned)(L.fort_angle & 0xFFFF) << 16),
            (unsigned)(L.fort_last & 0xFFFF) | ((L.fl & 0xFFFFu) << 16), L.kc0, L.kc1},
-      rs, o.o16, SF_GOFF(small, 0), aux);
+      rs, o.o16, SF_GOFF(small, 0));
 }
 
 __device__ __forceinline__ void store_lane(unsigned char* tb, const Off& o, const Lane& L) {
@@ -845,8 +870,8 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 // as 64 workgroups of four it leaves three CUs in four idle while the four waves of a CU share its address unit and LDS:
 // launched as 256 workgroups of ONE wave the same step takes 7.0 instead of 8.0 us (image batch, draw records included;
 // sf_launch_step picks the smallest BLK that still fills every CU).
-template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK, bool XTRA, int BLK>
-__global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
+template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK, bool XTRA, int BLKP>
+__global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
                                                           const void* actions, int n_envs_p, int act_type,
                                                           int32_t* reward_out, uint8_t* done_out, uint8_t* info_out,
                                                           SfKernelArgs a, void* obs, int obs_vec_ok, int n_steps) {
@@ -855,10 +880,18 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
   // SGPRs at wave launch and the state loads issue without a scalar-load round trip to the kernel-argument
   // segment first (on a firmware without the feature the compiler's compatibility preamble loads them).  The
   // three output pointers ride along: the epilogue then stores without a scalar load and its wait.
-  constexpr int kTrigPieces = (SF_LDS_DOUBLES / 2 + BLK - 1) / BLK;
-  constexpr int kLdsAtab = SF_LDS_DOUBLES + BLK, kLdsStage = kLdsAtab + SF_ATAB_DOUBLES;  // (the LDS map above, for BLK threads)
+  // BLKP = 512: a SPLIT launch -- 256 envs per workgroup and as many threads again, the tiles' MISSILE waves (below)
+  constexpr bool SPLIT = BLKP == 512;
+  constexpr int BLK = SPLIT ? 256 : BLKP;  // envs per workgroup
+  static_assert(!SPLIT || (!FUSED && OBSK == 1 && !XTRA), "the split launch exists for the plain step of the default observation");
+  constexpr int kTrigPieces = (SF_LDS_DOUBLES / 2 + BLKP - 1) / BLKP;
+  // (the LDS map above, for BLK envs; a split launch's hand-over words sit between the atan table and the staging rows:
+  //  the new missiles' (x, y) [BLK d2_t] and meta words [BLK], then four words per tile: fired, pool done | count, stores done)
+  constexpr int kLdsAtab = SF_LDS_DOUBLES + BLK, kLdsHand = kLdsAtab + SF_ATAB_DOUBLES, kLdsHandMeta = kLdsHand + 2 * BLK,
+                kLdsHandFlags = kLdsHandMeta + BLK / 2, kLdsStage = SPLIT ? kLdsHandFlags + BLK / 32 : kLdsHand;
   extern __shared__ double lds[];  // [SF_LDS_DOUBLES] cos/sin table, the event words, then the obs staging rows (SF_LDS_*)
-  const unsigned tid = threadIdx.x;
+  const unsigned tid_all = threadIdx.x;
+  const unsigned tid = SPLIT ? (tid_all & (unsigned)(BLK - 1)) : tid_all;  // the env of the workgroup this thread works for
   const unsigned i = blockIdx.x * BLK + tid;  // env index: actions and outputs
   const unsigned lane = tid & 63u;
   // this wave's tile: wave-uniform by construction, made scalar for the compiler
@@ -873,11 +906,11 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
     return __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, p ? o.o16 : SF_OOB, goff, 0));
   };
   auto pst16 = [&](unsigned goff, bool p, d2_t v) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, p ? o.o16 : SF_OOB, goff, kStAux);
+    sf_buf_st128<kStAux>(__builtin_bit_cast(u4_t, v), rs, p ? o.o16 : SF_OOB, goff);
   };
   // the same with a per-lane slot offset (`extra` = slot * row bytes)
   auto pst16_at = [&](unsigned goff, bool p, unsigned extra, d2_t v) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, p ? o.o16 + extra : SF_OOB, goff, kStAux);
+    sf_buf_st128<kStAux>(__builtin_bit_cast(u4_t, v), rs, p ? o.o16 + extra : SF_OOB, goff);
   };
 #ifdef SF_STAMPS
   unsigned long long stamp_[16] = {};
@@ -907,6 +940,90 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
   }
 #endif
 #endif
+  typedef volatile __attribute__((address_space(3))) unsigned lds_word_t;  // (named as LDS: a volatile access through a generic pointer is a flat_load)
+  lds_word_t* const hflags = (lds_word_t*)(reinterpret_cast<unsigned*>(lds + kLdsHandFlags) + 4u * (tid >> 6));  // (split launches: this tile's hand-over words)
+  if constexpr (SPLIT) {
+    // ================= the tile's MISSILE wave =================
+    // At the metric's batch a wave is alone on its SIMD and everything it does is one dependent chain; the missile pool --
+    // move, test, compact 64 entries a row, whoever owns them -- depends on the 64 games only through the missiles fired
+    // this tick, and the games depend on it only through the owners' event words.  A split launch gives every tile a
+    // second wave on the same SIMD (threads 256..511 of the workgroup: wave w + 4 works for wave w's tile) that does
+    // exactly that part under the first wave's ship / fortress / shell arithmetic.  Hand-over through LDS, both ways by a
+    // word the other side polls (a workgroup barrier would make the games wait for the pool's loads): the games' wave
+    // files its new missiles and sets `fired`; the missile wave sets `done | entries kept` behind its last event word.
+    if (tid_all >= (unsigned)BLK) {  // wave-uniform
+      // the pool's count rides in every lane's misc chunk: lane 0's word, by a scalar load
+      const unsigned n_word = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(
+          reinterpret_cast<const __attribute__((address_space(4))) void*>(
+              (unsigned long long)(tb + (unsigned)sfl::chunk_offset(SF_G_misc, 0) + 8u)));
+      const unsigned cpi0 = min(tid_all, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
+      const d2_t cst0 = SF_LD(d2_t, (const unsigned char*)consts_p, cpi0 * 16u);
+      const unsigned m_live = n_word >> SF_MPOOL_SHIFT;
+      d2_t prow[SF_MROWS];
+      unsigned pmeta[SF_MROWS];
+#pragma unroll
+      for (int r = 0; r < SF_MROWS; r++) {
+        const bool in_ = 64u * r + lane < m_live;
+        prow[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, in_ ? o.o16 : SF_OOB, SF_GOFF(missile_pos, r), 0));
+        pmeta[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_ ? o.o4 : SF_OOB, SF_GOFF(missile_meta, r), 0);
+      }
+      reinterpret_cast<d2_t*>(lds)[cpi0] = cst0;
+      if (lane < 4u) hflags[lane] = 0u;
+      __syncthreads();  // (the workgroup's one barrier: the cos/sin table is in LDS, the hand-over words are zero)
+      const double* trig = lds;
+      d2_t pcs[SF_MROWS];
+#pragma unroll
+      for (int r = 0; r < SF_MROWS; r++) pcs[r] = *reinterpret_cast<const d2_t*>(&trig[2 * SF_MM_ANGLE(pmeta[r])]);
+      double kv_speed = sfc::missile_speed, kv_fx = sfc::fort_x, kv_fy = sfc::fort_y, kv_w = sfc::width_d, kv_h = sfc::height_d,
+             kv_mr2 = sfc::missile_hit_r2;
+      asm volatile("" : "+v"(kv_speed), "+v"(kv_fx), "+v"(kv_fy), "+v"(kv_w), "+v"(kv_h), "+v"(kv_mr2));
+      unsigned wp = 0;
+      unsigned* const evw32 = reinterpret_cast<unsigned*>(lds + SF_LDS_EV) + 2u * (tid & ~63u);
+      auto m_row = [&](double x, double y, unsigned meta, d2_t cs, bool valid) __attribute__((always_inline)) {  // (as below)
+        const double nx = x + kv_speed * cs.x, ny = y + kv_speed * cs.y;
+        const double dx = nx - kv_fx, dy = ny - kv_fy;
+        const bool hit = valid & (dx * dx + dy * dy <= kv_mr2);
+        const bool gone = valid & (hit | (__builtin_fmax(__builtin_fmax(-nx, nx - kv_w), __builtin_fmax(-ny, ny - kv_h)) > 0));
+        if (__ballot(gone) != 0ull) {
+          if (gone)
+            __hip_atomic_fetch_or(evw32 + 2 * SF_MM_OWNER(meta) + (hit ? 0 : 1), 1u << SF_MM_SLOT(meta), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const bool keep = valid & !gone;
+        const unsigned long long kb = __ballot(keep);
+        const unsigned idx = wp + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u));
+        wp += (unsigned)__popcll(kb);
+        sf_buf_st128<kStAux>(__builtin_bit_cast(u4_t, (d2_t{nx, ny})), rs, keep ? idx * 16u : SF_OOB,
+                                               SF_GOFF(missile_pos, 0));
+        __builtin_amdgcn_raw_buffer_store_b32(meta, rs, keep ? idx * 4u : SF_OOB, SF_GOFF(missile_meta, 0), kStAux);
+      };
+#pragma unroll
+      for (int r = 0; r < SF_MROWS; r++)
+        if (m_live > 64u * r) m_row(prow[r].x, prow[r].y, pmeta[r], pcs[r], 64u * r + lane < m_live);
+      if (m_live > 64u * SF_MROWS) {
+#pragma unroll 1
+        for (unsigned r = SF_MROWS; 64u * r < m_live; r++) {
+          const d2_t pr = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, o.o16 + r * 1024u, SF_GOFF(missile_pos, 0), 16));
+          const unsigned pm = __builtin_amdgcn_raw_buffer_load_b32(rs, o.o4 + r * 256u, SF_GOFF(missile_meta, 0), 16);
+          m_row(pr.x, pr.y, pm, *reinterpret_cast<const d2_t*>(&trig[2 * SF_MM_ANGLE(pm)]), 64u * r + lane < m_live);
+        }
+      }
+      // the missiles fired this tick (SRC/game.cpp:237-238), one more row, lane = owner
+      unsigned fired;
+      while ((fired = (unsigned)__builtin_amdgcn_readfirstlane((int)hflags[0])) == 0u) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      if (fired == 2u) {
+        const d2_t nxy = reinterpret_cast<const d2_t*>(lds + kLdsHand)[tid];
+        const unsigned nm = reinterpret_cast<const unsigned*>(lds + kLdsHandMeta)[tid];
+        m_row(nxy.x, nxy.y, nm & 0x7FFFFFFFu, *reinterpret_cast<const d2_t*>(&trig[2 * SF_MM_ANGLE(nm)]), !(nm >> 31));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the event words are in
+      if (lane == 0u) hflags[1] = 0x80000000u | wp;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pool's rows are written (the rare purge below re-reads them)
+      if (lane == 0u) hflags[2] = 1u;
+      return;
+    }
+  }
   // ================= round trip 1: every unconditional load =================
   // act_type SF_ACT_SAMPLED: no action array -- `actions` is this batch's sampler records (SfActRec, one per tile) and the
   // lane draws its action itself: Philox4x32-10 keyed by the seed, counter (lane of the whole job, tick).  The record is
@@ -946,7 +1063,7 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
   unsigned cpi[kTrigPieces];
 #pragma unroll
   for (int k = 0; k < kTrigPieces; k++) {
-    cpi[k] = min(tid + k * BLK, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
+    cpi[k] = min(tid_all + k * BLKP, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
     cst[k] = SF_LD(d2_t, cb, cpi[k] * 16u);
   }
   // (behind the last load of the early set: the ten rounds run while those are in flight)
@@ -960,7 +1077,7 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
     prow[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, in_ ? o.o16 : SF_OOB, SF_GOFF(missile_pos, r), (aux)));   \
     pmeta[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_ ? o.o4 : SF_OOB, SF_GOFF(missile_meta, r), (aux));               \
   }
-  constexpr bool kPoolLoads = SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3;
+  constexpr bool kPoolLoads = !SPLIT && (SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3);
   d2_t prow[SF_MROWS];
   unsigned pmeta[SF_MROWS];
   LaneLate late;
@@ -1135,6 +1252,14 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
   // the missile created above starts at the ship's pre-move position and heading
   const double new_m_x = L.sx, new_m_y = L.sy;
   const int new_m_angle = L.angle;
+  if constexpr (SPLIT) {  // ... and goes to the tile's missile wave (LDS is in order per wave: the word last)
+    reinterpret_cast<d2_t*>(lds + kLdsHand)[tid] = d2_t{new_m_x, new_m_y};
+    reinterpret_cast<unsigned*>(lds + kLdsHandMeta)[tid] =
+        new_m_slot >= 0 ? SF_MM_PACK(new_m_angle, lane, new_m_slot & 31) : 0x80000000u;
+    asm volatile("" ::: "memory");
+    const unsigned fired = __ballot(new_m_slot >= 0) != 0ull ? 2u : 1u;
+    if (lane == 0u) hflags[0] = fired;
+  }
 
   // ---- monitorShipRespawn (SRC/game.cpp:151-157)
   if (will_respawn) {  // !alive && deathTimer >= shipExplodeDuration, evaluated (and fetched) above
@@ -1248,7 +1373,7 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
   d2_t pcs[SF_MROWS];
 #pragma unroll
   for (int r = 0; r < SF_MROWS; r++)
-    pcs[r] = (SF_ABL_PROJ == 1 || SF_ABL_PROJ == 2) ? d2_t{0, 0} : *reinterpret_cast<const d2_t*>(&trig[2 * SF_MM_ANGLE(pmeta[r])]);
+    pcs[r] = (SPLIT || SF_ABL_PROJ == 1 || SF_ABL_PROJ == 2) ? d2_t{0, 0} : *reinterpret_cast<const d2_t*>(&trig[2 * SF_MM_ANGLE(pmeta[r])]);
 
   // the tick's first two score() calls (fireMissile's penalty, then a hexagon death), in their order, now that the
   // score chunk is needed anyway (shell kills and missile events follow)
@@ -1406,15 +1531,15 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
       const unsigned long long kb = __ballot(keep);
       const unsigned idx = wp + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u));
       wp += (unsigned)__popcll(kb);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, (d2_t{nx, ny})), rs, keep ? idx * 16u : SF_OOB,
-                                             SF_GOFF(missile_pos, 0), kStAux);
+      sf_buf_st128<kStAux>(__builtin_bit_cast(u4_t, (d2_t{nx, ny})), rs, keep ? idx * 16u : SF_OOB,
+                                             SF_GOFF(missile_pos, 0));
       __builtin_amdgcn_raw_buffer_store_b32(meta, rs, keep ? idx * 4u : SF_OOB, SF_GOFF(missile_meta, 0), kStAux);
       if (draw_now) {  // uniform.  The survivor's transform goes to its OWNER's draw record, at its slot (sf_drawrec.h)
         typedef float f4_t __attribute__((ext_vector_type(4)));
         const unsigned doff = (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_MISSILE0 + SF_MM_SLOT(meta)) * (unsigned)SF_DR_PIECE_STRIDE +
                               SF_MM_OWNER(meta) * (unsigned)SF_DR_LANE_STRIDE;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, (f4_t{(float)nx, (float)ny, (float)cs.x, (float)cs.y})), rs_draw,
-                                               keep ? doff : SF_OOB, 0, SF_DR_AUX);
+        sf_buf_st128<SF_DR_AUX>(__builtin_bit_cast(u4_t, (f4_t{(float)nx, (float)ny, (float)cs.x, (float)cs.y})), rs_draw,
+                                               keep ? doff : SF_OOB, 0);
         const bool rows = keep & sfd::hud_rows_near((float)ny, sfd::kMissileExt);
         if (__ballot(rows) != 0ull) {  // (all but never) -> bits 24..27 of the owner's hit word
           if (rows)
@@ -1423,7 +1548,12 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
         }
       }
     };
-    if (SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3) {
+    if constexpr (SPLIT) {  // the tile's missile wave did all of that: wait for its word
+      unsigned dw;
+      while (!((dw = (unsigned)__builtin_amdgcn_readfirstlane((int)hflags[1])) >> 31)) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      wp = dw & 0x7FFFFFFFu;
+    } else if (SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3) {
 #pragma unroll
       for (int r = 0; r < SF_MROWS; r++)
         if (m_live > 64u * r) m_row(prow[r].x, prow[r].y, pmeta[r], pcs[r], 64u * r + lane < m_live);
@@ -1579,6 +1709,10 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
       } else {
         const unsigned n_before = (unsigned)__builtin_amdgcn_readfirstlane((int)L.mpool);
         unsigned wp = 0;
+        if constexpr (SPLIT) {  // the missile wave's stores of this tick's rows are acknowledged
+          while (__builtin_amdgcn_readfirstlane((int)hflags[2]) == 0) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+        }
 #pragma unroll 1
         for (unsigned r = 0; 64u * r < n_before; r++) {
           const u4_t pr = __builtin_amdgcn_raw_buffer_load_b128(rs, o.o16 + r * 1024u, SF_GOFF(missile_pos, 0), 16);
@@ -1587,7 +1721,7 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
           const unsigned long long kb = __ballot(keep);
           const unsigned idx = wp + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u));
           wp += (unsigned)__popcll(kb);
-          __builtin_amdgcn_raw_buffer_store_b128(pr, rs, keep ? idx * 16u : SF_OOB, SF_GOFF(missile_pos, 0), kStAux);
+          sf_buf_st128<kStAux>(pr, rs, keep ? idx * 16u : SF_OOB, SF_GOFF(missile_pos, 0));
           __builtin_amdgcn_raw_buffer_store_b32(pm, rs, keep ? idx * 4u : SF_OOB, SF_GOFF(missile_meta, 0), kStAux);
         }
         L.mpool = wp;
@@ -1604,14 +1738,14 @@ __global__ __launch_bounds__(BLK) void sf_step_kernel(unsigned char* state_p, co
     const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(
         a.draw + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * (size_t)SF_DR_TILE_BYTES, 0, SF_DR_TILE_BYTES, 0x00020000);
     const unsigned d0 = real ? lane * (unsigned)SF_DR_LANE_STRIDE : SF_OOB;
-    __builtin_amdgcn_raw_buffer_store_b128(u4_t{h.w[0], h.w[1], h.w[2], h.w[3]}, rs_dr, d0, 0, SF_DR_AUX);
-    __builtin_amdgcn_raw_buffer_store_b128(u4_t{h.w[4], h.w[5], h.w[6], h.w[7]}, rs_dr, d0, SF_DR_PIECE_STRIDE, SF_DR_AUX);
-    __builtin_amdgcn_raw_buffer_store_b128(
+    sf_buf_st128<SF_DR_AUX>(u4_t{h.w[0], h.w[1], h.w[2], h.w[3]}, rs_dr, d0, 0);
+    sf_buf_st128<SF_DR_AUX>(u4_t{h.w[4], h.w[5], h.w[6], h.w[7]}, rs_dr, d0, SF_DR_PIECE_STRIDE);
+    sf_buf_st128<SF_DR_AUX>(
         __builtin_bit_cast(u4_t, (f4_t{(float)L.sx, (float)L.sy, (float)SF_COS(L.angle), (float)SF_SIN(L.angle)})), rs_dr, d0,
-        (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE, SF_DR_AUX);
-    __builtin_amdgcn_raw_buffer_store_b128(
+        (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE);
+    sf_buf_st128<SF_DR_AUX>(
         __builtin_bit_cast(u4_t, (f4_t{(float)sfc::fort_x, (float)sfc::fort_y, (float)SF_COS(L.fort_angle), (float)SF_SIN(L.fort_angle)})),
-        rs_dr, d0, (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_FORT) * SF_DR_PIECE_STRIDE, SF_DR_AUX);
+        rs_dr, d0, (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_FORT) * SF_DR_PIECE_STRIDE);
   }
   if (!FUSED) store_lane_buf(rs, o, L);
   SF_STAMP(14, false);
@@ -2019,12 +2153,21 @@ hipError_t sf_launch_reset(const SfKernelArgs& a, int first, unsigned cursor0, u
 hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, const void* actions, int act_type, void* obs,
                           int32_t* reward, uint8_t* done, uint8_t* info, int n_steps, bool fused, hipStream_t stream) {
   // threads per workgroup: the smallest of 64 / 128 / 256 that still makes a workgroup per CU (256 of them) -- see sf_step_kernel
-  const int blk = fused ? SF_BLOCK : (a.lanes <= 64 * 256 ? 64 : (a.lanes <= 128 * 256 ? 128 : SF_BLOCK));
-  const unsigned grid = (unsigned)(a.lanes / blk);
+  int blk = fused ? SF_BLOCK : (a.lanes <= 64 * 256 ? 64 : (a.lanes <= 128 * 256 ? 128 : SF_BLOCK));
   const size_t elem = a.obs_f64 ? sizeof(double) : sizeof(float);
-  const size_t lds_bytes = (size_t)(SF_LDS_DOUBLES + blk + SF_ATAB_DOUBLES) * sizeof(double) + (size_t)blk * a.obs_dim * elem;
   // 16-byte obs stores need every tick's row of the output to start 16-byte aligned
   const int vec_ok = ((uintptr_t)obs & 15u) == 0 && (!fused || ((size_t)a.n_envs * a.obs_dim * elem) % 16 == 0);
+  // the default observation has its own instantiations (OBSK = 1): see write_features_f32
+  const bool fast_obs = obs != nullptr && a.obs_type == 0 && !a.obs_f64 && vec_ok && a.n_envs % 64 == 0 &&
+                        a.obs_dim == (autoturn ? 17 : 19);
+  const bool xtra = act_type == SF_ACT_SAMPLED || a.act_out != nullptr || !a.auto_reset;
+  // a split launch (sf_step_kernel: a missile wave per tile) where a tile's wave is alone on its SIMD otherwise
+  // (SF_SPLIT 2, for tests: every batch it can serve)
+  const bool split = SF_SPLIT && !fused && fast_obs && !xtra && (blk == SF_BLOCK || SF_SPLIT == 2) && a.draw == nullptr;
+  if (split) blk = SF_BLOCK;
+  const unsigned grid = (unsigned)(a.lanes / blk);
+  size_t lds_bytes = (size_t)(SF_LDS_DOUBLES + blk + SF_ATAB_DOUBLES) * sizeof(double) + (size_t)blk * a.obs_dim * elem;
+  if (split) lds_bytes += (size_t)(2 * SF_BLOCK + SF_BLOCK / 2 + SF_BLOCK / 32) * sizeof(double);
 #define SF_GO2(AT, SH, FU, OK, XT, BL)                                                                             \
   hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, OK, XT, BL>), dim3(grid), dim3(BL), lds_bytes, stream, a.state,    \
                      a.consts, actions, a.n_envs, act_type, reward, done, info, a, obs, vec_ok, n_steps)
@@ -2034,16 +2177,18 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
     else if (blk == 128) SF_GO2(AT, SH, false, OK, XT, 128);                                                       \
     else SF_GO2(AT, SH, false, OK, XT, 64);                                                                        \
   } while (0)
+#if SF_SPLIT
+#define SF_GO_SPLIT(AT, SH) if (split) SF_GO2(AT, SH, false, 1, false, 512); else
+#else
+#define SF_GO_SPLIT(AT, SH)
+#endif
 #define SF_GO(AT, SH, FU)                                                                                          \
+  SF_GO_SPLIT(AT, SH)                                                                                              \
   if (fast_obs) {                                                                                                  \
     if (xtra) SF_GO1(AT, SH, FU, 1, true); else SF_GO1(AT, SH, FU, 1, false);                                      \
   } else {                                                                                                         \
     if (xtra) SF_GO1(AT, SH, FU, 0, true); else SF_GO1(AT, SH, FU, 0, false);                                      \
   }
-  // the default observation has its own instantiations (OBSK = 1): see write_features_f32
-  const bool fast_obs = obs != nullptr && a.obs_type == 0 && !a.obs_f64 && vec_ok && a.n_envs % 64 == 0 &&
-                        a.obs_dim == (autoturn ? 17 : 19);
-  const bool xtra = act_type == SF_ACT_SAMPLED || a.act_out != nullptr || !a.auto_reset;
   // the four presets of SRC/configs.cpp:51-89 are exactly (autoTurn) x (shaped scoring)
   const int sel = (autoturn ? 4 : 0) | (shaped ? 2 : 0) | (fused ? 1 : 0);
   switch (sel) {
@@ -2058,6 +2203,7 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
   }
 #undef SF_GO
 #undef SF_GO1
+#undef SF_GO_SPLIT
 #undef SF_GO2
   return hipGetLastError();
 }

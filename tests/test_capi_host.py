@@ -45,6 +45,28 @@ def test_binary_is_stamped_with_the_hash_of_its_sources(L):
     assert not sfbuild.needs_build()
 
 
+def test_no_wide_buffer_store_without_its_wait_state(L):
+    """The shipped binary, disassembled: no 128-bit buffer store with an SGPR soffset whose next instruction overwrites
+    its data (build.py: scan_wide_store_hazard -- the compiler does not cover that form, and with more than one wave on a
+    SIMD lanes 12-15 of every 16 stored the next instruction's result: batches beyond 65 536 envs, rounds 1-3).  The
+    scanner itself is checked on a two-line sample of each kind."""
+    from spacefortress_amd import _lib
+    from spacefortress_amd import build as sfbuild
+
+    bad = "\tbuffer_store_dwordx4 v[0:3], v6, s[56:59], s0 offen sc1\n\tv_lshlrev_b32_e32 v0, 2, v5\n"
+    good = ["\tbuffer_store_dwordx4 v[0:3], v6, s[56:59], s0 offen sc1\n\ts_nop 1\n\tv_lshlrev_b32_e32 v0, 2, v5\n",
+            "\tbuffer_store_dwordx4 v[0:3], v6, s[56:59], s0 offen sc1\n\tv_lshlrev_b32_e32 v4, 2, v5\n",
+            "\tbuffer_store_dwordx4 v[0:3], v6, s[56:59], 0 offen\n\tv_lshlrev_b32_e32 v0, 2, v5\n",  # immediate: the compiler's case
+            "\tbuffer_store_dwordx2 v[0:1], v6, s[56:59], s0 offen\n\tv_lshlrev_b32_e32 v0, 2, v5\n"]
+    assert len(sfbuild.scan_wide_store_hazard(bad)) == 1
+    assert len(sfbuild.scan_wide_store_hazard(bad.replace("v_lshlrev_b32_e32 v0", "v_add_f64 v[2:3], v[8:9]"))) == 1
+    for g in good:
+        assert sfbuild.scan_wide_store_hazard(g) == []
+    text = sfbuild.device_disassembly(_lib.LIB_PATH)
+    assert text.count("buffer_store_dwordx4") > 500 and "sf_render_kernel" in text and "sf_step_kernel" in text
+    assert sfbuild.scan_wide_store_hazard(text) == []
+
+
 def test_no_cpu_fallback_symbols(L):
     """The product library carries no CPU implementation of the path and never links the oracle."""
     import subprocess

@@ -806,3 +806,50 @@ def test_full_size_hunter_sample(sfa, oracle_mod, gametype):
         snaps.append(out["snaps"][-1])
     bad = compare_state(sd, np.array(snaps), lanes=lanes)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("gametype,obs_type", [("youturn", "features"), ("autoturn", "normalized-features")])
+def test_batches_beyond_one_wave_per_simd(sfa, oracle_mod, gametype, obs_type):
+    """Up to 65 536 envs a wave is alone on its SIMD; beyond, several share one, and the hardware's timing differs: a 128-bit
+    buffer store whose data register the next instruction overwrites lost lanes 12-15 of every 16 there (found in round 4:
+    the compiler covers that hazard only for stores with an immediate soffset; sf_buf_st128 in sf_kernels.hip).  262 144
+    envs in ONE batch must play exactly the games of the same envs in four batches of 65 536 -- every field of the state,
+    bit for bit -- and 96 lanes of the big batch, the hazard's lanes among them, the oracle's games."""
+    O = oracle_mod
+    nb, n, T = 4, 65536, 160
+    rng = np.random.default_rng(5 + len(gametype))
+    n_act = 5 if gametype == "youturn" else 3
+    acts = rng.integers(0, n_act, (T, nb * n)).astype(np.uint8)
+    a = torch.from_numpy(acts).cuda()
+    big = sfa.SFVecEnv(nb * n, gametype=gametype, obs_type=obs_type, spawn_stride=1)
+    lanes = np.sort(np.concatenate([rng.choice(nb * n // 16, 48, replace=False) * 16 + rng.integers(12, 16, 48),
+                                    rng.choice(nb * n, 48, replace=False)]))
+    li = torch.from_numpy(lanes).to(big.device)
+    rew = torch.empty((T, len(lanes)), dtype=torch.int32, device=big.device)
+    obs = torch.empty((T, len(lanes), big.obs_dim), dtype=torch.float32, device=big.device)
+    for t in range(T):
+        o, r, _, _ = big.step_tensors(a[t])
+        rew[t], obs[t] = r[li], o[li]
+    sb = big.state_dict()
+    big.close()
+    rew, obs = rew.cpu().numpy(), obs.cpu().numpy()
+    for k in range(nb):
+        e = sfa.SFVecEnv(n, gametype=gametype, obs_type=obs_type, spawn_stride=1, spawn_skip=k * n)
+        ak = a[:, k * n:(k + 1) * n].contiguous()
+        for t in range(T):
+            e.step_tensors(ak[t])
+        sd = e.state_dict()
+        e.close()
+        for key in sd:
+            x, y = np.asarray(sb[key])[..., k * n:(k + 1) * n], np.asarray(sd[key])
+            assert x.tobytes() == y.tobytes(), (k, key, np.argwhere(x != y)[:8].tolist())
+    snaps = []
+    for j, lane in enumerate(lanes):
+        o = O.OracleEnv(gametype, obs_type=obs_type, spawn_skip=int(lane))
+        out = o.replay(acts[:, lane], want_obs=True)
+        assert np.array_equal(out["reward"], rew[:, j]), lane
+        assert obs_close(obs[:, j], out["obs"], False).all(), lane
+        snaps.append(out["snaps"][-1])
+    bad = compare_state(sb, np.array(snaps), lanes=lanes)
+    assert not bad, bad
+
