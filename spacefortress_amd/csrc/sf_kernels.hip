@@ -46,6 +46,8 @@
 //    store is write-through (sc1), so the end-of-kernel write-back has little left to flush;
 //  * no dense contraction anywhere on this path: no MFMA.  The bound is HBM traffic.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "sf_internal.h"
@@ -66,7 +68,7 @@
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #ifndef SF_MROWS
 #ifndef SF_SPLIT
-#define SF_SPLIT 0 /* 1: batches of 65 536 envs and more step by split launches (sf_step_kernel, BLKP = 512) */
+#define SF_SPLIT 1 /* 1: batches that put one wave on a SIMD (32 769 .. 65 536 envs) step by split launches (sf_step_kernel, BLKP = 512): A/B at 65 536 envs 6.51 -> 6.39 us; 0: never; 2: every batch the instantiation can serve (tests) */
 #endif
 #define SF_MROWS 3 /* rows of the tile's missile pool (64 entries each) loaded up front with the lane's chunks; more live
                       missiles than that (> 192 in 64 envs; random play averages 104) take the dependent-load loop */
@@ -870,6 +872,9 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 // as 64 workgroups of four it leaves three CUs in four idle while the four waves of a CU share its address unit and LDS:
 // launched as 256 workgroups of ONE wave the same step takes 7.0 instead of 8.0 us (image batch, draw records included;
 // sf_launch_step picks the smallest BLK that still fills every CU).
+// BLKP = 512 is a SPLIT launch: 256 envs per workgroup and a second wave per tile that moves the tile's missile pool while the
+// first plays the 64 games (see "the tile's MISSILE wave" below); what sf_launch_step takes for the plain step of the default
+// observation when the batch puts one wave on a SIMD (32 769 .. 65 536 envs): 6.51 -> 6.39 us at 65 536.
 template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK, bool XTRA, int BLKP>
 __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
                                                           const void* actions, int n_envs_p, int act_type,
@@ -951,6 +956,11 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
     // exactly that part under the first wave's ship / fortress / shell arithmetic.  Hand-over through LDS, both ways by a
     // word the other side polls (a workgroup barrier would make the games wait for the pool's loads): the games' wave
     // files its new missiles and sets `fired`; the missile wave sets `done | entries kept` behind its last event word.
+    // Both waves of a workgroup are resident before either starts, each sets its word on every path, the polls sleep.
+    // What it buys is the first wave's issue bubbles, not the missiles' whole cost (removing them: -0.68 us; moving them
+    // here: -0.12): in its arithmetic the first wave keeps the SIMD's one VALU busy most of the time, and the second wave's
+    // instructions take the same issue slots.  Issue priority for the first wave and a later start for the pool's loads
+    // changed nothing measurable; starting them 1 500 cycles later made the games wait (tools/ab.py, NOTES.md).
     if (tid_all >= (unsigned)BLK) {  // wave-uniform
       // the pool's count rides in every lane's misc chunk: lane 0's word, by a scalar load
       const unsigned n_word = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(
@@ -961,14 +971,26 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
       const unsigned m_live = n_word >> SF_MPOOL_SHIFT;
       d2_t prow[SF_MROWS];
       unsigned pmeta[SF_MROWS];
+#ifndef SF_SPLIT_LATE
+#define SF_SPLIT_LATE 1 /* the pool's rows are asked for once the table piece is in, i.e. behind the launch's first burst */
+#endif
+#if SF_SPLIT_LATE
+      reinterpret_cast<d2_t*>(lds)[cpi0] = cst0;
+      if (lane < 4u) hflags[lane] = 0u;
+#if SF_SPLIT_LATE > 1
+      __builtin_amdgcn_s_sleep(SF_SPLIT_LATE);
+#endif
+#endif
 #pragma unroll
       for (int r = 0; r < SF_MROWS; r++) {
         const bool in_ = 64u * r + lane < m_live;
         prow[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, in_ ? o.o16 : SF_OOB, SF_GOFF(missile_pos, r), 0));
         pmeta[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_ ? o.o4 : SF_OOB, SF_GOFF(missile_meta, r), 0);
       }
+#if !SF_SPLIT_LATE
       reinterpret_cast<d2_t*>(lds)[cpi0] = cst0;
       if (lane < 4u) hflags[lane] = 0u;
+#endif
       __syncthreads();  // (the workgroup's one barrier: the cos/sin table is in LDS, the hand-over words are zero)
       const double* trig = lds;
       d2_t pcs[SF_MROWS];
@@ -1024,6 +1046,12 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
       return;
     }
   }
+#ifndef SF_SPLIT_PRIO
+#define SF_SPLIT_PRIO 0 /* A/B: the games' wave at this issue priority over its missile wave (s_setprio) */
+#endif
+#if SF_SPLIT_PRIO
+  if constexpr (SPLIT) __builtin_amdgcn_s_setprio(SF_SPLIT_PRIO);
+#endif
   // ================= round trip 1: every unconditional load =================
   // act_type SF_ACT_SAMPLED: no action array -- `actions` is this batch's sampler records (SfActRec, one per tile) and the
   // lane draws its action itself: Philox4x32-10 keyed by the seed, counter (lane of the whole job, tick).  The record is
@@ -2163,7 +2191,15 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
   const bool xtra = act_type == SF_ACT_SAMPLED || a.act_out != nullptr || !a.auto_reset;
   // a split launch (sf_step_kernel: a missile wave per tile) where a tile's wave is alone on its SIMD otherwise
   // (SF_SPLIT 2, for tests: every batch it can serve)
-  const bool split = SF_SPLIT && !fused && fast_obs && !xtra && (blk == SF_BLOCK || SF_SPLIT == 2) && a.draw == nullptr;
+  // (SFMI_FORCE_SPLIT=1 in the environment, for tests: every batch the instantiation can serve; =2 says so once on stderr)
+  static const int force_split = [] { const char* e = getenv("SFMI_FORCE_SPLIT"); return e ? atoi(e) : 0; }();
+  const bool split = SF_SPLIT && !fused && fast_obs && !xtra && ((blk == SF_BLOCK && a.lanes <= 65536) || SF_SPLIT == 2 || force_split) &&
+                     a.draw == nullptr;
+  if (split && force_split == 2) {
+    static bool said = false;
+    if (!said) fprintf(stderr, "sfmi: split launch (%ld lanes)\n", (long)a.lanes);
+    said = true;
+  }
   if (split) blk = SF_BLOCK;
   const unsigned grid = (unsigned)(a.lanes / blk);
   size_t lds_bytes = (size_t)(SF_LDS_DOUBLES + blk + SF_ATAB_DOUBLES) * sizeof(double) + (size_t)blk * a.obs_dim * elem;

@@ -9,6 +9,7 @@ within 1e-9; observations within 1e-5 relative to the float32 the wrapper emits
 (float64 observations: 1e-9)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -827,17 +828,22 @@ def test_batches_beyond_one_wave_per_simd(sfa, oracle_mod, gametype, obs_type):
     li = torch.from_numpy(lanes).to(big.device)
     rew = torch.empty((T, len(lanes)), dtype=torch.int32, device=big.device)
     obs = torch.empty((T, len(lanes), big.obs_dim), dtype=torch.float32, device=big.device)
-    for t in range(T):
+    Ts = T - 40  # ... the last 40 ticks as ONE fused launch (sf_rollout: the other family of instantiations)
+    for t in range(Ts):
         o, r, _, _ = big.step_tensors(a[t])
         rew[t], obs[t] = r[li], o[li]
+    o, r, _, _ = big.rollout(a[Ts:].contiguous())
+    rew[Ts:], obs[Ts:] = r[:, li], o[:, li]
+    del o, r
     sb = big.state_dict()
     big.close()
     rew, obs = rew.cpu().numpy(), obs.cpu().numpy()
     for k in range(nb):
         e = sfa.SFVecEnv(n, gametype=gametype, obs_type=obs_type, spawn_stride=1, spawn_skip=k * n)
         ak = a[:, k * n:(k + 1) * n].contiguous()
-        for t in range(T):
+        for t in range(Ts):
             e.step_tensors(ak[t])
+        e.rollout(ak[Ts:].contiguous(), want_obs=False)
         sd = e.state_dict()
         e.close()
         for key in sd:
@@ -852,4 +858,23 @@ def test_batches_beyond_one_wave_per_simd(sfa, oracle_mod, gametype, obs_type):
         snaps.append(out["snaps"][-1])
     bad = compare_state(sb, np.array(snaps), lanes=lanes)
     assert not bad, bad
+
+
+def test_split_launches_on_every_scenario():
+    """Batches of 32 769 .. 65 536 envs step by SPLIT launches (sf_step_kernel<..., 512>: a second wave per tile moves the
+    missile pool and hands its events over through LDS).  The scenarios of this file run small batches, which never split;
+    here they run again in a child process with SFMI_FORCE_SPLIT=2 -- the launcher then splits every batch the
+    instantiation serves (features, float32, auto-reset) and says so on stderr: goldens, random and hunter lock-steps,
+    exhausted slots, pools beyond three rows, lanes of a tile finishing at different ticks (the purge that re-reads the rows
+    the missile wave wrote), fuzzed states."""
+    import subprocess
+
+    env = dict(os.environ, SFMI_FORCE_SPLIT="2")
+    sel = "golden or random or hunter or rollover or exhausted or many_shells or fuzzed or different_ticks or odd_batch or full_size_properties"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", sel, "-s",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout[-3000:] + r.stderr[-2000:])
+    assert r.returncode == 0, tail
+    assert "sfmi: split launch" in r.stderr + r.stdout, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
 

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--gametype", default="youturn")
     ap.add_argument("--obs-type", default="features")
+    ap.add_argument("--launch", default="auto", choices=("auto", "loop", "graph"),
+                    help="bench.py --launch: one launch per step from the Python loop, or HIP graphs of 256 launches")
     a = ap.parse_args()
     res = {l: [] for l in a.libs}
     for r in range(a.rounds):
@@ -33,7 +35,7 @@ def main():
                 [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "300",
                  "--no-cpu-baseline", "--envs", str(a.envs), "--gametype", a.gametype, "--obs-type", a.obs_type,
                  "--rollout-k", "0", "--image-envs", "0", "--kernel-timing-launches", "1", "--repeats", "1", "--numpy-api", "0",
-                 "--no-configs", "--steady-seconds", "0.2"],
+                 "--no-configs", "--steady-seconds", "0.2", "--launch", a.launch],
                 env=env, stderr=subprocess.DEVNULL, text=True)
             res[l].append(json.loads(out.strip().splitlines()[-1])["ms_per_step"] * 1e3)
     for l, v in res.items():
