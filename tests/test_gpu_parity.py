@@ -860,6 +860,54 @@ def test_batches_beyond_one_wave_per_simd(sfa, oracle_mod, gametype, obs_type):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("gametype,obs_type,f64", [("youturn", "features", False), ("autoturn", "normalized-features", True),
+                                                   ("youturn", "monitors", False)])
+def test_every_workgroup_size_plays_the_same_games(sfa, oracle_mod, gametype, obs_type, f64):
+    """sf_launch_step picks 64-, 128- or 256-thread workgroups (and split launches) by the batch's size: different
+    instantiations of the kernel.  Lane i of a batch with spawn_stride 1 plays spawn i whatever the batch's size, so the
+    first 8 192 lanes of batches of 8 192 (64-thread workgroups), 24 576 (128), 49 152 (256 / split) and 90 112 (256, two
+    waves on some SIMDs) must agree in every output of every step and every state field, single steps and a fused segment;
+    64 of them are checked against the oracle."""
+    O = oracle_mod
+    n0, T = 8192, 220
+    rng = np.random.default_rng(9 + len(gametype) + len(obs_type))
+    n_act = 5 if gametype == "youturn" else 3
+    acts0 = rng.integers(0, n_act, (T, n0)).astype(np.uint8)
+    ref = None
+    for n in (n0, 24576, 49152, 90112):
+        acts = np.concatenate([acts0, rng.integers(0, n_act, (T, n - n0)).astype(np.uint8)], axis=1)
+        a = torch.from_numpy(acts).cuda()
+        env = sfa.SFVecEnv(n, gametype=gametype, obs_type=obs_type, spawn_stride=1, obs_dtype=torch.float64 if f64 else torch.float32)
+        outs = []
+        for t in range(T - 60):
+            outs.append(tuple(x[:n0].clone() for x in env.step_tensors(a[t])))
+        fo, fr, fd, fi = env.rollout(a[T - 60:].contiguous())
+        obs = torch.cat([torch.stack([o[0] for o in outs]), fo[:, :n0]]).cpu().numpy()
+        rew = torch.cat([torch.stack([o[1] for o in outs]), fr[:, :n0]]).cpu().numpy()
+        done = torch.cat([torch.stack([o[2] for o in outs]), fd[:, :n0]]).cpu().numpy()
+        info = torch.cat([torch.stack([o[3] for o in outs]), fi[:, :n0]]).cpu().numpy()
+        sd = {k: np.asarray(v)[..., :n0] for k, v in env.state_dict().items()}
+        env.close()
+        if ref is None:
+            ref = (obs, rew, done, info, sd)
+            continue
+        assert obs.tobytes() == ref[0].tobytes(), (n, np.argwhere(obs != ref[0])[:5].tolist())
+        assert np.array_equal(rew, ref[1]) and np.array_equal(done, ref[2]) and np.array_equal(info, ref[3]), n
+        for k in sd:
+            assert sd[k].tobytes() == ref[4][k].tobytes(), (n, k, np.argwhere(sd[k] != ref[4][k])[:5].tolist())
+    obs, rew, done, info, sd = ref
+    lanes = np.sort(rng.choice(n0, 64, replace=False))
+    snaps = []
+    for lane in lanes:
+        o = O.OracleEnv(gametype, obs_type=obs_type, spawn_skip=int(lane))
+        out = o.replay(acts0[:, lane], want_obs=True)
+        assert np.array_equal(out["reward"], rew[:, lane]), lane
+        assert obs_close(obs[:, lane], out["obs"], f64).all(), lane
+        snaps.append(out["snaps"][-1])
+    bad = compare_state(sd, np.array(snaps), lanes=lanes)
+    assert not bad, bad
+
+
 def test_split_launches_on_every_scenario():
     """Batches of 32 769 .. 65 536 envs step by SPLIT launches (sf_step_kernel<..., 512>: a second wave per tile moves the
     missile pool and hands its events over through LDS).  The scenarios of this file run small batches, which never split;
