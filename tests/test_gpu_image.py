@@ -571,6 +571,38 @@ def test_draw_records_of_the_step_equal_records_from_the_state(sfa, gametype, po
     env.close()
 
 
+def test_image_batches_of_every_workgroup_size(sfa):
+    """An image batch's step launches go out as 64-, 128- or 256-thread workgroups by the batch's size (sf_launch_step):
+    three instantiations writing draw records.  Lane i plays spawn i in every batch (spawn_stride 1), so the first 4 096
+    envs of batches of 4 096, 20 480 and 36 864 show the same frames and leave the same records, and in the largest the
+    records of the step equal the records rebuilt from the state."""
+    from sfscript import open_loop_actions
+
+    n0, T = 4096, 260
+    rng = np.random.default_rng(12)
+    acts0 = open_loop_actions("hunter", (T, n0), 3, rng, phase=rng.integers(0, 96, n0))
+    ref = {}
+    for n in (n0, 20480, 36864):
+        env = sfa.SFVecEnv(n, gametype="autoturn", obs_type="image", spawn_stride=1)
+        env.reset()
+        acts = np.concatenate([acts0, open_loop_actions("hunter", (T, n - n0), 3, rng, phase=rng.integers(0, 96, n - n0))], axis=1) if n > n0 else acts0
+        a = torch.from_numpy(np.ascontiguousarray(acts)).to(env.device)
+        for t in range(T):
+            obs, *_ = env.step_tensors(a[t])
+            if t % 29 == 0 or t == T - 1:
+                rec = _live_record_bytes(env.draw_records(False)[:n0])
+                frame = obs[:n0].cpu().numpy()
+                if n == n0:
+                    ref[t] = (rec, frame)
+                else:
+                    assert np.array_equal(rec, ref[t][0]), (n, t, np.argwhere(rec != ref[t][0])[:6].tolist())
+                    assert np.array_equal(frame, ref[t][1]), (n, t)
+        if n != n0:
+            assert np.array_equal(_live_record_bytes(env.draw_records(False)), _live_record_bytes(env.draw_records(True))), n
+        env.close()
+    assert any(r[1].max() > 0 for r in ref.values())
+
+
 @pytest.mark.parametrize("scale,viewport,ls", [(.25, (100, 60, 500, 520), 2), (.3, (130, 80, 450, 460), 4.5)])
 def test_frames_in_another_geometry_vs_model(sfa, oracle_mod, scale, viewport, ls):
     """SSF_Env(scale, viewport, ls) (ENV:50-60): any geometry but the default one goes through the general renderer
