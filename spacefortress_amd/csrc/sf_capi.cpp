@@ -93,7 +93,7 @@ int flush_missile_view(sf_batch* b, hipStream_t stream) {
   } while (0)
 
 const unsigned long long kAccInit[SF_ACC_WORDS] = {
-    0, 0, 0, 0, 0, 0, (unsigned long long)LLONG_MAX, (unsigned long long)LLONG_MIN, 0, 0};
+    0, 0, 0, 0, 0, 0, (unsigned long long)LLONG_MAX, (unsigned long long)LLONG_MIN, 0, 0, 0};
 static_assert(SF_ACC_BAD_ACTION == SF_EPISODE_STATS_LEN && SF_ACC_OVERFLOW == SF_EPISODE_STATS_LEN + 1, "acc layout");
 
 // the sampler records of sf_step_sampled (sf_layout.h: SF_ACT_SAMPLED): per tile (tick, key0, key1, first lane of the job)
@@ -816,9 +816,16 @@ extern "C" int sf_rollout_sampled(sf_batch* b, int n_steps, uint8_t* actions_out
 extern "C" int sf_check_state(sf_batch* b, void* stream) {
   if (!b) return SF_ERR_ARG;
   DeviceGuard guard(b->device);
-  unsigned long long bad = 0;
-  HIP_TRY(hipMemcpyAsync(&bad, b->d_acc + SF_ACC_OVERFLOW, sizeof(bad), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  unsigned long long two[2] = {0, 0};
+  static_assert(SF_ACC_HANDOVER == SF_ACC_OVERFLOW + 1, "one copy for both");
+  HIP_TRY(hipMemcpyAsync(two, b->d_acc + SF_ACC_OVERFLOW, sizeof(two), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  const unsigned long long bad = two[0];
+  if (two[1]) {  // (sticky for the batch's life: its state cannot be trusted)
+    sf_set_error("%llu times a wave of a split step launch gave up waiting for its tile's other wave: the state of this batch is "
+                 "not the reference's any more (an internal error: please report it with the batch size and the GPU)", two[1]);
+    return SF_ERR_STATE;
+  }
   if (bad) {  // sticky: the fields stay wrapped until new games start (sf_reset clears the count)
     sf_set_error("%llu times since the last sf_reset a per-episode counter or timer left its packed width (a batch without "
                  "auto-reset stepped for several episodes without sf_reset): stats / timers of those envs have wrapped", bad);

@@ -945,6 +945,9 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
   }
 #endif
 #endif
+  // A poll of a hand-over word gives up after 2^18 rounds of 64+ cycles (10 ms; a launch lasts 6 us): a kernel must end
+  // whatever happens to the other wave.  Giving up is counted (SF_ACC_HANDOVER -> sf_check_state fails: the step is wrong).
+  constexpr unsigned kSpinLimit = 1u << 18;
   typedef volatile __attribute__((address_space(3))) unsigned lds_word_t;  // (named as LDS: a volatile access through a generic pointer is a flat_load)
   lds_word_t* const hflags = (lds_word_t*)(reinterpret_cast<unsigned*>(lds + kLdsHandFlags) + 4u * (tid >> 6));  // (split launches: this tile's hand-over words)
   if constexpr (SPLIT) {
@@ -1031,8 +1034,9 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
         }
       }
       // the missiles fired this tick (SRC/game.cpp:237-238), one more row, lane = owner
-      unsigned fired;
-      while ((fired = (unsigned)__builtin_amdgcn_readfirstlane((int)hflags[0])) == 0u) __builtin_amdgcn_s_sleep(1);
+      unsigned fired, spins = 0u;
+      while ((fired = (unsigned)__builtin_amdgcn_readfirstlane((int)hflags[0])) == 0u && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+      if (spins >= kSpinLimit && lane == 0u) atomicAdd(&a.acc[SF_ACC_HANDOVER], 1ull);  // (never seen; see kSpinLimit)
       asm volatile("" ::: "memory");
       if (fired == 2u) {
         const d2_t nxy = reinterpret_cast<const d2_t*>(lds + kLdsHand)[tid];
@@ -1577,8 +1581,9 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
       }
     };
     if constexpr (SPLIT) {  // the tile's missile wave did all of that: wait for its word
-      unsigned dw;
-      while (!((dw = (unsigned)__builtin_amdgcn_readfirstlane((int)hflags[1])) >> 31)) __builtin_amdgcn_s_sleep(1);
+      unsigned dw, spins = 0u;
+      while (!((dw = (unsigned)__builtin_amdgcn_readfirstlane((int)hflags[1])) >> 31) && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+      if (spins >= kSpinLimit && lane == 0u) atomicAdd(&a.acc[SF_ACC_HANDOVER], 1ull);
       asm volatile("" ::: "memory");
       wp = dw & 0x7FFFFFFFu;
     } else if (SF_ABL_PROJ == 0 || SF_ABL_PROJ == 3) {
@@ -1738,7 +1743,9 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
         const unsigned n_before = (unsigned)__builtin_amdgcn_readfirstlane((int)L.mpool);
         unsigned wp = 0;
         if constexpr (SPLIT) {  // the missile wave's stores of this tick's rows are acknowledged
-          while (__builtin_amdgcn_readfirstlane((int)hflags[2]) == 0) __builtin_amdgcn_s_sleep(1);
+          unsigned spins = 0u;
+          while (__builtin_amdgcn_readfirstlane((int)hflags[2]) == 0 && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+          if (spins >= kSpinLimit && lane == 0u) atomicAdd(&a.acc[SF_ACC_HANDOVER], 1ull);
           asm volatile("" ::: "memory");
         }
 #pragma unroll 1

@@ -59,7 +59,8 @@ for c in range(0, T, K):
         done_total += int(od.sum()); kills += int(oi.sum())
     bad = compare_state(env.state_dict(), orc.snapshots())
     assert not bad, (c, bad)
-    if (c // K) % 10 == 9:
+    env.check_state()  # (the sticky error counters: a packed field that wrapped, a split launch's poll that gave up)
+    if (c // K) % 10 == 9 or N * K >= 4000000:  # (big batches: every chunk takes seconds, say so)
         print("step %6d ok  (episodes finished %d, kills %d, %.0f s)" % (c + k, done_total, kills, time.time() - t0), flush=True)
 print("SOAK OK: %s (%s), %d lanes x %d steps = %.1fM env-steps, %d episodes finished, %d fortress kills" % (
     gametype, policy, N, T, N * T / 1e6, done_total, kills))
