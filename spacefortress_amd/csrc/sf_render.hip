@@ -287,9 +287,51 @@ struct Frame {
     const float b0 = __uint_as_float(tr.y), b1 = __uint_as_float(tr.z), b2 = __uint_as_float(tr.w);
     const uint8_t* r0 = fb + first + (int)tr.x * SF_IMG_W + (int)c0.x;
     unsigned long long w0, w1, w2;
+#ifndef SF_RQ_ALIGNED
+#define SF_RQ_ALIGNED 0 /* A/B: a row's eight bytes as three ALIGNED words + two v_alignbyte instead of one 8-byte read at any byte */
+#endif
+#if SF_RQ_ALIGNED
+    {
+      static_assert(SF_IMG_W % 4 == 2, "the rows' alignments below");
+      const unsigned A = (unsigned)(first + (int)tr.x * SF_IMG_W + (int)c0.x), al = A & 3u, al1 = (A + 2u) & 3u;  // (fb is 16-byte aligned)
+      const uint32_t* q0 = reinterpret_cast<const uint32_t*>(fb + (A & ~3u));
+      const uint32_t* q1 = reinterpret_cast<const uint32_t*>(fb + ((A + SF_IMG_W) & ~3u));
+      const uint32_t* q2 = reinterpret_cast<const uint32_t*>(fb + ((A + 2 * SF_IMG_W) & ~3u));
+      const unsigned a0 = q0[0], a1 = q0[1], a2 = q0[2], b0_ = q1[0], b1_ = q1[1], b2_ = q1[2], c0_ = q2[0], c1_ = q2[1], c2_ = q2[2];
+      w0 = (unsigned long long)__builtin_amdgcn_alignbyte(a1, a0, al) | ((unsigned long long)__builtin_amdgcn_alignbyte(a2, a1, al) << 32);
+      w1 = (unsigned long long)__builtin_amdgcn_alignbyte(b1_, b0_, al1) | ((unsigned long long)__builtin_amdgcn_alignbyte(b2_, b1_, al1) << 32);
+      w2 = (unsigned long long)__builtin_amdgcn_alignbyte(c1_, c0_, al) | ((unsigned long long)__builtin_amdgcn_alignbyte(c2_, c1_, al) << 32);
+    }
+#else
     __builtin_memcpy(&w0, r0, 8);
     __builtin_memcpy(&w1, r0 + SF_IMG_W, 8);
     __builtin_memcpy(&w2, r0 + 2 * SF_IMG_W, 8);
+#endif
+#ifndef SF_RQ_PERM
+#define SF_RQ_PERM 1 /* A/B: the pixel's two source bytes by v_perm_b32 (one selector for the three rows) instead of three 64-bit
+                        shifts, the rounded, saturated byte dropped into the word by v_cvt_pk_u8_f32 (round to nearest even,
+                        clamp to 0 .. 255: saturate_cast<uchar>(rint)) instead of rint + clamp + shift + or */
+#endif
+#if SF_RQ_PERM
+    unsigned word = 0u;
+    auto one = [&](const uint4& c, unsigned k) {
+      // bytes off, off + 1 of the row's eight (off = 0 .. 4), the upper half zero (selector byte 0x0c)
+      const unsigned sel = (c.x - c0.x) * 0x0101u + 0x0c0c0100u;
+      const unsigned p0 = __builtin_amdgcn_perm((unsigned)(w0 >> 32), (unsigned)w0, sel);
+      const unsigned p1 = __builtin_amdgcn_perm((unsigned)(w1 >> 32), (unsigned)w1, sel);
+      const unsigned p2 = __builtin_amdgcn_perm((unsigned)(w2 >> 32), (unsigned)w2, sel);
+      const float a0 = __uint_as_float(c.y), a1 = __uint_as_float(c.z);
+      const float h0 = (float)(p0 & 255u) * a0 + (float)(p0 >> 8) * a1;
+      const float h1 = (float)(p1 & 255u) * a0 + (float)(p1 >> 8) * a1;
+      const float h2 = (float)(p2 & 255u) * a0 + (float)(p2 >> 8) * a1;
+      const float sum = (b0 * h0 + b1 * h1) + b2 * h2;
+      word = __builtin_amdgcn_cvt_pk_u8_f32(sum, k, word);
+    };
+    one(c0, 0u);
+    one(c1, 1u);
+    one(c2, 2u);
+    one(c3, 3u);
+#else
     auto one = [&](const uint4& c) -> unsigned {
       const unsigned sh = 8u * (c.x - c0.x);  // 0 .. 32: the pixel's two source columns are bytes sh / 8 and sh / 8 + 1
       const unsigned p0 = (unsigned)(w0 >> sh), p1 = (unsigned)(w1 >> sh), p2 = (unsigned)(w2 >> sh);
@@ -303,6 +345,7 @@ struct Frame {
       return (unsigned)v;
     };
     const unsigned word = one(c0) | (one(c1) << 8) | (one(c2) << 16) | (one(c3) << 24);
+#endif
     *reinterpret_cast<uint32_t*>(obuf + (unsigned)(dy * SF_OUT + dx0)) = word;
   }
   __device__ __forceinline__ void resample_into(const Box& b, uint8_t* dst, int stride, int x_off, int y_off) const {
@@ -1393,7 +1436,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   if (bar_pre) hbar = hud_fetch<RESIZE>(hud_bar_picture(a.hud, bstate), SF_HUD_BAR_ROW, bbox, lane);
   // the 84x84 background's seven pieces
   Pieces frame0 = {};
-  if (RESIZE) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + bgi * (kOutBytes / 4)), kOutBytes / 16, lane);
+  if (RESIZE && !(SF_RENDER_SKIP & 8192)) frame0 = load_pieces(reinterpret_cast<const uint4*>(a.bg84 + bgi * (kOutBytes / 4)), kOutBytes / 16, lane);  // (bit 13: timing-only, no background copy)
   // ... and LAST of the round trip, the surface's ten direct-to-LDS loads: a wave's loads come back in issue order and the
   // compiler does not know of these ten, so every wait it counts out for something issued before them stays a wait for
   // that alone.
@@ -1424,7 +1467,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   }
   // the 84x84 background's seven stores, behind everything: stores count like loads, in the same order -- in front of the
   // surface's loads, the wait for the surface would be a wait for their acknowledgement from HBM as well
-  if (RESIZE) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
+  if (RESIZE && !(SF_RENDER_SKIP & 8192)) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
   // the frame stack's older slots
   const unsigned fin_b = (RESIZE && a.stack_done) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fin_v) : 0u;
   const bool stack_traffic = RESIZE && (a.stack_prev || fin_b != 0);  // more loads / stores behind the seven: see the wait below
@@ -1475,7 +1518,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // everything but these stores is done -- the surface is in LDS -- without waiting for the stores to be acknowledged.  The
   // byte stores that follow land on top of them anyway: one wave's stores to one address are performed in program order.
   static_assert(kFrameRounds == 7 && 6 * 64 < kOutBytes / 16, "all seven stores have lanes to do");
-  if (RESIZE && !stack_traffic) {
+  if (RESIZE && !stack_traffic && !(SF_RENDER_SKIP & 8192)) {
     asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
