@@ -1296,6 +1296,19 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     const int ti = lane < Frame<RESIZE>::kLtabCols ? lane : min(SF_OUT + lane - Frame<RESIZE>::kLtabCols, SF_OUT + 20);
     lt_e = reinterpret_cast<const uint4*>(a.tabs)[ti];
   }
+#ifndef SF_RENDER_STAGGER
+#define SF_RENDER_STAGGER 0 /* A/B: the first generation's workgroups (16 per CU, all launched at once) start in four phases
+                               SF_RENDER_STAGGER x 64 cycles apart, by SF_RENDER_STAGGER_SHIFT bits of the workgroup's index */
+#endif
+#ifndef SF_RENDER_STAGGER_SHIFT
+#define SF_RENDER_STAGGER_SHIFT 10
+#endif
+#if SF_RENDER_STAGGER
+  if (blockIdx.x < 4096u) {
+    const unsigned ph = (blockIdx.x >> SF_RENDER_STAGGER_SHIFT) & 3u;  // uniform
+    for (unsigned k = 0; k < ph; k++) __builtin_amdgcn_s_sleep(SF_RENDER_STAGGER);
+  }
+#endif
   // ---- which env (pick_env).  Nearly every workgroup behind the front draws env = its index - n_front, and learns that
   // from one word of the hint: the record's loads go out for that env at once, next to the word's load, instead of behind it.
   int env = blockIdx.x;
