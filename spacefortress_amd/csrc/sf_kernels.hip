@@ -68,7 +68,7 @@
 #define SF_MAX_MISSILES_D 20.0 /* sf.MAX_MISSILES / sf.MAX_SHELLS as divisors (ENV:124-125) */
 #ifndef SF_MROWS
 #ifndef SF_SPLIT
-#define SF_SPLIT 1 /* 1: batches that put one wave on a SIMD (32 769 .. 65 536 envs) step by split launches (sf_step_kernel, BLKP = 512): A/B at 65 536 envs 6.51 -> 6.39 us; 0: never; 2: every batch the instantiation can serve (tests) */
+#define SF_SPLIT 1 /* 1: batches up to 65 536 envs (at most one games' wave per SIMD) step by split launches (sf_step_kernel, BLKP = 1000 + BLK): A/B 4 096 envs 5.48 -> 5.29 us, 32 768: 6.11 -> 5.89, 65 536: 6.51 -> 6.39; 0: never; 2: every batch the instantiation can serve (tests) */
 #endif
 #define SF_MROWS 3 /* rows of the tile's missile pool (64 entries each) loaded up front with the lane's chunks; more live
                       missiles than that (> 192 in 64 envs; random play averages 104) take the dependent-load loop */
@@ -872,11 +872,11 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
 // as 64 workgroups of four it leaves three CUs in four idle while the four waves of a CU share its address unit and LDS:
 // launched as 256 workgroups of ONE wave the same step takes 7.0 instead of 8.0 us (image batch, draw records included;
 // sf_launch_step picks the smallest BLK that still fills every CU).
-// BLKP = 512 is a SPLIT launch: 256 envs per workgroup and a second wave per tile that moves the tile's missile pool while the
-// first plays the 64 games (see "the tile's MISSILE wave" below); what sf_launch_step takes for the plain step of the default
-// observation when the batch puts one wave on a SIMD (32 769 .. 65 536 envs): 6.51 -> 6.39 us at 65 536.
+// BLKP = 1000 + BLK is a SPLIT launch: BLK envs per workgroup and a second wave per tile that moves the tile's missile pool
+// while the first plays the 64 games (see "the tile's MISSILE wave" below); what sf_launch_step takes for the plain step of the
+// default observation of batches up to 65 536 envs (beyond, a SIMD has several games' waves to interleave anyway).
 template <bool AUTOTURN, bool SHAPED, bool FUSED, int OBSK, bool XTRA, int BLKP>
-__global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
+__global__ __launch_bounds__(BLKP > 1000 ? 2 * (BLKP - 1000) : BLKP) void sf_step_kernel(unsigned char* state_p, const double* consts_p,
                                                           const void* actions, int n_envs_p, int act_type,
                                                           int32_t* reward_out, uint8_t* done_out, uint8_t* info_out,
                                                           SfKernelArgs a, void* obs, int obs_vec_ok, int n_steps) {
@@ -885,11 +885,12 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
   // SGPRs at wave launch and the state loads issue without a scalar-load round trip to the kernel-argument
   // segment first (on a firmware without the feature the compiler's compatibility preamble loads them).  The
   // three output pointers ride along: the epilogue then stores without a scalar load and its wait.
-  // BLKP = 512: a SPLIT launch -- 256 envs per workgroup and as many threads again, the tiles' MISSILE waves (below)
-  constexpr bool SPLIT = BLKP == 512;
-  constexpr int BLK = SPLIT ? 256 : BLKP;  // envs per workgroup
+  // BLKP = 1000 + BLK: a SPLIT launch -- BLK envs per workgroup and as many threads again, the tiles' MISSILE waves (below)
+  constexpr bool SPLIT = BLKP > 1000;
+  constexpr int BLK = SPLIT ? BLKP - 1000 : BLKP;  // envs per workgroup
+  constexpr int NT = SPLIT ? 2 * BLK : BLK;        // threads per workgroup
   static_assert(!SPLIT || (!FUSED && OBSK == 1 && !XTRA), "the split launch exists for the plain step of the default observation");
-  constexpr int kTrigPieces = (SF_LDS_DOUBLES / 2 + BLKP - 1) / BLKP;
+  constexpr int kTrigPieces = (SF_LDS_DOUBLES / 2 + NT - 1) / NT;
   // (the LDS map above, for BLK envs; a split launch's hand-over words sit between the atan table and the staging rows:
   //  the new missiles' (x, y) [BLK d2_t] and meta words [BLK], then four words per tile: fired, pool done | count, stores done)
   constexpr int kLdsAtab = SF_LDS_DOUBLES + BLK, kLdsHand = kLdsAtab + SF_ATAB_DOUBLES, kLdsHandMeta = kLdsHand + 2 * BLK,
@@ -955,7 +956,8 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
     // At the metric's batch a wave is alone on its SIMD and everything it does is one dependent chain; the missile pool --
     // move, test, compact 64 entries a row, whoever owns them -- depends on the 64 games only through the missiles fired
     // this tick, and the games depend on it only through the owners' event words.  A split launch gives every tile a
-    // second wave on the same SIMD (threads 256..511 of the workgroup: wave w + 4 works for wave w's tile) that does
+    // second wave (threads BLK .. 2 BLK - 1 of the workgroup: wave w + BLK / 64 works for wave w's tile; with 256 envs per
+    // workgroup on the same SIMD, with fewer on one of the CU's idle ones) that does
     // exactly that part under the first wave's ship / fortress / shell arithmetic.  Hand-over through LDS, both ways by a
     // word the other side polls (a workgroup barrier would make the games wait for the pool's loads): the games' wave
     // files its new missiles and sets `fired`; the missile wave sets `done | entries kept` behind its last event word.
@@ -963,14 +965,20 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
     // What it buys is the first wave's issue bubbles, not the missiles' whole cost (removing them: -0.68 us; moving them
     // here: -0.12): in its arithmetic the first wave keeps the SIMD's one VALU busy most of the time, and the second wave's
     // instructions take the same issue slots.  Issue priority for the first wave and a later start for the pool's loads
-    // changed nothing measurable; starting them 1 500 cycles later made the games wait (tools/ab.py, NOTES.md).
+    // changed nothing measurable; starting them 1 500 cycles later made the games wait; asked for without waiting for the
+    // pool's count (SF_SPLIT_UNCOND): nothing either (tools/ab.py, NOTES.md, profiles/r04_split_ab.txt).
     if (tid_all >= (unsigned)BLK) {  // wave-uniform
       // the pool's count rides in every lane's misc chunk: lane 0's word, by a scalar load
       const unsigned n_word = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(
           reinterpret_cast<const __attribute__((address_space(4))) void*>(
               (unsigned long long)(tb + (unsigned)sfl::chunk_offset(SF_G_misc, 0) + 8u)));
-      const unsigned cpi0 = min(tid_all, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
-      const d2_t cst0 = SF_LD(d2_t, (const unsigned char*)consts_p, cpi0 * 16u);
+      unsigned cpi0[kTrigPieces];  // (this wave's share of the cos/sin table's pieces: one with 512 threads, up to three)
+      d2_t cst0[kTrigPieces];
+#pragma unroll
+      for (int k = 0; k < kTrigPieces; k++) {
+        cpi0[k] = min(tid_all + k * NT, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
+        cst0[k] = SF_LD(d2_t, (const unsigned char*)consts_p, cpi0[k] * 16u);
+      }
       const unsigned m_live = n_word >> SF_MPOOL_SHIFT;
       d2_t prow[SF_MROWS];
       unsigned pmeta[SF_MROWS];
@@ -978,7 +986,8 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
 #define SF_SPLIT_LATE 1 /* the pool's rows are asked for once the table piece is in, i.e. behind the launch's first burst */
 #endif
 #if SF_SPLIT_LATE
-      reinterpret_cast<d2_t*>(lds)[cpi0] = cst0;
+#pragma unroll
+      for (int k = 0; k < kTrigPieces; k++) reinterpret_cast<d2_t*>(lds)[cpi0[k]] = cst0[k];
       if (lane < 4u) hflags[lane] = 0u;
 #if SF_SPLIT_LATE > 1
       __builtin_amdgcn_s_sleep(SF_SPLIT_LATE);
@@ -986,12 +995,16 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
 #endif
 #pragma unroll
       for (int r = 0; r < SF_MROWS; r++) {
-        const bool in_ = 64u * r + lane < m_live;
+#ifndef SF_SPLIT_UNCOND
+#define SF_SPLIT_UNCOND 0 /* A/B: the rows asked for whatever the pool's count is (no wait for the count in front of them) */
+#endif
+        const bool in_ = SF_SPLIT_UNCOND || 64u * r + lane < m_live;
         prow[r] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, in_ ? o.o16 : SF_OOB, SF_GOFF(missile_pos, r), 0));
         pmeta[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_ ? o.o4 : SF_OOB, SF_GOFF(missile_meta, r), 0);
       }
 #if !SF_SPLIT_LATE
-      reinterpret_cast<d2_t*>(lds)[cpi0] = cst0;
+#pragma unroll
+      for (int k = 0; k < kTrigPieces; k++) reinterpret_cast<d2_t*>(lds)[cpi0[k]] = cst0[k];
       if (lane < 4u) hflags[lane] = 0u;
 #endif
       __syncthreads();  // (the workgroup's one barrier: the cos/sin table is in LDS, the hand-over words are zero)
@@ -1095,7 +1108,7 @@ __global__ __launch_bounds__(BLKP) void sf_step_kernel(unsigned char* state_p, c
   unsigned cpi[kTrigPieces];
 #pragma unroll
   for (int k = 0; k < kTrigPieces; k++) {
-    cpi[k] = min(tid_all + k * BLKP, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
+    cpi[k] = min(tid_all + k * NT, (unsigned)(SF_LDS_DOUBLES / 2 - 1));
     cst[k] = SF_LD(d2_t, cb, cpi[k] * 16u);
   }
   // (behind the last load of the early set: the ten rounds run while those are in flight)
@@ -2200,19 +2213,17 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
   // (SF_SPLIT 2, for tests: every batch it can serve)
   // (SFMI_FORCE_SPLIT=1 in the environment, for tests: every batch the instantiation can serve; =2 says so once on stderr)
   static const int force_split = [] { const char* e = getenv("SFMI_FORCE_SPLIT"); return e ? atoi(e) : 0; }();
-  const bool split = SF_SPLIT && !fused && fast_obs && !xtra && ((blk == SF_BLOCK && a.lanes <= 65536) || SF_SPLIT == 2 || force_split) &&
-                     a.draw == nullptr;
+  const bool split = SF_SPLIT && !fused && fast_obs && !xtra && (a.lanes <= 65536 || SF_SPLIT == 2 || force_split) && a.draw == nullptr;
   if (split && force_split == 2) {
     static bool said = false;
     if (!said) fprintf(stderr, "sfmi: split launch (%ld lanes)\n", (long)a.lanes);
     said = true;
   }
-  if (split) blk = SF_BLOCK;
   const unsigned grid = (unsigned)(a.lanes / blk);
   size_t lds_bytes = (size_t)(SF_LDS_DOUBLES + blk + SF_ATAB_DOUBLES) * sizeof(double) + (size_t)blk * a.obs_dim * elem;
-  if (split) lds_bytes += (size_t)(2 * SF_BLOCK + SF_BLOCK / 2 + SF_BLOCK / 32) * sizeof(double);
+  if (split) lds_bytes += (size_t)(2 * blk + blk / 2 + blk / 32) * sizeof(double);
 #define SF_GO2(AT, SH, FU, OK, XT, BL)                                                                             \
-  hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, OK, XT, BL>), dim3(grid), dim3(BL), lds_bytes, stream, a.state,    \
+  hipLaunchKernelGGL((sf_step_kernel<AT, SH, FU, OK, XT, BL>), dim3(grid), dim3((BL) > 1000 ? 2 * ((BL) - 1000) : (BL)), lds_bytes, stream, a.state,    \
                      a.consts, actions, a.n_envs, act_type, reward, done, info, a, obs, vec_ok, n_steps)
 #define SF_GO1(AT, SH, FU, OK, XT)                                                                                 \
   do {                                                                                                             \
@@ -2221,7 +2232,12 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
     else SF_GO2(AT, SH, false, OK, XT, 64);                                                                        \
   } while (0)
 #if SF_SPLIT
-#define SF_GO_SPLIT(AT, SH) if (split) SF_GO2(AT, SH, false, 1, false, 512); else
+#define SF_GO_SPLIT(AT, SH)                                                                                        \
+  if (split) {                                                                                                     \
+    if (blk == SF_BLOCK) SF_GO2(AT, SH, false, 1, false, 1256);                                                    \
+    else if (blk == 128) SF_GO2(AT, SH, false, 1, false, 1128);                                                    \
+    else SF_GO2(AT, SH, false, 1, false, 1064);                                                                    \
+  } else
 #else
 #define SF_GO_SPLIT(AT, SH)
 #endif

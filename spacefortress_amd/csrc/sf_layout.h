@@ -314,7 +314,7 @@ struct SfKernelArgs {
 // words of SfKernelArgs::acc behind the SF_EPISODE_STATS_LEN (8) episode statistics
 #define SF_ACC_BAD_ACTION 8 /* actions outside [0, n_actions) that ran as NOOP (sf_check_actions) */
 #define SF_ACC_OVERFLOW 9   /* times a packed per-episode field of some env left its bits: counted on the tick it wraps (sf_check_state; sticky until sf_reset) */
-#define SF_ACC_HANDOVER 10 /* split launches (sf_step_kernel<..., 512>): polls of a hand-over word that gave up (sf_check_state; never seen) */
+#define SF_ACC_HANDOVER 10 /* split launches (sf_step_kernel<..., 1000 + BLK>): polls of a hand-over word that gave up (sf_check_state; never seen) */
 #define SF_ACC_WORDS 11
 
 // act_type of the step kernel when the lanes draw their own actions (sf_step_sampled): `actions` then points at one

@@ -909,10 +909,10 @@ def test_every_workgroup_size_plays_the_same_games(sfa, oracle_mod, gametype, ob
 
 
 def test_split_launches_on_every_scenario():
-    """Batches of 32 769 .. 65 536 envs step by SPLIT launches (sf_step_kernel<..., 512>: a second wave per tile moves the
-    missile pool and hands its events over through LDS).  The scenarios of this file run small batches, which never split;
-    here they run again in a child process with SFMI_FORCE_SPLIT=2 -- the launcher then splits every batch the
-    instantiation serves (features, float32, auto-reset) and says so on stderr: goldens, random and hunter lock-steps,
+    """Batches up to 65 536 envs step by SPLIT launches (sf_step_kernel<..., 1000 + BLK>: a second wave per tile moves the
+    missile pool and hands its events over through LDS), which is what every test of the default observation in this file
+    runs on; here the scenarios run again in a child process with SFMI_FORCE_SPLIT=2 -- the launcher then splits every batch
+    the instantiation serves, the ones beyond 65 536 envs too, and says so on stderr: goldens, random and hunter lock-steps,
     exhausted slots, pools beyond three rows, lanes of a tile finishing at different ticks (the purge that re-reads the rows
     the missile wave wrote), fuzzed states."""
     import subprocess

@@ -47,8 +47,8 @@ rep["note"] = ("per-dispatch durations (End - Start timestamps) from the same ro
                "kernel_stats csv, whose sf_step_kernel row mixes this workload's launches with those of bench.py's other legs; "
                "command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 512 --warmup 100 --repeats 8 --launch graph --no-cpu-baseline")
 json.dump(rep, open(os.path.join(out, "%s_kernel_trace_%s_step65536.json" % (rnd, ver)), "w"), indent=1)
-# (a split launch -- sf_step_kernel<..., 512>, 131 072 threads for 65 536 envs -- where the library steps that way)
-main = [k for k in rep if k.endswith("grid 131072") and ", false, 1, false, 512>" in k] or \
+# (a split launch -- sf_step_kernel<..., 1256>, 131 072 threads for 65 536 envs -- where the library steps that way)
+main = [k for k in rep if k.endswith("grid 131072") and ", false, 1, false, 1256>" in k] or \
        [k for k in rep if k.endswith("grid 65536") and ", false, 1, false, 256>" in k]
 t = json.load(open(os.path.join(out, "%s_pmc_traffic_%s.json" % (rnd, ver))))
 latest = {"version": "%s_%s" % (rnd, ver), "workload": t["workload"], "kernel": "sf_step_kernel",
