@@ -968,6 +968,12 @@ __global__ __launch_bounds__(BLKP > 1000 ? 2 * (BLKP - 1000) : BLKP) void sf_ste
     // changed nothing measurable; starting them 1 500 cycles later made the games wait; asked for without waiting for the
     // pool's count (SF_SPLIT_UNCOND): nothing either (tools/ab.py, NOTES.md, profiles/r04_split_ab.txt).
     if (tid_all >= (unsigned)BLK) {  // wave-uniform
+#ifndef SF_SPLIT_PPRIO
+#define SF_SPLIT_PPRIO 0 /* A/B: the missile wave at this issue priority (s_setprio): the tiles with the fullest pools are the launch's last */
+#endif
+#if SF_SPLIT_PPRIO
+      __builtin_amdgcn_s_setprio(SF_SPLIT_PPRIO);
+#endif
       // the pool's count rides in every lane's misc chunk: lane 0's word, by a scalar load
       const unsigned n_word = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(
           reinterpret_cast<const __attribute__((address_space(4))) void*>(

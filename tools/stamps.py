@@ -43,7 +43,9 @@ def main():
     global DIAG
     if a.lite:
         DIAG = DIAG.replace("_stamps.so", "_stamps_lite.so")
-    if not os.path.exists(DIAG) or a.build_only:
+    if os.environ.get("SF_STAMPS_LIB"):  # a -DSF_STAMPS build made elsewhere (tools/variant.py NAME -DSF_STAMPS ...)
+        DIAG = os.path.abspath(os.environ["SF_STAMPS_LIB"])
+    elif not os.path.exists(DIAG) or a.build_only:
         DIAG = DIAG.replace("_stamps_lite.so", "_stamps.so")
         build(a.lite)
     if a.build_only:
