@@ -1021,14 +1021,43 @@ __device__ __forceinline__ Pieces load_pieces(const uint4* src, int n, int lane)
   return Pieces{src[min(lane, last)],       src[min(lane + 64, last)],  src[min(lane + 128, last)], src[min(lane + 192, last)],
                 src[min(lane + 256, last)], src[min(lane + 320, last)], src[min(lane + 384, last)]};
 }
+#ifndef SF_FRAME_NT
+#define SF_FRAME_NT 1 /* the 84x84 background's stores leave non-temporal when the frame is a slot of a frame stack (out_stride >
+                         a frame): the 4-frame ring of 16 384 envs is 462 MB that cycle through the 256 MB Infinity Cache and
+                         push out what the step and the frame kernel read every step -- 52.3 -> 51.2 us per step into the
+                         ring.  A flat output (115 MB, rewritten in place every step) stays resident and wants plain stores:
+                         non-temporal there costs +1.1 us.  0: always plain; 2: always non-temporal (A/B) */
+#endif
+template <bool NT>
+__device__ __forceinline__ void store_piece(uint4* p, const uint4& v) {
+  if (NT) {
+    typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(u4v_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u4v_t*>(p));
+  } else {
+    *p = v;
+  }
+}
+// (the non-temporal form stores last piece first: written in the same order, the optimiser finds the two branches of the
+//  caller's `if` starting with identical stores, hoists them in front of it and drops the hint they do not share)
+template <bool NT = false>
 __device__ __forceinline__ void store_pieces(const Pieces& p, uint4* dst, int n, int lane) {
-  if (lane < n) dst[lane] = p.v0;
-  if (lane + 64 < n) dst[lane + 64] = p.v1;
-  if (lane + 128 < n) dst[lane + 128] = p.v2;
-  if (lane + 192 < n) dst[lane + 192] = p.v3;
-  if (lane + 256 < n) dst[lane + 256] = p.v4;
-  if (lane + 320 < n) dst[lane + 320] = p.v5;
-  if (lane + 384 < n) dst[lane + 384] = p.v6;
+  if (NT) {
+    if (lane + 384 < n) store_piece<true>(dst + lane + 384, p.v6);
+    if (lane + 320 < n) store_piece<true>(dst + lane + 320, p.v5);
+    if (lane + 256 < n) store_piece<true>(dst + lane + 256, p.v4);
+    if (lane + 192 < n) store_piece<true>(dst + lane + 192, p.v3);
+    if (lane + 128 < n) store_piece<true>(dst + lane + 128, p.v2);
+    if (lane + 64 < n) store_piece<true>(dst + lane + 64, p.v1);
+    if (lane < n) store_piece<true>(dst + lane, p.v0);
+    return;
+  }
+  if (lane < n) store_piece<false>(dst + lane, p.v0);
+  if (lane + 64 < n) store_piece<false>(dst + lane + 64, p.v1);
+  if (lane + 128 < n) store_piece<false>(dst + lane + 128, p.v2);
+  if (lane + 192 < n) store_piece<false>(dst + lane + 192, p.v3);
+  if (lane + 256 < n) store_piece<false>(dst + lane + 256, p.v4);
+  if (lane + 320 < n) store_piece<false>(dst + lane + 320, p.v5);
+  if (lane + 384 < n) store_piece<false>(dst + lane + 384, p.v6);
 }
 __device__ __forceinline__ void copy_pieces(const uint4* src, uint4* dst, int n, int lane) {
   store_pieces(load_pieces(src, n, lane), dst, n, lane);
@@ -1480,12 +1509,19 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   }
   // the 84x84 background's seven stores, behind everything: stores count like loads, in the same order -- in front of the
   // surface's loads, the wait for the surface would be a wait for their acknowledgement from HBM as well
-  if (RESIZE && !(SF_RENDER_SKIP & 8192)) store_pieces(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
+  if (RESIZE && !(SF_RENDER_SKIP & 8192)) {
+    if (SF_FRAME_NT == 2 || (SF_FRAME_NT == 1 && a.out_stride > (size_t)kOutBytes))  // uniform: a slot of a frame stack (SF_FRAME_NT)
+      store_pieces<true>(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
+    else
+      store_pieces<false>(frame0, reinterpret_cast<uint4*>(frame_out), kOutBytes / 16, lane);
+  }
   // the frame stack's older slots
-  const unsigned fin_b = (RESIZE && a.stack_done) ? (unsigned)__builtin_amdgcn_readfirstlane((int)fin_v) : 0u;
-  const bool stack_traffic = RESIZE && (a.stack_prev || fin_b != 0);  // more loads / stores behind the seven: see the wait below
+  // (the done flag is looked at where it costs nothing: behind the wait for the surface, below -- asked for in front of it, the
+  //  compiler's wait for that one byte counts only the loads it knows of and ends up waiting for part of the surface's ten as
+  //  well, with the strokes' arithmetic still to come: 1.4 us per step of a frame stack)
+  const bool stack_traffic = RESIZE && a.stack_prev;  // more loads / stores behind the seven: see the wait below
   if (RESIZE && a.stack_prev) {
-    const bool fin = fin_b != 0;
+    const bool fin = a.stack_done && __builtin_amdgcn_readfirstlane((int)fin_v) != 0;
     const uint4 z = {0u, 0u, 0u, 0u};
     const uint4* src = reinterpret_cast<const uint4*>(a.stack_prev + (size_t)env * a.out_stride + kOutBytes);
     uint4* dst = reinterpret_cast<uint4*>(frame_out - (ptrdiff_t)a.stack_slot * kOutBytes);
@@ -1495,13 +1531,6 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     } else {
       // a frame's worth of loads in flight, then its stores (a plain loop waits for each 16 bytes before the next load)
       for (int base = 0; base < n; base += 64 * kFrameRounds) copy_pieces(src + base, dst + base, n - base, lane);
-    }
-  } else if (RESIZE && fin_b != 0) {
-    const uint4 z = {0u, 0u, 0u, 0u};
-    for (int sl = 0; sl < a.stack_n; sl++) {
-      if (sl == a.stack_slot) continue;
-      uint4* dst = reinterpret_cast<uint4*>(frame_out + (ptrdiff_t)(sl - a.stack_slot) * kOutBytes);
-      for (int i = lane; i < kOutBytes / 16; i += 64) dst[i] = z;
     }
   }
 
@@ -1537,6 +1566,17 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  // a frame stack's finished env (`current_obs *= masks`, rl/train.py:92-93): its other slots are zeroed
+  if (RESIZE && a.stack_done && !a.stack_prev) {
+    if (__builtin_amdgcn_readfirstlane((int)fin_v) != 0) {
+      const uint4 z = {0u, 0u, 0u, 0u};
+      for (int sl = 0; sl < a.stack_n; sl++) {
+        if (sl == a.stack_slot) continue;
+        uint4* dst = reinterpret_cast<uint4*>(frame_out + (ptrdiff_t)(sl - a.stack_slot) * kOutBytes);
+        for (int i = lane; i < kOutBytes / 16; i += 64) dst[i] = z;
+      }
+    }
+  }
   const Frame<RESIZE> F{fb, frame_out, tabw, nullptr, lane, srec, slist, reinterpret_cast<uint32_t*>(srec) + Frame<RESIZE>::kLtabAt, lt_e};
   if (SF_RENDER_STOP == 1) return;
 
