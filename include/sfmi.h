@@ -123,7 +123,9 @@ int sf_reset(sf_batch* b, void* obs_dev, void* stream);
  *      worker's auto-reset (rl/train.py:80).  One fused kernel launch.
  *      actions_dev [n_envs] of act_type; obs_dev [n_envs, obs_dim]; reward_dev int32[n_envs];
  *      done_dev, info_dev uint8[n_envs] (info is the bare fort_kill bool, ENV:253).
- *      Any output pointer may be NULL. ---- */
+ *      Any output pointer may be NULL.  Every env plays the game it would play alone, whatever the batch's size and
+ *      however the launch is shaped for it (workgroups of 64 / 128 / 256 envs, a second wave per tile for the missile pool
+ *      up to 65 536 envs, several waves per SIMD beyond): checked between 1 and 1 048 576 envs per batch. ---- */
 int sf_step(sf_batch* b, const void* actions_dev, int act_type, void* obs_dev, int32_t* reward_dev,
             uint8_t* done_dev, uint8_t* info_dev, void* stream);
 
