@@ -604,8 +604,11 @@ static void draw_spawn_discard(sfo_env* e) {
   sfo_game_init(&tmp, &e->cfg, &e->rng);
 }
 
-int sfo_env_init(sfo_env* e, const char* gametype, int action_set, int obs_type, unsigned seed,
-                 int spawn_skip) {
+/* `from`: the libc stream where this env's process stands when its first Game is made, or NULL = srand(seed) advanced by
+ * spawn_skip spawns.  (sfo_vec_create hands every env a COPY of one stream it advances once, lane by lane: the same state
+ * as seeding each env anew and skipping spawn_skip + i * spawn_stride spawns, in O(n * stride) instead of O(n^2).) */
+static int env_init_from(sfo_env* e, const char* gametype, int action_set, int obs_type, unsigned seed, int spawn_skip,
+                         const sfo_rng* from) {
   int i;
   memset(e, 0, sizeof(*e));
   if (sfo_preset(gametype, &e->cfg) != 0) return -1;
@@ -643,10 +646,19 @@ int sfo_env_init(sfo_env* e, const char* gametype, int action_set, int obs_type,
   e->prev_vlner = 0;                      /* ENV:92 */
   e->pb_width = (int)(450 * .2);          /* ENV:57 */
   e->pb_height = (int)(460 * .2);         /* ENV:58 */
-  sfo_srand(&e->rng, seed);
-  for (i = 0; i < spawn_skip; i++) draw_spawn_discard(e);
+  if (from) {
+    e->rng = *from;
+  } else {
+    sfo_srand(&e->rng, seed);
+    for (i = 0; i < spawn_skip; i++) draw_spawn_discard(e);
+  }
   sfo_game_init(&e->g, &e->cfg, &e->rng); /* ENV:93 -> reset() -> ENV:164 */
   return 0;
+}
+
+int sfo_env_init(sfo_env* e, const char* gametype, int action_set, int obs_type, unsigned seed,
+                 int spawn_skip) {
+  return env_init_from(e, gametype, action_set, obs_type, seed, spawn_skip, NULL);
 }
 
 int sfo_env_obs_dim(const sfo_env* e) {
@@ -787,13 +799,26 @@ sfo_vec_env* sfo_vec_create(const char* gametype, int n, int action_set, int obs
   v->n = n;
   v->envs = (sfo_env*)calloc((size_t)n, sizeof(sfo_env));
   if (!v->envs) { free(v); return NULL; }
-  for (i = 0; i < n; i++) {
-    if (sfo_env_init(&v->envs[i], gametype, action_set, obs_type, seed, spawn_skip + i * spawn_stride) != 0) {
+  {
+    /* one stream, advanced once: lane i starts where srand(seed) stands after spawn_skip + i * spawn_stride spawns */
+    sfo_env walker;
+    int k;
+    if (env_init_from(&walker, gametype, action_set, obs_type, seed, spawn_skip, NULL) != 0) {
       free(v->envs);
       free(v);
       return NULL;
     }
-    v->envs[i].g.rng = &v->envs[i].rng;
+    sfo_srand(&walker.rng, seed); /* (env_init_from drew the walker's own first Game: start over, skip only) */
+    for (k = 0; k < spawn_skip; k++) draw_spawn_discard(&walker);
+    for (i = 0; i < n; i++) {
+      if (env_init_from(&v->envs[i], gametype, action_set, obs_type, seed, 0, &walker.rng) != 0) {
+        free(v->envs);
+        free(v);
+        return NULL;
+      }
+      v->envs[i].g.rng = &v->envs[i].rng;
+      for (k = 0; k < spawn_stride; k++) draw_spawn_discard(&walker);
+    }
   }
   return v;
 }

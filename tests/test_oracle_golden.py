@@ -248,3 +248,31 @@ def test_oracle_vs_reference_live_kills(oracle_mod, gametype):
         else:
             # 0 big-hex, 1 small-hex, 2 shell deaths, 3 ship deaths (autoturn ships charge INTO the small hexagon)
             assert tot[0] + tot[1] >= 100 and tot[0] >= 1 and tot[1] >= 1 and tot[2] >= 1 and tot[3] == tot[:3].sum(), (gametype, tot)
+
+
+@pytest.mark.parametrize("gametype", ["youturn", "autoturn"])
+def test_vec_oracle_lanes_are_single_envs(oracle_mod, gametype):
+    """OracleVecEnv hands lane i a copy of ONE libc stream advanced lane by lane (O(n * stride) to create instead of seeding
+    every lane anew and skipping spawn_skip + i * spawn_stride spawns: 65 536 lanes in a second instead of minutes).  Lane i
+    must be OracleEnv(spawn_skip = spawn_skip + i * spawn_stride): same first spawn, same game over 400 random steps
+    (ship deaths draw further spawns from the lane's own copy), same snapshot."""
+    O = oracle_mod
+    n, skip, stride, T = 24, 2, 3, 400
+    rng = np.random.default_rng(3)
+    v = O.OracleVecEnv(gametype, n, spawn_skip=skip, spawn_stride=stride)
+    n_act = 5 if gametype == "youturn" else 3
+    acts = np.where(rng.random((T, n)) < 0.5, 2, rng.integers(0, n_act, (T, n))).astype(np.int32)  # (thrust: deaths, respawns)
+    ob0 = v.reset()
+    outs = [v.step(acts[t]) for t in range(T)]
+    snaps = v.snapshots()
+    for i in (0, 1, 5, 23):
+        e = O.OracleEnv(gametype, spawn_skip=skip + i * stride)
+        assert np.array_equal(e.reset(), ob0[i])
+        for t in range(T):
+            o, r, d, info = e.step(int(acts[t, i]))
+            assert np.array_equal(o, outs[t][0][i]) and r == outs[t][1][i] and bool(d) == bool(outs[t][2][i]), (i, t)
+            if d:
+                e.reset()
+        assert e.snapshot().tobytes() == snaps[i].tobytes(), i
+    assert int(snaps["stats"][:, 3].sum()) > 0  # ships died: the respawn draws were exercised
+

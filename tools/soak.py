@@ -4,8 +4,8 @@ tolerance), the full state at every chunk end.  python tools/soak.py [gametype] 
 `hunter`: an open-loop firing pattern per lane (a shot every 8 ticks = 272 ms > the 250 ms vulnerability window
 until the fortress is kill-ready, then a double shot), random phase per lane, 10 % of the actions random: thousands
 of fortress kills, resets and misses instead of the handful random play produces.
-(The oracle finds lane i's spawn by skipping 1 + 3 i accepted spawns from the seed: O(lanes^2) before the first step -- a minute
-at 40 960 lanes, many at 65 536.  Bigger batches: tools/big_batch_soak.py, device against device.)"""
+(The oracle steps 1.7e6 envs/s on one core: 65 536 lanes x 3 000 steps take two minutes.  Bigger batches:
+tools/big_batch_soak.py, device against device.)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
