@@ -860,6 +860,33 @@ def test_batches_beyond_one_wave_per_simd(sfa, oracle_mod, gametype, obs_type):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("gametype", ["youturn", "autoturn"])
+def test_full_size_every_lane_vs_oracle(sfa, oracle_mod, gametype):
+    """BASELINE.json's batch, ALL 65 536 lanes in lock-step with the oracle (its vector env is created in O(n) since round 4):
+    240 steps of hunter play -- every reward, done, info and observation of every lane at every step, the full state of every
+    lane at the end.  (tools/soak.py does the same for thousands of steps: profiles/r04_soak_65536.txt.)"""
+    from sfscript import open_loop_actions
+
+    O = oracle_mod
+    n, T = 65536, 240
+    rng = np.random.default_rng(41 + len(gametype))
+    env = sfa.SFVecEnv(n, gametype=gametype, spawn_stride=1)
+    orc = O.OracleVecEnv(gametype, n, spawn_stride=1)
+    acts = open_loop_actions("hunter", (T, n), env.n_actions, rng, phase=rng.integers(0, 96, n))
+    assert obs_close(env.reset().cpu().numpy(), orc.reset(), False).all()
+    obs, rew, done, info = run_device(env, acts)
+    for t in range(T):
+        oo, orw, od, oi = orc.step(acts[t].astype(np.int32))
+        assert np.array_equal(rew[t], orw), (t, np.flatnonzero(rew[t] != orw)[:5])
+        assert np.array_equal(done[t], od) and np.array_equal(info[t], oi), t
+        ok = obs_close(obs[t], oo, False)
+        assert ok.all(), (t, np.argwhere(~ok)[:5])
+    bad = compare_state(env.state_dict(), orc.snapshots())
+    assert not bad, bad
+    assert info.sum() > (200 if gametype == "autoturn" else 0)
+    env.close()
+
+
 @pytest.mark.parametrize("gametype,obs_type,f64", [("youturn", "features", False), ("autoturn", "normalized-features", True),
                                                    ("youturn", "monitors", False)])
 def test_every_workgroup_size_plays_the_same_games(sfa, oracle_mod, gametype, obs_type, f64):
