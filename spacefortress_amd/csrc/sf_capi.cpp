@@ -745,17 +745,27 @@ extern "C" int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, in
     sf_set_error("sf_rollout: act_type must be 1, 4 or 8 (got %d)", act_type);
     return SF_ERR_ARG;
   }
-  if (is_image(b) && obs_dev) {
-    sf_set_error("sf_rollout: image observations are rendered from the state in HBM, one frame per sf_step; "
-                 "pass obs_dev = NULL");
-    return SF_ERR_ARG;
-  }
   if (n_steps <= 0 || (double)n_steps * b->n_envs * 8.0 >= 4294967296.0) {
     sf_set_error("sf_rollout: n_steps must be positive and n_steps * n_envs * 8 < 2^32 (got %d)", n_steps);
     return SF_ERR_ARG;
   }
   DeviceGuard guard(b->device);
   SF_FLUSH_VIEW(b, stream);
+  if (is_image(b) && obs_dev) {
+    // frames are rendered from the state in HBM, which the fused launch keeps in registers: with frames asked for, the K ticks
+    // go out as K step launches, each followed by its frames -- what K sf_step calls do, in one call
+    const size_t n = (size_t)b->n_envs, frame = (size_t)sf_obs_dim(b);
+    for (int t = 0; t < n_steps; t++) {
+      const size_t row = (size_t)t * n;
+      HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, (const unsigned char*)actions_dev + row * (size_t)act_type,
+                             act_type, nullptr, reward_dev ? reward_dev + row : nullptr, done_dev ? done_dev + row : nullptr,
+                             info_dev ? info_dev + row : nullptr, 1, false, (hipStream_t)stream));
+      b->draw_current = b->args.draw != nullptr;
+      const int rc = render(b, b->obs_mode, (uint8_t*)obs_dev + row * frame, 0, (hipStream_t)stream);
+      if (rc != SF_OK) return rc;
+    }
+    return SF_OK;
+  }
   HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, actions_dev, act_type, obs_dev, reward_dev, done_dev, info_dev,
                          n_steps, true, (hipStream_t)stream));
   b->draw_current = b->args.draw != nullptr;  // (an image batch's step launch leaves the draw records of the new state)

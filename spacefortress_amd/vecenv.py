@@ -151,7 +151,8 @@ class SFVecEnv:
         """K steps whose actions are all known up front, fused into one launch (sfmi.h: sf_rollout).
         `actions`: contiguous uint8/int32/int64 tensor [K, N] on this device.  Returns
         (obs [K, N, obs_dim] or None, reward int32 [K, N], done uint8 [K, N], info uint8 [K, N]);
-        bit-identical to K `step_tensors` calls."""
+        bit-identical to K `step_tensors` calls.  (An image batch with want_obs gets its frames [K, N, h, w] from K step
+        launches each followed by its frames -- the fused launch keeps the state in registers --, in the one call.)"""
         if actions.device != self.device or not actions.is_contiguous() or actions.dim() != 2 \
                 or actions.shape[1] != self.num_envs:
             raise ValueError("actions must be a contiguous [K, %d] tensor on %s" % (self.num_envs, self.device))
@@ -162,9 +163,6 @@ class SFVecEnv:
         if out is not None:
             obs, rew, done, info = out
         else:
-            if self.is_image and want_obs:
-                raise ValueError("rollout() keeps the state in registers between ticks; image frames are rendered "
-                                 "from the state in HBM, one per step(): pass want_obs=False")
             obs = torch.empty((K, n) + self.obs_shape, dtype=self.obs_dtype, device=self.device) if want_obs else None
             rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
             done = torch.empty((K, n), dtype=torch.uint8, device=self.device)

@@ -170,11 +170,25 @@ def test_image_env_surfaces(sfa):
     o, r, d, i = v.step(np.zeros(5, np.int64))
     assert o.shape == (5, 1, 84, 84) and o.dtype == np.uint8 and r.dtype == np.int64
     assert np.array_equal(o, v.render("image").cpu().numpy())
-    with pytest.raises(ValueError):
-        v.rollout(torch.zeros((4, 5), dtype=torch.uint8, device=v.device))
     ob, rw, dn, inf = v.rollout(torch.zeros((4, 5), dtype=torch.uint8, device=v.device), want_obs=False)
     assert ob is None and rw.shape == (4, 5)
     v.close()
+    # a rollout WITH frames: K step launches each followed by its frames, in the one call = K step_tensors calls
+    rng = np.random.default_rng(2)
+    acts = torch.from_numpy(rng.integers(0, 5, (40, 192)).astype(np.uint8)).cuda()
+    va, vb = sfa.SFVecEnv(192, obs_type="image", spawn_stride=1), sfa.SFVecEnv(192, obs_type="image", spawn_stride=1)
+    va.reset()
+    vb.reset()
+    ob, rw, dn, inf = va.rollout(acts)
+    assert ob.shape == (40, 192, 1, 84, 84) and ob.dtype == torch.uint8
+    for t in range(40):
+        o, r, d, i = vb.step_tensors(acts[t])
+        assert torch.equal(ob[t], o) and torch.equal(rw[t], r) and torch.equal(dn[t], d) and torch.equal(inf[t], i), t
+    assert torch.equal(va.render("image"), vb.render("image")) and ob[-1].max() > 0
+    for k, x in va.state_dict().items():
+        assert np.array_equal(x, vb.state_dict()[k]), k
+    va.close()
+    vb.close()
 
 
 def test_image_full_batch_properties(sfa):
