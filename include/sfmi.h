@@ -167,7 +167,7 @@ int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, 
  *      frames to obs_dev themselves (sf_obs_dim = 7056 / 8280 bytes per env); sf_rollout with
  *      obs_dev [n_steps][n_envs][frame] then issues its ticks as n_steps step launches, each followed
  *      by its frames (the fused launch keeps the state in registers), with obs_dev = NULL it stays fused;
- *      sf_rollout_sampled takes obs_dev = NULL only.  Pixel-level anti-aliasing is this library's own model: see
+ *      sf_rollout_sampled likewise.  Pixel-level anti-aliasing is this library's own model: see
  *      DESIGN.md "image observation". ---- */
 int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, void* stream);
 

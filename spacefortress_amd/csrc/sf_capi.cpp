@@ -757,7 +757,9 @@ extern "C" int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, in
     const size_t n = (size_t)b->n_envs, frame = (size_t)sf_obs_dim(b);
     for (int t = 0; t < n_steps; t++) {
       const size_t row = (size_t)t * n;
-      HIP_TRY(sf_launch_step(b->args, b->autoturn, b->preset.shaped != 0, (const unsigned char*)actions_dev + row * (size_t)act_type,
+      SfKernelArgs args = b->args;
+      if (args.events) args.events += row;  // (a rollout's event masks are [n_steps][n_envs], like its other outputs)
+      HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, (const unsigned char*)actions_dev + row * (size_t)act_type,
                              act_type, nullptr, reward_dev ? reward_dev + row : nullptr, done_dev ? done_dev + row : nullptr,
                              info_dev ? info_dev + row : nullptr, 1, false, (hipStream_t)stream));
       b->draw_current = b->args.draw != nullptr;
@@ -805,10 +807,6 @@ extern "C" int sf_rollout_sampled(sf_batch* b, int n_steps, uint8_t* actions_out
     sf_set_error("sf_rollout_sampled: null batch");
     return SF_ERR_ARG;
   }
-  if (is_image(b) && obs_dev) {
-    sf_set_error("sf_rollout_sampled: image observations are rendered one frame per sf_step; pass obs_dev = NULL");
-    return SF_ERR_ARG;
-  }
   if (n_steps <= 0 || (double)n_steps * b->n_envs >= 4294967296.0) {  // (no action array here: the outputs' 32-bit row offsets bound it)
     sf_set_error("sf_rollout_sampled: n_steps must be positive and n_steps * n_envs < 2^32 (got %d)", n_steps);
     return SF_ERR_ARG;
@@ -817,6 +815,24 @@ extern "C" int sf_rollout_sampled(sf_batch* b, int n_steps, uint8_t* actions_out
   SfKernelArgs args = b->args;
   args.act_out = actions_out_dev;
   SF_FLUSH_VIEW(b, stream);
+  if (is_image(b) && obs_dev) {
+    // with frames: n_steps sampled step launches, each followed by its frames (sf_rollout does the same); the tiles' tick
+    // counters move on by one per launch, so the actions drawn are the fused launch's
+    const size_t n = (size_t)b->n_envs, frame = (size_t)sf_obs_dim(b);
+    for (int t = 0; t < n_steps; t++) {
+      const size_t row = (size_t)t * n;
+      SfKernelArgs at = b->args;
+      at.act_out = actions_out_dev ? actions_out_dev + row : nullptr;
+      if (at.events) at.events += row;
+      HIP_TRY(sf_launch_step(at, b->autoturn, b->preset.shaped != 0, b->d_actrec, SF_ACT_SAMPLED, nullptr,
+                             reward_dev ? reward_dev + row : nullptr, done_dev ? done_dev + row : nullptr,
+                             info_dev ? info_dev + row : nullptr, 1, false, (hipStream_t)stream));
+      b->draw_current = b->args.draw != nullptr;
+      const int rc = render(b, b->obs_mode, (uint8_t*)obs_dev + row * frame, 0, (hipStream_t)stream);
+      if (rc != SF_OK) return rc;
+    }
+    return SF_OK;
+  }
   HIP_TRY(sf_launch_step(args, b->autoturn, b->preset.shaped != 0, b->d_actrec, SF_ACT_SAMPLED, obs_dev, reward_dev, done_dev,
                          info_dev, n_steps, true, (hipStream_t)stream));
   b->draw_current = b->args.draw != nullptr;  // (an image batch's step launch leaves the draw records of the new state)

@@ -262,8 +262,6 @@ class SFVecEnv:
     def rollout_sampled(self, n_steps, want_obs=True, want_actions=True):
         """`rollout` on sampled actions: K ticks in one launch.  Returns (obs, reward, done, info, actions uint8 [K, N])."""
         K, n = int(n_steps), self.num_envs
-        if self.is_image and want_obs:
-            raise ValueError("image frames are rendered one per step(): pass want_obs=False")
         obs = torch.empty((K, n) + self.obs_shape, dtype=self.obs_dtype, device=self.device) if want_obs else None
         rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
         done = torch.empty((K, n), dtype=torch.uint8, device=self.device)

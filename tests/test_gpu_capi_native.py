@@ -89,7 +89,6 @@ def test_new_entry_points_reject_bad_arguments():
     assert L.sf_set_event_output(env._h, p(buf, 2)) == _lib.SF_ERR_ARG
     a = torch.zeros(8, dtype=torch.uint8, device=env.device)
     assert L.sf_rollout(img._h, p(a), 1, 1, p(buf), None, None, None, None) == 0  # (with frames: step launches + frames, round 4)
-    assert L.sf_rollout_sampled(img._h, 1, None, p(buf), None, None, None, None) == _lib.SF_ERR_ARG  # sampled: fused only, no frames
     assert L.sf_step_record(env._h, p(a), 1, None, None, None, None, None, None, None, None, None, None) == _lib.SF_ERR_ARG
     assert L.sf_compute_returns(0, 8, None, None, None, None, None, 1, 0.99, 0.95, None) == _lib.SF_ERR_ARG
     z = C.c_void_p()

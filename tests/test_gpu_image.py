@@ -187,6 +187,19 @@ def test_image_env_surfaces(sfa):
     assert torch.equal(va.render("image"), vb.render("image")) and ob[-1].max() > 0
     for k, x in va.state_dict().items():
         assert np.array_equal(x, vb.state_dict()[k]), k
+    # ... and on actions drawn in the kernel, with the event masks of every step: the same stream as single sampled steps
+    va.seed_actions(9)
+    vb.seed_actions(9)
+    va.enable_events()
+    vb.enable_events()
+    ob, rw, dn, inf, pa = va.rollout_sampled(12)
+    ev = va.rollout_events  # [12, N]: one row of masks per tick
+    assert ev is not None and tuple(ev.shape) == (12, 192)
+    for t in range(12):
+        pb = torch.empty(192, dtype=torch.uint8, device=vb.device)
+        o, r, d, i = vb.step_sampled(actions_out=pb)
+        assert torch.equal(ob[t], o) and torch.equal(rw[t], r) and torch.equal(pa[t], pb), t
+        assert torch.equal(ev[t], vb.events), t
     va.close()
     vb.close()
 
