@@ -271,3 +271,72 @@ long sfref_rollout(void* h, long n_steps, unsigned lcg_seed) {
 }
 
 }  // extern "C"
+
+/* Write a snapshot INTO the reference game (its members are public): every field sfref_snapshot reads.
+ * Lets the fixtures place the reference's own objects anywhere (a ship at every heading, crowded pools). */
+extern "C" void sfref_load_snapshot(void* h, const sfo_snapshot* s) {
+  Game* g = ((RefGame*)h)->game;
+  g->mTime = s->time;
+  g->mTick = s->tick;
+  g->mShip.mAlive = s->ship_alive;
+  g->mShip.mPos.mX = s->ship_x;
+  g->mShip.mPos.mY = s->ship_y;
+  g->mShip.mVel.mX = s->ship_vx;
+  g->mShip.mVel.mY = s->ship_vy;
+  g->mShip.mAngle = s->ship_angle;
+  g->mShip.mDeathTimer = s->ship_death_timer;
+  g->mFortress.mAlive = s->fort_alive;
+  g->mFortress.mAngle = s->fort_angle;
+  g->mFortress.mLastAngle = s->fort_last_angle;
+  g->mFortress.mTimer = s->fort_timer;
+  g->mFortress.mDeathTimer = s->fort_death_timer;
+  g->mFortress.mVulnerabilityTimer = s->fort_vuln_timer;
+  g->mScore.mPoints = s->points;
+  g->mScore.mRawPoints = s->raw_points;
+  g->mScore.mVulnerability = s->vlner;
+  for (int i = 0; i < MAX_MISSILES; i++) {
+    g->mMissiles[i].mAlive = s->missile_alive[i];
+    g->mMissiles[i].mPos.mX = s->missile_x[i];
+    g->mMissiles[i].mPos.mY = s->missile_y[i];
+    g->mMissiles[i].mVel.mX = s->missile_vx[i];
+    g->mMissiles[i].mVel.mY = s->missile_vy[i];
+    g->mMissiles[i].mAngle = s->missile_angle[i];
+  }
+  for (int i = 0; i < MAX_SHELLS; i++) {
+    g->mShells[i].mAlive = s->shell_alive[i];
+    g->mShells[i].mPos.mX = s->shell_x[i];
+    g->mShells[i].mPos.mY = s->shell_y[i];
+    g->mShells[i].mVel.mX = s->shell_vx[i];
+    g->mShells[i].mVel.mY = s->shell_vy[i];
+    g->mShells[i].mAngle = s->shell_angle[i];
+  }
+}
+
+#ifdef SFREF_WITH_DRAW
+/* Only in oracle/_ref/libsfrefdraw.so (`make refdraw`): the reference's REAL renderer -- draw.cpp and wireframe.cpp
+ * compiled where they lie and linked with the image's cairo 1.16 (/opt/conda).  What `Game.draw` + `pb_pixels` do
+ * (SRC/pymodule.cpp:242-254, :351): newPixelBuffer(width, height, viewport, line width, grayscale), initWireframes()
+ * (:485), drawGameStateScaled (SRC/draw.cpp:256-270); out = byte 0 of every RGB24 pixel, which in grayscale mode is
+ * what cv2.COLOR_RGBA2GRAY leaves of it (ENV:205: R = G = B).  `out` holds width * height bytes, row-major. */
+#include <cairo/cairo.h>
+extern "C" int sfref_draw_geom(void* h, int width, int height, int vp_x, int vp_y, int vp_w, int vp_h,
+                               double line_width, int grayscale, int channel, unsigned char* out) {
+  initWireframes();
+  PixelBuffer* pb = newPixelBuffer(width, height, vp_x, vp_y, vp_w, vp_h, line_width, grayscale != 0);
+  if (!pb) return -1;
+  drawGameStateScaled(((RefGame*)h)->game, pb);
+  cairo_surface_flush(pb->surface);
+  const unsigned char* raw = (const unsigned char*)pb->raw;
+  for (int y = 0; y < pb->height; y++)
+    for (int x = 0; x < pb->width; x++) out[y * pb->width + x] = raw[y * pb->stride + 4 * x + channel];
+  freePixelBuffer(pb);
+  return 0;
+}
+
+/* SSF_Env's default: SSF_Env(scale=.2, viewport=(130,80,450,460), ls=3) -> Game(..., 3.0, True, 90, 92, viewport) (ENV:57-60) */
+extern "C" int sfref_draw(void* h, unsigned char* out) {
+  return sfref_draw_geom(h, 90, 92, 130, 80, 450, 460, 3.0, 1, 0, out);
+}
+
+extern "C" const char* sfref_cairo_version(void) { return cairo_version_string(); }
+#endif
