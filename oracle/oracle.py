@@ -16,6 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libsforacle.so")
 REF_SO = os.path.join(HERE, "_ref", "libsfref.so")
+REFDRAW_SO = os.path.join(HERE, "_ref", "libsfrefdraw.so")  # engine + the reference's REAL renderer (cairo): `make refdraw`
 
 MAXP = 20
 
@@ -129,6 +130,10 @@ def ref_lib():
         L.sfref_rollout.argtypes = [C.c_void_p, C.c_long, C.c_uint]
         _ref = L
     return _ref
+
+
+def have_refdraw():
+    return os.path.exists(REFDRAW_SO)
 
 
 def _ptr(a):
@@ -373,3 +378,58 @@ class RefGame(_GameApi):
         out = np.empty(24, np.float64)
         self.L.sfref_hex_points(self.h, _ptr(out))
         return out
+
+
+class RefDrawGame(RefGame):
+    """The reference engine AND its real renderer (SRC/draw.cpp, SRC/wireframe.cpp against the image's cairo 1.16):
+    oracle/_ref/libsfrefdraw.so, built by `make -C oracle refdraw` in the build container only.  Used by
+    tests/golden/frames/make_frames_golden.py to draw the frame fixtures and by the live frame tests."""
+
+    _lib = None
+
+    def __init__(self, gametype="youturn", seed=1, spawn_skip=0):
+        if RefDrawGame._lib is None:
+            L = C.CDLL(REFDRAW_SO)
+            L.sfref_create.restype = C.c_void_p
+            L.sfref_create.argtypes = [C.c_char_p, C.c_uint, C.c_int]
+            L.sfref_destroy.argtypes = [C.c_void_p]
+            L.sfref_new_game.argtypes = [C.c_void_p]
+            L.sfref_press_key.argtypes = [C.c_void_p, C.c_int]
+            L.sfref_release_key.argtypes = [C.c_void_p, C.c_int]
+            L.sfref_step_one_tick.argtypes = [C.c_void_p, C.c_int]
+            L.sfref_is_game_over.argtypes = [C.c_void_p]
+            L.sfref_snapshot.argtypes = [C.c_void_p, C.c_void_p]
+            L.sfref_load_snapshot.argtypes = [C.c_void_p, C.c_void_p]
+            L.sfref_hex_points.argtypes = [C.c_void_p, C.c_void_p]
+            L.sfref_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.sfref_rollout.restype = C.c_long
+            L.sfref_rollout.argtypes = [C.c_void_p, C.c_long, C.c_uint]
+            L.sfref_draw.argtypes = [C.c_void_p, C.c_void_p]
+            L.sfref_draw_geom.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_double, C.c_int, C.c_int, C.c_void_p]
+            L.sfref_cairo_version.restype = C.c_char_p
+            RefDrawGame._lib = L
+        self.L = RefDrawGame._lib
+        self.h = self.L.sfref_create(gametype.encode(), seed, spawn_skip)
+        if not self.h:
+            raise RuntimeError("unknown gametype %r" % (gametype,))
+        self.gametype = gametype
+        self.youturn = gametype in ("youturn", "test-youturn")
+
+    def load_snapshot(self, snap):
+        s = np.ascontiguousarray(snap, SNAPSHOT_DTYPE).reshape(())
+        self.L.sfref_load_snapshot(self.h, _ptr(s))
+
+    def draw(self, scale=None, viewport=(130, 80, 450, 460), ls=3.0, grayscale=True, channel=0):
+        """What Game.draw() + pb_pixels give SSF_Env._draw (ENV:203-206), one channel: [int(vh * scale)][int(vw * scale)] uint8."""
+        if scale is None:
+            out = np.zeros((92, 90), np.uint8)
+            assert self.L.sfref_draw(self.h, _ptr(out)) == 0
+            return out
+        w, h = int(viewport[2] * scale), int(viewport[3] * scale)
+        out = np.zeros((h, w), np.uint8)
+        assert self.L.sfref_draw_geom(self.h, w, h, int(viewport[0]), int(viewport[1]), int(viewport[2]), int(viewport[3]),
+                                      float(ls), int(grayscale), channel, _ptr(out)) == 0
+        return out
+
+    def cairo_version(self):
+        return self.L.sfref_cairo_version().decode()

@@ -1,47 +1,90 @@
-"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the image observation.
+"""TEST INFRASTRUCTURE ONLY -- the image observation, restated: what the reference draws and what cairo makes of it.
 
-What the reference draws, where, in which order and in which grey comes from its renderer
+What is drawn, where, in which order and in which grey comes from the reference's renderer
 (SRC = /root/reference/python/spacefortress/src):
 
-  drawGameStateScaled   SRC/draw.cpp:257-270   scale .2, translate (-130,-80), black paint
-  drawJustGameStuff     SRC/draw.cpp:227-255   hexagons, ship|explosion, fortress|explosion,
+  drawGameStateScaled   SRC/draw.cpp:256-270   scale(w / vp_w, h / vp_h), translate(-vp_x, -vp_y), black paint
+  drawJustGameStuff     SRC/draw.cpp:227-254   hexagons, ship|explosion, fortress|explosion,
                                                missiles, shells (only when > 21 from the fortress)
-  drawWireFrame         SRC/draw.cpp:112-129   translate, rotate(int angle), lines, one stroke
+  drawWireFrame         SRC/draw.cpp:82-100    translate, rotate(int angle), lines as separate sub-paths, ONE stroke
+  drawHexagon           SRC/draw.cpp:102-114   closed path, miter joins
   wireframes            SRC/wireframe.cpp:11-67
-  drawExplosion         SRC/draw.cpp:145-175
-  drawScore             SRC/draw.cpp:190-203   "%07d", grey .5
-  drawVlner             SRC/draw.cpp:205-225
+  drawExplosion         SRC/draw.cpp:116-145   84 arcs, each its own stroke, and the radius-7 circle
+  drawScore             SRC/draw.cpp:161-173   "%07d", grey .5
+  drawVlner             SRC/draw.cpp:207-225   two filled rectangles
   SSF_Env._draw         ENV:203-206            grey channel of the RGB24 surface, [92][90] uint8
   WrapPyTorch           rl/envs.py:28-30       cv2.resize(.., (84, 84), INTER_AREA)
 
-PARITY UNPINNED at the pixel level: cairo, freetype and cv2 are not in this image and the
-reference ships no frame fixtures.  Its documentation screenshot rl/imgs/screens.png (full colour, scale 1)
-pins the layout of the score text and the bar and the grey levels 128 / 84 / 168
-(tests/golden/telemetry/screens_layout.json); how a 0.6-pixel stroke turns into grey levels is a MODEL here -- exact area coverage of
-each stroke's rectangles, 8-bit OVER compositing, seven-segment digits for the score text, one chord
-per explosion arc and a 12-gon ring for its circle; INTER_AREA follows OpenCV's published algorithm (imgproc/resize.cpp,
-computeResizeAreaTab + resizeArea_).  This file restates that model independently of the HIP
-kernel (float64, polygon clipping instead of the kernel's edge integrals) so that the kernel can be
-checked against it; geometry-level checks (where the ship is, what lights up) are in the tests.
+HOW a stroke becomes grey levels is cairo's image backend (1.16.0 in this image).  oracle/cairo_model.c restates it
+(stroker, 15-sub-row scan converter with its full-row shortcut, box converter, 8-bit lerp) and is pinned bit for bit to the
+real library (tests/test_cairo_model.py) and to frames of the reference's real draw.cpp (tests/golden/frames/, made by
+make_frames_golden.py through oracle/_ref/libsfrefdraw.so): this module builds the draw script of a frame and runs it through
+that model.  PINNED: every pixel outside the score text.  NOT pinned: the score text itself -- cairo's toy font API resolves
+"monospace bold" through whatever fontconfig finds on the box, so its pixels are not a property of the reference; it is
+modelled as seven-segment glyphs of the same metrics (layout pinned to rl/imgs/screens.png) and its rows (0..8) are masked
+in every comparison with reference frames.  cv2 is not in this image: INTER_AREA follows OpenCV's published algorithm
+(imgproc/resize.cpp, computeResizeAreaTab + resizeArea_).
 """
+import ctypes as _C
+import os as _os
+import subprocess as _sp
 import math
 
 import numpy as np
 
 W, H, OUT = 90, 92, 84
-VP_X, VP_Y, SCALE, LINE_W = 130.0, 80.0, 0.2, 3.0
+VP_X, VP_Y, VP_W, VP_H, SCALE, LINE_W = 130.0, 80.0, 450.0, 460.0, 0.2, 3.0
+SX, SY = W / VP_W, H / VP_H  # newPixelBuffer: scale_x = width / vp_width, scale_y = height / vp_height (SRC/draw.cpp:70-71)
 FORT = (355.0, 315.0)
+TEXT_ROWS = 9  # rows 0..8 of the default 92 x 90 surface hold the score text: masked against reference frames
+
+HERE = _os.path.dirname(_os.path.abspath(__file__))
+MODEL_SO = _os.path.join(HERE, "libsfcairomodel.so")
+_model = None
+
+# the draw-script vocabulary of oracle/cairo_model.h
+(END, SAVE, RESTORE, SCALE_OP, TRANSLATE, ROTATE, LINE_WIDTH, GREY, MOVE_TO, LINE_TO, CLOSE, ARC, RECT, STROKE, FILL, PAINT,
+ CURVE_TO, NEW_PATH) = range(18)
+
+
+def model_lib():
+    global _model
+    if _model is None:
+        src = _os.path.join(HERE, "cairo_model.c")
+        if not _os.path.exists(MODEL_SO) or (_os.path.exists(src) and _os.path.getmtime(MODEL_SO) < _os.path.getmtime(src)):
+            _sp.check_call(["make", "-C", HERE, "liboracle"], stdout=_sp.DEVNULL)
+        L = _C.CDLL(MODEL_SO)
+        for f in ("cm_run", "cm_run_over"):
+            getattr(L, f).argtypes = [_C.c_void_p, _C.c_int, _C.c_int, _C.c_int, _C.c_void_p]
+        L.cm_last_polygon.argtypes = [_C.c_void_p, _C.c_int]
+        _model = L
+    return _model
+
+
+def run_script(script, w=None, h=None, onto=None):
+    """The script through oracle/cairo_model.c: a fresh black surface, or composited onto a copy of `onto`."""
+    w, h = W if w is None else w, H if h is None else h
+    s = np.ascontiguousarray(script, np.float64)
+    out = np.zeros((h, w), np.uint8) if onto is None else np.ascontiguousarray(onto, np.uint8).copy()
+    rc = (model_lib().cm_run if onto is None else model_lib().cm_run_over)(
+        s.ctypes.data_as(_C.c_void_p), len(s), w, h, out.ctypes.data_as(_C.c_void_p))
+    assert rc == 0, rc
+    return out
 
 
 def set_geometry(scale=.2, viewport=(130, 80, 450, 460), ls=3):
-    """The geometry SSF_Env(scale, viewport, ls) asks for (ENV:50-60): surface int(vw * scale) x int(vh * scale), device =
-    (user - (vx, vy)) * scale, line width ls user units.  Module-wide (the functions below read the globals); returns the
-    previous (scale, viewport, ls) so that a test can put it back."""
-    global W, H, VP_X, VP_Y, SCALE, LINE_W
-    prev = (SCALE, (VP_X, VP_Y, W / SCALE, H / SCALE), LINE_W)
-    VP_X, VP_Y, SCALE, LINE_W = float(viewport[0]), float(viewport[1]), float(scale), float(ls)
-    W, H = int(viewport[2] * scale), int(viewport[3] * scale)
+    """The geometry SSF_Env(scale, viewport, ls) asks for (ENV:50-60): surface int(vw * scale) x int(vh * scale)
+    (pymodule.cpp:351 -> newPixelBuffer), device = (user - (vx, vy)) * (w / vw, h / vh) -- NOT `scale` itself when vw * scale
+    is not whole (SRC/draw.cpp:70-71,259) --, line width ls user units.  Module-wide (the functions below read the globals);
+    returns the previous (scale, viewport, ls) so that a test can put it back."""
+    global W, H, VP_X, VP_Y, VP_W, VP_H, SCALE, LINE_W, SX, SY
+    prev = (SCALE, (VP_X, VP_Y, VP_W, VP_H), LINE_W)
+    VP_X, VP_Y, VP_W, VP_H = (float(v) for v in viewport)
+    SCALE, LINE_W = float(scale), float(ls)
+    W, H = int(VP_W * SCALE), int(VP_H * SCALE)
+    SX, SY = W / VP_W, H / VP_H
     return prev
+
 
 SHIP_LINES = [(-18, 0, 18, 0), (-18, 18, 0, 0), (0, 0, -18, -18)]
 FORT_LINES = [(0, 0, 36, 0), (0, -18, 18, -18), (18, -18, 18, 18), (18, 18, 0, 18)]
@@ -55,10 +98,83 @@ TXT_TOP = 97.0 - 0.5 * TXT_H
 SEGS = {"0": "ABCDEF", "1": "BC", "2": "ABDEG", "3": "ABCDG", "4": "BCFG", "5": "ACDFG", "6": "ACDEFG",
         "7": "ABC", "8": "ABCDEFG", "9": "ABCDFG", "-": "G"}
 
+M_PI = 3.14159265358979323846
 
+
+def deg2rad(a):
+    """SRC/vector.cpp:34-36"""
+    return a * M_PI / 180.0
+
+
+# ---- draw scripts: the calls of SRC/draw.cpp, one for one ---------------------------------------------------------------
+def s_begin():
+    """drawGameStateScaled up to the paint, SRC/draw.cpp:256-263"""
+    return [SCALE_OP, SX, SY, TRANSLATE, -VP_X, -VP_Y, LINE_WIDTH, LINE_W, GREY, 0.0, PAINT]
+
+
+def s_hexagon(pts, grey=1.0):
+    """drawHexagon, SRC/draw.cpp:102-114 (the line width is the context's: set in drawGameStateScaled)"""
+    pts = np.asarray(pts, np.float64).reshape(6, 2)
+    s = [GREY, grey, MOVE_TO, pts[0, 0], pts[0, 1]]
+    for x, y in pts[1:]:
+        s += [LINE_TO, x, y]
+    return s + [CLOSE, STROKE]
+
+
+def s_wireframe(lines, pos, angle, grey=1.0):
+    """drawWireFrame, SRC/draw.cpp:82-100: `angle` arrives as an int (a double heading is truncated by the call)"""
+    s = [SAVE, TRANSLATE, float(pos[0]), float(pos[1]), ROTATE, deg2rad(int(angle)), LINE_WIDTH, LINE_W, GREY, grey]
+    for ax, ay, bx, by in lines:
+        s += [MOVE_TO, ax, ay, LINE_TO, bx, by]
+    return s + [STROKE, RESTORE]
+
+
+def explosion_arcs():
+    """(radius, start degree, end degree, grey) of the 84 arcs of drawExplosion, SRC/draw.cpp:121-137."""
+    arcs, ofs = [], 0
+    for radius in range(15, 70, 8):
+        ofs += 3
+        grey = 191 if radius < 60 else 128  # .75 (yellow in colour mode), .5 (red)
+        for angle in range(0, 360, 30):
+            arcs.append((radius, angle + ofs, angle + ofs + 10, grey))
+    return arcs
+
+
+def s_explosion(pos):
+    """drawExplosion, SRC/draw.cpp:116-145: every arc is stroked on its own; the line width STAYS set for what follows"""
+    x, y = float(pos[0]), float(pos[1])
+    s = [LINE_WIDTH, float(np.float32(LINE_W))]  # `float ls`
+    for radius, a0, a1, grey in explosion_arcs():
+        s += [GREY, .75 if grey == 191 else .5, ARC, x, y, float(radius), deg2rad(a0), deg2rad(a1), STROKE]
+    return s + [GREY, .75, ARC, x, y, 7.0, 0.0, M_PI * 2, STROKE]
+
+
+def s_bar(vlner, kill):
+    """drawVlner, SRC/draw.cpp:207-225"""
+    return [LINE_WIDTH, float(np.float32(LINE_W)) - 1, GREY, .33, RECT, 355.0 - 100, 335.0 + 187, 200.0, 10.0, FILL,
+            GREY, 1.0 if kill else .66, RECT, 355.0 - 100, 335.0 + 187, float(20 * (10 if vlner > 10 else vlner)), 10.0, FILL]
+
+
+def s_objects(snap):
+    """drawJustGameStuff after the hexagons, SRC/draw.cpp:233-253"""
+    s = []
+    ship = (float(snap["ship_x"]), float(snap["ship_y"]))
+    s += s_wireframe(SHIP_LINES, ship, snap["ship_angle"]) if snap["ship_alive"] else s_explosion(ship)
+    s += s_wireframe(FORT_LINES, FORT, snap["fort_angle"]) if snap["fort_alive"] else s_explosion(FORT)
+    for i in range(len(snap["missile_alive"])):
+        if snap["missile_alive"][i]:
+            s += s_wireframe(MISSILE_LINES, (snap["missile_x"][i], snap["missile_y"][i]), snap["missile_angle"][i])
+    for i in range(len(snap["shell_alive"])):
+        d = math.sqrt((snap["shell_x"][i] - FORT[0]) ** 2 + (snap["shell_y"][i] - FORT[1]) ** 2)
+        if snap["shell_alive"][i] and d > 21:
+            s += s_wireframe(SHELL_LINES, (snap["shell_x"][i], snap["shell_y"][i]), snap["shell_angle"][i])
+    return s
+
+
+# ---- the score text: our glyph model (not pinned, see the module docstring) ------------------------------------------------
 def _dev(pts):
     pts = np.asarray(pts, np.float64)
-    return np.stack([(pts[:, 0] - VP_X) * SCALE, (pts[:, 1] - VP_Y) * SCALE], 1)
+    return np.stack([(pts[:, 0] - VP_X) * SX, (pts[:, 1] - VP_Y) * SY], 1)
 
 
 def _clip_unit(poly, e):
@@ -97,73 +213,21 @@ def mul_un8(a, b):
 
 
 def over(fb, poly, grey):
-    """Composite convex polygon `poly` (device coordinates) in `grey` OVER the uint8 frame."""
+    """Composite convex polygon `poly` (device coordinates) in `grey` OVER the uint8 frame: exact area, pixman's rounding
+    (the glyph model's arithmetic; everything cairo draws goes through run_script instead)."""
     poly = np.asarray(poly, np.float64)
     x0, y0 = np.floor(poly.min(0)).astype(int)
     x1, y1 = np.ceil(poly.max(0)).astype(int)
-    for py in range(max(y0, 0), min(y1, H)):
-        for px in range(max(x0, 0), min(x1, W)):
+    for py in range(max(y0, 0), min(y1, fb.shape[0])):
+        for px in range(max(x0, 0), min(x1, fb.shape[1])):
             a = min(pixel_area(poly, px, py), 1.0)
             m = int(a * 255.0 + 0.5)
             if m > 0:
                 fb[py, px] = mul_un8(grey, m) + mul_un8(int(fb[py, px]), 255 - m)
 
 
-def line_poly(line, angle_deg, pos):
-    ax, ay, bx, by = line
-    ux, uy = bx - ax, by - ay
-    ln = math.hypot(ux, uy)
-    nx, ny = -uy / ln * LINE_W / 2, ux / ln * LINE_W / 2
-    local = [(ax + nx, ay + ny), (bx + nx, by + ny), (bx - nx, by - ny), (ax - nx, ay - ny)]
-    c, s = math.cos(math.radians(angle_deg)), math.sin(math.radians(angle_deg))
-    return _dev([(pos[0] + c * x - s * y, pos[1] + s * x + c * y) for x, y in local])
-
-
 def rect_poly(x0, y0, x1, y1):
     return _dev([(x0, y0), (x1, y0), (x1, y1), (x0, y1)])
-
-
-def wireframe(fb, lines, angle, pos, grey=255):
-    for ln in lines:
-        over(fb, line_poly(ln, int(angle), pos), grey)
-
-
-def explosion_arcs():
-    """(radius, start degree, end degree, grey) of the 84 arcs of drawExplosion, SRC/draw.cpp:149-166."""
-    arcs, ofs = [], 0
-    for radius in range(15, 70, 8):
-        ofs += 3
-        grey = 191 if radius < 60 else 128  # .75 (yellow in colour mode), .5 (red)
-        for angle in range(0, 360, 30):
-            arcs.append((radius, angle + ofs, angle + ofs + 10, grey))
-    return arcs
-
-
-def explosion(fb, pos):
-    for radius, a0, a1, grey in explosion_arcs():
-        _arc(fb, pos, radius, a0, a1, grey)
-    # the radius-7 circle: ONE stroke (cairo_arc 0..2pi + cairo_stroke), modelled as the ring between
-    # two regular 12-gons of circumradius 7 -/+ half the line width
-    gons = []
-    for r in (7 + LINE_W / 2, 7 - LINE_W / 2):
-        gons.append(_dev([(pos[0] + r * math.cos(math.radians(30 * k)), pos[1] + r * math.sin(math.radians(30 * k)))
-                          for k in range(12)]))
-    x0, y0 = np.floor(gons[0].min(0)).astype(int)
-    x1, y1 = np.ceil(gons[0].max(0)).astype(int)
-    for py in range(max(y0, 0), min(y1, H)):
-        for px in range(max(x0, 0), min(x1, W)):
-            a = min(max(pixel_area(gons[0], px, py) - pixel_area(gons[1], px, py), 0.0), 1.0)
-            m = int(a * 255.0 + 0.5)
-            if m > 0:
-                fb[py, px] = mul_un8(191, m) + mul_un8(int(fb[py, px]), 255 - m)
-
-
-def _arc(fb, pos, r, a0, a1, grey):
-    ri, ro = r - LINE_W / 2, r + LINE_W / 2
-    c0, s0 = math.cos(math.radians(a0)), math.sin(math.radians(a0))
-    c1, s1 = math.cos(math.radians(a1)), math.sin(math.radians(a1))
-    over(fb, _dev([(pos[0] + ri * c0, pos[1] + ri * s0), (pos[0] + ro * c0, pos[1] + ro * s0),
-                   (pos[0] + ro * c1, pos[1] + ro * s1), (pos[0] + ri * c1, pos[1] + ri * s1)]), grey)
 
 
 def score_text(fb, points):
@@ -180,77 +244,26 @@ def score_text(fb, points):
                 over(fb, rect_poly(gx + x0, TXT_TOP + y0, gx + x1, TXT_TOP + y1), 128)
 
 
-_BG = None
-
-
+# ---- frames -------------------------------------------------------------------------------------------------------------------
 def background(hex_big, hex_small):
-    """Both hexagons as closed strokes with miter joins: outline polygon minus inline polygon."""
-    fb = np.zeros((H, W), np.uint8)
-    for pts in (hex_big, hex_small):
-        pts = np.asarray(pts, np.float64).reshape(6, 2)
-        outer, inner = _offset(pts, LINE_W / 2), _offset(pts, -LINE_W / 2)
-        o, i = _dev(outer), _dev(inner)
-        for py in range(H):
-            for px in range(W):
-                a = pixel_area(o, px, py) - pixel_area(i, px, py)
-                if a <= 0:
-                    continue
-                m = int(min(a, 1.0) * 255.0 + 0.5)
-                fb[py, px] = mul_un8(255, m) + mul_un8(int(fb[py, px]), 255 - m)
-    return fb
+    """Both hexagons on black (drawJustGameStuff's first two calls)."""
+    return run_script(s_begin() + s_hexagon(hex_big) + s_hexagon(hex_small))
 
 
-def _offset(pts, off):
-    """Vertices of the hexagon's edges moved by `off` along their outward normals (miter joins)."""
-    px, py = [float(v) for v in pts[:, 0]], [float(v) for v in pts[:, 1]]
-    area2 = 0.0
-    for i in range(6):
-        j = (i + 1) % 6
-        area2 += px[i] * py[j] - px[j] * py[i]
-    orient = 1.0 if area2 > 0 else -1.0
-    nx, ny, c = [], [], []
-    for i in range(6):
-        j = (i + 1) % 6
-        ex, ey = px[j] - px[i], py[j] - py[i]
-        ln = math.sqrt(ex * ex + ey * ey)
-        nx.append(orient * ey / ln)
-        ny.append(-orient * ex / ln)
-        c.append(nx[i] * px[i] + ny[i] * py[i] + off)
-    out = []
-    for i in range(6):
-        h = (i + 5) % 6
-        det = nx[h] * ny[i] - ny[h] * nx[i]
-        out.append(((c[h] * ny[i] - ny[h] * c[i]) / det, (nx[h] * c[i] - c[h] * nx[i]) / det))
-    return np.array(out)
+def bar_frame(fb, vlner, kill):
+    return run_script(s_begin()[:8] + s_bar(vlner, kill), fb.shape[1], fb.shape[0], onto=fb)
 
 
-def render_raw(snap, hex_big, hex_small, vuln_time=250, bg=None):
-    """One [92][90] uint8 frame from an oracle snapshot record (oracle.SNAPSHOT_DTYPE)."""
-    fb = (background(hex_big, hex_small) if bg is None else bg).copy()
-    ship = (float(snap["ship_x"]), float(snap["ship_y"]))
-    if snap["ship_alive"]:
-        wireframe(fb, SHIP_LINES, snap["ship_angle"], ship)
-    else:
-        explosion(fb, ship)
-    if snap["fort_alive"]:
-        wireframe(fb, FORT_LINES, snap["fort_angle"], FORT)
-    else:
-        explosion(fb, FORT)
-    for i in range(len(snap["missile_alive"])):
-        if snap["missile_alive"][i]:
-            wireframe(fb, MISSILE_LINES, snap["missile_angle"][i], (snap["missile_x"][i], snap["missile_y"][i]))
-    for i in range(len(snap["shell_alive"])):
-        if snap["shell_alive"][i]:
-            d = math.sqrt((snap["shell_x"][i] - FORT[0]) ** 2 + (snap["shell_y"][i] - FORT[1]) ** 2)
-            if d > 21:
-                wireframe(fb, SHELL_LINES, snap["shell_angle"][i], (snap["shell_x"][i], snap["shell_y"][i]))
-    score_text(fb, snap["points"])
+def render_raw(snap, hex_big, hex_small, vuln_time=250, bg=None, text=True):
+    """One [H][W] uint8 frame from an oracle snapshot record (oracle.SNAPSHOT_DTYPE): drawGameStateScaled's calls in its
+    order -- hexagons, objects, score, bar.  `bg` (the hexagons' frame) is accepted for the callers that keep one; the
+    hexagons are the first strokes on black either way."""
+    fb = run_script(s_begin() + s_hexagon(hex_big) + s_hexagon(hex_small) + s_objects(snap))
+    if text:
+        score_text(fb, snap["points"])
     vlner = int(snap["vlner"])
     kill = vlner > 10 and int(snap["fort_vuln_timer"]) < vuln_time
-    over(fb, rect_poly(255, 522, 455, 532), 84)
-    if vlner > 0:
-        over(fb, rect_poly(255, 522, 255 + 20 * min(vlner, 10), 532), 255 if kill else 168)
-    return fb
+    return bar_frame(fb, vlner, kill)
 
 
 def area_tab(ssize, dsize):
