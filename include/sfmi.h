@@ -368,7 +368,21 @@ int sf_hex_points(int radius, double* out);
 int sf_image_background(uint8_t* out);
 /* ... for any geometry (sf_set_image_geometry): a w x h surface under scale(scale) translate(-vx, -vy), line width lw user
  * units; out is uint8[h][w] */
-int sf_image_background_geom(double scale, double vx, double vy, int w, int h, double lw, uint8_t* out);
+int sf_image_background_geom(int w, int h, double vx, double vy, double vw, double vh, double lw, uint8_t* out);
+/* the live fortress's 8-bit coverage over its 16 x 16 box of the default surface, heading 10 * sector (one cairo_stroke of four
+ * lines, SRC/draw.cpp:238-242); the explosion's 86 arcs as Bezier constants, 8 doubles each (SRC/draw.cpp:116-145) */
+int sf_image_fort_alpha(int sector, uint8_t* out256);
+int sf_arc_table(double* out);
+/* test hooks: ONE wireframe (kind 0 ship, 1 fortress, 2 missile, 3 shell; SRC/wireframe.cpp:11-67) as 8-bit coverage, and
+ * drawExplosion composited onto fb, both through the frame kernels' formulation (sf_tor.h) run on the host */
+int sf_image_object_alpha(int kind, double x, double y, int angle_deg, int w, int h, double vp_x, double vp_y, double vp_w,
+                          double vp_h, double lw, uint8_t* alpha);
+int sf_image_explosion_host(double x, double y, int w, int h, double vp_x, double vp_y, double vp_w, double vp_h, double lw,
+                            uint8_t* fb);
+int sf_trig_deg(int deg, double* cos_sin);
+/* ... and ONE arc cairo_arc(xc, yc, r, a1, a2) + cairo_stroke, a2 - a1 <= pi / 2; returns the number of pieces it was flattened into */
+int sf_image_arc_alpha(double xc, double yc, double r, double a1, double a2, int w, int h, double vp_x, double vp_y, double vp_w,
+                       double vp_h, double lw, uint8_t* alpha);
 /* the background plus the overlays the render kernel starts from when they are static: variant bit 0 =
  * the score text "0000000", bit 1 = the vulnerability bar at 0 (drawScore / drawVlner, SRC/draw.cpp:
  * 190-225); out is uint8[92][90] */
@@ -396,7 +410,7 @@ int sf_set_render_order_hint(sf_batch* b, const uint64_t* words_host, int n_word
  *      from the state.  from_state = 0: the records as they are (SF_ERR_ARG if the batch has none yet); 1: rebuilt from the
  *      state into the batch's buffer first.  host: n_envs * SF_DRAW_RECORD_BYTES bytes.  Synchronous.  Tests compare the
  *      two ways of making them byte for byte (live entries). ---- */
-#define SF_DRAW_RECORD_BYTES 384
+#define SF_DRAW_RECORD_BYTES 432
 int sf_draw_records(sf_batch* b, void* host, size_t bytes, int from_state);
 
 const char* sf_last_error(void);

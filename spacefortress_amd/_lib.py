@@ -107,7 +107,13 @@ SYMBOLS = {
     "sf_set_event_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sf_render": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sf_image_background": (C.c_int, [C.c_void_p]),
-    "sf_image_background_geom": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_void_p]),
+    "sf_image_background_geom": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "sf_image_fort_alpha": (C.c_int, [C.c_int, C.c_void_p]),
+    "sf_arc_table": (C.c_int, [C.c_void_p]),
+    "sf_image_object_alpha": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_double] * 5 + [C.c_void_p]),
+    "sf_image_explosion_host": (C.c_int, [C.c_double, C.c_double, C.c_int, C.c_int] + [C.c_double] * 5 + [C.c_void_p]),
+    "sf_trig_deg": (C.c_int, [C.c_int, C.c_void_p]),
+    "sf_image_arc_alpha": (C.c_int, [C.c_double] * 5 + [C.c_int, C.c_int] + [C.c_double] * 5 + [C.c_void_p]),
     "sf_image_static": (C.c_int, [C.c_int, C.c_void_p]),
     "sf_resize_area_tab": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_resize_area_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),

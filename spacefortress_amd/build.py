@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfmi.so")
-SOURCES = ["sf_kernels.hip", "sf_render.hip", "sf_render_generic.hip", "sf_normalize.hip", "sf_rollout_ops.hip", "sf_capi.cpp", "sf_norm_capi.cpp", "sf_host.cpp", "sf_image.cpp"]
-HEADERS = ["sf_layout.h", "sf_drawrec.h", "sf_cover.h", "sf_internal.h", "sf_raster.h", "sf_render_tables.h", "sf_deg_dd.h", os.path.join(ROOT, "include", "sfmi.h")]
+SOURCES = ["sf_kernels.hip", "sf_render.hip", "sf_render_generic.hip", "sf_normalize.hip", "sf_rollout_ops.hip", "sf_capi.cpp", "sf_norm_capi.cpp", "sf_host.cpp", "sf_image.cpp", "sf_cairo_host.cpp"]
+HEADERS = ["sf_layout.h", "sf_drawrec.h", "sf_internal.h", "sf_raster.h", "sf_tor.h", "sf_tor_dev.h", "sf_cairo_host.h", "sf_deg_dd.h", os.path.join(ROOT, "include", "sfmi.h")]
 
 
 # -amdgpu-kernarg-preload-count: the first eight kernel parameters (as many as fit the 14 free user SGPRs) arrive in
@@ -139,10 +139,27 @@ def build(force=False, verbose=False, extra_flags=()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     bid = source_hash(extra_flags)
-    cmd = [hipcc] + FLAGS + list(extra_flags) + ['-DSFMI_BUILD_ID="%s"' % bid] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # one compiler process per source, in parallel (the step kernel and the frame kernel take two minutes each), then the link
+    import concurrent.futures
+    import tempfile
+
+    cflags = [f for f in FLAGS if f != "-shared"] + list(extra_flags) + ['-DSFMI_BUILD_ID="%s"' % bid]
+    with tempfile.TemporaryDirectory() as td:
+        objs = [os.path.join(td, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+
+        def one(job):
+            src, obj = job
+            cmd = [hipcc] + cflags + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+            list(ex.map(one, zip(SOURCES, objs)))
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "--hip-link"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     bare = scan_wide_store_hazard(device_disassembly(LIB))
     if bare:  # (see scan_wide_store_hazard: such a library plays wrong games in batches beyond 65 536 envs)
         os.remove(LIB)

@@ -30,6 +30,8 @@ struct sf_batch {
   int obs_mode;              // the caller's SF_OBS_*; args.obs_type is SF_OBS_NONE for the image modes
   uint32_t* d_bg;            // image observation: static background, 92*90 bytes
   uint32_t* d_bg84;          // ... resampled to 84x84
+  double* d_arcs;            // the explosion's arc constants (sf_arc_table), then nothing
+  unsigned char* d_falpha;   // the live fortress's coverage at its 36 headings (sf_image_fort_alpha)
   uint32_t* d_tabs;          // INTER_AREA taps (sf_raster.h)
   unsigned char* d_xcache;   // explosion cache, SF_XC_BYTES per env; allocated by the first render
   // The missile fields as the reference has them (per env and slot), kept only while a caller looks at or edits them
@@ -49,7 +51,7 @@ struct sf_batch {
   bool draw_current;
   // sf_set_image_geometry: a geometry other than the default one (sf_render_generic.hip); g_w == 0: the default
   int g_w, g_h;
-  double g_scale, g_vx, g_vy, g_lw;
+  double g_sx, g_sy, g_vx, g_vy, g_lw;  // scale_x = g_w / vp_w, scale_y = g_h / vp_h: NOT the caller's scale when vp_w * scale is not whole (SRC/draw.cpp:70-71)
   uint8_t* d_gbg;            // g_w * g_h bytes: the hexagons
   uint32_t* d_gtabs;         // the INTER_AREA taps g_w -> 84, g_h -> 84
   bool render_ready;         // the render caches and pictures exist (or were declined: SFMI_NO_EXPLOSION_CACHE)
@@ -131,7 +133,7 @@ int ensure_render_resources(sf_batch* b, hipStream_t stream) {
     HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes + tail));
     HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes + tail, stream));
     HIP_TRY(sf_launch_hud_pictures(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes + 36 * SF_FP_BYTES + SF_XC_BYTES, stream));
-    HIP_TRY(sf_launch_fort_patches(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes, stream));
+    HIP_TRY(sf_launch_fort_patches(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes, b->d_arcs, b->d_falpha, stream));
   }
   HIP_TRY(hipStreamSynchronize(stream));
   b->render_ready = true;
@@ -297,6 +299,20 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
     HIP_TRY_FREE(hipMemcpy(b->d_bg84, bg84.data(), bg84.size(), hipMemcpyHostToDevice));
     HIP_TRY_FREE(hipMalloc((void**)&b->d_bg, (size_t)SF_BG_COUNT * SF_BG_STRIDE));
     HIP_TRY_FREE(hipMemset(b->d_bg, 0, (size_t)SF_BG_COUNT * SF_BG_STRIDE));
+    {
+      std::vector<double> arcs(86 * 8);
+      std::vector<uint8_t> fa(36 * 256);
+      int rc = sf_arc_table(arcs.data());
+      for (int k = 0; k < 36 && rc == SF_OK; k++) rc = sf_image_fort_alpha(k, fa.data() + 256 * k);
+      if (rc != SF_OK) {
+        sf_destroy(b);
+        return rc;
+      }
+      HIP_TRY_FREE(hipMalloc((void**)&b->d_arcs, arcs.size() * sizeof(double)));
+      HIP_TRY_FREE(hipMemcpy(b->d_arcs, arcs.data(), arcs.size() * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY_FREE(hipMalloc((void**)&b->d_falpha, fa.size()));
+      HIP_TRY_FREE(hipMemcpy(b->d_falpha, fa.data(), fa.size(), hipMemcpyHostToDevice));
+    }
     HIP_TRY_FREE(hipMalloc((void**)&b->d_tabs, tabs.size() * sizeof(uint32_t)));
     HIP_TRY_FREE(hipMemcpy(b->d_bg, bg.data(), bg.size(), hipMemcpyHostToDevice));
     HIP_TRY_FREE(hipMemcpy(b->d_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -402,6 +418,8 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_tabs) (void)hipFree(b->d_tabs);
   if (b->d_xcache) (void)hipFree(b->d_xcache);
   if (b->d_bg84) (void)hipFree(b->d_bg84);
+  if (b->d_arcs) (void)hipFree(b->d_arcs);
+  if (b->d_falpha) (void)hipFree(b->d_falpha);
   if (b->d_draw) (void)hipFree(b->d_draw);
   if (b->d_gbg) (void)hipFree(b->d_gbg);
   if (b->d_gtabs) (void)hipFree(b->d_gtabs);
@@ -464,7 +482,7 @@ extern "C" int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, dou
   const int w = (int)(vp_w * scale), h = (int)(vp_h * scale);  // ENV:57-58
   DeviceGuard guard(b->device);
   HIP_TRY(hipDeviceSynchronize());
-  if (scale == SF_SCALE && vp_x == SF_VP_X && vp_y == SF_VP_Y && w == SF_IMG_W && h == SF_IMG_H && line_width == SF_LINE_W) {
+  if (vp_x == SF_VP_X && vp_y == SF_VP_Y && vp_w == 450.0 && vp_h == 460.0 && w == SF_IMG_W && h == SF_IMG_H && line_width == SF_LINE_W) {
     b->g_w = b->g_h = 0;  // the default geometry: the fast frame kernel
     return SF_OK;
   }
@@ -475,7 +493,7 @@ extern "C" int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, dou
     return SF_ERR_ARG;
   }
   std::vector<uint8_t> bg(((size_t)w * h + 15) & ~(size_t)15, 0);  // (whole 16-byte pieces: the kernel copies it that way)
-  int rc = sf_image_background_geom(scale, vp_x, vp_y, w, h, line_width, bg.data());
+  int rc = sf_image_background_geom(w, h, vp_x, vp_y, vp_w, vp_h, line_width, bg.data());
   if (rc != SF_OK) return rc;
   std::vector<uint32_t> tabs(16 * SF_OUT, 0u);
   const int ssize[2] = {w, h};
@@ -498,16 +516,21 @@ extern "C" int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, dou
   uint8_t* nbg = nullptr;
   uint32_t* ntabs = nullptr;
   HIP_TRY(hipMalloc((void**)&nbg, bg.size()));
-  HIP_TRY(hipMalloc((void**)&ntabs, tabs.size() * sizeof(uint32_t)));
-  HIP_TRY(hipMemcpy(nbg, bg.data(), bg.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ntabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (hipMalloc((void**)&ntabs, tabs.size() * sizeof(uint32_t)) != hipSuccess || hipMemcpy(nbg, bg.data(), bg.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ntabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(nbg);
+    if (ntabs) (void)hipFree(ntabs);
+    sf_set_error("sf_set_image_geometry: device allocation / copy failed");
+    return SF_ERR_HIP;
+  }
   if (b->d_gbg) (void)hipFree(b->d_gbg);
   if (b->d_gtabs) (void)hipFree(b->d_gtabs);
   b->d_gbg = nbg;
   b->d_gtabs = ntabs;
   b->g_w = w;
   b->g_h = h;
-  b->g_scale = scale;
+  b->g_sx = (double)w / vp_w;
+  b->g_sy = (double)h / vp_h;
   b->g_vx = vp_x;
   b->g_vy = vp_y;
   b->g_lw = line_width;
@@ -532,7 +555,7 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
     SF_FLUSH_VIEW(b, stream);
     if (stack_done)  // `current_obs *= masks` for the finished envs, then the new frame into its slot
       HIP_TRY(sf_launch_stack_clear(frames_dev - (size_t)stack_slot * frame, (size_t)stack_n * frame, stack_done, b->n_envs, stream));
-    HIP_TRY(sf_launch_render_generic(b->d_state, b->n_envs, b->g_w, b->g_h, b->g_scale, b->g_vx, b->g_vy, b->g_lw, b->d_gbg,
+    HIP_TRY(sf_launch_render_generic(b->d_state, b->n_envs, b->g_w, b->g_h, b->g_sx, b->g_sy, b->g_vx, b->g_vy, b->g_lw, b->d_consts + SF_LDS_TRIG, b->d_arcs, b->d_gbg,
                                      b->d_gtabs, frames_dev, env_stride, mode == SF_OBS_IMAGE ? 1 : 0, stream));
     return SF_OK;
   }
@@ -559,7 +582,7 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
   const unsigned char* fpatch = b->d_xcache ? b->d_xcache + (size_t)b->n_envs * SF_XC_BYTES : nullptr;
   HIP_TRY(sf_launch_render(b->d_state, b->d_draw, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache, fpatch,
                            mode == SF_OBS_IMAGE ? 1 : 0, stack_done, stack_slot, stack_n, stack_prev, b->args.hint,
-                           fpatch ? fpatch + 36 * SF_FP_BYTES + SF_XC_BYTES : nullptr, stream));
+                           fpatch ? fpatch + 36 * SF_FP_BYTES + SF_XC_BYTES : nullptr, b->d_consts + SF_LDS_TRIG, b->d_arcs, b->d_falpha, stream));
   return SF_OK;
 }
 
@@ -587,10 +610,9 @@ extern "C" int sf_draw_records(sf_batch* b, void* host, size_t bytes, int from_s
   // (the caller gets them env by env, whatever the device layout: sf_drawrec.h SF_DR_LAYOUT)
   std::vector<unsigned char> raw((size_t)b->args.lanes * SF_DR_BYTES);
   HIP_TRY(hipMemcpy(raw.data(), b->d_draw, raw.size(), hipMemcpyDeviceToHost));
-  for (long e = 0; e < b->n_envs; e++)
-    for (int r = 0; r < SF_DR_PIECES; r++)
-      memcpy((unsigned char*)host + (size_t)e * SF_DR_BYTES + 16 * r,
-             raw.data() + (size_t)(e >> 6) * SF_DR_TILE_BYTES + (size_t)r * SF_DR_PIECE_STRIDE + (size_t)(e & 63) * SF_DR_LANE_STRIDE, 16);
+  for (long e = 0; e < b->n_envs; e++)  // (a record is contiguous: header, positions, headings)
+    memcpy((unsigned char*)host + (size_t)e * SF_DR_BYTES, raw.data() + (size_t)(e >> 6) * SF_DR_TILE_BYTES + (size_t)(e & 63) * SF_DR_LANE_STRIDE,
+           SF_DR_BYTES);
   return SF_OK;
 }
 

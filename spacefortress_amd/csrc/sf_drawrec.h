@@ -9,9 +9,11 @@
 // leave, per env, SF_DR_BYTES of HBM:
 //   * a 32-byte header of finished decisions, which the frame kernel reads with ONE scalar load (s_load_dwordx8: the
 //     values arrive in SGPRs, uniform by construction -- no v_readfirstlane, no 64-bit lane masks for uniform booleans);
-//   * SF_DR_OBJS transforms of 16 bytes, (x, y, cos, sin) as float32: the ship, the fortress, the 20 missile slots --
-//     lane s of the frame kernel loads the transform of the object its stroke belongs to.  A missile's entry is written
-//     by whichever lane of the step kernel holds it in the tile's pool, at [owner][slot], as the pool is compacted.
+//   * SF_DR_OBJS positions of 16 bytes, (x, y) as float64 -- cairo transforms path points in double precision and rounds them
+//     to 1/256 pixel: a float32 position would move a corner now and then --: the ship, (the fortress: unused), the 20 missile
+//     slots; lane s of the frame kernel loads the position of the object its line belongs to.  A missile's entry is written
+//     by whichever lane of the step kernel holds it in the tile's pool, at [owner][slot], as the pool is compacted;
+//   * the missiles' headings, 20 x int16 (whole degrees), behind the positions (the ship's and the fortress's: header word 7).
 // Shells keep their (position, velocity) in the state and are read from there by the 14 % of the frames that have one.
 //
 // What is drawn where follows SRC/draw.cpp:227-270 (see sf_render.hip); nothing here changes a pixel: the functions below
@@ -31,7 +33,8 @@
 #define SF_DR_OBJ_FORT 1
 #define SF_DR_OBJ_MISSILE0 2
 #define SF_DR_OBJS (2 + SF_NSLOT)
-#define SF_DR_BYTES (SF_DR_HDR_BYTES + SF_DR_OBJS * SF_DR_OBJ_BYTES) /* 384 */
+#define SF_DR_ANGLES_OFF (SF_DR_HDR_BYTES + SF_DR_OBJS * SF_DR_OBJ_BYTES) /* 384: int16 heading of missile slot s at + 2 s */
+#define SF_DR_BYTES (SF_DR_ANGLES_OFF + 48) /* 432 */
 // In HBM the records of a wave tile (64 envs, sf_layout.h) form one block of SF_DR_TILE_BYTES; env lane l's 16-byte piece p
 // (pieces 0, 1 = header words 0..3, 4..7; piece 2 + k = object k's transform) sits at l * SF_DR_LANE_STRIDE + p *
 // SF_DR_PIECE_STRIDE.  SF_DR_LAYOUT 0: env by env (384 contiguous bytes per env).  The frame kernel is a wave per env: its
@@ -44,6 +47,9 @@
 #endif
 #define SF_DR_PIECES (2 + SF_DR_OBJS)
 #define SF_DR_TILE_BYTES (64 * SF_DR_BYTES)
+#if SF_DR_LAYOUT != 0
+#error "the rows-of-64 layout of round 4's A/B is gone: the headings' array has no place in it"
+#endif
 #if SF_DR_LAYOUT == 0
 #define SF_DR_LANE_STRIDE SF_DR_BYTES
 #define SF_DR_PIECE_STRIDE 16
@@ -68,7 +74,7 @@
                             top lanes of the missiles' range (SF_DRF_MERGE_SHELLS) */
 #define SF_DRW_FLAGS 5
 #define SF_DRW_SERIAL 6  /* the env's time (ms) when the record was made: diagnostics only */
-#define SF_DRW_SPARE 7
+#define SF_DRW_ANGLES 7  /* the ship's heading (low 16 bits, whole degrees) | the fortress's (high 16) */
 
 // SF_DRW_FLAGS: bits 0..7 = index of the background the frame starts from (4 (1 + sector) + variant with the fortress's
 // picture in it, else the variant: sf_raster.h SF_BG_COUNT); bits 8..11 = the bar's state (0..10 tenths, 11 kill-ready)
@@ -186,7 +192,7 @@ struct FBox {
 //   proj  = OR of hud_flags_near over the env's live missiles and shells
 //   pics  = the batch has its pictures (the 36 fortress headings baked into backgrounds, the destroyed fortress's
 //           explosion, the score / bar pictures): not with SFMI_NO_EXPLOSION_CACHE, which draws everything in place
-SFD_FN Header make_header(double sx, double sy, bool ship_alive, bool fort_alive, int fort_angle, float points, int vlner,
+SFD_FN Header make_header(double sx, double sy, int ship_angle, bool ship_alive, bool fort_alive, int fort_angle, float points, int vlner,
                           int fort_vuln_timer, unsigned mmask, unsigned smask, unsigned proj, bool pics, int time_ms) {
   Header h;
   const float ship_x = (float)sx, ship_y = (float)sy;
@@ -234,7 +240,7 @@ SFD_FN Header make_header(double sx, double sy, bool ship_alive, bool fort_alive
                       (baked_text ? SF_DRF_BAKED_TEXT : 0u) | (baked_bar ? SF_DRF_BAKED_BAR : 0u) | (merge ? SF_DRF_MERGE_SHELLS : 0u) |
                       (((mmask >> 19) & 1u) ? SF_DRF_MISSILE19 : 0u);
   h.w[SF_DRW_SERIAL] = (unsigned)time_ms;
-  h.w[SF_DRW_SPARE] = 0u;
+  h.w[SF_DRW_ANGLES] = ((unsigned)ship_angle & 0xFFFFu) | ((unsigned)fort_angle << 16);
   return h;
 }
 

@@ -206,6 +206,14 @@ extern "C" int sf_hex_points(int radius, double* out) {
   return SF_OK;
 }
 
+// cos / sin of deg2rad(deg), 0 <= deg < 360, as the reference computes them (two libm calls on vector.cpp's deg2rad)
+extern "C" int sf_trig_deg(int deg, double* cos_sin) {
+  const double r = deg2rad((double)deg);
+  cos_sin[0] = libm_cos(r);
+  cos_sin[1] = libm_sin(r);
+  return SF_OK;
+}
+
 extern "C" int sf_trig_table(double* out) {
   if (!out) {
     sf_set_error("sf_trig_table: null output");

@@ -1,82 +1,106 @@
 // sf_image.cpp -- host-side tables of the image observation (no HIP calls; tested without a GPU):
 //   * the static background: the two hexagons, which the reference strokes first on every frame
-//     (SRC/draw.cpp:131-143,230-231) and which never change, as 8-bit coverage of a 92x90 surface;
+//     (SRC/draw.cpp:102-114,230-231) and which never change: a closed path with miter joins through cairo's stroker and
+//     scan converter (sf_cairo_host.cpp), for any geometry;
+//   * the live fortress's coverage at its 36 headings (one cairo_stroke of four lines: SRC/draw.cpp:238-242), the explosion's
+//     arc constants;
 //   * the INTER_AREA resampling tables of cv2.resize(frame, (84, 84)) (rl/envs.py:29).
 // cv2 (OpenCV) is a dependency of the reference that is not vendored in /root/reference and not
 // installed in this image; the table follows OpenCV's published algorithm (modules/imgproc/src/
-// resize.cpp, computeResizeAreaTab, the general non-integer-scale area path).  See sf_raster.h for
-// what is and is not pinned about pixel values.
+// resize.cpp, computeResizeAreaTab, the general non-integer-scale area path).
 #include <math.h>
 #include <string.h>
 
 #include <vector>
 
+#include "sf_cairo_host.h"
+#include "sf_drawrec.h"
 #include "sf_internal.h"
 #include "sf_raster.h"
 
-namespace {
-
-// vertices of the polygon whose edges are the hexagon's edges moved by `off` along their outward
-// normals: the outline (off > 0) / inline (off < 0) of a closed stroke with miter joins
-void offset_polygon(const double* p /* [6][2] */, double off, double* qx, double* qy) {
-  double area2 = 0;
-  for (int i = 0; i < 6; i++) {
-    const int j = (i + 1) % 6;
-    area2 += p[2 * i] * p[2 * j + 1] - p[2 * j] * p[2 * i + 1];
-  }
-  const double orient = area2 > 0 ? 1.0 : -1.0;
-  // edge i: from p[i] to p[i+1]; outward unit normal n_i; offset line: n_i . x = n_i . p[i] + off
-  double nx[6], ny[6], c[6];
-  for (int i = 0; i < 6; i++) {
-    const int j = (i + 1) % 6;
-    const double ex = p[2 * j] - p[2 * i], ey = p[2 * j + 1] - p[2 * i + 1];
-    const double len = sqrt(ex * ex + ey * ey);
-    nx[i] = orient * ey / len;
-    ny[i] = -orient * ex / len;
-    c[i] = nx[i] * p[2 * i] + ny[i] * p[2 * i + 1] + off;
-  }
-  // vertex i of the offset polygon = intersection of offset edges i-1 and i
-  for (int i = 0; i < 6; i++) {
-    const int h = (i + 5) % 6;
-    const double det = nx[h] * ny[i] - ny[h] * nx[i];
-    qx[i] = (c[h] * ny[i] - ny[h] * c[i]) / det;
-    qy[i] = (nx[h] * c[i] - c[h] * nx[i]) / det;
-  }
-}
-
-}  // namespace
-
-// the two hexagons stroked on black for a surface of w x h pixels under scale(s) translate(-vx, -vy), line width lw user units
-// (drawGameStateScaled, SRC/draw.cpp:256-263; Game(width, height, viewport, lw), SRC/pymodule.cpp:319-354)
-extern "C" int sf_image_background_geom(double scale, double vx, double vy, int w, int h, double lw, uint8_t* out) {
-  if (!out || w <= 0 || h <= 0 || !(scale > 0) || !(lw > 0)) {
+// the two hexagons stroked on black for a surface of w x h pixels showing the viewport (vx, vy, vw, vh): scale(w / vw, h / vh)
+// translate(-vx, -vy), line width lw user units (drawGameStateScaled, SRC/draw.cpp:256-263; newPixelBuffer :59-76)
+extern "C" int sf_image_background_geom(int w, int h, double vx, double vy, double vw, double vh, double lw, uint8_t* out) {
+  if (!out || w <= 0 || h <= 0 || !(vw > 0) || !(vh > 0) || !(lw > 0)) {
     sf_set_error("sf_image_background_geom: bad argument");
     return SF_ERR_ARG;
   }
   memset(out, 0, (size_t)w * h);   // cairo_paint of black, SRC/draw.cpp:262-263
+  const sfh::Geometry g{w, h, (double)w / vw, (double)h / vh, vx, vy, lw};
   const int radii[2] = {200, 40};  // bigHex, smallHex (SRC/configs.cpp:34-35), drawn in this order
   for (int k = 0; k < 2; k++) {
-    double p[12], ox[6], oy[6], ix[6], iy[6];
+    double p[12];
     sf_hex_points(radii[k], p);
-    offset_polygon(p, lw / 2, ox, oy);
-    offset_polygon(p, -lw / 2, ix, iy);
-    for (int i = 0; i < 6; i++) {
-      ox[i] = (ox[i] - vx) * scale;
-      oy[i] = (oy[i] - vy) * scale;
-      ix[i] = (ix[i] - vx) * scale;
-      iy[i] = (iy[i] - vy) * scale;
-    }
-    for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++) {
-        // ring = outline minus inline; both convex, the inline inside the outline
-        double a = sfr::clip_area<double>(ox, oy, 6, (double)x, (double)y) -
-                   sfr::clip_area<double>(ix, iy, 6, (double)x, (double)y);
-        if (a <= 0) continue;
-        if (a > 1) a = 1;
-        const int m = (int)(a * 255.0 + 0.5);
-        out[(size_t)y * w + x] = (uint8_t)sfr::over_un8(out[(size_t)y * w + x], 255, m);  // white, :133-136
-      }
+    sfh::stroke_hexagon(p, g, 255, out);  // white, SRC/draw.cpp:104-107
   }
+  return SF_OK;
+}
+
+// the live fortress (SRC/draw.cpp:238-242: translate(355, 315) rotate(heading), four lines, ONE stroke) over the 16 x 16 box
+// the frame kernel keeps for it (sf_drawrec.h: kFpX0 ..), as 8-bit coverage, sector = heading / 10.  Heading 0 is the one
+// pose whose path is rectilinear under a matrix without rotation: cairo strokes that as boxes
+// (cairo-path-stroke-boxes.c: _cairo_rectilinear_stroker) through the box converter, exact area instead of sub-rows.
+extern "C" int sf_image_fort_alpha(int sector, uint8_t* out256) {
+  if (sector < 0 || sector > 35 || !out256) {
+    sf_set_error("sf_image_fort_alpha: sector 0..35, out non-null");
+    return SF_ERR_ARG;
+  }
+  const sfh::Geometry g{SF_IMG_W, SF_IMG_H, (double)SF_IMG_W / 450.0, (double)SF_IMG_H / 460.0, SF_VP_X, SF_VP_Y, SF_LINE_W};
+  std::vector<uint8_t> a((size_t)SF_IMG_W * SF_IMG_H, 0);
+  if (sector == 0) {
+    static const double L[4][4] = {{0, 0, 36, 0}, {0, -18, 18, -18}, {18, -18, 18, 18}, {18, 18, 0, 18}};
+    const sft::Affine v = sft::view_matrix(g.sx, g.sy, g.vp_x, g.vp_y);
+    const sft::Affine m = sft::object_matrix(v, 355.0, 315.0, 1.0, 0.0);
+    const int hx = sft::fx_from_double(fabs(m.xx) * g.lw / 2.0), hy = sft::fx_from_double(fabs(m.yy) * g.lw / 2.0);
+    sfh::Box4 bx[4];
+    for (int k = 0; k < 4; k++) {
+      int x1, y1, x2, y2;
+      sft::to_device(m, L[k][0], L[k][1], &x1, &y1);
+      sft::to_device(m, L[k][2], L[k][3], &x2, &y2);
+      if (y1 == y2) { y1 -= hy; y2 += hy; } else { x1 -= hx; x2 += hx; }
+      bx[k] = sfh::Box4{x1 < x2 ? x1 : x2, y1 < y2 ? y1 : y2, x1 < x2 ? x2 : x1, y1 < y2 ? y2 : y1};
+    }
+    sfh::boxes_cover(bx, 4, g.w, g.h, 255, a.data());  // white on black: the pixel IS the alpha
+  } else {
+    double cs[2];
+    sf_trig_deg(10 * sector, cs);
+    const sfh::Object ob = sfh::wireframe_object(1, 355.0, 315.0, 10 * sector, g, cs);
+    std::vector<int> acc((size_t)g.w * g.h, 0);
+    sfh::object_coverage(ob, g.w, g.h, acc.data());
+    for (int i = 0; i < g.w * g.h; i++) a[i] = (uint8_t)sft::area_to_alpha(acc[i]);
+  }
+  for (int y = 0; y < 16; y++)
+    for (int x = 0; x < 16; x++) out256[16 * y + x] = a[(sfd::kFpY0 + y) * SF_IMG_W + sfd::kFpX0 + x];
+  // nothing of it may lie outside the box
+  for (int y = 0; y < SF_IMG_H; y++)
+    for (int x = 0; x < SF_IMG_W; x++)
+      if (a[y * SF_IMG_W + x] && !(x >= sfd::kFpX0 && x < sfd::kFpX0 + 16 && y >= sfd::kFpY0 && y < sfd::kFpY0 + 16)) {
+        sf_set_error("sf_image_fort_alpha: the fortress leaves its box");
+        return SF_ERR_ARG;
+      }
+  return SF_OK;
+}
+
+// drawExplosion's arcs (SRC/draw.cpp:116-145) as sft::ArcK, 8 doubles each: [12 ring + k] for ring 0..6, then the circle's two
+// halves; made with this host's libm, which is the reference's
+extern "C" int sf_arc_table(double* out /* 86 x 8 */) {
+  if (!out) {
+    sf_set_error("sf_arc_table: null output");
+    return SF_ERR_ARG;
+  }
+  const double kPi = 3.14159265358979323846;
+  int n = 0, ofs = 0;
+  auto put = [&](const sft::ArcK& k) {
+    const double v[8] = {k.rca, k.rsa, k.hrsa, k.hrca, k.rcb, k.rsb, k.hrsb, k.hrcb};
+    memcpy(out + 8 * n++, v, sizeof(v));
+  };
+  for (int radius = 15; radius < 70; radius += 8) {
+    ofs += 3;
+    for (int angle = 0; angle < 360; angle += 30) put(sft::arc_k((double)radius, (angle + ofs) * kPi / 180, (angle + ofs + 10) * kPi / 180));
+  }
+  const double mid = 0.0 + (2 * kPi - 0.0) / 2.0;  // cairo halves an arc longer than pi (_cairo_arc_in_direction)
+  put(sft::arc_k(7.0, 0.0, mid));
+  put(sft::arc_k(7.0, mid, 2 * kPi));
   return SF_OK;
 }
 
@@ -85,8 +109,8 @@ extern "C" int sf_image_background(uint8_t* out) {
     sf_set_error("sf_image_background: null output");
     return SF_ERR_ARG;
   }
-  // (user space -> device space: cairo_scale(.2) then cairo_translate(-130, -80), SRC/draw.cpp:259-260)
-  return sf_image_background_geom(SF_SCALE, SF_VP_X, SF_VP_Y, SF_IMG_W, SF_IMG_H, SF_LINE_W, out);
+  // (user space -> device space: cairo_scale(90 / 450, 92 / 460) then cairo_translate(-130, -80), SRC/draw.cpp:259-260)
+  return sf_image_background_geom(SF_IMG_W, SF_IMG_H, SF_VP_X, SF_VP_Y, 450.0, 460.0, SF_LINE_W, out);
 }
 
 extern "C" int sf_resize_area_tab(int ssize, int dsize, int32_t* first, int32_t* count, float* alpha) {

@@ -35,13 +35,13 @@ hipError_t sf_launch_render(const unsigned char* state, const unsigned char* dra
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
                             const uint8_t* stack_prev, const unsigned long long* hint, const unsigned char* hud,
-                            hipStream_t stream);
+                            const double* trig, const double* arcs, const unsigned char* falpha, hipStream_t stream);
 // the score / bar pictures (SF_HUD_BYTES, sf_raster.h)
 hipError_t sf_launch_hud_pictures(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* hud,
                                   hipStream_t stream);
 // ... and the 36 x 4 backgrounds with the fortress in them, behind the four plain ones (SF_BG_COUNT, sf_raster.h)
-hipError_t sf_launch_fort_patches(uint32_t* bg, uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
-                                  hipStream_t stream);
+hipError_t sf_launch_fort_patches(uint32_t* bg, uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch, const double* arcs,
+                                  const unsigned char* falpha, hipStream_t stream);
 
 // sf_normalize.hip: reduce + apply (two launches); partials = SF_NORM_GROUPS x 2 (dim + 1) doubles; stats is the
 // buffer of this step's parity, stats_next the other parity's
@@ -54,9 +54,9 @@ hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, cons
 // sf_render_generic.hip: the image observation in any geometry (sf_set_image_geometry): one workgroup per env, the W x H
 // surface in dynamic LDS, bg = W * H bytes (the hexagons), tabs = the INTER_AREA taps (8 words per destination column, then
 // per row: first, count, 4 weights, 2 pad)
-hipError_t sf_launch_render_generic(const unsigned char* state, int n_envs, int W, int H, double scale, double vp_x, double vp_y,
-                                    double line_w, const uint8_t* bg, const uint32_t* tabs, uint8_t* out, size_t out_stride,
-                                    int resize, hipStream_t stream);
+hipError_t sf_launch_render_generic(const unsigned char* state, int n_envs, int W, int H, double sx, double sy, double vp_x, double vp_y,
+                                    double line_w, const double* trig, const double* arcs, const uint8_t* bg, const uint32_t* tabs,
+                                    uint8_t* out, size_t out_stride, int resize, hipStream_t stream);
 hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n, hipStream_t stream);
 
 hipError_t sf_launch_normalize_after_step(const void* obs, void* obs_out, int obs_f64, const int32_t* rew, float* rew_out, int n,

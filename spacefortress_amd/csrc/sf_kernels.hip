@@ -1589,8 +1589,10 @@ __global__ __launch_bounds__(BLKP > 1000 ? 2 * (BLKP - 1000) : BLKP) void sf_ste
         typedef float f4_t __attribute__((ext_vector_type(4)));
         const unsigned doff = (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_MISSILE0 + SF_MM_SLOT(meta)) * (unsigned)SF_DR_PIECE_STRIDE +
                               SF_MM_OWNER(meta) * (unsigned)SF_DR_LANE_STRIDE;
-        sf_buf_st128<SF_DR_AUX>(__builtin_bit_cast(u4_t, (f4_t{(float)nx, (float)ny, (float)cs.x, (float)cs.y})), rs_draw,
-                                               keep ? doff : SF_OOB, 0);
+        sf_buf_st128<SF_DR_AUX>(__builtin_bit_cast(u4_t, (d2_t{nx, ny})), rs_draw, keep ? doff : SF_OOB, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((short)SF_MM_ANGLE(meta), rs_draw,
+                                              keep ? SF_DR_ANGLES_OFF + 2u * SF_MM_SLOT(meta) + SF_MM_OWNER(meta) * (unsigned)SF_DR_LANE_STRIDE : SF_OOB,
+                                              0, SF_DR_AUX);
         const bool rows = keep & sfd::hud_rows_near((float)ny, sfd::kMissileExt);
         if (__ballot(rows) != 0ull) {  // (all but never) -> bits 24..27 of the owner's hit word
           if (rows)
@@ -1786,7 +1788,7 @@ __global__ __launch_bounds__(BLKP > 1000 ? 2 * (BLKP - 1000) : BLKP) void sf_ste
   SF_STAMP(11, false);
   if (draw_now) {  // uniform: the env's draw record (sf_drawrec.h) -- header, ship, fortress; the missiles' entries went out above
     typedef float f4_t __attribute__((ext_vector_type(4)));
-    const sfd::Header h = sfd::make_header(L.sx, L.sy, (L.fl & SF_FL_SHIP_ALIVE) != 0u, (L.fl & SF_FL_FORT_ALIVE) != 0u, L.fort_angle,
+    const sfd::Header h = sfd::make_header(L.sx, L.sy, L.angle, (L.fl & SF_FL_SHIP_ALIVE) != 0u, (L.fl & SF_FL_FORT_ALIVE) != 0u, L.fort_angle,
                                            L.points, L.vlner, L.fort_vuln_t, L.mmask, L.smask,
                                            (done && a.auto_reset) ? 0u : dr_proj /* a new game has no projectiles */, a.draw_pics != 0, L.time);
     const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(
@@ -1794,12 +1796,7 @@ __global__ __launch_bounds__(BLKP > 1000 ? 2 * (BLKP - 1000) : BLKP) void sf_ste
     const unsigned d0 = real ? lane * (unsigned)SF_DR_LANE_STRIDE : SF_OOB;
     sf_buf_st128<SF_DR_AUX>(u4_t{h.w[0], h.w[1], h.w[2], h.w[3]}, rs_dr, d0, 0);
     sf_buf_st128<SF_DR_AUX>(u4_t{h.w[4], h.w[5], h.w[6], h.w[7]}, rs_dr, d0, SF_DR_PIECE_STRIDE);
-    sf_buf_st128<SF_DR_AUX>(
-        __builtin_bit_cast(u4_t, (f4_t{(float)L.sx, (float)L.sy, (float)SF_COS(L.angle), (float)SF_SIN(L.angle)})), rs_dr, d0,
-        (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE);
-    sf_buf_st128<SF_DR_AUX>(
-        __builtin_bit_cast(u4_t, (f4_t{(float)sfc::fort_x, (float)sfc::fort_y, (float)SF_COS(L.fort_angle), (float)SF_SIN(L.fort_angle)})),
-        rs_dr, d0, (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_FORT) * SF_DR_PIECE_STRIDE);
+    sf_buf_st128<SF_DR_AUX>(__builtin_bit_cast(u4_t, (d2_t{L.sx, L.sy})), rs_dr, d0, (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE);
   }
   if (!FUSED) store_lane_buf(rs, o, L);
   SF_STAMP(14, false);
@@ -1916,9 +1913,8 @@ __global__ __launch_bounds__(64) void sf_drawrec_kernel(const unsigned char* sta
   for (unsigned k = lane; k < n_pool; k += 64) {
     const d2_t p = SF_LD(d2_t, SF_CHUNK(missile_pos, 0), k * 16u);
     const unsigned m = SF_LD(unsigned, SF_CHUNK(missile_meta, 0), k * 4u);
-    const double* cs = consts + 2 * SF_MM_ANGLE(m);  // cos, sin of the heading (sf_host_fill_consts)
-    *reinterpret_cast<f4_t*>(dr + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_MISSILE0 + SF_MM_SLOT(m)) * SF_DR_PIECE_STRIDE + SF_MM_OWNER(m) * SF_DR_LANE_STRIDE) =
-        f4_t{(float)p.x, (float)p.y, (float)cs[0], (float)cs[1]};
+    *reinterpret_cast<d2_t*>(dr + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_MISSILE0 + SF_MM_SLOT(m)) * SF_DR_PIECE_STRIDE + SF_MM_OWNER(m) * SF_DR_LANE_STRIDE) = p;
+    *reinterpret_cast<int16_t*>(dr + SF_DR_ANGLES_OFF + 2 * SF_MM_SLOT(m) + SF_MM_OWNER(m) * SF_DR_LANE_STRIDE) = (int16_t)SF_MM_ANGLE(m);
     const unsigned f = sfd::hud_flags_near((float)p.x, (float)p.y, sfd::kMissileExt);
     if (f) atomicOr(&near[SF_MM_OWNER(m)], f);
   }
@@ -1934,17 +1930,14 @@ __global__ __launch_bounds__(64) void sf_drawrec_kernel(const unsigned char* sta
   if (tile_i * 64 + lane >= n_envs) return;
   const int ship_angle = (int16_t)(sm.x & 0xFFFF), fort_angle = (int16_t)((unsigned)sm.x >> 16);
   const unsigned fl = ((unsigned)sm.y >> 16) & 0xFFu;
-  const sfd::Header h = sfd::make_header(sp.x, sp.y, (fl & SF_FL_SHIP_ALIVE) != 0u, (fl & SF_FL_FORT_ALIVE) != 0u, fort_angle,
+  const sfd::Header h = sfd::make_header(sp.x, sp.y, ship_angle, (fl & SF_FL_SHIP_ALIVE) != 0u, (fl & SF_FL_FORT_ALIVE) != 0u, fort_angle,
                                          __int_as_float(sc.x), sc.z & 0xFFF, tc.w, mmask, smask, proj, pics != 0,
                                          (int)((unsigned)sc.w & 0xFFFFFFu));
   unsigned char* const me = dr + lane * SF_DR_LANE_STRIDE;
   *reinterpret_cast<u4_t*>(me) = u4_t{h.w[0], h.w[1], h.w[2], h.w[3]};
   *reinterpret_cast<u4_t*>(me + SF_DR_PIECE_STRIDE) = u4_t{h.w[4], h.w[5], h.w[6], h.w[7]};
-  const int sa = ship_angle < 0 ? 0 : (ship_angle > 359 ? 359 : ship_angle), fa = fort_angle < 0 ? 0 : (fort_angle > 359 ? 359 : fort_angle);
-  *reinterpret_cast<f4_t*>(me + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE) =
-      f4_t{(float)sp.x, (float)sp.y, (float)consts[2 * sa], (float)consts[2 * sa + 1]};
-  *reinterpret_cast<f4_t*>(me + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_FORT) * SF_DR_PIECE_STRIDE) =
-      f4_t{(float)sfc::fort_x, (float)sfc::fort_y, (float)consts[2 * fa], (float)consts[2 * fa + 1]};
+  *reinterpret_cast<d2_t*>(me + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE) = sp;
+  (void)consts;
 }
 
 hipError_t sf_launch_drawrec(const SfKernelArgs& a, hipStream_t stream) {

@@ -1,11 +1,14 @@
 // sf_raster.h -- geometry of the image observation, shared by the HIP render kernel and the host
 // (static background, resize tables).  What is drawn, where, in which order and colour follows the
 // reference renderer (SRC/draw.cpp:227-270, SRC/wireframe.cpp:8-70, ENV:50-58,203-206,
-// rl/envs.py:28-30); HOW a stroke becomes pixel coverage is cairo's business and cairo is not in
-// this image, so the anti-aliasing here is our own model -- exact area coverage of the stroke
-// rectangles -- and pixel parity with cairo + cv2 is UNPINNED ("image observation").
+// rl/envs.py:28-30); HOW a stroke or a filled rectangle becomes pixel values is cairo's image backend,
+// restated in sf_tor.h and pinned to the reference's own frames (tests/golden/frames).  The one thing here
+// that is a MODEL is the score text: cairo's toy font API draws it with whatever font fontconfig resolves
+// on the box, so its pixels are not a property of the reference (see below).
 #pragma once
 #include <math.h>
+
+#include "sf_tor.h"
 
 #ifdef __HIPCC__
 #define SF_HD __host__ __device__ __forceinline__
@@ -63,57 +66,6 @@
 #define SF_FP_BYTES 640
 
 namespace sfr {
-
-// Area of (convex polygon, n <= 8 vertices, counter-clockwise or clockwise) intersected with the unit
-// pixel [px, px+1] x [py, py+1]: Sutherland-Hodgman against the four pixel edges, then the shoelace
-// formula.  T = float on the device, double on the host.
-template <typename T>
-SF_HD T clip_area(const T* vx, const T* vy, int n, T px, T py) {
-  T ax[12], ay[12], bx[12], by[12];
-  for (int i = 0; i < n; i++) {
-    ax[i] = vx[i] - px;
-    ay[i] = vy[i] - py;
-  }
-  int m = n;
-  // clip against x >= 0, x <= 1, y >= 0, y <= 1 in turn
-  for (int e = 0; e < 4; e++) {
-    int k = 0;
-    for (int i = 0; i < m; i++) {
-      const int j = (i + 1 == m) ? 0 : i + 1;
-      const T x0 = ax[i], y0 = ay[i], x1 = ax[j], y1 = ay[j];
-      T d0, d1;
-      if (e == 0) { d0 = x0; d1 = x1; }
-      else if (e == 1) { d0 = (T)1 - x0; d1 = (T)1 - x1; }
-      else if (e == 2) { d0 = y0; d1 = y1; }
-      else { d0 = (T)1 - y0; d1 = (T)1 - y1; }
-      const bool in0 = d0 >= 0, in1 = d1 >= 0;
-      if (in0) {
-        bx[k] = x0;
-        by[k] = y0;
-        k++;
-      }
-      if (in0 != in1) {
-        const T t = d0 / (d0 - d1);
-        bx[k] = x0 + t * (x1 - x0);
-        by[k] = y0 + t * (y1 - y0);
-        k++;
-      }
-    }
-    m = k;
-    if (m == 0) return (T)0;
-    for (int i = 0; i < m; i++) {
-      ax[i] = bx[i];
-      ay[i] = by[i];
-    }
-  }
-  T s = 0;
-  for (int i = 0; i < m; i++) {
-    const int j = (i + 1 == m) ? 0 : i + 1;
-    s += ax[i] * ay[j] - ax[j] * ay[i];
-  }
-  s = s < 0 ? -s : s;
-  return (T)0.5 * s;
-}
 
 // pixman's 8-bit multiply: round(a * b / 255)
 SF_HD int mul_un8(int a, int b) {
@@ -192,18 +144,22 @@ SF_HD int text_pixel(int px, int py, unsigned long long masks, int d) {
   return d;
 }
 
-// drawVlner (SRC/draw.cpp:205-225): the .33 grey bar, then `v` (0..10) tenths of it in grey `vg`
+// drawVlner (SRC/draw.cpp:207-225): the .33 grey bar, then `v` (0..10) tenths of it in grey `vg`: two cairo_rectangle +
+// cairo_fill -> pixel-unaligned boxes -> cairo-rectangular-scan-converter.c: the box's exact area inside the pixel in
+// 1/65536, c = area >> 8, alpha = c - (c >> 8), then the image compositor's lerp (sf_tor.h).  In the default geometry the
+// rectangle's corners in 24.8 fixed point are compile-time facts: x = (255 - 130) * .2 = 25 exactly, widths 40 and 4 v
+// pixels exactly, y = fixed(88.4) = 22630 / 256 and 2 pixels down (cairo adds the rounded HEIGHT to the rounded corner).
 SF_HD int bar_pixel(int px, int py, int v, int vg, int d) {
-  const float bx0 = dev_x(255.f), bx1 = dev_x(455.f), by0 = dev_y(522.f), by1 = dev_y(532.f);
-  const float vx1 = dev_x(255.f + 20.f * (float)v);
-  const float fpx = (float)px, fpy = (float)py;
-  const float oy = fmaxf(fminf(by1, fpy + 1.f) - fmaxf(by0, fpy), 0.f);
-  const float o1 = fmaxf(fminf(bx1, fpx + 1.f) - fmaxf(bx0, fpx), 0.f);
-  const float o2 = fmaxf(fminf(vx1, fpx + 1.f) - fmaxf(bx0, fpx), 0.f);
-  const int ma = cover_to_mask(o1 * oy);
-  if (ma > 0) d = over_un8(d, 84, ma);
-  const int mb = cover_to_mask(o2 * oy);
-  if (v > 0 && mb > 0) d = over_un8(d, vg, mb);
+  constexpr int bx0 = 25 * 256, bx1 = 65 * 256, by0 = 22630, by1 = 22630 + 512;
+  const int vx1 = bx0 + 1024 * v;
+  const int X0 = px * 256, Y0 = py * 256;
+  const int oy = (by1 < Y0 + 256 ? by1 : Y0 + 256) - (by0 > Y0 ? by0 : Y0);
+  if (oy <= 0) return d;
+  auto ov = [&](int x1) { const int o = (x1 < X0 + 256 ? x1 : X0 + 256) - (bx0 > X0 ? bx0 : X0); return o > 0 ? o : 0; };
+  const int ca = (ov(bx1) * oy) >> 8, cb = (ov(vx1) * oy) >> 8;
+  const int aa = ca - (ca >> 8), ab = cb - (cb >> 8);
+  if (aa > 0) d = sft::lerp8(84, aa, d);
+  if (v > 0 && ab > 0) d = sft::lerp8(vg, ab, d);
   return d;
 }
 

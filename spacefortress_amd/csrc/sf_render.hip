@@ -8,34 +8,29 @@
 // Here: ONE WAVEFRONT PER ENV, fed by the env's DRAW RECORD (sf_drawrec.h): what a frame decides from its env's state alone --
 // which of the 148 backgrounds it starts from, whether the cached pictures apply, where the ship's box lies relative to the
 // fortress's, the score's and the bar's -- was decided by the step kernel, where it costs a lane instead of a wave, and arrives
-// as a 32-byte header through scalar loads; the objects' transforms (x, y, cos, sin) arrive one per lane.  The kernel reads the
-// state only for the shells (14 % of the frames have one).
-// The 90x92 frame lives in LDS as bytes (10 240 B per workgroup with the stroke records: 16 workgroups per CU), starts as a
-// copy of the background the record names (hexagons; score 0000000 / empty bar / the live fortress at its heading baked in;
-// ten direct-to-LDS loads), and every stroke of the reference's draw order is a convex quad (a line with butt caps, an arc
-// chord, a filled rectangle) composited OVER it with 8-bit arithmetic, like the image backend does.  Quads are built one per
-// lane from a table of the lane's corners (kLaneStroke) and the object's transform.  The small objects -- ship, missiles,
-// shells, the fortress when it has to be drawn in place -- go through draw_strokes all at once: stroke records in LDS, cheap
-// rounds (a lane per box pixel, an across-axis test) list the touched pixels, dense rounds evaluate the exact area coverage
-// (edge integrals, sf_cover.h) and composite stroke after stroke, ONE pass resamples the objects' 84x84 boxes; explosions go
-// ring by ring, twelve arcs at once.  Whatever is a function of little is drawn once and copied afterwards: a dead ship's
-// explosion (per env, keyed by where the ship died; with the score / bar box under it), and once per batch the live fortress
-// at its 36 headings (baked into backgrounds), the destroyed fortress's explosion, 1 024 scores and the bar's 12 states.  The
-// 84x84 frame is built IN PLACE in the caller's buffer in HBM: it starts as the resampled background (host-made) and the wave
-// re-evaluates INTER_AREA for exactly the output pixels that read a drawn object's box (out_box) -- a frame is a few dozen
-// changed pixels on a static picture.  The frames whose ship just died (the expensive ones) are started first (pick_env).
-// Issue-bound (1 488 instructions per frame, 949 of them vector; VALU busy 64 % of the launch), not memory-bound.
-// profiles/r04_render_versions.md has the version table; DESIGN.md section 5 the design.
+// as a 32-byte header through scalar loads; the objects' positions (float64) and headings arrive one per lane.  The kernel reads
+// the state only for the shells (14 % of the frames have one).
+// The 90x92 frame lives in LDS as bytes, starts as a copy of the background the record names (hexagons; score 0000000 / empty
+// bar / the live fortress at its heading baked in; ten direct-to-LDS loads), and every cairo_stroke of the reference's draw order
+// is rasterised the way cairo's image backend does it (sf_tor.h: 24.8 fixed-point corners, 15 sub-rows per pixel row or the whole
+// row at once, the union of an object's lines, 8-bit lerp) by sf_tor_dev.h's lane arrangement: ship, missiles and shells in
+// chunks of up to sixteen lines; an explosion ring by ring, twelve arcs at once, then its circle.  Whatever is a function of
+// little is drawn once and copied afterwards: a dead ship's explosion (per env, keyed by where the ship died; with the score /
+// bar box under it), and once per batch the live fortress at its 36 headings (an alpha map from the host, baked into
+// backgrounds), the destroyed fortress's explosion, 1 024 scores and the bar's 12 states.  The 84x84 frame is built IN PLACE in
+// the caller's buffer in HBM: it starts as the resampled background (host-made) and the wave re-evaluates INTER_AREA for exactly
+// the output pixels that read a drawn object's box (out_box) -- a frame is a few dozen changed pixels on a static picture.  The
+// frames whose ship just died (the expensive ones) are started first (pick_env).
 //
-// Pixel values: what is drawn where, in which order and grey follows the reference; the
-// anti-aliasing model is ours (cairo is not in this image).  Pixel parity with cairo + cv2 is
-// UNPINNED; tests pin this kernel to the numpy restatement of the same model (oracle/render_np.py).
+// Pixel values: PINNED to the reference's own renderer (SRC/draw.cpp against cairo 1.16): tests/golden/frames holds frames it
+// drew, oracle/cairo_model.c restates cairo's rasteriser bit for bit, and tests/test_gpu_image.py holds this kernel to both.
+// Not pinned: the score text (a font-dependent glyph model, sf_raster.h) and cv2's INTER_AREA (OpenCV's published algorithm).
 #include <hip/hip_runtime.h>
 
 #include "sf_drawrec.h"
-#include "sf_cover.h"
 #include "sf_internal.h"
 #include "sf_raster.h"
+#include "sf_tor_dev.h"
 
 // diagnostic builds only (tools/variant.py NAME -DSF_RENDER_SKIP=bits): bit 0 ship + fortress strokes, 1 missiles + shells,
 // 2 score, 3 bar, 4 the resampling, 5 the coverage of the dense rounds, 6 their compositing, 8 the dead ship's explosion,
@@ -59,8 +54,6 @@
 
 namespace {
 
-using namespace sfcov;
-
 constexpr int kFbBytes = SF_IMG_W * SF_IMG_H;          // 8280
 constexpr int kFbWords = kFbBytes / 4;                 // 2070
 constexpr int kFbPadWords = (SF_IMG_W * (SF_IMG_H + 1) + 3) / 4 + 1;  // one spare row for zero-weight taps
@@ -78,9 +71,6 @@ struct i4_t {
 #define R_LD(T, base, off) (*reinterpret_cast<const T*>((base) + (off)))
 
 
-#include "sf_render_tables.h"  // kArcs[7][12], kGon[12], kSinCosDeg[360]
-
-
 // i / w and i % w for the pixel loops: i indexes a box of the 90x92 surface (i < 8 280), 1 <= w <= 92, `rw` = 1 / w
 // (v_rcp_f32, hoisted out of the loop).  The general 32-bit division is two dozen instructions, once per pixel and loop:
 // a sixth of what this kernel issued.  EXACT: (i + 0.5) / w lies at least 0.5 / w away from every integer and the float
@@ -96,7 +86,6 @@ __device__ __forceinline__ DivMod fast_divmod(int i, int w, float rw) {
 }
 __device__ __forceinline__ float recip_i(int w) { return __builtin_amdgcn_rcpf((float)w); }
 
-using sfr::cover_to_mask;
 using sfr::dev_x;
 using sfr::dev_y;
 
@@ -115,19 +104,17 @@ using sfd::kFpX1;
 using sfd::kFpY0;
 using sfd::kFpY1;
 
-// pixel box of a quad, clipped to the surface (empty for NaN / far-away geometry)
-__device__ __forceinline__ Box quad_box(const Quad& q) {
-  const float fx0 = fminf(fminf(q.x[0], q.x[1]), fminf(q.x[2], q.x[3]));
-  const float fx1 = fmaxf(fmaxf(q.x[0], q.x[1]), fmaxf(q.x[2], q.x[3]));
-  const float fy0 = fminf(fminf(q.y[0], q.y[1]), fminf(q.y[2], q.y[3]));
-  const float fy1 = fmaxf(fmaxf(q.y[0], q.y[1]), fmaxf(q.y[2], q.y[3]));
+// pixel box of a fixed-point quad, clipped to the surface
+__device__ __forceinline__ Box quad_box(const sft::Quad& q) {
+  const int fx0 = min(min(q.x[0], q.x[1]), min(q.x[2], q.x[3])), fx1 = max(max(q.x[0], q.x[1]), max(q.x[2], q.x[3]));
+  const int fy0 = min(min(q.y[0], q.y[1]), min(q.y[2], q.y[3])), fy1 = max(max(q.y[0], q.y[1]), max(q.y[2], q.y[3]));
   Box b;
   b.clear();
-  if (fx1 > 0.f && fy1 > 0.f && fx0 < (float)SF_IMG_W && fy0 < (float)SF_IMG_H) {
-    b.x0 = (int)floorf(fmaxf(fx0, 0.f));
-    b.y0 = (int)floorf(fmaxf(fy0, 0.f));
-    b.x1 = (int)ceilf(fminf(fx1, (float)SF_IMG_W));
-    b.y1 = (int)ceilf(fminf(fy1, (float)SF_IMG_H));
+  if (fx1 > 0 && fy1 > 0 && fx0 < SF_IMG_W * 256 && fy0 < SF_IMG_H * 256) {
+    b.x0 = max(fx0 >> 8, 0);
+    b.y0 = max((sft::to_grid_y(fy0) - 1) / sft::kGridY, 0);  // (a sub-row's centre may lie a thirtieth of a pixel outside the corners)
+    b.x1 = min((fx1 + 255) >> 8, SF_IMG_W);
+    b.y1 = min((sft::to_grid_y(fy1) + sft::kGridY) / sft::kGridY, SF_IMG_H);
   }
   return b;
 }
@@ -174,8 +161,7 @@ struct Frame {
   const uint32_t* tab;  // the tap tables (sf_raster.h): global memory, or an LDS copy (the picture kernels)
   const uint32_t* ptab; // LDS: one PERIOD of the tap tables, or null (then `tab` is read): see resample_into
   int lane;
-  float* srec;          // LDS: kChunk stroke records of kRecFloats floats (draw_strokes)
-  uint32_t* slist;      // LDS: kListCap touched (stroke, x, y) entries (draw_strokes)
+  uint32_t* tor;        // LDS: sf_tor_dev.h's records, objects and accumulators (kTorWords); the resample pass's records after them
   // One PERIOD of the tap tables for resample_quad, in LDS behind the resample pass's own records (the strokes' records are
   // dead by then): 90 / 84 = 15 / 14 and 92 / 84 = 23 / 21, so the column taps repeat every 14 destination columns -- every 28
   // = 7 quads of four -- with the first source column moving on by 30, the row taps every 21 rows with the first source row
@@ -361,248 +347,47 @@ struct Frame {
     __builtin_amdgcn_wave_barrier();
   }
 
-  // Composite this round's quads (one per lane, `valid` lanes only) in lane order; lanes
-  // [k*per, (k+1)*per) belong to one object, whose pixels are resampled when it is complete.
-  __device__ __forceinline__ void draw_quads(const Quad& mine, int grey, bool valid, int per) const {
-    unsigned long long live = __ballot(valid);
-    Box dirty;
-    dirty.clear();
-    int obj = -1;
-    while (live) {
-      const int src = __builtin_ctzll(live);
-      live &= live - 1;
-      if (src / per != obj) {
-        resample(dirty);
-        dirty.clear();
-        obj = src / per;
-      }
-      Quad q;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        q.x[k] = bcast(mine.x[k], src);
-        q.y[k] = bcast(mine.y[k], src);
-      }
-      const int c = __builtin_amdgcn_readlane(grey, src);
-      const Box qb = quad_box(q);
-      if (qb.empty()) continue;
-      const int bx0 = qb.x0, by0 = qb.y0;
-      dirty.add(qb.x0, qb.y0, qb.x1, qb.y1);
-      const int bw = qb.x1 - qb.x0, n = bw * (qb.y1 - qb.y0);
-      const float r_bw = recip_i(bw);
-      for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        if (i < n) {
-          const DivMod dm = fast_divmod(i, bw, r_bw);
-          const int ry = dm.q, rx = dm.r;
-          const int px = bx0 + rx, py = by0 + ry;
-          const int m = cover_to_mask(quad_cover(q, (float)px, (float)py));
-          if (m > 0) {
-            uint8_t* p = fb + py * SF_IMG_W + px;
-            *p = (uint8_t)sfr::over_un8(*p, c, m);
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    resample(dirty);
-  }
-
-  // ---- Small objects: the ship (3 strokes), the fortress drawn in place (4), missiles (3 each), shells (4 each).
-  // Lane s holds stroke s of the frame's draw order (`mine`, `valid`); `obj0` = the first lane of the stroke's object.
-  //
-  // A stroke is a 0.6 x 3.6 .. 7.2 pixel rectangle at any angle: its bounding box holds two to four times the pixels it
-  // touches, and an object is a couple of dozen touched pixels -- a third of a wave.  Round 2 drew one object at a time,
-  // every lane on a (stroke, box pixel) pair paying the full edge integrals (165 vector instructions) whether the pixel
-  // is touched or not: the ship's 70 box pixels took two rounds of lanes, every missile one.  Here, for up to kChunk
-  // strokes of ANY objects at once:
-  //   1. the strokes' owners put a record in LDS: box, the stroke's two axes for a separating-axis test, the quad and its
-  //      edge slopes;
-  //   2. cheap rounds: a lane per box pixel of all the chunk's strokes tests pixel-square against stroke-rectangle (the
-  //      box is the other two axes: the test is exact, made conservative by a margin) -- a dozen instructions -- and the
-  //      touched ones are appended, ballot + prefix count, to a list in LDS: (stroke, x, y), in stroke order;
-  //   3. dense rounds over the list: the exact coverage (quad_cover: the same arithmetic on the same operands as before, so
-  //      the same pixels), kept in a register, then the strokes present in the round composite one after the other in
-  //      stroke order -- no two lanes of a stroke share a pixel, and LDS is in order per wave;
-  //   4. every object's box of the 84x84 image is resampled once everything is drawn (a destination pixel that reads a
-  //      changed source pixel lies in some object's out_box, and is evaluated after the last change).
-  // A live ship and a missile or two are one dense round instead of three or four sparse ones.
-#ifndef SF_LISTCAP
-#define SF_LISTCAP 128
-#endif
-#ifndef SF_CHUNK
-#define SF_CHUNK 16  // (records: 80 B each; with them the workgroup's LDS is 10 240 B exactly = 16 workgroups per CU, the most its
-                     //  surface allows.  A frame with a live ship, the fortress in place and two missiles is 13 strokes: with 12 per
-                     //  chunk -- what fitted while a record was 96 B -- it paid a second chunk.  A/B 12 / 14 / 16: 49.6 / 49.5 / 49.3 us)
-#endif
-  static constexpr int kChunk = SF_CHUNK, kListCap = SF_LISTCAP;
-  static_assert(kListCap >= 127, "a round appends up to 64 entries behind the 63 kept");
-#ifndef SF_MAPBITS  /* (tests: tiny maps -- 64 / 128 -- send every frame through the "chunk ends where the map ends" path) */
-#define SF_MAPBITS 512
-#define SF_MAPBITS_OUT 1024
-#endif
-  static constexpr int kMapBits = SF_MAPBITS;      // the map of the strokes' starts (behind the records): 12 boxes of 6 x 7
-  static constexpr int kMapBitsOut = SF_MAPBITS_OUT;  // ... and of the objects' 84x84 boxes (in the records' space, behind the objects' own)
-  // (LDS words of `srec`: the strokes' records and the map of their starts; the resample pass reuses the space -- its own records
-  //  and map, then one period of the tap tables)
-  static constexpr int kLtabAt = 4 * kChunk + kMapBitsOut / 32;  // words into srec: behind that pass's records and map
-  static constexpr int kRecFloats = 20;  // [0,12) quad x, y, slopes; [12,16) nx, ny, cn, hn; [16,19) x0 | y0 << 8, w, offset (ints); [19] 1 / w
-  static constexpr int kStrokeWords = kChunk * kRecFloats + (kMapBits + 63) / 64 * 2, kResampleWords = kLtabAt + 4 * kLtabEntries;
-  static constexpr int kSrecWords = kStrokeWords > kResampleWords ? kStrokeWords : kResampleWords;
+  // ---- Small objects: the ship (3 lines), missiles (3 each), shells (4 each): each object ONE cairo_stroke of the reference
+  // (drawWireFrame, SRC/draw.cpp:82-100), i.e. the union of its lines' rectangles through cairo's scan conversion.  Lane s holds
+  // line s of the frame's draw order as a fixed-point quad (`mine`, `valid`); `obj0` = the first lane of the line's object, `kind`
+  // the object's (sf_tor_dev.h).  sftd::raster takes up to sixteen lines of whole objects at a time.
+  static constexpr int kChunk = 16;
+  static constexpr int kMapBitsOut = 1024;  // the map of the objects' 84x84 boxes in the resample pass
+  static constexpr int kLtabAt = 4 * kChunk + kMapBitsOut / 32;  // words into `tor`: behind that pass's records and map
+  static constexpr int kResampleWords = kLtabAt + 4 * kLtabEntries;
+  static constexpr int kTorWords = sftd::kLdsWords > kResampleWords ? sftd::kLdsWords : kResampleWords;
   static_assert(kLtabAt % 4 == 0, "the period of the tap tables is 16-byte aligned");
-  __device__ __forceinline__ void flush_list(int cnt) const {
-    for (int base = 0; base < cnt; base += 64) {
-      const int i = base + lane;
-      int k = -1, m = 0;
-      uint8_t* p = fb;
-      if (i < cnt) {
-        const uint32_t ent = slist[i];
-        k = (int)(ent >> 16);
-        const int px = (int)(ent & 255u), py = (int)((ent >> 8) & 255u);
-        const float* g = srec + k * kRecFloats;
-        Quad q;
-        Slopes sl;
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-          q.x[v] = g[v];
-          q.y[v] = g[4 + v];
-          sl.s[v] = g[8 + v];
-        }
-        if (!(SF_RENDER_SKIP & 32)) m = cover_to_mask(quad_cover(q, sl, (float)px, (float)py));
-        p = fb + py * SF_IMG_W + px;
-      }
-      // the list is in stroke order: this round holds the strokes klo .. khi, composited one after the other
-      const int klo = __builtin_amdgcn_readfirstlane(k);
-      const int last = min(cnt - base, 64) - 1;
-      const int khi = __builtin_amdgcn_readlane(k, last);
-      // (every stroke of draw_strokes is white: over_un8(d, 255, m) = mul_un8(255, m) + mul_un8(d, 255 - m), and pixman's
-      //  mul_un8(255, m) is m for every m in 0 .. 255 -- asserted by tests/test_image_host.py -- so the turn of a stroke is
-      //  one multiply-round instead of two; a lane whose stroke leaves its pixel alone takes no turn)
-      const int kx = m > 0 ? k : -1, im = 255 - m;
-      for (int kk = klo; kk <= khi; kk++) {
-        if (!(SF_RENDER_SKIP & 64) && kx == kk) *p = (uint8_t)(m + sfr::mul_un8((int)*p, im));
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
-  __device__ __forceinline__ void draw_strokes(const Quad& mine, bool valid, int obj0) const {
-// diagnostic builds (SF_RENDER_STOP 41 .. 44, tools/pmc_render_stops.sh): leave behind the set-up / the records / the cheap and dense
-    // rounds of the first chunk / everything but the resample pass -- instruction counts of the parts by difference
+  __device__ __forceinline__ sftd::Ctx tor_ctx() const { return sftd::Ctx{tor, fb, SF_IMG_W, SF_IMG_H, lane}; }
+  __device__ __forceinline__ void draw_strokes(const sft::Quad& mine, bool valid, int obj0, int kind) const {
 #define SF_DS_STAMP(k) do { if (SF_RENDER_STOP == 41 + (k)) return; } while (0)
     const Box myb = quad_box(mine);
-    const int mybw = myb.x1 - myb.x0, mybh = myb.y1 - myb.y0;
-    const int myn = (valid && !myb.empty()) ? mybw * mybh : 0;
-    unsigned long long live = __ballot(myn > 0);
-    const unsigned long long drawn = live;
-    // the stroke's frame: edge 0 -> 1 runs along the stroke, edge 1 -> 2 across it (line_quad's vertex order)
-    // (the cheap rounds test the ACROSS axis only: a stroke's bounding box already cuts the strip |n . (c - m)| <= hn down to the
-    //  stroke but for a sliver at its two ends -- a pixel or two per stroke that get coverage 0 in the dense round --, and the
-    //  along-axis test cost more than that: a reciprocal square root, a reciprocal and a dozen instructions per stroke, five per
-    //  box pixel, four words per record: 50.5 -> 49.7 us per image step)
-    float nx, ny, cn, hn;
-    {
-      const float fx = mine.x[2] - mine.x[1], fy = mine.y[2] - mine.y[1];
-      // (v_rsq / v_rcp: an ulp or two, far inside the margin below; the IEEE forms are ten instructions each)
-      const float jf = __builtin_amdgcn_rsqf(fx * fx + fy * fy), lf = __builtin_amdgcn_rcpf(jf);
-      nx = fx * jf; ny = fy * jf;
-      const float mx = 0.25f * ((mine.x[0] + mine.x[1]) + (mine.x[2] + mine.x[3]));
-      const float my = 0.25f * ((mine.y[0] + mine.y[1]) + (mine.y[2] + mine.y[3]));
-      // |n . (c - m)| <= width / 2 + the pixel square's half extent along n; c = pixel centre.  The margin makes float
-      // rounding err on the side of keeping a pixel: a kept pixel outside the stroke gets coverage 0.
-      cn = -(nx * mx + ny * my);
-      hn = 0.5f * lf + 0.5f * (fabsf(nx) + fabsf(ny)) + 1e-3f;
-    }
+    const bool mineok = valid && !myb.empty();
+    // an object whose box is empty in one of its lines may still touch the surface with another: keep whole objects
+    unsigned long long live = __ballot(valid);
+    const unsigned long long drawn = __ballot(mineok);
+    const int nq = kind == sftd::kKindShell ? 4 : 3;  // (per lane: the object's)
     SF_DS_STAMP(0);
     while (live) {
-      // this chunk: the lowest kChunk strokes still to draw -- fewer if their box pixels would start beyond what the map of
-      // starts below holds (never with this game's strokes: 8 boxes of at most 10 x 10)
-      const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u));
-      const bool cand = ((live >> lane) & 1ull) && rank < kChunk;
-      // where each stroke's box pixels start in the chunk's enumeration: an exclusive prefix sum over the owners, in lane
-      // (= rank) order -- six DPP adds across the wave instead of a scalar loop of readlanes with their wait states
-      int incl = cand ? myn : 0;
-      const int mine_n = incl;
-      incl = wave_inclusive_sum(incl);
-      const int myoff = incl - mine_n;
-      const bool own = cand && myoff <= kMapBits;
-      const unsigned long long chunk = __ballot(own);
+      // this chunk: the first objects whose lines fit sixteen records
+      const int rank0 = (int)__popcll(live & ((1ull << obj0) - 1ull));
+      const bool in = ((live >> lane) & 1ull) && rank0 + nq <= kChunk;
+      const unsigned long long chunk = __ballot(in);
       live &= ~chunk;
-      const int total = __builtin_amdgcn_readlane(incl, 63 - __builtin_clzll(chunk));
-      // ... and which stroke a box pixel belongs to: bit p - 1 of a map in LDS is set for every start p >= 1; pixel i of
-      // the enumeration then belongs to stroke #(set bits below i) -- per round of 64 pixels one 64-bit word of the map, a
-      // v_mbcnt pair and the running count, where a compare-and-add chain over the kChunk starts was fourteen instructions
-      uint32_t* const smap = reinterpret_cast<uint32_t*>(srec + kChunk * kRecFloats);
-      if (lane < kMapBits / 32) smap[lane] = 0u;
-      if (own) {
-        if (myoff > 0) atomicOr(&smap[(myoff - 1) >> 5], 1u << ((myoff - 1) & 31));
-        const Slopes ms = quad_slopes(mine);
-        float* g = srec + rank * kRecFloats;
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-          g[v] = mine.x[v];
-          g[4 + v] = mine.y[v];
-          g[8 + v] = ms.s[v];
-        }
-        g[12] = nx; g[13] = ny; g[14] = cn; g[15] = hn;
-        int* gi = reinterpret_cast<int*>(g + 16);
-        gi[0] = myb.x0 | (myb.y0 << 8); gi[1] = mybw; gi[2] = myoff;
-        g[19] = recip_i(mybw);  // (per stroke, not per box pixel: a quarter-rate instruction)
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      SF_DS_STAMP(1);
-      int cnt = 0;
-      int kb = 0;
-      for (int base = 0; base < total; base += 64) {
-        const int i = base + lane;
-        bool touched = false;
-        uint32_t ent = 0;
-        const uint2 mw = base < kMapBits ? *reinterpret_cast<const uint2*>(smap + (base >> 5)) : uint2{0u, 0u};  // (uniform)
-        const int k = kb + (int)__builtin_amdgcn_mbcnt_hi(mw.y, __builtin_amdgcn_mbcnt_lo(mw.x, 0u));
-        kb += __popc(mw.x) + __popc(mw.y);
-        if (i < total) {
-          const float* g = srec + k * kRecFloats;
-          const int* gi = reinterpret_cast<const int*>(g + 16);
-          const int x0 = gi[0] & 255, y0 = gi[0] >> 8, w = gi[1], j = i - gi[2];
-          const DivMod dm = fast_divmod(j, w, g[19]);
-          const int px = x0 + dm.r, py = y0 + dm.q;
-          const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
-          touched = fabsf(g[12] * cx + g[13] * cy + g[14]) <= g[15];
-          ent = ((uint32_t)k << 16) | ((uint32_t)py << 8) | (uint32_t)px;
-        }
-        const unsigned long long tb = __ballot(touched);
-        if (touched)
-          slist[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tb, 0u))] = ent;
-        cnt += (int)__popcll(tb);
-        if (cnt >= 64) {  // uniform: a full round's worth is listed -- draw exactly that, keep the rest for the next full round
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (drawing all of it was a second, nearly empty dense round)
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          flush_list(64);
-          cnt -= 64;
-          const uint32_t keep = lane < cnt ? slist[64 + lane] : 0u;
-          __builtin_amdgcn_wave_barrier();
-          if (lane < cnt) slist[lane] = keep;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      flush_list(cnt);
+      sftd::raster(tor_ctx(), mine, in, obj0, kind, 255);
       SF_DS_STAMP(2);
-      // (the next chunk's records overwrite these: every listed pixel has been drawn)
     }
     // ---- the 84x84 pixels that read what was drawn.  An object = the (at most four, consecutive) strokes that share
-    // `obj0`; its box = the union of their boxes, gathered at its first lane with three whole-wave DPP shifts (round 2 and the
-    // first form of this function walked the strokes with scalar readlanes, object by object, and resampled object by object:
-    // a round of lanes each, two thirds full).  Then ONE enumeration over the destination pixels of all the objects' boxes --
-    // the cheap rounds' machinery: prefix sum, starts in LDS, a lane per pixel finds its object --, everything being drawn
-    // by now (a destination pixel that reads a changed source pixel lies in some object's box).
+    // `obj0`; its box = the union of their boxes, gathered at its first lane with three whole-wave DPP shifts.  Then ONE
+    // enumeration over the destination pixels of all the objects' boxes: prefix sum, starts in LDS, a lane per pixel finds its
+    // object --, everything being drawn by now (a destination pixel that reads a changed source pixel lies in some object's box).
     SF_DS_STAMP(3);
     if (RESIZE && !(SF_RENDER_SKIP & 16) && drawn) {
       fill_ltab();  // (behind the objects' records and map of this pass: nothing below writes there)
       const bool me = (drawn >> lane) & 1ull;
       int ux0 = me ? myb.x0 : (1 << 20), uy0 = me ? myb.y0 : (1 << 20), ux1 = me ? myb.x1 : -1, uy1 = me ? myb.y1 : -1;
+      // (gathered at the object's first lane WITH a box: its first line's may be empty)
+      const unsigned long long same_before = drawn & ((1ull << lane) - 1ull) & ~((1ull << obj0) - 1ull);
+      const bool head = me && same_before == 0ull;
       {
         int sx0 = ux0, sy0 = uy0, sx1 = ux1, sy1 = uy1, so = obj0;
 #pragma unroll
@@ -623,7 +408,7 @@ struct Frame {
       // (SF_RESAMPLE_QUADS: the unit of the enumeration is four pixels of a row, at multiples of four: resample_quad)
       const int ogx0 = SF_RESAMPLE_QUADS ? o.x0 >> 2 : o.x0;
       const int ow = SF_RESAMPLE_QUADS ? ((o.x1 + 3) >> 2) - ogx0 : o.x1 - o.x0;
-      const int on = (lane == obj0 && ux1 > ux0 && uy1 > uy0) ? ow * (o.y1 - o.y0) : 0;
+      const int on = (head && ux1 > ux0 && uy1 > uy0) ? ow * (o.y1 - o.y0) : 0;
       unsigned long long todo = __ballot(on > 0);
       while (todo) {
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo, 0u));
@@ -636,8 +421,8 @@ struct Frame {
         const unsigned long long chunk = __ballot(own);
         todo &= ~chunk;
         const int total = __builtin_amdgcn_readlane(incl, 63 - __builtin_clzll(chunk));
-        int* const orec = reinterpret_cast<int*>(srec);  // (the strokes' records are done with) per object: x0 | y0 << 8, w, start, 1 / w
-        uint32_t* const omap = reinterpret_cast<uint32_t*>(srec + 4 * kChunk);
+        int* const orec = reinterpret_cast<int*>(tor);  // per object: x0 | y0 << 8, w, start, 1 / w
+        uint32_t* const omap = tor + 4 * kChunk;
         if (lane < kMapBitsOut / 32) omap[lane] = 0u;
         if (own) {
           if (myoff > 0) atomicOr(&omap[(myoff - 1) >> 5], 1u << ((myoff - 1) & 31));
@@ -664,176 +449,72 @@ struct Frame {
         }
         __builtin_amdgcn_wave_barrier();
       }
+      // (the accumulators behind the records were zero and must be again: the pass above wrote over the records only --
+      //  kResampleWords <= the records' and objects' space)
     }
 #undef SF_DS_STAMP
   }
 };
+static_assert(Frame<true>::kResampleWords <= sftd::kMaxQuads * sftd::kRecWords + sftd::kMaxObjs * sftd::kObjWords,
+              "the resample pass's records, map and tap period stay clear of sf_tor_dev.h's accumulators (which must stay zero)");
 
-// Stroke of the segment A-B (wireframe coordinates), butt caps, width SF_LINE_W, under
-// translate(pos) rotate(angle) (drawWireFrame, SRC/draw.cpp:112-129)
-struct Seg {  // a wireframe segment with its transform: everything line_quad reads
-  float ax, ay, bx, by, ca, sa, posx, posy;
-  float inv;  // half the line width over the segment's length: a constant of the stroke (stroke_inv)
+// ---- the objects' lines as cairo has them: path points through the matrices of drawGameStateScaled + drawWireFrame
+// (sf_tor.h: view_matrix, object_matrix, to_device), in float64 like cairo, then one butt-capped rectangle per line
+// wireframe segments (ax, ay, bx, by), SRC/wireframe.cpp:11-67, as functions of the line's index (small whole numbers)
+struct Seg4 {
+  double ax, ay, bx, by;
 };
-// (float)(SF_LINE_W / 2) / sqrtf(ux * ux + uy * uy) for a segment (ux, uy) = B - A.  The segments are compile-time tables:
-// on constant arguments the compiler folds this -- with the IEEE square root and division the run-time form has, so the
-// same float -- and a stroke carries the value instead of twenty-odd instructions of correctly rounded sqrt and division.
-__device__ __forceinline__ float stroke_inv(float ux, float uy) {
-  return (float)(SF_LINE_W / 2) / __builtin_sqrtf(ux * ux + uy * uy);
+__device__ __forceinline__ Seg4 ship_seg(int k) {      // {-18, 0, 18, 0}, {-18, 18, 0, 0}, {0, 0, -18, -18}
+  return Seg4{k == 2 ? 0.0 : -18.0, k == 1 ? 18.0 : 0.0, k == 0 ? 18.0 : (k == 1 ? 0.0 : -18.0), k == 2 ? -18.0 : 0.0};
 }
-__device__ __forceinline__ Quad line_quad(const Seg& g);
-__device__ __forceinline__ Quad line_quad(const float* ln, float ca, float sa, float posx, float posy) {
-  return line_quad(Seg{ln[0], ln[1], ln[2], ln[3], ca, sa, posx, posy, stroke_inv(ln[2] - ln[0], ln[3] - ln[1])});
+__device__ __forceinline__ Seg4 missile_seg(int k) {   // {0, 0, -25, 0}, {0, 0, -5, 5}, {0, 0, -5, -5}
+  return Seg4{0.0, 0.0, k == 0 ? -25.0 : -5.0, k == 0 ? 0.0 : (k == 1 ? 5.0 : -5.0)};
 }
-__device__ __forceinline__ Quad line_quad(const Seg& g) {
-  const float ax = g.ax, ay = g.ay, bx = g.bx, by = g.by, ca = g.ca, sa = g.sa, posx = g.posx, posy = g.posy;
-  const float ux = bx - ax, uy = by - ay;
-  const float inv = g.inv;
-  const float nx = -uy * inv, ny = ux * inv;
-  const float lx[4] = {ax + nx, bx + nx, bx - nx, ax - nx};
-  const float ly[4] = {ay + ny, by + ny, by - ny, ay - ny};
-  Quad q;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    q.x[k] = dev_x(posx + ca * lx[k] - sa * ly[k]);
-    q.y[k] = dev_y(posy + sa * lx[k] + ca * ly[k]);
-  }
-  return q;
+__device__ __forceinline__ Seg4 shell_seg(int k) {     // {-8, 0, 0, -6}, {0, -6, 16, 0}, {16, 0, 0, 6}, {0, 6, -8, 0}
+  return Seg4{k == 0 ? -8.0 : (k == 2 ? 16.0 : 0.0), k == 1 ? -6.0 : (k == 3 ? 6.0 : 0.0), k == 1 ? 16.0 : (k == 3 ? -8.0 : 0.0),
+              k == 0 ? -6.0 : (k == 2 ? 6.0 : 0.0)};
 }
-
-// every wireframe heading is an integer number of degrees in [0, 360) (the state keeps them as int16; a shell's is
-// truncated to an int like drawWireFrame does): one 8-byte load from a 2.9 KB table instead of a sincosf
-__device__ __forceinline__ void sincos_deg(int deg, float* s, float* c) {
+__device__ __forceinline__ sft::Affine default_view() { return sft::view_matrix(SF_SCALE, SF_SCALE, SF_VP_X, SF_VP_Y); }
+// one line of a wireframe at (px, py), heading `deg` (cos / sin of deg2rad(deg) from the batch's table: the host's libm)
+__device__ __forceinline__ sft::Quad line_quad(const Seg4& g, double px, double py, const double* trig, int deg) {
   deg = deg < 0 ? 0 : (deg > 359 ? 359 : deg);  // (never out of range for a state the step kernel produced)
-  const float2 sc = *reinterpret_cast<const float2*>(kSinCosDeg[deg]);
-  *s = sc.x;
-  *c = sc.y;
+  const double2 cs = *reinterpret_cast<const double2*>(trig + 2 * deg);
+  const sft::Affine m = sft::object_matrix(default_view(), px, py, cs.x, cs.y);
+  int x1, y1, x2, y2;
+  sft::to_device(m, g.ax, g.ay, &x1, &y1);
+  sft::to_device(m, g.bx, g.by, &x2, &y2);
+  return sft::stroke_quad(x1, y1, x2, y2, SF_SCALE, SF_SCALE, SF_LINE_W / 2);
 }
 
-// wireframe segments (ax, ay, bx, by), SRC/wireframe.cpp:11-67.  As functions of the stroke index, not tables in memory:
-// a table indexed by the lane is a vector load from .rodata, a dependent round trip in front of every object (small whole
-// numbers: the selects give the same floats).
-struct Line {
-  float ax, ay, bx, by, inv;  // inv = stroke_inv(bx - ax, by - ay), folded at compile time
-};
-__device__ __forceinline__ Line fort_line(int k) {     // {0, 0, 36, 0}, {0, -18, 18, -18}, {18, -18, 18, 18}, {18, 18, 0, 18}
-  return Line{k >= 2 ? 18.f : 0.f, k == 0 ? 0.f : (k == 3 ? 18.f : -18.f), k == 0 ? 36.f : (k == 3 ? 0.f : 18.f),
-              k == 0 ? 0.f : (k == 1 ? -18.f : 18.f),
-              k == 0 ? stroke_inv(36.f, 0.f) : (k == 1 ? stroke_inv(18.f, 0.f) : (k == 2 ? stroke_inv(0.f, 36.f) : stroke_inv(-18.f, 0.f)))};
-}
-__device__ __forceinline__ Line shell_line(int k) {    // {-8, 0, 0, -6}, {0, -6, 16, 0}, {16, 0, 0, 6}, {0, 6, -8, 0}
-  return Line{k == 0 ? -8.f : (k == 2 ? 16.f : 0.f), k == 1 ? -6.f : (k == 3 ? 6.f : 0.f), k == 1 ? 16.f : (k == 3 ? -8.f : 0.f),
-              k == 0 ? -6.f : (k == 2 ? 6.f : 0.f),
-              k == 0 ? stroke_inv(8.f, -6.f) : (k == 1 ? stroke_inv(16.f, 6.f) : (k == 2 ? stroke_inv(-16.f, 6.f) : stroke_inv(-8.f, -6.f)))};
-}
-__device__ __forceinline__ Quad line_quad(const Line& ln, float ca, float sa, float posx, float posy) {
-  return line_quad(Seg{ln.ax, ln.ay, ln.bx, ln.by, ca, sa, posx, posy, ln.inv});
-}
-
-// drawExplosion (SRC/draw.cpp:145-175): 7 rings (radius 15 + 8i) of twelve 10-degree arcs starting at
-// 30k + 3(i+1) degrees, each its own stroke, then one radius-7 circle.  An arc is one chord quad
-// between radius -/+ half the line width; the circle is ONE stroke: the ring between two regular
-// 12-gons.  cos/sin of every angle involved are compile-time constants.
-
-__device__ __forceinline__ Quad arc_quad(const ArcCS& t, float radius, float cx, float cy) {
-  const float ri = radius - (float)(SF_LINE_W / 2), ro = radius + (float)(SF_LINE_W / 2);
-  Quad q;
-  q.x[0] = dev_x(cx + ri * t.c0); q.y[0] = dev_y(cy + ri * t.s0);
-  q.x[1] = dev_x(cx + ro * t.c0); q.y[1] = dev_y(cy + ro * t.s0);
-  q.x[2] = dev_x(cx + ro * t.c1); q.y[2] = dev_y(cy + ro * t.s1);
-  q.x[3] = dev_x(cx + ri * t.c1); q.y[3] = dev_y(cy + ri * t.s1);
-  return q;
-}
-
-// area of the regular 12-gon (centre (gx, gy), circumradius r, device pixels) inside the pixel at (px, py)
-__device__ __forceinline__ float gon_cover(float gx, float gy, float r, float px, float py) {
-  float s = 0.f;
-  float x0 = gx + r * kGon[0][0] - px, y0 = gy + r * kGon[0][1] - py;
-#pragma unroll 1
-  for (int k = 1; k <= 12; k++) {
-    const float x1 = gx + r * kGon[k % 12][0] - px, y1 = gy + r * kGon[k % 12][1] - py;
-    s += edge_term(x0, y0, x1, edge_slope(x0, y0, x1, y1));
-    x0 = x1;
-    y0 = y1;
-  }
-  return fabsf(s);
-}
-
-__device__ __forceinline__ bool quad_misses_pixel(const Quad& q, float px, float py) {
-  const float fx0 = fminf(fminf(q.x[0], q.x[1]), fminf(q.x[2], q.x[3]));
-  const float fx1 = fmaxf(fmaxf(q.x[0], q.x[1]), fmaxf(q.x[2], q.x[3]));
-  const float fy0 = fminf(fminf(q.y[0], q.y[1]), fminf(q.y[2], q.y[3]));
-  const float fy1 = fmaxf(fmaxf(q.y[0], q.y[1]), fmaxf(q.y[2], q.y[3]));
-  return fx1 <= px || fx0 >= px + 1.f || fy1 <= py || fy0 >= py + 1.f;
-}
-
-// The 96 strokes in the reference's order, without walking them one by one:
-//   * ring 0 (whose arcs lie less than a pixel apart) and the circle: a lane per pixel of the 8x8
-//     box around the centre; it composites the ring-0 arcs that touch it in arc order, then the
-//     circle.  Rings 1..6 never share a pixel with the circle, so the circle may come before them.
-//   * rings 1..6 in order; inside a ring the arcs are >= 1.49 px apart (chord of 20 degrees at the
-//     inner radius 21.5 * .2) and cannot touch the same pixel: twelve arcs at once, five lanes each.
+// drawExplosion (SRC/draw.cpp:116-145): 7 rings (radius 15 + 8 i) of twelve 10-degree arcs starting at 30 k + 3 (i + 1)
+// degrees, each its own cairo_stroke -- one quad between the faces at its two ends (sf_tor.h: arc_quad_fixed) --, then the
+// radius-7 circle, one stroke of sixteen pieces.  `arcs` = the batch's table of the 84 + 2 arcs' constants (sft::ArcK, made
+// by the host's libm like cairo makes them).  Ring by ring: twelve arcs at once, each its own object.
 template <bool RESIZE>
-__device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, float cx, float cy) {
-  uint8_t* fb = F.fb;
+__device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, const double* arcs, double cx, double cy) {
   const int lane = F.lane;
-  const float gx = dev_x(cx), gy = dev_y(cy);
+  const sft::Affine v = default_view();
+  const sftd::Ctx C = F.tor_ctx();
+#pragma unroll 1
+  for (int ring = 0; ring < 7; ring++) {
+    sft::Quad q = {};
+    if (lane < 12) {
+      const double* kp = arcs + 8 * (12 * ring + lane);
+      const sft::ArcK k{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
+      q = sft::arc_quad_fixed(sft::arc_knots(v, cx, cy, k), SF_SCALE, SF_SCALE, (double)(float)SF_LINE_W / 2);
+    }
+    sftd::raster(C, q, lane < 12, lane, sftd::kKindSingle, 15 + 8 * ring < 60 ? 191 : 128);  // .75 / .5
+  }
   {
-    const int bx0 = (int)floorf(gx - 16.5f * (float)SF_SCALE), by0 = (int)floorf(gy - 16.5f * (float)SF_SCALE);
-    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
-    if (px >= 0 && px < SF_IMG_W && py >= 0 && py < SF_IMG_H) {
-      const float fpx = (float)px, fpy = (float)py;
-      int d = fb[py * SF_IMG_W + px];
-      const int d0 = d;
-      // (rolled on purpose, like the two loops below: unrolled, the twelve arcs' integrals are interleaved and want 130+
-      //  vector registers -- of a kernel whose every other path lives in 96; a fresh explosion is one frame in seventy)
-#pragma unroll 1
-      for (int k = 0; k < 12; k++) {
-        const Quad q = arc_quad(kArcs[0][k], 15.f, cx, cy);
-        if (quad_misses_pixel(q, fpx, fpy)) continue;
-        const int m = cover_to_mask(quad_cover(q, fpx, fpy));
-        if (m > 0) d = sfr::over_un8(d, 191, m);
-      }
-      const float ro = 8.5f * (float)SF_SCALE, ri = 5.5f * (float)SF_SCALE;  // radius 7 -/+ half the line width
-      if (fabsf(fpx + 0.5f - gx) < ro + 0.5f && fabsf(fpy + 0.5f - gy) < ro + 0.5f) {
-        const float area = gon_cover(gx, gy, ro, fpx, fpy) - gon_cover(gx, gy, ri, fpx, fpy);
-        const int m = cover_to_mask(fmaxf(area, 0.f));
-        if (m > 0) d = sfr::over_un8(d, 191, m);
-      }
-      if (d != d0) fb[py * SF_IMG_W + px] = (uint8_t)d;
+    sft::Quad q = {};
+    if (lane < 16) {
+      const double* kp = arcs + 8 * (84 + (lane >> 3));
+      const sft::ArcK k{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
+      q = sft::ring_piece_quad(sft::arc_knots(v, cx, cy, k), lane & 7, SF_SCALE, SF_SCALE, (double)(float)SF_LINE_W / 2);
     }
-    __builtin_amdgcn_wave_barrier();
+    sftd::raster(C, q, lane < 16, 0, sftd::kKindRing | (8 << 8), 191);
   }
-  const int arc = lane / 5, sub = lane - arc * 5;
-#pragma unroll 1
-  for (int ring = 1; ring < 7; ring++) {
-    const int radius = 15 + 8 * ring;
-    const int grey = radius < 60 ? 191 : 128;  // .75 / .5
-    const Quad q = arc_quad(kArcs[ring][arc < 12 ? arc : 0], (float)radius, cx, cy);
-    const Box qb = quad_box(q);
-    int n = 0, bx0 = 0, by0 = 0, bw = 1;
-    if (arc < 12 && !qb.empty()) {
-      bx0 = qb.x0;
-      by0 = qb.y0;
-      bw = qb.x1 - qb.x0;
-      n = bw * (qb.y1 - qb.y0);
-    }
-    const float r_bw = recip_i(bw);
-    for (int i = sub; __any(i < n); i += 5) {
-      if (i < n) {
-        const DivMod dm = fast_divmod(i, bw, r_bw);
-        const int ry = dm.q, rx = dm.r;
-        const int px = bx0 + rx, py = by0 + ry;
-        const int m = cover_to_mask(quad_cover(q, (float)px, (float)py));
-        if (m > 0) {
-          uint8_t* p = fb + py * SF_IMG_W + px;
-          *p = (uint8_t)sfr::over_un8(*p, grey, m);
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  F.resample(explosion_box(cx, cy));
+  F.resample(explosion_box((float)cx, (float)cy));
 }
 
 // four bytes of a cached rectangle to p (any alignment; global memory and LDS both take an unaligned 32-bit store),
@@ -882,7 +563,7 @@ struct XcState {
 };
 
 template <bool RESIZE>
-__device__ __forceinline__ XcState ship_explosion(const Frame<RESIZE>& F, unsigned char* xc, double x, double y,
+__device__ __forceinline__ XcState ship_explosion(const Frame<RESIZE>& F, const double* arcs, unsigned char* xc, double x, double y,
                                                   const bool fill = true, const bool skip_lookup = false) {
   const float cx = (float)x, cy = (float)y;
   const Box b = explosion_box(cx, cy), o = out_box(b);
@@ -929,7 +610,7 @@ __device__ __forceinline__ XcState ship_explosion(const Frame<RESIZE>& F, unsign
     __builtin_amdgcn_wave_barrier();
     return st;
   }
-  draw_explosion(F, cx, cy);
+  draw_explosion(F, arcs, x, y);
   st.flags = 0;
   if (xc && fits && fill) {
     for (int i = lane; i < kXcFbRows * kXcRow; i += 64) {
@@ -1088,6 +769,9 @@ struct SfRenderArgs {
   const unsigned long long* hint;
   int n_front;
   const unsigned char* hud;  // SF_HUD_BYTES: the score / bar pictures (sf_hud_kernel), or null
+  const double* trig;        // cos, sin of deg2rad(k), k = 0 .. 359, as the reference's libm gives them (sf_trig_table)
+  const double* arcs;        // 86 x 8: the explosion's arcs (sft::ArcK; sf_arc_table)
+  const unsigned char* falpha;  // 36 x 256: the live fortress's coverage over its 16 x 16 box, heading 10 k (sf_image_fort_alpha)
 };
 
 // ---- Which env a workgroup draws.  The first frame of a dead ship's explosion costs about three ordinary frames (96
@@ -1196,6 +880,21 @@ __device__ __forceinline__ void fort_patch_copy(const Frame<RESIZE>& F, unsigned
   __builtin_amdgcn_wave_barrier();
 }
 
+
+// the live fortress drawn IN PLACE (something the ship drew lies under it): its four lines are one cairo_stroke whose coverage
+// depends on the heading alone -- an alpha map per sector, made by the host (sf_image_fort_alpha) --, white, lerped in
+template <bool RESIZE>
+__device__ __forceinline__ void fort_in_place(const Frame<RESIZE>& F, const unsigned char* falpha, int sector) {
+  const uint32_t aw = reinterpret_cast<const uint32_t*>(falpha + 256 * sector)[F.lane];  // four pixels of a row of sixteen
+  uint8_t* p = F.fb + (kFpY0 + (F.lane >> 2)) * SF_IMG_W + kFpX0 + (F.lane & 3) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int a = (int)((aw >> (8 * k)) & 255u);
+    if (a) p[k] = (uint8_t)sft::lerp8(255, a, p[k]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  F.resample(Box{kFpX0, kFpY0, kFpX1, kFpY1});
+}
 
 // ---- score (drawScore, SRC/draw.cpp:190-203): "%07d", grey .5, seven-segment digits; a lane per pixel of the box
 template <bool RESIZE>
@@ -1309,16 +1008,11 @@ template <bool RESIZE>
 __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
   const uint32_t* const tabw = a.tabs;  // 2.7 KB read by every wave: L1/L2 resident; LDS is better spent on waves
-  __shared__ __attribute__((aligned(16))) float srec[Frame<RESIZE>::kSrecWords];  // records, then the map of the strokes' starts (Frame::kSrecWords)
-  __shared__ __attribute__((aligned(16))) uint32_t slist[Frame<RESIZE>::kListCap];
+  __shared__ __attribute__((aligned(16))) uint32_t torw[Frame<RESIZE>::kTorWords];  // sf_tor_dev.h's records / objects / accumulators
   uint8_t* fb = reinterpret_cast<uint8_t*>(fbw);
   const int lane = threadIdx.x;
-  typedef float f4_t __attribute__((ext_vector_type(4)));
-  // ---- this lane's stroke of the frame's draw order (lanes 0..2 the ship's three, 3..6 the fortress's four, 7..63 those of
-  // missile slots 0..18): its four corners in the wireframe's own coordinates depend on the lane alone -- two loads, asked
-  // for before anything is known, where round 3 selected segment constants and built the rectangle per frame
-  const f4_t lsx = *reinterpret_cast<const f4_t*>(kLaneStroke[lane].x);
-  const f4_t lsy = *reinterpret_cast<const f4_t*>(kLaneStroke[lane].y);
+  // ---- this lane's line of the frame's draw order: lanes 0..2 the ship's three, 3..6 idle (the fortress comes from pictures
+  // and alpha maps), 7..63 those of missile slots 0..18
   // ... and this lane's entry of the tap tables' period (Frame::ltab): columns 0 .. 27, then rows 0 .. 20
   uint4 lt_e = {0u, 0u, 0u, 0u};
   if (RESIZE) {
@@ -1370,7 +1064,9 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   static_assert(kFirstMissileLane + 3 * 19 == 64, "slots 0 .. 18 fill the wave behind the ship's and the fortress's strokes");
   const int mslot = ((lane - kFirstMissileLane) * 171) >> 9;  // (lane - 7) / 3 for lanes 7 .. 63
   const int obj = lane < 3 ? SF_DR_OBJ_SHIP : (lane < kFirstMissileLane ? SF_DR_OBJ_FORT : SF_DR_OBJ_MISSILE0 + mslot);
-  const f4_t tf = *reinterpret_cast<const f4_t*>(rec + (unsigned)((SF_DR_PIECE_OBJ0 + obj) * SF_DR_PIECE_STRIDE));
+  const d2_t tf = *reinterpret_cast<const d2_t*>(rec + (unsigned)((SF_DR_PIECE_OBJ0 + obj) * SF_DR_PIECE_STRIDE));  // position, float64
+  const int mheading = *reinterpret_cast<const int16_t*>(rec + (unsigned)(SF_DR_ANGLES_OFF + 2 * max(mslot, 0)));  // (a missile's)
+  const d2_t shipd = *reinterpret_cast<const d2_t*>(rec + (unsigned)((SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE));  // (uniform)
   // (a frame stack's done flag of this env: asked for here, read where the older slots are handled)
   // (through an index the compiler cannot see is the same in every lane: a byte it knows to be uniform it moves to a scalar
   //  register at once -- v_readfirstlane behind a wait, i.e. a memory round trip in front of everything else, 7 % of the
@@ -1485,9 +1181,9 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   if (!(SF_RENDER_SKIP & 4096)) start_surface(bgi);  // (bit 12: timing-only, no surface)
 
   // ---- the shells' strokes, built here with the surface's loads in flight
-  Quad sq0 = {};
+  sft::Quad sq0 = {};
   bool sq0_valid = false;
-  auto shell_quad = [&](d2_t s, d2_t v, int k, bool have, Quad* q) -> bool {
+  auto shell_quad = [&](d2_t s, d2_t v, int k, bool have, sft::Quad* q) -> bool {
     const double dx = s.x - sfc::fort_x, dy = s.y - sfc::fort_y;
     const bool valid = have && sqrt(dx * dx + dy * dy) > 21.0;  // drawn only once clear of the fortress (SRC/draw.cpp:249-250)
     int ideg = 0;
@@ -1498,9 +1194,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       if (ang < 0) ang += 360.0;
       ideg = (int)ang;
     }
-    float sn, cs;
-    sincos_deg(ideg, &sn, &cs);
-    if (valid) *q = line_quad(shell_line(k), cs, sn, (float)s.x, (float)s.y);
+    if (valid) *q = line_quad(shell_seg(k), s.x, s.y, a.trig, ideg);
     return valid;
   };
   if (smask) {  // uniform
@@ -1537,23 +1231,24 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   // ---- the frame's strokes in draw order, one per lane: the live ship's three, the fortress's four when it has to be
   // drawn in place, the missiles' (SRC/draw.cpp:233-247) -- the lane's corners under the object's transform, translate(pos)
   // rotate(angle) (drawWireFrame, SRC/draw.cpp:112-129), in device pixels
-  const bool svalid = ((objmask >> obj) & 1u) && !((SF_RENDER_SKIP & 1) && lane < kFirstMissileLane);
+  const bool fort_lane = lane >= 3 && lane < kFirstMissileLane;
+  const bool svalid = ((objmask >> obj) & 1u) && !fort_lane && !((SF_RENDER_SKIP & 1) && lane < kFirstMissileLane);
   const int sobj = lane < 3 ? 0 : (lane < kFirstMissileLane ? 3 : kFirstMissileLane + 3 * mslot);
-  Quad mq = {};
+  sft::Quad mq = {};
   if (svalid) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      mq.x[k] = dev_x(tf.x + tf.z * lsx[k] - tf.w * lsy[k]);
-      mq.y[k] = dev_y(tf.y + tf.w * lsx[k] + tf.z * lsy[k]);
-    }
+    const int k = lane < 3 ? lane : lane - kFirstMissileLane - 3 * mslot;
+    const int heading = lane < 3 ? (int)(int16_t)(hd[SF_DRW_ANGLES] & 0xFFFFu) : mheading;
+    mq = line_quad(lane < 3 ? ship_seg(k) : missile_seg(k), tf.x, tf.y, a.trig, heading);
   }
   bool dvalid = svalid;  // what draw_strokes is given: with the shells' strokes in the top lanes when they fit there
-  int dobj = sobj;
+  int dobj = sobj, dkind = sftd::kKindLines3;
   if (merge_shells && shl >= 0) {
     mq = sq0;
     dvalid = sq0_valid;
     dobj = lane & ~3;
+    dkind = sftd::kKindShell;
   }
+  // (a shell is drawn or not as a whole: its four lanes agree on `valid`)
 
   // The 84x84 background's seven stores are the LAST vector-memory instructions in front of this wait (but for a frame
   // stack's shifted / cleared slots): vmcnt counts loads, stores and LDS-DMA together in issue order, so `vmcnt(7)` =
@@ -1577,59 +1272,59 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       }
     }
   }
-  const Frame<RESIZE> F{fb, frame_out, tabw, nullptr, lane, srec, slist, reinterpret_cast<uint32_t*>(srec) + Frame<RESIZE>::kLtabAt, lt_e};
+  const Frame<RESIZE> F{fb, frame_out, tabw, nullptr, lane, torw, torw + Frame<RESIZE>::kLtabAt, lt_e};
   if (SF_RENDER_STOP == 1) return;
 
+  // (sf_tor_dev.h's accumulators start out zero and every call leaves them so)
+  for (int i = lane; i < sftd::kAccPixels / 2; i += 64) F.tor_ctx().acc()[i] = 0u;
+  __builtin_amdgcn_wave_barrier();
   // ---- what is restored from round trip 2's registers: the dead ship's explosion if its cache entry is this one
-  // (the entry is keyed by where the ship died as the picture sees it: the float32 position)
+  // (the entry is keyed by where the ship died: the float64 position the picture is a function of)
+  const double ship_xd = shipd.x, ship_yd = shipd.y;
   XcState xst{0u, 0, 0};
   bool explosion_done = false;
   const bool explosion = dead_ship && !(SF_RENDER_SKIP & (1 | 256));
-  if (explosion && xc_mine) explosion_done = xc_apply(F, xf, (double)ship_x, (double)ship_y, &xst);
+  if (explosion && xc_mine) explosion_done = xc_apply(F, xf, ship_xd, ship_yd, &xst);
   if (SF_RENDER_STOP == 2) return;
   // ---- ship (SRC/draw.cpp:233-237): a dead ship's explosion that was not in the cache is the first thing drawn
-  if (explosion && !explosion_done) xst = ship_explosion(F, xc_mine, (double)ship_x, (double)ship_y, true, /*skip_lookup=*/true);
+  if (explosion && !explosion_done) xst = ship_explosion(F, a.arcs, xc_mine, ship_xd, ship_yd, true, /*skip_lookup=*/true);
   // ---- fortress (:238-242), destroyed: it explodes for 1000 ms where it stands: one more picture drawn once per batch, in
   // the layout of the per-env explosion cache (a trained agent destroys it every few seconds -- 30 frames each time).
   // Restored when what the ship drew stays clear of it (wider by the reach: what its 84x84 pixels read) -- the two touch no
   // pixel in common then, so it may go in before the ship --; else drawn in place between the ship and the missiles.
   if ((fl & SF_DRF_FORT_EX_PATCH) && !(SF_RENDER_SKIP & (1 | 512)))
-    ship_explosion(F, const_cast<unsigned char*>(a.fpatch) + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y, false);
+    ship_explosion(F, a.arcs, const_cast<unsigned char*>(a.fpatch) + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y, false);
   const bool fort_explodes_in_place = (fl & SF_DRF_FORT_EX_PLACE) && !(SF_RENDER_SKIP & (1 | 512));
   if (SF_RENDER_STOP == 3) return;
   // ---- the live ship, the fortress in place, the missiles (:233-247): all their strokes at once
-  if (!fort_explodes_in_place) {
-    F.draw_strokes(mq, dvalid, dobj);
+  const bool fort_lines_in_place = (objmask >> SF_DR_OBJ_FORT) & 1u;
+  if (!fort_explodes_in_place && !fort_lines_in_place) {
+    F.draw_strokes(mq, dvalid, dobj, dkind);
     if (SF_RENDER_STOP > 40) return;
-  } else {  // (rare: the ship, or its explosion, next to an exploding fortress)
-    F.draw_strokes(mq, dvalid && lane < 3, dobj);
-    draw_explosion(F, (float)sfc::fort_x, (float)sfc::fort_y);
-    F.draw_strokes(mq, dvalid && lane >= kFirstMissileLane, dobj);
+  } else {  // (rare: the ship, or its explosion, next to the fortress or its explosion: the reference's order, one by one)
+    F.draw_strokes(mq, dvalid && lane < 3, dobj, dkind);
+    if (fort_explodes_in_place) draw_explosion(F, a.arcs, sfc::fort_x, sfc::fort_y);
+    else fort_in_place(F, a.falpha, min(max((int)(int16_t)(hd[SF_DRW_ANGLES] >> 16) / 10, 0), 35));
+    F.draw_strokes(mq, dvalid && lane >= kFirstMissileLane, dobj, dkind);
   }
   if ((fl & SF_DRF_MISSILE19) && !(SF_RENDER_SKIP & 2)) {  // (the twentieth missile: its strokes have no lanes of their own)
-    const f4_t t19 = *reinterpret_cast<const f4_t*>(rec + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_MISSILE0 + 19) * SF_DR_PIECE_STRIDE);
-    const int ml = kFirstMissileLane + (lane < 3 ? lane : 0);  // a missile's three strokes: the corners of lanes 7 .. 9
-    const f4_t mx = *reinterpret_cast<const f4_t*>(kLaneStroke[ml].x), my = *reinterpret_cast<const f4_t*>(kLaneStroke[ml].y);
-    Quad q19;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      q19.x[k] = dev_x(t19.x + t19.z * mx[k] - t19.w * my[k]);
-      q19.y[k] = dev_y(t19.y + t19.w * mx[k] + t19.z * my[k]);
-    }
-    F.draw_strokes(q19, lane < 3, 0);
+    const d2_t t19 = *reinterpret_cast<const d2_t*>(rec + (SF_DR_PIECE_OBJ0 + SF_DR_OBJ_MISSILE0 + 19) * SF_DR_PIECE_STRIDE);
+    const int h19 = *reinterpret_cast<const int16_t*>(rec + SF_DR_ANGLES_OFF + 2 * 19);
+    const sft::Quad q19 = line_quad(missile_seg(lane < 3 ? lane : 0), t19.x, t19.y, a.trig, h19);
+    F.draw_strokes(q19, lane < 3, 0, sftd::kKindLines3);
   }
   if (SF_RENDER_STOP == 4) return;
   // ---- shells (:248-253): slot order
   if (smask && !merge_shells) {
-    F.draw_strokes(sq0, sq0_valid, lane & ~3);
+    F.draw_strokes(sq0, sq0_valid, lane & ~3, sftd::kKindShell);
     if (smask >> 16) {  // (slots 16 .. 19)
       const int slot = 16 + (lane >> 2);
       const bool have = lane < 16 && ((smask >> slot) & 1u);
-      Quad sq = {};
+      sft::Quad sq = {};
       const d2_t s = R_LD(d2_t, R_CHUNK(shell_pos, have ? slot : 0), o16);
       const d2_t v = R_LD(d2_t, R_CHUNK(shell_vel, have ? slot : 0), o16);
       const bool valid = shell_quad(s, v, lane & 3, have, &sq);
-      F.draw_strokes(sq, valid, lane & ~3);
+      F.draw_strokes(sq, valid, lane & ~3, sftd::kKindShell);
     }
   }
   if (SF_RENDER_STOP == 5) return;
@@ -1702,29 +1397,28 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   }
 }
 
-// one workgroup per sector: the live fortress drawn on the bare background, its box of the surface and of the
-// 84x84 image saved for fort_patch_copy
+// one workgroup per sector: the live fortress on the bare background -- its alpha map (the host's: sf_image_fort_alpha)
+// lerped in like a frame does in place --, its box of the surface and of the 84x84 image saved for fort_patch_copy; workgroup 36:
+// the destroyed fortress's explosion, drawn by the frames' own code
 __global__ __launch_bounds__(64) void sf_fort_patch_kernel(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs,
-                                                           unsigned char* fpatch) {
+                                                           unsigned char* fpatch, const double* arcs, const unsigned char* falpha) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
   __shared__ __attribute__((aligned(16))) uint32_t obufw[kOutBytes / 4];
   __shared__ __attribute__((aligned(16))) uint32_t tabw[SF_TAB_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t torw[Frame<true>::kTorWords];
   const int lane = threadIdx.x, sector = blockIdx.x;
   for (int i = lane; i < kFbPadWords; i += 64) fbw[i] = i < kFbWords ? bg[i] : 0u;
   for (int i = lane; i < kOutBytes / 4; i += 64) obufw[i] = bg84[i];
   for (int i = lane; i < SF_TAB_WORDS; i += 64) tabw[i] = tabs[i];
+  for (int i = lane; i < Frame<true>::kTorWords; i += 64) torw[i] = 0u;
   __syncthreads();
-  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr, nullptr, uint4{0u, 0u, 0u, 0u}};
+  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, torw, nullptr, uint4{0u, 0u, 0u, 0u}};
   if (sector == 36) {  // the destroyed fortress's explosion, behind the 36 headings
-    ship_explosion(F, fpatch + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y);  // (a zeroed entry: draws and fills it)
+    ship_explosion(F, arcs, fpatch + 36 * SF_FP_BYTES, sfc::fort_x, sfc::fort_y);  // (a zeroed entry: draws and fills it)
     return;
   }
-  float s, c;
-  sincos_deg(10 * sector, &s, &c);
-  const Quad q = line_quad(fort_line(lane < 4 ? lane : 0), c, s, (float)sfc::fort_x, (float)sfc::fort_y);
-  F.draw_quads(q, 255, lane < 4, 64);
-  // (draw_quads has resampled what the strokes touch; the rest of the patch keeps the background's values,
-  //  exactly as when the fortress is drawn in place)
+  fort_in_place(F, falpha, sector);
+  // (the rest of the patch keeps the background's values, exactly as when the fortress is drawn in place)
   __syncthreads();
   fort_patch_copy(F, fpatch + sector * SF_FP_BYTES, true);
 }
@@ -1754,9 +1448,9 @@ __global__ __launch_bounds__(256) void sf_bg_fort_kernel(uint32_t* bg, uint32_t*
     if (c < ow) d84[(o.y0 + r) * SF_OUT + o.x0 + c] = gp[kFpOutAt + i];
   }
 }
-hipError_t sf_launch_fort_patches(uint32_t* bg, uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch,
-                                  hipStream_t stream) {
-  hipLaunchKernelGGL(sf_fort_patch_kernel, dim3(37), dim3(64), 0, stream, bg, bg84, tabs, fpatch);
+hipError_t sf_launch_fort_patches(uint32_t* bg, uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch, const double* arcs,
+                                  const unsigned char* falpha, hipStream_t stream) {
+  hipLaunchKernelGGL(sf_fort_patch_kernel, dim3(37), dim3(64), 0, stream, bg, bg84, tabs, fpatch, arcs, falpha);
   hipLaunchKernelGGL(sf_bg_fort_kernel, dim3(36 * 4), dim3(256), 0, stream, bg, bg84, fpatch);
   return hipGetLastError();
 }
@@ -1773,7 +1467,7 @@ __global__ __launch_bounds__(64) void sf_hud_kernel(const uint32_t* bg, const ui
   for (int i = lane; i < kOutBytes / 4; i += 64) obufw[i] = bg84[i];
   for (int i = lane; i < SF_TAB_WORDS; i += 64) tabw[i] = tabs[i];
   __syncthreads();
-  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr, nullptr, uint4{0u, 0u, 0u, 0u}};
+  const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr, uint4{0u, 0u, 0u, 0u}};
   if (pic < 2 * SF_HUD_SCORE_HALF) {
     const int pnts = pic - SF_HUD_SCORE_HALF;
     draw_score(F, pnts);
@@ -1812,13 +1506,13 @@ hipError_t sf_launch_render(const unsigned char* state, const unsigned char* dra
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
                             const uint8_t* stack_prev, const unsigned long long* hint, const unsigned char* hud,
-                            hipStream_t stream) {
+                            const double* trig, const double* arcs, const unsigned char* falpha, hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
   // the front of the grid: a sixteenth of the batch (ships die in about 1.3 % of the ticks of random play); batches
   // whose hint words no longer fit a short scan (> 32 per lane) are drawn in env order
   const int n_front = hint && n_envs <= 64 * 64 * 32 ? (n_envs / 16 > 64 ? n_envs / 16 : 64) : 0;
   SfRenderArgs a{state, draw, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n, stack_prev,
-                 n_front ? hint : nullptr, n_front, hud};
+                 n_front ? hint : nullptr, n_front, hud, trig, arcs, falpha};
   const unsigned grid = (unsigned)(n_envs + n_front);
   if (resize)
     hipLaunchKernelGGL(sf_render_kernel<true>, dim3(grid), dim3(64), 0, stream, a);

@@ -1,32 +1,24 @@
 // sf_render_generic.hip -- the image observation in ANY geometry the reference's constructor takes:
 //   SSF_Env(scale, viewport, ls)  ENV:50-60  ->  sf.Game(width = int(vw * scale), height = int(vh * scale), viewport, lw = ls)
-//   drawGameStateScaled           SRC/draw.cpp:256-270: scale(s), translate(-vx, -vy), line width ls user units
+//   drawGameStateScaled           SRC/draw.cpp:256-270: scale(w / vw, h / vh), translate(-vx, -vy), line width ls user units
 // sf_render.hip is the frame kernel of the DEFAULT geometry (scale .2, viewport (130, 80, 450, 460), ls 3: the trainer's,
-// BASELINE configs[4]): a wave per env, the 90x92 surface, its tap periods, picture caches and stroke tables all compile-time
+// BASELINE configs[4]): a wave per env, the 90x92 surface, its tap periods, picture caches and tables all compile-time
 // facts.  This file is the general renderer behind sf_set_image_geometry: one WORKGROUP per env, the W x H surface in
-// dynamic LDS, every stroke of the reference's draw order (SRC/draw.cpp:227-254,266-268) composited in place one after the
-// other with the same coverage model (sf_cover.h) and 8-bit OVER arithmetic (sf_raster.h), no caches, no shortcuts; then
-// cv2.resize(.., (84, 84), INTER_AREA) with per-batch tap tables for W, H < 3 * 84 (OpenCV's resizeArea_ arithmetic,
-// sf_image.cpp).  It reads the state, not the draw records.  Phases: all four waves copy the background in (16-byte pieces);
-// wave 0 alone composites the strokes, one after the other, wave-synchronously (no workgroup barrier per stroke) and the
-// score's glyphs with a lane per pixel of their box; all four waves resample, four pixels and one 32-bit store per thread.
-// Measured (tools/geometry_probe.py, 16 384 envs, 125 x 130 surface): 0.96 ms per launch for the raw frame, 1.24 ms with the
-// 84x84 image -- 14.8 k vector instructions per frame (tools/pmc_generic.sh) against 0.95 k in the default geometry's kernel,
-// most of them the 85 strokes of a dead ship's explosion drawn afresh in every frame of its 30 (no cache here).  Correctness
-// in every geometry; speed in the one the benchmark names.  tests/test_gpu_image.py compares it with oracle/render_np.py
-// parametrised the same way.
+// dynamic LDS, every cairo_stroke of the reference's draw order (SRC/draw.cpp:227-254,266-268) rasterised in place, one object
+// after the other, the way cairo's image backend does it (sf_tor.h / sf_tor_dev.h: the same code as the default geometry's
+// kernel, the geometry a run-time argument), no caches, no shortcuts; then cv2.resize(.., (84, 84), INTER_AREA) with per-batch
+// tap tables for W, H < 3 * 84 (OpenCV's resizeArea_ arithmetic, sf_image.cpp).  It reads the state, not the draw records.
+// Phases: all four waves copy the background in (16-byte pieces); wave 0 alone rasterises the objects, wave-synchronously, and
+// the score's glyphs with a lane per pixel of their box; all four waves resample, four pixels and one 32-bit store per thread.
+// Correctness in every geometry (tests/test_gpu_image.py: against frames the reference's own renderer drew in four of them);
+// speed in the one the benchmark names.
 #include <hip/hip_runtime.h>
 
-#include "sf_cover.h"
 #include "sf_internal.h"
 #include "sf_raster.h"
+#include "sf_tor_dev.h"
 
 namespace {
-
-using namespace sfcov;
-using sfr::cover_to_mask;
-
-#include "sf_render_tables.h"  // kArcs[7][12], kGon[12], kSinCosDeg[360]
 
 constexpr int kThreads = 256;
 
@@ -39,126 +31,158 @@ struct i4_t {
 #define G_CHUNK(group, s) (tile + sfl::chunk_offset(SF_G_##group, (s)))
 #define G_LD(T, base, off) (*reinterpret_cast<const T*>((base) + (off)))
 
+struct Seg4 {
+  double ax, ay, bx, by;
+};
+// wireframe segments, SRC/wireframe.cpp:11-67: kind 0 ship, 1 fortress, 2 missile, 3 shell
+__device__ __forceinline__ Seg4 wire_seg(int kind, int k) {
+  if (kind == 0) return Seg4{k == 2 ? 0.0 : -18.0, k == 1 ? 18.0 : 0.0, k == 0 ? 18.0 : (k == 1 ? 0.0 : -18.0), k == 2 ? -18.0 : 0.0};
+  if (kind == 1) return Seg4{k >= 2 ? 18.0 : 0.0, k == 0 ? 0.0 : (k == 3 ? 18.0 : -18.0), k == 0 ? 36.0 : (k == 3 ? 0.0 : 18.0), k == 0 ? 0.0 : (k == 1 ? -18.0 : 18.0)};
+  if (kind == 2) return Seg4{0.0, 0.0, k == 0 ? -25.0 : -5.0, k == 0 ? 0.0 : (k == 1 ? 5.0 : -5.0)};
+  return Seg4{k == 0 ? -8.0 : (k == 2 ? 16.0 : 0.0), k == 1 ? -6.0 : (k == 3 ? 6.0 : 0.0), k == 1 ? 16.0 : (k == 3 ? -8.0 : 0.0), k == 0 ? -6.0 : (k == 2 ? 6.0 : 0.0)};
+}
+
 struct Ctx {
   uint8_t* fb;
+  uint32_t* tor;
   int W, H, tid;
-  float vx, vy, sc, half_lw;  // user -> device: (x - vx) * sc; half the line width in user units
-  __device__ __forceinline__ float dx(float x) const { return (x - vx) * sc; }
-  __device__ __forceinline__ float dy(float y) const { return (y - vy) * sc; }
-
-  // one stroke, composited OVER the surface by wave 0 (a lane per pixel of its bounding box)
-  __device__ void stroke(const Quad& q, int grey) const {
-    const float fx0 = fminf(fminf(q.x[0], q.x[1]), fminf(q.x[2], q.x[3])), fx1 = fmaxf(fmaxf(q.x[0], q.x[1]), fmaxf(q.x[2], q.x[3]));
-    const float fy0 = fminf(fminf(q.y[0], q.y[1]), fminf(q.y[2], q.y[3])), fy1 = fmaxf(fmaxf(q.y[0], q.y[1]), fmaxf(q.y[2], q.y[3]));
-    if (fx1 > 0.f && fy1 > 0.f && fx0 < (float)W && fy0 < (float)H) {  // (uniform: the quad is)
-      const int x0 = (int)floorf(fmaxf(fx0, 0.f)), y0 = (int)floorf(fmaxf(fy0, 0.f));
-      const int x1 = (int)ceilf(fminf(fx1, (float)W)), y1 = (int)ceilf(fminf(fy1, (float)H));
-      const int bw = x1 - x0, n = bw * (y1 - y0);
-      const Slopes sl = quad_slopes(q);
-      for (int i = tid; i < n; i += 64) {
-        const int ry = i / bw, px = x0 + (i - ry * bw), py = y0 + ry;
-        const int m = cover_to_mask(quad_cover(q, sl, (float)px, (float)py));
-        if (m > 0) {
-          uint8_t* p = fb + py * W + px;
-          *p = (uint8_t)sfr::over_un8(*p, grey, m);
-        }
-      }
-    }
-    order();
-  }
-  // the strokes are composited by ONE wave (tid = its lane): LDS is in order per wave, the fences pin the compiler
+  double sx, sy, vx, vy, lw;  // scale_x = W / vp_w, scale_y = H / vp_h (SRC/draw.cpp:70-71), viewport origin, line width
+  const double* trig;         // cos, sin of deg2rad(k)
+  const double* arcs;         // sf_arc_table
+  __device__ __forceinline__ sftd::Ctx tc() const { return sftd::Ctx{tor, fb, W, H, tid, sftd::kMaxQuadsBig}; }
   __device__ __forceinline__ static void order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  // a wireframe segment (ax, ay) - (bx, by) under translate(pos) rotate(angle): a rectangle, butt caps
-  __device__ void line(float ax, float ay, float bx, float by, float ca, float sa, float px, float py, int grey) const {
-    const float ux = bx - ax, uy = by - ay;
-    const float inv = half_lw / sqrtf(ux * ux + uy * uy);
-    const float nx = -uy * inv, ny = ux * inv;
-    const float lx[4] = {ax + nx, bx + nx, bx - nx, ax - nx}, ly[4] = {ay + ny, by + ny, by - ny, ay - ny};
-    Quad q;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      q.x[k] = dx(px + ca * lx[k] - sa * ly[k]);
-      q.y[k] = dy(py + sa * lx[k] + ca * ly[k]);
-    }
-    stroke(q, grey);
-  }
-  // a filled axis-aligned rectangle in user units
-  __device__ void rect(float x0, float y0, float x1, float y1, int grey) const {
-    Quad q;
-    q.x[0] = dx(x0); q.y[0] = dy(y0);
-    q.x[1] = dx(x1); q.y[1] = dy(y0);
-    q.x[2] = dx(x1); q.y[2] = dy(y1);
-    q.x[3] = dx(x0); q.y[3] = dy(y1);
-    stroke(q, grey);
-  }
-  __device__ void wireframe(const float (*lines)[4], int n, int deg, float px, float py) const {
+  // drawWireFrame (SRC/draw.cpp:82-100): one cairo_stroke of the wireframe's lines
+  __device__ void wireframe(int kind, int deg, double px, double py) const {
     deg = deg < 0 ? 0 : (deg > 359 ? 359 : deg);
-    const float sa = kSinCosDeg[deg][0], ca = kSinCosDeg[deg][1];
-    for (int k = 0; k < n; k++) line(lines[k][0], lines[k][1], lines[k][2], lines[k][3], ca, sa, px, py, 255);
-  }
-  // drawExplosion (SRC/draw.cpp:145-175): 7 rings (radius 15 + 8 i) of twelve 10-degree arcs, each its own stroke -- one
-  // chord quad between radius -/+ half the line width --, then one radius-7 circle: the ring between two regular 12-gons
-  __device__ void explosion(float cx, float cy) const {
-    for (int ring = 0; ring < 7; ring++) {
-      const float radius = 15.f + 8.f * (float)ring, ri = radius - half_lw, ro = radius + half_lw;
-      const int grey = radius < 60.f ? 191 : 128;
-      for (int k = 0; k < 12; k++) {
-        const ArcCS t = kArcs[ring][k];
-        Quad q;
-        q.x[0] = dx(cx + ri * t.c0); q.y[0] = dy(cy + ri * t.s0);
-        q.x[1] = dx(cx + ro * t.c0); q.y[1] = dy(cy + ro * t.s0);
-        q.x[2] = dx(cx + ro * t.c1); q.y[2] = dy(cy + ro * t.s1);
-        q.x[3] = dx(cx + ri * t.c1); q.y[3] = dy(cy + ri * t.s1);
-        stroke(q, grey);
-      }
+    const int n = (kind == 0 || kind == 2) ? 3 : 4;
+    const sft::Affine v = sft::view_matrix(sx, sy, vx, vy);
+    const double2 cs = *reinterpret_cast<const double2*>(trig + 2 * deg);
+    const sft::Affine m = sft::object_matrix(v, px, py, cs.x, cs.y);
+    if (kind == 1 && m.xy == 0.0 && m.yx == 0.0) {  // the rectilinear stroker (heading 0): boxes, exact area
+      fort_boxes(m);
+      return;
     }
-    const float gx = dx(cx), gy = dy(cy), ro = (7.f + half_lw) * sc, ri = (7.f - half_lw) * sc;
-    const int x0 = max((int)floorf(gx - ro), 0), y0 = max((int)floorf(gy - ro), 0);
-    const int x1 = min((int)ceilf(gx + ro), W), y1 = min((int)ceilf(gy + ro), H);
-    const int bw = x1 - x0, n = bw > 0 && y1 > y0 ? bw * (y1 - y0) : 0;
+    sft::Quad q = {};
+    if (tid < n) {
+      const Seg4 g = wire_seg(kind, tid);
+      int x1, y1, x2, y2;
+      sft::to_device(m, g.ax, g.ay, &x1, &y1);
+      sft::to_device(m, g.bx, g.by, &x2, &y2);
+      q = sft::stroke_quad(x1, y1, x2, y2, sx, sy, lw / 2);
+    }
+    sftd::raster(tc(), q, tid < n, 0, kind == 1 ? sftd::kKindFort : (kind == 3 ? sftd::kKindShell : sftd::kKindLines3), 255);
+  }
+  // the fortress at heading 0 under a matrix without rotation: cairo strokes the four axis-aligned lines as BOXES
+  // (cairo-path-stroke-boxes.c) and fills their union through the box converter: exact area, alpha = c - (c >> 8)
+  __device__ void fort_boxes(const sft::Affine& m) const {
+    const int hx = sft::fx_from_double(fabs(m.xx) * lw / 2.0), hy = sft::fx_from_double(fabs(m.yy) * lw / 2.0);
+    int bx[4][4];
+    int X0 = 1 << 30, Y0 = 1 << 30, X1 = -(1 << 30), Y1 = -(1 << 30);
+    for (int k = 0; k < 4; k++) {
+      const Seg4 g = wire_seg(1, k);
+      int x1, y1, x2, y2;
+      sft::to_device(m, g.ax, g.ay, &x1, &y1);
+      sft::to_device(m, g.bx, g.by, &x2, &y2);
+      if (y1 == y2) { y1 -= hy; y2 += hy; } else { x1 -= hx; x2 += hx; }
+      bx[k][0] = min(x1, x2); bx[k][1] = min(y1, y2); bx[k][2] = max(x1, x2); bx[k][3] = max(y1, y2);
+      X0 = min(X0, bx[k][0]); Y0 = min(Y0, bx[k][1]); X1 = max(X1, bx[k][2]); Y1 = max(Y1, bx[k][3]);
+    }
+    const int px0 = max(X0 >> 8, 0), py0 = max(Y0 >> 8, 0), px1 = min((X1 + 255) >> 8, W), py1 = min((Y1 + 255) >> 8, H);
+    const int bw = px1 - px0, n = bw > 0 && py1 > py0 ? bw * (py1 - py0) : 0;
     for (int i = tid; i < n; i += 64) {
-      const int ry = i / bw, px = x0 + (i - ry * bw), py = y0 + ry;
-      const float area = gon(gx, gy, ro, (float)px, (float)py) - (ri > 0.f ? gon(gx, gy, ri, (float)px, (float)py) : 0.f);
-      const int m = cover_to_mask(fmaxf(area, 0.f));
-      if (m > 0) {
+      const int ry = i / bw, px = px0 + (i - ry * bw), py = py0 + ry;
+      // |A u B u C u D| = sum of the four - the overlaps of the pairs that can overlap: the bar through the upright
+      // (0, 2) and the two corners (1, 2), (2, 3)
+      auto ov = [&](int a0, int a1, int b0, int b1, int c0, int c1) { const int o = min(min(a1, b1), c1) - max(max(a0, b0), c0); return o > 0 ? o : 0; };
+      const int PX0 = px << 8, PX1 = PX0 + 256, PY0 = py << 8, PY1 = PY0 + 256;
+      long long area = 0;
+      for (int k = 0; k < 4; k++)
+        area += (long long)ov(bx[k][0], bx[k][2], PX0, PX1, PX0, PX1) * ov(bx[k][1], bx[k][3], PY0, PY1, PY0, PY1);
+      const int pr[3][2] = {{0, 2}, {1, 2}, {2, 3}};
+      for (int j = 0; j < 3; j++) {
+        const int a = pr[j][0], b = pr[j][1];
+        area -= (long long)ov(bx[a][0], bx[a][2], bx[b][0], bx[b][2], PX0, PX1) * ov(bx[a][1], bx[a][3], bx[b][1], bx[b][3], PY0, PY1);
+      }
+      const int al = sft::box_area_to_alpha(area);
+      if (al) {
         uint8_t* p = fb + py * W + px;
-        *p = (uint8_t)sfr::over_un8(*p, 191, m);
+        *p = (uint8_t)sft::lerp8(255, al, *p);
       }
     }
     order();
   }
-  // the score (drawScore, SRC/draw.cpp:190-203): "%07d", grey .5, seven-segment glyphs (sf_raster.h) -- a lane per pixel of the
-  // text's box composites the segments that touch it in the strokes' order (cell by cell, A..G): what one stroke after the
-  // other gives, without 42 strokes.  A segment is an axis-aligned rectangle: its coverage of a pixel is the overlap's area.
+  // drawExplosion (SRC/draw.cpp:116-145): 7 rings of twelve 10-degree arcs, each its own stroke, then the radius-7 circle.
+  // Every curve is flattened as cairo flattens it at THIS geometry's scale (sft::flatten_faces: one piece per arc at scale .2,
+  // two at .4; eight per half circle, or sixteen): four arcs of up to four pieces per call, then the circle's up to 32 pieces.
+  __device__ void explosion(double cx, double cy) const {
+    const sft::Affine v = sft::view_matrix(sx, sy, vx, vy);
+    const double hw = (double)(float)lw / 2;
+    for (int ring = 0; ring < 7; ring++)
+      for (int chunk = 0; chunk < 3; chunk++) {
+        sft::Quad q = {};
+        bool valid = false;
+        if (tid < 16) {
+          const double* kp = arcs + 8 * (12 * ring + 4 * chunk + (tid >> 2));
+          int px[6], py[6], tx[6], ty[6];
+          const int n = sft::flatten_faces(sft::arc_knots(v, cx, cy, sft::ArcK{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]}), px, py, tx, ty, 5);
+          const int p = tid & 3;
+          if (p < n - 1) {
+            valid = true;
+            q = sft::faces_quad(px[p], py[p], tx[p], ty[p], px[p + 1], py[p + 1], tx[p + 1], ty[p + 1], sx, sy, hw);
+          }
+        }
+        sftd::raster(tc(), q, valid, tid & ~3, sftd::kKindSingle, 15 + 8 * ring < 60 ? 191 : 128);
+      }
+    sft::Quad q = {};
+    bool valid = false;
+    int m0 = 0;
+    {
+      int px[18], py[18], tx[18], ty[18];
+      const double* kp = arcs + 8 * (84 + ((tid >> 4) & 1));
+      const int n = sft::flatten_faces(sft::arc_knots(v, cx, cy, sft::ArcK{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]}), px, py, tx, ty, 17);
+      const int p = tid & 15;
+      if (tid < 32 && p < n - 1) {
+        valid = true;
+        q = sft::faces_quad(px[p], py[p], tx[p], ty[p], px[p + 1], py[p + 1], tx[p + 1], ty[p + 1], sx, sy, hw);
+      }
+      m0 = __builtin_amdgcn_readfirstlane(n - 1);  // (lane 0 flattened the first half)
+    }
+    sftd::raster<8>(tc(), q, valid, 0, sftd::kKindRing | (m0 << 8), 191);
+  }
+  // the score (drawScore, SRC/draw.cpp:161-173): "%07d", grey .5, seven-segment glyphs (sf_raster.h: the font is the box's, the
+  // glyphs are a model) -- a lane per pixel of the text's box composites the segments that touch it in the strokes' order
   __device__ void score(int pnts) const {
+    // (float64 here: the glyph model is ours, oracle/render_np.py evaluates it in float64, and this kernel has the time)
     const unsigned long long masks = sfr::score_masks(pnts);
-    const float Wg = SF_TXT_W, Hg = SF_TXT_H, T = SF_TXT_T, m0 = 0.5f * (SF_TXT_H - SF_TXT_T), m1 = 0.5f * (SF_TXT_H + SF_TXT_T);
-    const float sx0[7] = {0, Wg - T, Wg - T, 0, 0, 0, 0}, sx1[7] = {Wg, Wg, Wg, Wg, T, T, Wg};
-    const float sy0[7] = {0, T, m1, Hg - T, m1, T, m0}, sy1[7] = {T, m0, Hg - T, Hg, Hg - T, m0, m1};
-    const float tx0 = dx(SF_TXT_X0 + SF_TXT_PAD), tx1 = dx(SF_TXT_X0 + 6.f * SF_TXT_ADV + SF_TXT_PAD + SF_TXT_W);
-    const float ty0 = dy(SF_TXT_TOP), ty1 = dy(SF_TXT_TOP + SF_TXT_H);
-    const int bx0 = max((int)floorf(tx0), 0), by0 = max((int)floorf(ty0), 0), bx1 = min((int)ceilf(tx1), W), by1 = min((int)ceilf(ty1), H);
+    auto dx = [&](double x) { return (x - vx) * sx; };
+    auto dy = [&](double y) { return (y - vy) * sy; };
+    const double Wg = SF_TXT_W, Hg = SF_TXT_H, T = SF_TXT_T, m0 = 0.5 * (SF_TXT_H - SF_TXT_T), m1 = 0.5 * (SF_TXT_H + SF_TXT_T);
+    const double sx0[7] = {0, Wg - T, Wg - T, 0, 0, 0, 0}, sx1[7] = {Wg, Wg, Wg, Wg, T, T, Wg};
+    const double sy0[7] = {0, T, m1, Hg - T, m1, T, m0}, sy1[7] = {T, m0, Hg - T, Hg, Hg - T, m0, m1};
+    const double tx0 = dx((double)SF_TXT_X0 + SF_TXT_PAD), tx1 = dx((double)SF_TXT_X0 + 6.0 * SF_TXT_ADV + SF_TXT_PAD + SF_TXT_W);
+    const double ty0 = dy((double)SF_TXT_TOP), ty1 = dy((double)SF_TXT_TOP + SF_TXT_H);
+    const int bx0 = max((int)floor(tx0), 0), by0 = max((int)floor(ty0), 0), bx1 = min((int)ceil(tx1), W), by1 = min((int)ceil(ty1), H);
     const int bw = bx1 - bx0, n = bw > 0 && by1 > by0 ? bw * (by1 - by0) : 0;
     for (int i = tid; i < n; i += 64) {
       const int ry = i / bw, px = bx0 + (i - ry * bw), py = by0 + ry;
-      const float fpx = (float)px, fpy = (float)py;
+      const double fpx = (double)px, fpy = (double)py;
       uint8_t* p = fb + py * W + px;
       int d = *p;
       for (int cell = 0; cell < 7; cell++) {
-        const float gx = SF_TXT_X0 + SF_TXT_ADV * (float)cell + SF_TXT_PAD, gy = SF_TXT_TOP;
-        if (dx(gx + Wg) <= fpx || dx(gx) >= fpx + 1.f) continue;
+        const double gx = (double)SF_TXT_X0 + (double)SF_TXT_ADV * (double)cell + SF_TXT_PAD, gy = SF_TXT_TOP;
         const unsigned bits = (unsigned)(masks >> (7 * cell)) & 0x7Fu;
 #pragma unroll
         for (int seg = 0; seg < 7; seg++) {
           if (!((bits >> seg) & 1u)) continue;
-          const float ox = fminf(dx(gx + sx1[seg]), fpx + 1.f) - fmaxf(dx(gx + sx0[seg]), fpx);
-          const float oy = fminf(dy(gy + sy1[seg]), fpy + 1.f) - fmaxf(dy(gy + sy0[seg]), fpy);
-          if (ox > 0.f && oy > 0.f) {
-            const int m = cover_to_mask(ox * oy);
+          // the model's own arithmetic: the segment's rectangle clipped to the pixel, its area (render_np.pixel_area)
+          const double ox = fmin(dx(gx + sx1[seg]), fpx + 1.0) - fmax(dx(gx + sx0[seg]), fpx);
+          const double oy = fmin(dy(gy + sy1[seg]), fpy + 1.0) - fmax(dy(gy + sy0[seg]), fpy);
+          if (ox > 0.0 && oy > 0.0) {
+            const int m = (int)(fmin(ox * oy, 1.0) * 255.0 + 0.5);
             if (m > 0) d = sfr::over_un8(d, 128, m);
           }
         }
@@ -167,32 +191,39 @@ struct Ctx {
     }
     order();
   }
-  // area of the regular 12-gon (centre (gx, gy), circumradius r, device pixels) inside the pixel at (px, py)
-  __device__ static float gon(float gx, float gy, float r, float px, float py) {
-    float s = 0.f;
-    float x0 = gx + r * kGon[0][0] - px, y0 = gy + r * kGon[0][1] - py;
-#pragma unroll 1
-    for (int k = 1; k <= 12; k++) {
-      const float x1 = gx + r * kGon[k % 12][0] - px, y1 = gy + r * kGon[k % 12][1] - py;
-      s += edge_term(x0, y0, x1, edge_slope(x0, y0, x1, y1));
-      x0 = x1;
-      y0 = y1;
+  // drawVlner (SRC/draw.cpp:207-225): cairo_rectangle(x, y, w, h) + cairo_fill: the box converter
+  __device__ void rect(double x, double y, double w, double h, int grey) const {
+    const sft::Affine v = sft::view_matrix(sx, sy, vx, vy);
+    int x0, y0;
+    sft::to_device(v, x, y, &x0, &y0);
+    int x1 = x0 + sft::fx_from_double(v.xx * w + v.xy * 0.0), y1 = y0 + sft::fx_from_double(v.yx * 0.0 + v.yy * h);
+    if (x1 < x0) { const int t = x0; x0 = x1; x1 = t; }
+    if (y1 < y0) { const int t = y0; y0 = y1; y1 = t; }
+    const int px0 = max(x0 >> 8, 0), py0 = max(y0 >> 8, 0), px1 = min((x1 + 255) >> 8, W), py1 = min((y1 + 255) >> 8, H);
+    const int bw = px1 - px0, n = bw > 0 && py1 > py0 ? bw * (py1 - py0) : 0;
+    for (int i = tid; i < n; i += 64) {
+      const int ry = i / bw, px = px0 + (i - ry * bw), py = py0 + ry;
+      const int ox = min(x1, (px + 1) << 8) - max(x0, px << 8), oy = min(y1, (py + 1) << 8) - max(y0, py << 8);
+      if (ox > 0 && oy > 0) {
+        const int al = sft::box_area_to_alpha((long long)ox * oy);
+        if (al) {
+          uint8_t* p = fb + py * W + px;
+          *p = (uint8_t)sft::lerp8(grey, al, *p);
+        }
+      }
     }
-    return fabsf(s);
+    order();
   }
 };
-
-__constant__ float kShipLines[3][4] = {{-18, 0, 18, 0}, {-18, 18, 0, 0}, {0, 0, -18, -18}};              // SRC/wireframe.cpp:11-67
-__constant__ float kFortLines[4][4] = {{0, 0, 36, 0}, {0, -18, 18, -18}, {18, -18, 18, 18}, {18, 18, 0, 18}};
-__constant__ float kMissileLines[3][4] = {{0, 0, -25, 0}, {0, 0, -5, 5}, {0, 0, -5, -5}};
-__constant__ float kShellLines[4][4] = {{-8, 0, 0, -6}, {0, -6, 16, 0}, {16, 0, 0, 6}, {0, 6, -8, 0}};
 
 }  // namespace
 
 struct SfGenericArgs {
   const unsigned char* state;
   int n_envs, W, H;
-  float vx, vy, sc, half_lw;
+  double sx, sy, vx, vy, lw;
+  const double* trig;
+  const double* arcs;
   const uint8_t* bg;      // W * H bytes: the hexagons on black (sf_image.cpp: sf_image_background_geom)
   const uint32_t* tabs;   // resize != 0: 8 words per destination column, then per row: first, count, 4 weights, 2 pad
   uint8_t* out;
@@ -202,10 +233,12 @@ struct SfGenericArgs {
 
 __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t g_fb[];
-  __shared__ float mtab[SF_NSLOT][3];
+  __shared__ double mtab[SF_NSLOT][3];
+  __shared__ __attribute__((aligned(16))) uint32_t torw[sftd::kLdsWordsBig];
   const int tid = threadIdx.x, env = blockIdx.x;
   const int W = a.W, H = a.H;
-  const Ctx C{g_fb, W, H, tid, a.vx, a.vy, a.sc, a.half_lw};
+  const Ctx C{g_fb, torw, W, H, tid, a.sx, a.sy, a.vx, a.vy, a.lw, a.trig, a.arcs};
+  for (int i = tid; i < sftd::kLdsWordsBig; i += kThreads) torw[i] = 0u;
   const unsigned char* tile = a.state + (long)(env >> 6) * sfl::kTileBytes;
   const int l = env & 63, o16 = l * 16;
   const d2_t sp = G_LD(d2_t, G_CHUNK(ship_pos, 0), o16);
@@ -238,21 +271,21 @@ __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericAr
     const unsigned meta = G_LD(uint32_t, G_CHUNK(missile_meta, 0), e * 4u);
     if (SF_MM_OWNER(meta) == (unsigned)l) {
       const d2_t m = G_LD(d2_t, G_CHUNK(missile_pos, 0), e * 16u);
-      float* t = mtab[SF_MM_SLOT(meta)];
-      t[0] = (float)m.x;
-      t[1] = (float)m.y;
-      t[2] = (float)SF_MM_ANGLE(meta);
+      double* t = mtab[SF_MM_SLOT(meta)];
+      t[0] = m.x;
+      t[1] = m.y;
+      t[2] = (double)SF_MM_ANGLE(meta);
     }
   }
   __syncthreads();
   if (tid < 64) {  // ---- wave 0 composites: ship (:233-237), fortress (:238-242)
-  if (flags & SF_FL_SHIP_ALIVE) C.wireframe(kShipLines, 3, ship_angle, (float)sp.x, (float)sp.y);
-  else C.explosion((float)sp.x, (float)sp.y);
-  if (flags & SF_FL_FORT_ALIVE) C.wireframe(kFortLines, 4, fort_angle, (float)sfc::fort_x, (float)sfc::fort_y);
-  else C.explosion((float)sfc::fort_x, (float)sfc::fort_y);
+  if (flags & SF_FL_SHIP_ALIVE) C.wireframe(0, ship_angle, sp.x, sp.y);
+  else C.explosion(sp.x, sp.y);
+  if (flags & SF_FL_FORT_ALIVE) C.wireframe(1, fort_angle, sfc::fort_x, sfc::fort_y);
+  else C.explosion(sfc::fort_x, sfc::fort_y);
   // missiles (:243-247), shells (:248-253: only once clear of the fortress; drawWireFrame takes the heading as an int)
   for (int s = 0; s < SF_NSLOT; s++)
-    if ((mmask >> s) & 1u) C.wireframe(kMissileLines, 3, (int)mtab[s][2], mtab[s][0], mtab[s][1]);
+    if ((mmask >> s) & 1u) C.wireframe(2, (int)mtab[s][2], mtab[s][0], mtab[s][1]);
   for (int s = 0; s < SF_NSLOT; s++)
     if ((smask >> s) & 1u) {
       const d2_t p = G_LD(d2_t, G_CHUNK(shell_pos, s), o16), v = G_LD(d2_t, G_CHUNK(shell_vel, s), o16);
@@ -260,15 +293,15 @@ __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericAr
       if (sqrt(ddx * ddx + ddy * ddy) > 21.0) {
         double ang = atan2(v.y, v.x) * 180.0 / M_PI;
         if (ang < 0) ang += 360.0;
-        C.wireframe(kShellLines, 4, (int)ang, (float)p.x, (float)p.y);
+        C.wireframe(3, (int)ang, p.x, p.y);
       }
     }
   C.score(pnts);
   // vulnerability bar (drawVlner, :205-225,268)
   {
     const bool kill = vlner > 10 && tb.w < sfc::vuln_time;
-    C.rect(255.f, 522.f, 455.f, 532.f, 84);
-    if (vlner > 0) C.rect(255.f, 522.f, 255.f + 20.f * (float)(vlner > 10 ? 10 : vlner), 532.f, kill ? 255 : 168);
+    C.rect(355.0 - 100, 335.0 + 187, 200.0, 10.0, 84);
+    if (vlner > 0) C.rect(355.0 - 100, 335.0 + 187, (double)(20 * (vlner > 10 ? 10 : vlner)), 10.0, kill ? 255 : 168);
   }
   }  // (wave 0)
   __syncthreads();
@@ -325,11 +358,11 @@ __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericAr
   }
 }
 
-hipError_t sf_launch_render_generic(const unsigned char* state, int n_envs, int W, int H, double scale, double vp_x, double vp_y,
-                                    double line_w, const uint8_t* bg, const uint32_t* tabs, uint8_t* out, size_t out_stride,
-                                    int resize, hipStream_t stream) {
+hipError_t sf_launch_render_generic(const unsigned char* state, int n_envs, int W, int H, double sx, double sy, double vp_x, double vp_y,
+                                    double line_w, const double* trig, const double* arcs, const uint8_t* bg, const uint32_t* tabs,
+                                    uint8_t* out, size_t out_stride, int resize, hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
-  SfGenericArgs a{state, n_envs, W, H, (float)vp_x, (float)vp_y, (float)scale, (float)(line_w / 2), bg, tabs, out, out_stride, resize};
+  SfGenericArgs a{state, n_envs, W, H, sx, sy, vp_x, vp_y, line_w, trig, arcs, bg, tabs, out, out_stride, resize};
   const size_t lds = ((size_t)W * H + 15) & ~(size_t)15;
   hipLaunchKernelGGL(sf_render_generic_kernel, dim3((unsigned)n_envs), dim3(kThreads), lds, stream, a);
   return hipGetLastError();

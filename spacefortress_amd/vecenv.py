@@ -352,10 +352,10 @@ class SFVecEnv:
         return out
 
     def draw_records(self, from_state=False):
-        """Diagnostics: the envs' draw records (sfmi.h: sf_draw_records) as uint8 [N, 384] -- what the frame kernel reads
+        """Diagnostics: the envs' draw records (sfmi.h: sf_draw_records) as uint8 [N, 432] -- what the frame kernel reads
         instead of the state.  from_state=True rebuilds them from the state first (what a frame does after reset() /
         set_field()); False returns what the last step launch of an image batch left."""
-        out = np.empty((self.num_envs, 384), np.uint8)
+        out = np.empty((self.num_envs, 432), np.uint8)
         _lib.check(self._L.sf_draw_records(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes, int(bool(from_state))))
         return out
 

@@ -43,6 +43,13 @@ GAMETYPES = ["youturn", "autoturn", "test-youturn", "test-autoturn"]
 FORT = (355.0, 315.0)
 
 
+def set_shell_heading(s, i, a):
+    """A shell's heading with the velocity that has it (the engine keeps both, SRC/game.cpp:159-173; a batch keeps the velocity
+    and derives the drawn heading): away from whole degrees, where float noise could truncate to the neighbour."""
+    s["shell_angle"][i] = a
+    s["shell_vx"][i], s["shell_vy"][i] = 6.0 * np.cos(np.radians(a)), 6.0 * np.sin(np.radians(a))
+
+
 def base_snap(g):
     s = g.snapshot().copy()
     s["missile_alive"][:] = 0
@@ -124,11 +131,11 @@ def main():
             s["vlner"], s["fort_vuln_timer"] = v, timer
             emit(s, "bar_%d_%d" % (v, timer))
     for k, d in enumerate((0.0, 10.0, 20.9, 21.0, 21.000001, 21.5, 25.0, 60.0, 150.0)):  # the 21-unit rule
-        for a in (0.0, 33.7, 180.0, 271.2, 359.9):
+        for a in (0.4, 33.7, 180.3, 271.2, 359.9):
             s = b.copy()
             s["shell_alive"][3] = 1
             s["shell_x"][3], s["shell_y"][3] = FORT[0] + d * np.cos(np.radians(a)), FORT[1] + d * np.sin(np.radians(a))
-            s["shell_angle"][3] = a  # a double: drawWireFrame's int parameter truncates it
+            set_shell_heading(s, 3, a)  # a double: drawWireFrame's int parameter truncates it
             emit(s, "shell_rule_%d_%g" % (k, a))
     for k in range(40):  # crowded pools
         s = b.copy()
@@ -140,7 +147,7 @@ def main():
         for i in rng.permutation(20)[:ns]:
             s["shell_alive"][i] = 1
             s["shell_x"][i], s["shell_y"][i] = rng.uniform(100, 620), rng.uniform(50, 570)
-            s["shell_angle"][i] = rng.uniform(0, 360)
+            set_shell_heading(s, i, int(rng.integers(0, 360)) + rng.uniform(.05, .95))
         s["ship_x"], s["ship_y"], s["ship_angle"] = rng.uniform(200, 500), rng.uniform(150, 480), int(rng.integers(0, 360))
         s["ship_alive"] = int(k % 5 != 0)
         s["fort_alive"] = int(k % 7 != 0)
@@ -155,7 +162,8 @@ def main():
                 (130 + 450 * t, 80 + rng.uniform(-6, 6)), (130 + 450 * t, 540 + rng.uniform(-6, 6))][side]
         i = int(rng.integers(0, 20))
         if k % 3 == 2:
-            s["shell_alive"][i], s["shell_x"][i], s["shell_y"][i], s["shell_angle"][i] = 1, x, y, rng.uniform(0, 360)
+            s["shell_alive"][i], s["shell_x"][i], s["shell_y"][i] = 1, x, y
+            set_shell_heading(s, i, int(rng.integers(0, 360)) + rng.uniform(.05, .95))
         else:
             s["missile_alive"][i], s["missile_x"][i], s["missile_y"][i], s["missile_angle"][i] = 1, x, y, int(rng.integers(0, 360))
         j = (i + 7) % 20  # ... and one over the score text / the bar
@@ -186,7 +194,8 @@ def main():
         s["vlner"] = 3 * k
         for i in range(3):
             s["missile_alive"][i], s["missile_x"][i], s["missile_y"][i], s["missile_angle"][i] = 1, rng.uniform(110, 600), rng.uniform(70, 560), int(rng.integers(0, 360))
-        s["shell_alive"][0], s["shell_x"][0], s["shell_y"][0], s["shell_angle"][0] = 1, rng.uniform(150, 550), rng.uniform(100, 500), rng.uniform(0, 360)
+        s["shell_alive"][0], s["shell_x"][0], s["shell_y"][0] = 1, rng.uniform(150, 550), rng.uniform(100, 500)
+        set_shell_heading(s, 0, int(rng.integers(0, 360)) + rng.uniform(.05, .95))
         extra.append(s)
     S = np.concatenate([S, np.array(extra, O.SNAPSHOT_DTYPE)])
     out["snaps"] = S

@@ -1,5 +1,7 @@
-"""CPU-side checks of the image observation: the library's host tables against the numpy model
-(oracle/render_np.py), and properties of the model itself.  No GPU."""
+"""CPU-side checks of the image observation: the library's host tables and its formulation of cairo's rasterisation
+(sf_tor.h, run on the host through sf_image_object_alpha / sf_image_explosion_host) against the model
+(oracle/render_np.py over oracle/cairo_model.c, itself pinned to the reference's frames and to the real cairo), and
+properties of the model itself.  No GPU."""
 import ctypes as C
 import os
 
@@ -33,7 +35,7 @@ def test_background_matches_model_and_reference_hexagons():
             assert bg[int(min(y, 91.9)), int(min(x, 89.9))] > 0 or bg[int(y) - 1, int(x)] > 0
     assert bg[47, 45] == 0
     per = sum(np.hypot(*(q - p)) for pts in (hb, hs) for p, q in zip(pts.reshape(6, 2), np.roll(pts.reshape(6, 2), -1, 0)))
-    assert abs(bg.astype(np.float64).sum() / 255.0 - per * 0.2 * 0.6) < 0.02 * per * 0.2 * 0.6
+    assert abs(bg.astype(np.float64).sum() / 255.0 - per * 0.2 * 0.6) < 0.03 * per * 0.2 * 0.6  # (15 sub-rows per row, not exact area)
     assert L.sf_image_background(None) < 0
 
 
@@ -110,13 +112,13 @@ def test_host_tables_of_another_geometry_match_model():
     L = _lib()
     hb, hs = _hex()
     rng = np.random.default_rng(4)
-    for scale, vp, ls in ((.25, (100, 60, 500, 520), 2), (.3, (130, 80, 450, 460), 4.5)):
+    for scale, vp, ls in ((.25, (100, 60, 500, 520), 2), (.3, (130, 80, 450, 460), 4.5), (.25, (130, 80, 450, 460), 3), (.4, (130, 80, 450, 460), 3)):
         prev = R.set_geometry(scale, vp, ls)
         try:
             w, h = int(vp[2] * scale), int(vp[3] * scale)
             assert (R.W, R.H) == (w, h)
             bg = np.zeros((h, w), np.uint8)
-            assert L.sf_image_background_geom(scale, vp[0], vp[1], w, h, ls, bg.ctypes.data_as(C.c_void_p)) == 0
+            assert L.sf_image_background_geom(w, h, vp[0], vp[1], vp[2], vp[3], ls, bg.ctypes.data_as(C.c_void_p)) == 0
             assert np.array_equal(bg, R.background(hb, hs)) and bg.max() > 100
             for img in (bg, rng.integers(0, 256, (h, w)).astype(np.uint8)):
                 out = np.zeros((84, 84), np.uint8)
@@ -188,7 +190,7 @@ def test_static_variants_match_model():
         if v & 1:
             R.score_text(want, 0)
         if v & 2:
-            R.over(want, R.rect_poly(255, 522, 455, 532), 84)
+            want = R.bar_frame(want, 0, False)
         assert np.array_equal(out, want), v
     assert L.sf_image_static(4, bg.ctypes.data_as(C.c_void_p)) < 0
 
@@ -350,10 +352,122 @@ def test_fast_divmod_of_the_pixel_loops_is_exact():
             assert np.array_equal(q, i // w), (w, rw)
 
 
-def test_white_over_is_one_multiply():
-    """sf_render.hip composites the wireframes' strokes (all white) as m + mul_un8(d, 255 - m): pixman's mul_un8(255, m) is m."""
-    mul = lambda a, b: ((a * b + 128) + ((a * b + 128) >> 8)) >> 8
-    for m in range(256):
-        assert mul(255, m) == m
-        for d in range(256):
-            assert m + mul(d, 255 - m) == mul(255, m) + mul(d, 255 - m) <= 255
+def test_lerp_of_white_is_the_alpha():
+    """cairo's 8-bit lerp (cairo-image-compositor.c: mul8x2_8, + 0x7f): white through alpha a onto black is a."""
+    mul = lambda a, b: (((a * b + 0x7f) + ((a * b + 0x7f) >> 8)) >> 8) & 0xff
+    for a in range(256):
+        assert mul(255, a) == a
+
+
+def _object_alpha(L, kind, x, y, ang, geom=(90, 92, 130., 80., 450., 460., 3.0)):
+    w, h = geom[0], geom[1]
+    got = np.zeros((h, w), np.uint8)
+    assert L.sf_image_object_alpha(kind, x, y, ang, w, h, *geom[2:], got.ctypes.data_as(C.c_void_p)) == 0
+    return got
+
+
+def test_kernel_formulation_of_a_wireframe_equals_the_model():
+    """sf_tor.h -- an object as convex quads united by inclusion-exclusion, a pixel row sampled in 15 sub-rows or taken whole,
+    cairo's integer quotients carried as doubles -- against the edge-list restatement (oracle/cairo_model.c), bit for bit:
+    every kind of wireframe at random poses, whole-pixel and quarter-pixel positions, the diagonal and axis headings where
+    edges tie, and across the surface's four borders (cairo clips the polygon there: extra vertices)."""
+    from oracle import render_np as R
+    L = _lib()
+    lines = [R.SHIP_LINES, R.FORT_LINES, R.MISSILE_LINES, R.SHELL_LINES]
+    rng = np.random.default_rng(5)
+    for it in range(6000):
+        kind, mode = it % 4, it % 5
+        if mode == 0:
+            side, t = rng.integers(0, 4), rng.uniform(0, 1)
+            x, y = [(130 + rng.uniform(-7, 7), 80 + 460 * t), (580 + rng.uniform(-7, 7), 80 + 460 * t),
+                    (130 + 450 * t, 80 + rng.uniform(-7, 7)), (130 + 450 * t, 540 + rng.uniform(-7, 7))][side]
+        elif mode == 1:
+            x, y = float(rng.integers(125, 585)), float(rng.integers(75, 545))
+        elif mode == 2:
+            x, y = rng.integers(125 * 4, 585 * 4) / 4.0, rng.integers(75 * 4, 545 * 4) / 4.0
+        else:
+            x, y = rng.uniform(120, 590), rng.uniform(70, 550)
+        ang = int(rng.integers(0, 360)) if it % 3 else int(rng.choice([0, 45, 90, 135, 180, 225, 270, 315, 30, 60]))
+        if kind == 1 and ang == 0:
+            ang = 10  # (the rectilinear stroker's pose: sf_image_fort_alpha below)
+        want = R.run_script(R.s_begin() + R.s_wireframe(lines[kind], (x, y), ang))
+        assert np.array_equal(_object_alpha(L, kind, x, y, ang), want), (kind, x, y, ang)
+
+
+def test_kernel_formulation_in_other_geometries():
+    from oracle import render_np as R
+    L = _lib()
+    lines = [R.SHIP_LINES, R.FORT_LINES, R.MISSILE_LINES, R.SHELL_LINES]
+    rng = np.random.default_rng(6)
+    for scale, vp, ls in ((.25, (100, 60, 500, 520), 2), (.3, (130, 80, 450, 460), 4.5), (.25, (130, 80, 450, 460), 3)):
+        prev = R.set_geometry(scale, vp, ls)
+        try:
+            for it in range(400):
+                kind = it % 4
+                x, y, ang = rng.uniform(vp[0] - 5, vp[0] + vp[2] + 5), rng.uniform(vp[1] - 5, vp[1] + vp[3] + 5), int(rng.integers(1, 360))
+                want = R.run_script(R.s_begin() + R.s_wireframe(lines[kind], (x, y), ang))
+                got = _object_alpha(L, kind, x, y, ang, (R.W, R.H, float(vp[0]), float(vp[1]), float(vp[2]), float(vp[3]), float(ls)))
+                assert np.array_equal(got, want), (scale, kind, x, y, ang)
+        finally:
+            R.set_geometry(*prev)
+
+
+def test_kernel_formulation_of_the_explosion_equals_the_model():
+    """drawExplosion: 84 arcs as single quads between the faces cairo's stroker puts at their ends, the circle as sixteen
+    pieces of two flattened Bezier halves."""
+    from oracle import render_np as R
+    L = _lib()
+    rng = np.random.default_rng(7)
+    for it in range(400):
+        x, y = (355.0, 315.0) if it == 0 else (rng.uniform(125, 585), rng.uniform(75, 545))
+        if it % 5 == 1:
+            x, y = float(int(x)), float(int(y))
+        want = R.run_script(R.s_begin() + R.s_explosion((x, y)))
+        got = np.zeros((92, 90), np.uint8)
+        assert L.sf_image_explosion_host(x, y, 90, 92, 130., 80., 450., 460., 3.0, got.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(got, want), (x, y)
+
+
+def test_explosions_in_other_geometries_flatten_like_cairo():
+    """At a larger scale cairo cuts a 10-degree arc into two pieces (its control points lie further than the tolerance 0.1
+    pixel from the chord) and the circle's halves into sixteen: the adaptive form (sft::flatten_faces), where the faces
+    BETWEEN the pieces bound them without being edges of the polygon."""
+    from oracle import render_np as R
+    L = _lib()
+    rng = np.random.default_rng(8)
+    pieces = set()
+    for scale, vp, ls in ((.25, (100, 60, 500, 520), 2), (.3, (130, 80, 450, 460), 4.5), (.4, (130, 80, 450, 460), 3), (.55, (130, 80, 450, 460), 3)):
+        prev = R.set_geometry(scale, vp, ls)
+        g = (R.W, R.H, float(vp[0]), float(vp[1]), float(vp[2]), float(vp[3]), float(ls))
+        try:
+            for it in range(60):
+                x, y = rng.uniform(vp[0] - 5, vp[0] + vp[2] + 5), rng.uniform(vp[1] - 5, vp[1] + vp[3] + 5)
+                want = R.run_script(R.s_begin() + R.s_explosion((x, y)))
+                got = np.zeros((R.H, R.W), np.uint8)
+                assert L.sf_image_explosion_host(x, y, *g, got.ctypes.data_as(C.c_void_p)) == 0
+                assert np.array_equal(got, want), (scale, x, y)
+            for it in range(200):
+                x, y, r = rng.uniform(vp[0], vp[0] + vp[2]), rng.uniform(vp[1], vp[1] + vp[3]), rng.uniform(10, 70)
+                a1 = rng.uniform(0, 6.2)
+                a2 = a1 + rng.uniform(.05, 1.5)
+                want = R.run_script(R.s_begin() + [R.LINE_WIDTH, float(ls), R.GREY, 1.0, R.ARC, x, y, r, a1, a2, R.STROKE])
+                got = np.zeros((R.H, R.W), np.uint8)
+                n = L.sf_image_arc_alpha(x, y, r, a1, a2, *g, got.ctypes.data_as(C.c_void_p))
+                assert n >= 1 and np.array_equal(got, want), (scale, x, y, r, a1, a2)
+                pieces.add(n)
+        finally:
+            R.set_geometry(*prev)
+    assert {1, 2, 4} <= pieces, pieces
+
+
+def test_fortress_alpha_maps_equal_the_model():
+    """The 36 pictures of the live fortress the frame kernel lerps in or starts from: heading 0 through cairo's rectilinear
+    stroker and box converter, the others through the scan converter."""
+    from oracle import render_np as R
+    L = _lib()
+    for sector in range(36):
+        a = np.zeros((16, 16), np.uint8)
+        assert L.sf_image_fort_alpha(sector, a.ctypes.data_as(C.c_void_p)) == 0
+        want = R.run_script(R.s_begin() + R.s_wireframe(R.FORT_LINES, R.FORT, 10 * sector))
+        assert np.array_equal(a, want[39:55, 37:53]) and want.sum() == want[39:55, 37:53].sum(), sector
+    assert L.sf_image_fort_alpha(36, a.ctypes.data_as(C.c_void_p)) < 0

@@ -28,6 +28,6 @@ def test_host_entry_points_are_clean_under_asan_ubsan(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-ffp-contract=off"] + SAN +
                           ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
                            os.path.join(ROOT, "tests", "sanitize", "host_main.cpp"), os.path.join(csrc, "sf_host.cpp"),
-                           os.path.join(csrc, "sf_image.cpp"), "-o", exe])
+                           os.path.join(csrc, "sf_image.cpp"), os.path.join(csrc, "sf_cairo_host.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
