@@ -433,7 +433,10 @@ void object_coverage(const Object& ob, int W, int H, int* acc) {
         const Quad& qr = ob.q[rq];
         auto edge_of = [&](const Quad& q, const sft::QuadScan& sc, int e) {
           if (s0 >= sc.out_s0[e] && s0 < sc.out_s1[e]) return sft::row_edge(sc.out_x[e], 0, sc.out_x[e], 256, s0);  // along the border
-          return sft::row_edge(q.x[e], q.y[e], q.x[(e + 1) & 3], q.y[(e + 1) & 3], s0);
+          // (the division-free form the lanes use; row_edge is the plain restatement, and the general polygons' sweep uses that)
+          int x1 = q.x[e], y1 = q.y[e], x2 = q.x[(e + 1) & 3], y2 = q.y[(e + 1) & 3];
+          if (y2 < y1) { std::swap(x1, x2); std::swap(y1, y2); }
+          return sft::row_edge_ab(sc.e[e], x2 - x1, y2 - y1, x1, s0);
         };
         const sft::RowEdge L = edge_of(ql, qs[lq], le), R = edge_of(qr, qs[rq], re);
         for (int px = 0; px < W; px++) acc[row * W + px] += sign * (sft::row_edge_area(L, px) - sft::row_edge_area(R, px));

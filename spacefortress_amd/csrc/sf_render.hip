@@ -355,9 +355,24 @@ struct Frame {
   static constexpr int kMapBitsOut = 1024;  // the map of the objects' 84x84 boxes in the resample pass
   static constexpr int kLtabAt = 4 * kChunk + kMapBitsOut / 32;  // words into `tor`: behind that pass's records and map
   static constexpr int kResampleWords = kLtabAt + 4 * kLtabEntries;
-  static constexpr int kTorWords = sftd::kLdsWords > kResampleWords ? sftd::kLdsWords : kResampleWords;
+  static constexpr int kTorWords = sftd::kLdsWordsF > sftd::kLdsWords ? sftd::kLdsWordsF : sftd::kLdsWords;
+  static_assert(kTorWords >= kResampleWords, "the resample pass's records fit");
   static_assert(kLtabAt % 4 == 0, "the period of the tap tables is 16-byte aligned");
-  __device__ __forceinline__ sftd::Ctx tor_ctx() const { return sftd::Ctx{tor, fb, SF_IMG_W, SF_IMG_H, lane}; }
+  __device__ __forceinline__ sftd::Ctx tor_ctx() const { return sftd::Ctx{tor, fb, SF_IMG_W, SF_IMG_H, lane, sftd::kMaxQuads, sftd::kAccAtF}; }
+  __device__ __forceinline__ sftd::CtxF tor_ctx_fast() const { return sftd::CtxF{tor, fb, SF_IMG_W, SF_IMG_H, lane}; }
+  // one call of sf_tor_dev.h: the fast arrangement unless a quad of the call reaches over a border or is oddly shaped
+  __device__ __forceinline__ void raster_any(const sft::Quad& q, bool valid, int obj0, int kind, int grey) const {
+#ifdef SF_NO_GENERAL /* timing experiment: what the kernel is without the general arrangement in it (wrong frames at the borders) */
+    sftd::raster_fast(tor_ctx_fast(), q, valid && !sftd::needs_general(q, SF_IMG_W * 256), obj0, kind, grey);
+#else
+    if (__ballot(valid && sftd::needs_general(q, SF_IMG_W * 256)) || !sftd::raster_fast(tor_ctx_fast(), q, valid, obj0, kind, grey))
+      raster_general(tor_ctx(), q, valid, obj0, kind, grey);
+#endif
+  }
+  // (a real call: the general arrangement is the rare path -- a missile leaving the view -- and its registers are its own)
+  __device__ __attribute__((noinline)) static void raster_general(const sftd::Ctx C, const sft::Quad q, bool valid, int obj0, int kind, int grey) {
+    sftd::raster(C, q, valid, obj0, kind, grey);
+  }
   __device__ __forceinline__ void draw_strokes(const sft::Quad& mine, bool valid, int obj0, int kind) const {
 #define SF_DS_STAMP(k) do { if (SF_RENDER_STOP == 41 + (k)) return; } while (0)
     const Box myb = quad_box(mine);
@@ -373,7 +388,7 @@ struct Frame {
       const bool in = ((live >> lane) & 1ull) && rank0 + nq <= kChunk;
       const unsigned long long chunk = __ballot(in);
       live &= ~chunk;
-      sftd::raster(tor_ctx(), mine, in, obj0, kind, 255);
+      raster_any(mine, in, obj0, kind, 255);
       SF_DS_STAMP(2);
     }
     // ---- the 84x84 pixels that read what was drawn.  An object = the (at most four, consecutive) strokes that share
@@ -455,7 +470,8 @@ struct Frame {
 #undef SF_DS_STAMP
   }
 };
-static_assert(Frame<true>::kResampleWords <= sftd::kMaxQuads * sftd::kRecWords + sftd::kMaxObjs * sftd::kObjWords,
+static_assert(Frame<true>::kResampleWords <= sftd::kMaxQuads * sftd::kRecWords + sftd::kMaxObjs * sftd::kObjWords &&
+              Frame<true>::kResampleWords <= sftd::kMaxQuads * sftd::kRecWordsF + sftd::kMaxObjs * sftd::kObjWordsF,
               "the resample pass's records, map and tap period stay clear of sf_tor_dev.h's accumulators (which must stay zero)");
 
 // ---- the objects' lines as cairo has them: path points through the matrices of drawGameStateScaled + drawWireFrame
@@ -494,7 +510,6 @@ template <bool RESIZE>
 __device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, const double* arcs, double cx, double cy) {
   const int lane = F.lane;
   const sft::Affine v = default_view();
-  const sftd::Ctx C = F.tor_ctx();
 #pragma unroll 1
   for (int ring = 0; ring < 7; ring++) {
     sft::Quad q = {};
@@ -503,7 +518,7 @@ __device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, const dou
       const sft::ArcK k{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
       q = sft::arc_quad_fixed(sft::arc_knots(v, cx, cy, k), SF_SCALE, SF_SCALE, (double)(float)SF_LINE_W / 2);
     }
-    sftd::raster(C, q, lane < 12, lane, sftd::kKindSingle, 15 + 8 * ring < 60 ? 191 : 128);  // .75 / .5
+    F.raster_any(q, lane < 12, lane, sftd::kKindSingle, 15 + 8 * ring < 60 ? 191 : 128);  // .75 / .5
   }
   {
     sft::Quad q = {};
@@ -512,7 +527,7 @@ __device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, const dou
       const sft::ArcK k{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
       q = sft::ring_piece_quad(sft::arc_knots(v, cx, cy, k), lane & 7, SF_SCALE, SF_SCALE, (double)(float)SF_LINE_W / 2);
     }
-    sftd::raster(C, q, lane < 16, 0, sftd::kKindRing | (8 << 8), 191);
+    F.raster_any(q, lane < 16, 0, sftd::kKindRing | (8 << 8), 191);
   }
   F.resample(explosion_box((float)cx, (float)cy));
 }
@@ -1276,7 +1291,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   if (SF_RENDER_STOP == 1) return;
 
   // (sf_tor_dev.h's accumulators start out zero and every call leaves them so)
-  for (int i = lane; i < sftd::kAccPixels / 2; i += 64) F.tor_ctx().acc()[i] = 0u;
+  for (int i = lane; i < Frame<RESIZE>::kTorWords; i += 64) torw[i] = 0u;
   __builtin_amdgcn_wave_barrier();
   // ---- what is restored from round trip 2's registers: the dead ship's explosion if its cache entry is this one
   // (the entry is keyed by where the ship died: the float64 position the picture is a function of)

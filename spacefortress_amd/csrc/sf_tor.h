@@ -301,10 +301,47 @@ SFT_HD RowEdge row_edge(int x1, int y1, int x2, int y2, int s0) {
   r.DX = (q2 - q1) * U + (r2 - r1);
   return r;
 }
+// The same WITHOUT a division, from the edge's A + B s (edge_ab) -- what the lanes use.  x(s) is a rational with denominator
+// U = 30 dy: where it is not a whole number it lies at least 1 / U from one, and the float form is good to 1e-10: quotient
+// floor(x + 1 / (2 U)), remainder round((x - quotient) U), both exact; likewise the step 512 dx / U = B itself.
+// (dx, dy: the edge's run in fixed point, dy > 0 after orienting it downwards; x1: its upper end's x; vertical edges: dx == 0.)
+SFT_HD RowEdge row_edge_ab(const EdgeAB& e, int dx, int dy, int x1, int s0) {
+  RowEdge r;
+  const double U = 30.0 * (double)dy, hU = 0.5 / U;
+  double q1, r1, q2, r2;
+  if (dx == 0) {
+    q1 = q2 = (double)x1; r1 = r2 = 0.0;
+  } else {
+    const double off = 0.5 + 0.25 / (2.0 * U);  // what edge_ab folded into A
+    const double xa = fma(e.B, (double)s0, e.A) - off, xb = fma(e.B, (double)(s0 + kGridY), e.A) - off;
+    q1 = floor(xa + hU); r1 = rint((xa - q1) * U);
+    q2 = floor(xb + hU); r2 = rint((xb - q2) * U);
+    const double Q = e.B >= 0.0 ? floor(e.B + hU) : -floor(-e.B + hU), R = rint((e.B - Q) * U);
+    const double hq = Q >= 0.0 ? floor(Q * 0.5) : -floor(-Q * 0.5), hr = R * 0.5;
+    q1 -= hq; r1 -= hr;
+    if (r1 < 0.0) { q1 -= 1.0; r1 += U; } else if (r1 >= U) { q1 += 1.0; r1 -= U; }
+    q2 -= hq; r2 -= hr;
+    if (r2 < 0.0) { q2 -= 1.0; r2 += U; } else if (r2 >= U) { q2 += 1.0; r2 -= U; }
+  }
+  int a = (int)q1, b = (int)q2;
+  r.ix1 = a >> 8; r.fx1 = a & 255; r.ix2 = b >> 8; r.fx2 = b & 255;
+  r.single = r.ix1 == r.ix2;
+  if (r.ix2 < r.ix1) {
+    int t = r.ix1; r.ix1 = r.ix2; r.ix2 = t;
+    t = r.fx1; r.fx1 = r.fx2; r.fx2 = t;
+    double d = q1; q1 = q2; q2 = d;
+    d = r1; r1 = r2; r2 = d;
+  }
+  r.U = U;
+  r.X1 = q1 * U + r1;
+  r.DX = (q2 - q1) * U + (r2 - r1);
+  return r;
+}
 // whole sub-rows the edge needs to reach column boundary 256 c (multi-column case), cairo's quotient stepping = exact floors
+// (the quotient is 0 .. 15 and its numerator and denominator are whole: off a whole number by 1 / DX at least)
 SFT_HD int row_edge_y(const RowEdge& e, int c) {
   const double t = ((double)c * 256.0 * e.U - e.X1) * 15.0;
-  return (int)floor_div(t, e.DX);
+  return (int)floor(t / e.DX + 0.5 / e.DX);
 }
 SFT_HD int row_edge_area(const RowEdge& e, int c) {
   if (c < e.ix1) return 0;

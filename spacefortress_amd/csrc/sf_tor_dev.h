@@ -51,9 +51,11 @@ struct Ctx {
   uint8_t* fb;     // the surface
   int W, H, lane;
   int maxq = kMaxQuads;
+  int acc_at = -1;  // where the accumulators start (words); -1: right behind the objects.  A kernel that uses BOTH arrangements
+                    // gives them one accumulator (each call leaves it zero; what lies below it is scratch of either)
   __device__ __forceinline__ uint32_t* rec(int q) const { return lds + q * kRecWords; }
   __device__ __forceinline__ uint32_t* obj(int o) const { return lds + maxq * kRecWords + o * kObjWords; }
-  __device__ __forceinline__ uint32_t* acc() const { return lds + maxq * kRecWords + kMaxObjs * kObjWords; }
+  __device__ __forceinline__ uint32_t* acc() const { return lds + (acc_at >= 0 ? acc_at : maxq * kRecWords + kMaxObjs * kObjWords); }
   __device__ __forceinline__ void sync() const {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -129,8 +131,12 @@ __device__ __forceinline__ int slot_of(int okind, int k, int nq, int m0) {
 
 // MAXACT: how many quads of one object a pixel row taken whole may hold (4: lines; 8: a circle at a large scale -- more and the
 // row is sampled in sub-rows instead, which cairo does not do: the general kernel's circles stay below)
+#ifndef SFTD_STOP
+#define SFTD_STOP 9 /* diagnostic builds: leave raster() behind phase N (0: at once, 1 records + boxes, 2 rows, 3 sub-rows) */
+#endif
 template <int MAXACT = 4>
 __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool valid, int obj0, int kind, int grey) {
+  if (SFTD_STOP == 0) return;
   const int lane = C.lane, XM = C.W * 256;
   uint32_t* const acc = C.acc();
   // ---- records
@@ -209,6 +215,7 @@ __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool
     o[7] = (uint32_t)(sbase - nsub);           // where its sub-rows start
   }
   C.sync();
+  if (SFTD_STOP == 1) return;
   // (the scans as per-lane constants for the searches below: the start of object j's rows / sub-rows / pixels)
   auto find_obj = [&](int t, int which) {  // the object whose range of the enumeration holds t
     int o = 0;
@@ -352,6 +359,7 @@ __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool
     }
   }
   C.sync();
+  if (SFTD_STOP == 2) return;
   // ---- sub-rows of the other rows
   for (int base = 0; base < tot_sub; base += 64) {
     const int t = base + lane;
@@ -393,6 +401,7 @@ __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool
     }
   }
   C.sync();
+  if (SFTD_STOP == 3) return;
   // ---- pixels: object after object (the reference composites its strokes in order; boxes of different objects may overlap)
   for (int o = 0; o < nobj; o++) {
     const uint32_t* ob = C.obj(o);
@@ -411,6 +420,515 @@ __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool
   }
   for (int i = lane; i < (tot_pix + 1) / 2; i += 64) acc[i] = 0u;
   C.sync();
+}
+
+
+// =====================================================================================================================================
+// The FAST arrangement (the default geometry's frame kernel): the same arithmetic, organised for the common case -- objects that
+// stay inside the surface's left and right borders, quads with at most two edges on either side (every stroke rectangle, every
+// arc piece).  A call that holds anything else goes through raster() above (the caller asks needs_general()).
+//   * a quad's record holds its edges SORTED: the two left ones, then the two right ones (a side with one edge holds it twice), as
+//     (A, B) with the rounding folded in: cell = low word of (A + B s + 1.5 * 2^52) -- two float64 operations per edge;
+//   * the rows that contain a vertex are known from a bit map the quads' owners OR together (no per-row search);
+//   * a row taken whole is handed to one lane per (row, quad) for its two trapezoid edges; rows in which two quads of an object
+//     overlap while taken whole (rare: the overlap of two lines is shorter than a pixel) go to one lane with the general code;
+//   * spans are added with straight-line code for the one- and two-pixel cases.
+constexpr int kRecWordsF = 32;  // slots L1 L2 R1 R2 (16), s0, s1, slot -> edge (2 bits each) | counts, object (4), gy[4], x[4], y[4]
+constexpr int kHdrWordsF = 4;   // per quad, for the sub-rows' lanes: see raster_fast
+constexpr int kObjWordsF = 12;  // as kObjWords, + the rows that hold a vertex: 96 bits
+constexpr int kTasksF = 64;     // (row, quad) pairs taken whole
+constexpr int kMapWordsF = 192; // the sub-rows' enumeration: a bit per start of a quad's run (6 144 sub-rows: more, and the general
+                                // arrangement takes the call)
+constexpr int kAccAtF = kMaxQuads * (kRecWordsF + kHdrWordsF) + kMaxObjs * kObjWordsF + kTasksF + 8 + kMapWordsF;
+constexpr int kLdsWordsF = kAccAtF + kAccPixels / 2;
+static_assert(kAccAtF >= kMaxQuads * kRecWords + kMaxObjs * kObjWords, "one accumulator behind both arrangements' records");
+
+struct CtxF {
+  uint32_t* lds;
+  uint8_t* fb;
+  int W, H, lane;
+  __device__ __forceinline__ uint32_t* rec(int q) const { return lds + q * kRecWordsF; }
+  __device__ __forceinline__ uint32_t* hdr(int q) const { return lds + kMaxQuads * kRecWordsF + q * kHdrWordsF; }
+  __device__ __forceinline__ uint32_t* obj(int o) const { return lds + kMaxQuads * (kRecWordsF + kHdrWordsF) + o * kObjWordsF; }
+  __device__ __forceinline__ uint32_t* tasks() const { return obj(kMaxObjs); }  // [kTasksF], the count, (3 free)
+  __device__ __forceinline__ uint8_t* qtab() const { return reinterpret_cast<uint8_t*>(tasks() + kTasksF + 4); }  // [16]: the r-th run's quad
+  __device__ __forceinline__ uint32_t* map() const { return tasks() + kTasksF + 8; }
+  __device__ __forceinline__ uint32_t* acc() const { return lds + kAccAtF; }
+  __device__ __forceinline__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+};
+
+constexpr double kMagic52 = 6755399441055744.0;  // 1.5 * 2^52: adding it leaves round-to-nearest(x) in the low word
+__device__ __forceinline__ int cell_fast(const uint32_t* slot, double sd) {  // slot = (A - 1/2, B) as two doubles; sd = (double)s
+  const double2 ab = *reinterpret_cast<const double2*>(slot);
+  return __double2loint(fma(ab.y, sd, ab.x) + kMagic52);
+}
+// 1 / d to a few ulp: v_rcp_f64 and two Newton steps (the A + B s form tolerates 1e-11: sf_tor.h)
+__device__ __forceinline__ double rcp_fast(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+// does this quad need the general arrangement: it reaches over the left / right border, or has three edges on one side
+__device__ __forceinline__ bool needs_general(const sft::Quad& q, int xmax) {
+  const int lo = min(min(q.x[0], q.x[1]), min(q.x[2], q.x[3])), hi = max(max(q.x[0], q.x[1]), max(q.x[2], q.x[3]));
+  if (lo < 0 || hi > xmax) return true;
+  // edges that go down lie on one side, edges that go up on the other: three on a side is the odd shape
+  int down = 0, up = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int d = q.y[(k + 1) & 3] - q.y[k];
+    down += d > 0;
+    up += d < 0;
+  }
+  return down > 2 || up > 2;
+}
+
+__device__ __forceinline__ void add_span_fast(uint32_t* acc, int arow, int bx0, int bw, int L, int R, int sign) {
+  if (R <= L) return;
+  const int p0 = max(L >> 8, bx0), p1 = min((R - 1) >> 8, bx0 + bw - 1);
+  if (p0 > p1) return;
+  const int lo = max(L, p0 << 8);
+  if (p0 == p1) {
+    acc_add(acc, arow + p0 - bx0, sign * 2 * (min(R, (p0 + 1) << 8) - lo));
+    return;
+  }
+  acc_add(acc, arow + p0 - bx0, sign * 2 * (((p0 + 1) << 8) - lo));
+  acc_add(acc, arow + p1 - bx0, sign * 2 * (min(R, (p1 + 1) << 8) - (p1 << 8)));
+  for (int px = p0 + 1; px < p1; px++) acc_add(acc, arow + px - bx0, sign * 512);
+}
+
+// the two edges of a quad's record through a row taken whole, as cairo's trapezoid edges (slots ls, rs)
+__device__ __forceinline__ sft::RowEdge rec_row_edge(const uint32_t* rc, int slot, int s0) {
+  const int e = (int)((rc[18] >> (2 * slot)) & 3u), j = (e + 1) & 3;
+  int x1 = (int)rc[24 + e], y1 = (int)rc[28 + e], x2 = (int)rc[24 + j], y2 = (int)rc[28 + j];
+  if (y2 < y1) { int t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+  const double2 ab = *reinterpret_cast<const double2*>(rc + 4 * slot);
+  return sft::row_edge_ab(sft::EdgeAB{ab.x + 0.5, ab.y}, x2 - x1, y2 - y1, x1, s0);
+}
+
+// false: too many sub-rows for the enumeration's bit map -- nothing drawn, the caller takes the general arrangement
+__device__ __forceinline__ bool raster_fast(const CtxF& C, const sft::Quad& mine, bool valid, int obj0, int kind, int grey) {
+  if (SFTD_STOP == 0) return true;
+  const int lane = C.lane;
+  uint32_t* const acc = C.acc();
+  const unsigned long long vmask = __ballot(valid);
+  if (!vmask) return true;
+  const int qi = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vmask, 0u));
+  const int nquads = (int)__popcll(vmask);
+  const bool leader = valid && lane == obj0;
+  const unsigned long long lmask = __ballot(leader);
+  const int oi = (int)__popcll(lmask & ((2ull << obj0) - 1ull)) - 1;
+  const int nobj = (int)__popcll(lmask);
+  // ---- records
+  if (leader) {
+    uint32_t* o = C.obj(oi);
+    o[0] = 0x7fffffffu; o[1] = 0x7fffffffu; o[2] = 0x80000000u; o[3] = 0x80000000u;  // min x, min s, max x, max s
+    o[4] = (uint32_t)qi | ((uint32_t)(kind & 255) << 16) | ((uint32_t)grey << 24);
+    o[5] = 0u; o[6] = 0u; o[7] = (uint32_t)(kind >> 8);
+    o[8] = 0u; o[9] = 0u; o[10] = 0u; o[11] = 0u;
+  }
+  if (lane == 0) C.tasks()[kTasksF] = 0u;
+#pragma unroll
+  for (int i = 0; i < kMapWordsF; i += 64) C.map()[i + lane] = 0u;
+  C.sync();
+  int my_lo = 0, my_hi = 0;
+  if (valid) {
+    uint32_t* r = C.rec(qi);
+    int gy[4], lo = 1 << 30, hi = -(1 << 30), minx = 1 << 30, maxx = -(1 << 30);
+    unsigned vr0 = 0u, vr1 = 0u, vr2 = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      gy[k] = sft::to_grid_y(mine.y[k]);
+      lo = min(lo, gy[k]); hi = max(hi, gy[k]);
+      minx = min(minx, mine.x[k]); maxx = max(maxx, mine.x[k]);
+      // the row that holds this vertex strictly inside (a vertex on a row's boundary is no event for either row)
+      const int vrow = (gy[k] * 34953) >> 19;  // gy / 15 for 0 <= gy < 2^16
+      if (gy[k] > 0 && vrow < 96 && gy[k] != vrow * sft::kGridY) {
+        vr0 |= vrow < 32 ? 1u << vrow : 0u;
+        vr1 |= (vrow >= 32 && vrow < 64) ? 1u << (vrow - 32) : 0u;
+        vr2 |= vrow >= 64 ? 1u << (vrow - 64) : 0u;
+      }
+    }
+    *reinterpret_cast<int4*>(r + 20) = int4{gy[0], gy[1], gy[2], gy[3]};
+    *reinterpret_cast<int4*>(r + 24) = int4{mine.x[0], mine.x[1], mine.x[2], mine.x[3]};
+    *reinterpret_cast<int4*>(r + 28) = int4{mine.y[0], mine.y[1], mine.y[2], mine.y[3]};
+    // which side an edge is on: with the corners in order, the edges that go down are all on one side (the right one when the
+    // doubled area (x2 - x0)(y3 - y1) - (x3 - x1)(y2 - y0) is positive: y points down)
+    const int area2 = (mine.x[2] - mine.x[0]) * (mine.y[3] - mine.y[1]) - (mine.x[3] - mine.x[1]) * (mine.y[2] - mine.y[0]);
+    // a parallelogram's opposite edges share their slope: two reciprocals instead of four
+    const bool para = mine.x[1] - mine.x[0] == mine.x[2] - mine.x[3] && mine.y[1] - mine.y[0] == mine.y[2] - mine.y[3];
+    double Kc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int j = (k + 1) & 3;
+      const int dx = mine.x[j] - mine.x[k], dy = mine.y[j] - mine.y[k];
+      // K = dx / (30 dy) of the line (the same whichever way the edge is read)
+      if (k >= 2 && para) Kc[k] = Kc[k - 2];
+      else Kc[k] = dy != 0 ? (double)dx * rcp_fast(30.0 * (double)dy) : 0.0;
+    }
+    int nl = 0, nr = 0;
+    unsigned slot_edges = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int j = (k + 1) & 3;
+      const int dy = mine.y[j] - mine.y[k];
+      if (dy == 0 || area2 == 0) continue;
+      const bool right = (dy > 0) == (area2 > 0);
+      const int slot = right ? 2 + nr : nl;
+      if (right) nr++; else nl++;
+      const int xt = dy > 0 ? mine.x[k] : mine.x[j], yt = dy > 0 ? mine.y[k] : mine.y[j];  // the upper end
+      const double ady30 = 30.0 * (double)(dy > 0 ? dy : -dy);
+      // cell(s) = round(A + B s): A = x + (256 - 30 y) K + a quarter of the least distance to a rounding boundary (sf_tor.h: edge_ab)
+      const double A = (double)xt + (256.0 - 30.0 * (double)yt) * Kc[k] + 0.25 * rcp_fast(2.0 * ady30);
+      if (slot < 4) *reinterpret_cast<double2*>(r + 4 * slot) = double2{A, 512.0 * Kc[k]};
+      slot_edges |= (unsigned)k << (2 * (slot & 3));
+    }
+    if (nl == 1) { *reinterpret_cast<double2*>(r + 4) = *reinterpret_cast<const double2*>(r); slot_edges |= (slot_edges & 3u) << 2; }
+    if (nr == 1) { *reinterpret_cast<double2*>(r + 12) = *reinterpret_cast<const double2*>(r + 8); slot_edges |= ((slot_edges >> 4) & 3u) << 6; }
+    if (nl == 0 || nr == 0) hi = lo;  // (a degenerate quad spans nothing)
+    my_lo = lo; my_hi = hi;
+    *reinterpret_cast<int4*>(r + 16) = int4{lo, hi, (int)(slot_edges | ((unsigned)nl << 8) | ((unsigned)nr << 10)), oi};
+    int* o = reinterpret_cast<int*>(C.obj(oi));
+    __hip_atomic_fetch_min(o + 0, minx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_min(o + 1, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_max(o + 2, maxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_max(o + 3, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(C.obj(oi) + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (vr0) __hip_atomic_fetch_or(C.obj(oi) + 8, vr0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (vr1) __hip_atomic_fetch_or(C.obj(oi) + 9, vr1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (vr2) __hip_atomic_fetch_or(C.obj(oi) + 10, vr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  C.sync();
+  // ---- the objects' boxes (lane o < nobj) and the scans over them
+  int bx0 = 0, by0 = 0, bw = 0, bh = 0;
+  if (lane < nobj) {
+    const int* o = reinterpret_cast<const int*>(C.obj(lane));
+    const int x0 = max(o[0] >> 8, 0), x1 = min((o[2] + 255) >> 8, C.W);
+    const int s0 = max(o[1], 0), s1 = min(o[3], C.H * sft::kGridY);
+    if (x1 > x0 && s1 > s0) {
+      bx0 = x0; bw = x1 - x0;
+      by0 = (s0 * 34953) >> 19; bh = (((s1 - 1) * 34953) >> 19) + 1 - by0;
+    }
+  }
+  int abase = bw * bh, rbase = bh;
+#pragma unroll
+  for (int d = 1; d < kMaxObjs; d <<= 1) {
+    const int a = __shfl_up(abase, d), r = __shfl_up(rbase, d);
+    if (lane >= d) { abase += a; rbase += r; }
+  }
+  const int tot_rows = __builtin_amdgcn_readlane(rbase, kMaxObjs - 1), tot_pix = __builtin_amdgcn_readlane(abase, kMaxObjs - 1);
+  if (lane < nobj) {
+    uint32_t* o = C.obj(lane);
+    const uint32_t nq = o[5];
+    o[0] = (uint32_t)bx0 | ((uint32_t)by0 << 8) | ((uint32_t)bw << 16) | ((uint32_t)bh << 24);
+    o[1] = o[7] << 16;            // (a circle's first half)
+    o[3] = (uint32_t)(abase - bw * bh);
+    o[4] |= nq << 8;
+    o[5] = (uint32_t)(rbase - bh);
+    o[6] = 0u;
+  }
+  // ... and the quads' runs of sub-rows (their owners' lanes): counts, scan, the headers the sub-rows' lanes read
+  int cnt = 0, s_lo = 0;
+  if (valid) {
+    s_lo = max(my_lo, 0);
+    cnt = max(min(my_hi, C.H * sft::kGridY) - s_lo, 0);
+  }
+  // (the scan runs over the owners' lanes: any lanes of the wave)
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int a = __shfl_up(incl, d);
+    if (lane >= d) incl += a;
+  }
+  const int tot_sub = __builtin_amdgcn_readlane(incl, 63);
+  if (tot_sub > 32 * kMapWordsF) return false;
+  C.sync();
+  if (valid) {
+    const uint32_t* ob = C.obj(oi);
+    const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u);
+    const int q0 = (int)(ob[4] & 255u), nq = (int)((ob[4] >> 8) & 255u), okind = (int)((ob[4] >> 16) & 255u), m0 = (int)(ob[1] >> 16);
+    const int start = incl - cnt, k = qi - q0;
+    // the earlier quads this one may overlap (at most two, and whether all three can meet): by kind
+    int p1 = 255, p2 = 255, triple = 0;
+    if (okind == kKindLines3) { p1 = k >= 1 ? q0 : 255; p2 = k == 2 ? q0 + 1 : 255; triple = k == 2; }
+    else if (okind == kKindShell) { p1 = k >= 1 ? q0 + k - 1 : 255; p2 = k == 3 ? q0 : 255; }
+    else if (okind == kKindRing) { p1 = k == m0 ? q0 + m0 - 1 : (k == nq - 1 ? q0 : 255); }
+    *reinterpret_cast<int4*>(C.hdr(qi)) =
+        int4{start | (s_lo << 16), (int)ob[3] - oby0 * obw, obx0 | (obw << 8) | (oby0 << 16) | (oi << 24), p1 | (p2 << 8) | (triple << 16)};
+    if (cnt > 0 && start > 0) __hip_atomic_fetch_or(C.map() + ((start - 1) >> 5), 1u << ((start - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  // (which quad a run belongs to: the r-th run with sub-rows is the r-th such quad: a small table)
+  {
+    const unsigned long long nz = __ballot(valid && cnt > 0);
+    const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nz >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nz, 0u));
+    if (valid && cnt > 0) C.qtab()[rk] = (uint8_t)qi;
+  }
+  C.sync();
+  if (SFTD_STOP == 1) return true;
+  auto find_obj = [&](int t, int which) {
+    int o = 0;
+    for (int j = 1; j < nobj; j++) o += t >= (int)C.obj(j)[which] ? 1 : 0;
+    return o;
+  };
+  // ---- rows: which are taken whole; their (row, quad) pairs go on the task list
+  for (int base = 0; base < tot_rows; base += 64) {
+    const int t = base + lane;
+    const bool have = t < tot_rows;
+    const int o = have ? find_obj(t, 5) : 0;
+    const uint32_t* ob = C.obj(o);
+    const int oby0 = (int)((ob[0] >> 8) & 255u), q0 = (int)(ob[4] & 255u), nq = (int)((ob[4] >> 8) & 255u), okind = (int)((ob[4] >> 16) & 255u);
+    const int r = t - (int)ob[5], row = oby0 + r, s0 = row * sft::kGridY;
+    const unsigned vbits = row < 32 ? ob[8] : (row < 64 ? ob[9] : ob[10]);
+    bool full = have && !((vbits >> (row & 31)) & 1u);
+    int nsp = 0;
+    unsigned sp0 = 0u, sp1 = 0u, sp2 = 0u, sp3 = 0u;  // k | left slot << 8 | right slot << 10
+    if (__ballot(full)) {
+      for (int k = 0; __ballot(full && k < nq); k++) {
+        if (!(full && k < nq)) continue;
+        const uint32_t* rc = C.rec(q0 + k);
+        const int4 hd = *reinterpret_cast<const int4*>(rc + 16);
+        if (!(hd.x <= s0 && hd.y >= s0 + sft::kGridY)) continue;
+        const int4 gy = *reinterpret_cast<const int4*>(rc + 20);
+        const unsigned se = (unsigned)hd.z;
+        int ls = -1, rs = -1;
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) {
+          const int e = (int)((se >> (2 * sl)) & 3u);
+          const int ga = e == 0 ? gy.x : (e == 1 ? gy.y : (e == 2 ? gy.z : gy.w)), gb = e == 0 ? gy.y : (e == 1 ? gy.z : (e == 2 ? gy.w : gy.x));
+          const bool spans = min(ga, gb) <= s0 && max(ga, gb) >= s0 + sft::kGridY;
+          if (spans) { if (sl < 2) ls = sl; else rs = sl; }
+        }
+        if (ls < 0 || rs < 0) continue;
+        if (nsp == 4) { full = false; continue; }
+        const unsigned ent = (unsigned)k | ((unsigned)ls << 8) | ((unsigned)rs << 10);
+        sp0 = nsp == 0 ? ent : sp0; sp1 = nsp == 1 ? ent : sp1; sp2 = nsp == 2 ? ent : sp2; sp3 = nsp == 3 ? ent : sp3;
+        nsp++;
+      }
+    }
+    bool complex_row = false;
+    if (__ballot(full && nsp >= 2)) {
+      if (full && nsp >= 2) {
+        const unsigned sp[4] = {sp0, sp1, sp2, sp3};
+        const double sd0 = (double)s0, sd1 = (double)(s0 + sft::kGridY), sdm = (double)(s0 - 1);
+        int top[8], bot[8], tie[8], nw[8], rk[8];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+#pragma unroll
+          for (int side = 0; side < 2; side++) {
+            const int i = 2 * a + side;
+            top[i] = bot[i] = tie[i] = rk[i] = 0;
+            nw[i] = -1;
+            if (a < nsp) {
+              const int k = (int)(sp[a] & 255u), sl = (int)((sp[a] >> (side ? 10 : 8)) & 3u);
+              const uint32_t* rc = C.rec(q0 + k);
+              const int e = (int)((rc[18] >> (2 * sl)) & 3u);
+              top[i] = cell_fast(rc + 4 * sl, sd0);
+              bot[i] = cell_fast(rc + 4 * sl, sd1);
+              const int ga = (int)rc[20 + e], gb = (int)rc[20 + ((e + 1) & 3)];
+              const int start = max(min(ga, gb), 0);
+              const int rank = 8 * k + (e == 0 ? 0 : (e == 1 ? 1 : (e == 2 ? 3 : 2)));
+              nw[i] = start == s0 ? 1 : 0;
+              tie[i] = nw[i] ? rank : cell_fast(rc + 4 * sl, sdm);
+              rk[i] = rank;
+              // (a face between two pieces of a flattened curve is no edge of the polygon: out of the order test)
+              if ((okind == kKindSingle || okind == kKindRing) && ((e == 1 && k < nq - 1) || (e == 3 && k > 0))) nw[i] = -1;
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+          for (int j = i + 1; j < 8; j++) {
+            const bool both = nw[i] >= 0 && nw[j] >= 0;
+            bool i_first;
+            if (top[i] != top[j]) i_first = top[i] < top[j];
+            else if (nw[i] != nw[j]) i_first = nw[i] < nw[j];
+            else if (tie[i] != tie[j]) i_first = tie[i] < tie[j];
+            else i_first = rk[i] < rk[j];
+            const bool ok = i_first ? bot[i] <= bot[j] : bot[j] <= bot[i];
+            full = full && (!both || ok);
+          }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = a + 1; b < 4; b++)
+            if (b < nsp) complex_row |= top[2 * b] <= top[2 * a + 1] && top[2 * a] <= top[2 * b + 1];
+      }
+    }
+    if (full) {
+      const int n_tasks = complex_row ? 1 : nsp;
+      unsigned at = 0u;
+      if (n_tasks) at = __hip_atomic_fetch_add(C.tasks() + kTasksF, (unsigned)n_tasks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // (a list that is full -- never with this game's objects -- leaves the row to the sub-rows: nothing is lost, cairo's
+      //  whole-row arithmetic is not reproduced there)
+      if (at + (unsigned)n_tasks <= (unsigned)kTasksF) {
+        __hip_atomic_fetch_or(const_cast<uint32_t*>(ob) + 6, 1u << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned head = (unsigned)o | ((unsigned)r << 8);
+        const unsigned sp[4] = {sp0, sp1, sp2, sp3};
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+          if (a < n_tasks)
+            C.tasks()[at + a] = head | (complex_row ? 0x80000000u : ((sp[a] & 255u) << 16) | (((sp[a] >> 8) & 15u) << 24));
+      }
+    }
+  }
+  C.sync();
+  // ---- the rows taken whole: a lane per (row, quad): the area between the quad's two edges (cell_list_render_edge)
+  {
+    const unsigned n_tasks = min(C.tasks()[kTasksF], (unsigned)kTasksF);  // (a row that did not fit has added to the count only)
+    const unsigned tk = (unsigned)lane < n_tasks ? C.tasks()[lane] : 0u;
+    const bool on = (unsigned)lane < n_tasks;
+    const uint32_t* ob = C.obj((int)(tk & 255u));
+    const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u);
+    const int q0 = (int)(ob[4] & 255u), nq = (int)((ob[4] >> 8) & 255u), okind = (int)((ob[4] >> 16) & 255u), m0 = (int)(ob[1] >> 16);
+    const int r = (int)((tk >> 8) & 255u), s0 = (oby0 + r) * sft::kGridY, arow = (int)ob[3] + r * obw;
+    if (__ballot(on && !(tk >> 31))) {
+      if (on && !(tk >> 31)) {
+        const uint32_t* rc = C.rec(q0 + (int)((tk >> 16) & 255u));
+        const sft::RowEdge EL = rec_row_edge(rc, (int)((tk >> 24) & 3u), s0), ER = rec_row_edge(rc, (int)((tk >> 26) & 3u), s0);
+        const int c0 = max(EL.ix1, obx0), c1 = min(ER.ix2, obx0 + obw - 1);
+        for (int c = c0; c <= c1; c++) {
+          const int v = sft::row_edge_area(EL, c) - sft::row_edge_area(ER, c);
+          if (v) acc_add(acc, arow + c - obx0, v);
+        }
+      }
+    }
+    if (__ballot(on && (tk >> 31))) {  // a row with overlapping quads: every source, the general way
+      if (on && (tk >> 31)) {
+        const unsigned multi = multi_sources(okind);
+        int a_quad[4], a_ls[4], a_rs[4], a_lt[4], a_lb[4], a_rt[4], a_rb[4], nact = 0;
+        const double sd0 = (double)s0, sd1 = (double)(s0 + sft::kGridY);
+        for (int k = 0; k < nq && nact < 4; k++) {
+          const uint32_t* rc = C.rec(q0 + k);
+          if (!((int)rc[16] <= s0 && (int)rc[17] >= s0 + sft::kGridY)) continue;
+          int ls = -1, rs = -1;
+          for (int sl = 0; sl < 4; sl++) {
+            const int e = (int)((rc[18] >> (2 * sl)) & 3u);
+            const int ga = (int)rc[20 + e], gb = (int)rc[20 + ((e + 1) & 3)];
+            if (min(ga, gb) <= s0 && max(ga, gb) >= s0 + sft::kGridY) { if (sl < 2) ls = sl; else rs = sl; }
+          }
+          if (ls < 0 || rs < 0) continue;
+          a_quad[nact] = k; a_ls[nact] = ls; a_rs[nact] = rs;
+          a_lt[nact] = cell_fast(rc + 4 * ls, sd0); a_lb[nact] = cell_fast(rc + 4 * ls, sd1);
+          a_rt[nact] = cell_fast(rc + 4 * rs, sd0); a_rb[nact] = cell_fast(rc + 4 * rs, sd1);
+          nact++;
+        }
+        for (int si = 0; si < nact + 4; si++) {
+          unsigned members = 0u;
+          int sign = 1;
+          if (si >= nact) {
+            members = (multi >> (4 * (si - nact))) & 15u;
+            if (!members) continue;
+            sign = (__popc(members) & 1) ? 1 : -1;
+          }
+          int lq = -1, rq = -1, lt = 0, lb = 0, rt = 0, rb = 0, ls = 0, rs = 0, cn = 0;
+          for (int a = 0; a < nact; a++) {
+            if (si < nact) { if (a != si) continue; }
+            else {
+              const int sl = slot_of(okind, a_quad[a], nq, m0);
+              if (sl < 0 || !((members >> sl) & 1u)) continue;
+            }
+            cn++;
+            if (lq < 0 || a_lt[a] > lt || (a_lt[a] == lt && a_lb[a] > lb)) { lq = a_quad[a]; lt = a_lt[a]; lb = a_lb[a]; ls = a_ls[a]; }
+            if (rq < 0 || a_rt[a] < rt || (a_rt[a] == rt && a_rb[a] < rb)) { rq = a_quad[a]; rt = a_rt[a]; rb = a_rb[a]; rs = a_rs[a]; }
+          }
+          if (cn != (si < nact ? 1 : __popc(members)) || lt > rt) continue;
+          const sft::RowEdge EL = rec_row_edge(C.rec(q0 + lq), ls, s0), ER = rec_row_edge(C.rec(q0 + rq), rs, s0);
+          const int c0 = max(EL.ix1, obx0), c1 = min(ER.ix2, obx0 + obw - 1);
+          for (int c = c0; c <= c1; c++) {
+            const int v = sft::row_edge_area(EL, c) - sft::row_edge_area(ER, c);
+            if (v) acc_add(acc, arow + c - obx0, sign * v);
+          }
+        }
+      }
+    }
+  }
+  C.sync();
+  if (SFTD_STOP == 2) return true;
+  // ---- sub-rows of the other rows: a lane per (quad, sub-row of the quad).  The lane adds its quad's span; what the quad shares
+  // with the EARLIER quads it may overlap is taken off again by the same lane: -(pairs) +(the triple): the union of the object's
+  // quads by inclusion-exclusion.  Which quad a lane's sub-row belongs to: the bit map of the runs' starts (a v_mbcnt pair).
+  {
+    const uint8_t* qtab = C.qtab();
+    int kb = 0;
+    for (int base = 0; base < tot_sub; base += 64) {
+      const int t = base + lane;
+      const uint2 mw = *reinterpret_cast<const uint2*>(C.map() + (base >> 5));
+      const int rk = kb + (int)__builtin_amdgcn_mbcnt_hi(mw.y, __builtin_amdgcn_mbcnt_lo(mw.x, 0u));
+      kb += __popc(mw.x) + __popc(mw.y);
+      const bool have = t < tot_sub;
+      const int q = have ? (int)qtab[rk] : 0;
+      const int4 hd = *reinterpret_cast<const int4*>(C.hdr(q));
+      const uint32_t* rc = C.rec(q);
+      const int s = (int)((unsigned)hd.x >> 16) + t - (int)(hd.x & 0xffff);
+      const int obx0 = hd.z & 255, obw = (hd.z >> 8) & 255, oby0 = (hd.z >> 16) & 255, o = (int)((unsigned)hd.z >> 24);
+      const int row = (s * 34953) >> 19;
+      const bool live = have && !((C.obj(o)[6] >> (row - oby0)) & 1u);
+      const int arow = hd.y + row * obw;
+      const double sd = (double)s;
+      int L = 0, R = 0;
+      if (live) {
+        L = max(cell_fast(rc, sd), cell_fast(rc + 4, sd));
+        R = min(cell_fast(rc + 8, sd), cell_fast(rc + 12, sd));
+        add_span_fast(acc, arow, obx0, obw, L, R, 1);
+      }
+      const int p1 = hd.w & 255, p2 = (hd.w >> 8) & 255;
+      const bool want = live && R > L && p1 != 255;
+      if (__ballot(want)) {
+        int L1 = 1, R1 = 0, L2 = 1, R2 = 0;
+        if (want) {
+          const uint32_t* r1 = C.rec(p1);
+          const int2 rg = *reinterpret_cast<const int2*>(r1 + 16);
+          if (s >= rg.x && s < rg.y) {
+            L1 = max(max(cell_fast(r1, sd), cell_fast(r1 + 4, sd)), L);
+            R1 = min(min(cell_fast(r1 + 8, sd), cell_fast(r1 + 12, sd)), R);
+            add_span_fast(acc, arow, obx0, obw, L1, R1, -1);
+          }
+        }
+        const bool want2 = want && p2 != 255;
+        if (__ballot(want2)) {
+          if (want2) {
+            const uint32_t* r2 = C.rec(p2);
+            const int2 rg = *reinterpret_cast<const int2*>(r2 + 16);
+            if (s >= rg.x && s < rg.y) {
+              L2 = max(max(cell_fast(r2, sd), cell_fast(r2 + 4, sd)), L);
+              R2 = min(min(cell_fast(r2 + 8, sd), cell_fast(r2 + 12, sd)), R);
+              add_span_fast(acc, arow, obx0, obw, L2, R2, -1);
+              if ((hd.w >> 16) & 1) add_span_fast(acc, arow, obx0, obw, max(L1, L2), min(R1, R2), 1);
+            }
+          }
+        }
+      }
+    }
+  }
+  C.sync();
+  if (SFTD_STOP == 3) return true;
+  // ---- pixels: object after object (the reference composites its strokes in order; boxes of different objects may overlap)
+  for (int o = 0; o < nobj; o++) {
+    const uint32_t* ob = C.obj(o);
+    const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u), obh = (int)(ob[0] >> 24);
+    const int ab = (int)ob[3], ogrey = (int)(ob[4] >> 24), n = obw * obh;
+    const float rw = __builtin_amdgcn_rcpf((float)obw);
+    for (int i = lane; i < n; i += 64) {
+      const int ry = (int)(((float)i + 0.5f) * rw), rx = i - ry * obw;
+      const int cov = (int)((acc[(ab + i) >> 1] >> (16 * ((ab + i) & 1))) & 0xffffu);
+      const int a = sft::area_to_alpha(cov);
+      if (a) {
+        uint8_t* p = C.fb + (oby0 + ry) * C.W + obx0 + rx;
+        *p = (uint8_t)sft::lerp8(ogrey, a, *p);
+      }
+    }
+    C.sync();
+  }
+  for (int i = lane; i < (tot_pix + 1) / 2; i += 64) acc[i] = 0u;
+  C.sync();
+  return true;
 }
 
 }  // namespace sftd

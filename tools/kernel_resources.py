@@ -23,4 +23,4 @@ with tempfile.TemporaryDirectory() as td:
             name = g("name")
             if len(sys.argv) > 2 and sys.argv[2] not in name:
                 continue
-            print("%-90s vgpr %4s sgpr %4s scratch %6s lds %6s" % (name[:90], g("vgpr_count"), g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size")))
+            print("%-70s vgpr %4s agpr %4s sgpr %4s scratch %6s lds %6s spill_v %s" % (name[:70], g("vgpr_count"), g("agpr_count") if "agpr_count" in blk else blk.split()[1], g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size"), g("vgpr_spill_count")))
