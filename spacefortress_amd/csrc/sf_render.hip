@@ -352,26 +352,18 @@ struct Frame {
   // line s of the frame's draw order as a fixed-point quad (`mine`, `valid`); `obj0` = the first lane of the line's object, `kind`
   // the object's (sf_tor_dev.h).  sftd::raster takes up to sixteen lines of whole objects at a time.
   static constexpr int kChunk = 16;
+  static_assert(SF_IMG_H * sft::kGridY < 4096 && SF_IMG_W * 256 + 65536 < (1 << 18) && SF_IMG_H <= 96, "sf_tor_dev.h's fast arrangement: packed sub-rows, cells, rows");
   static constexpr int kMapBitsOut = 1024;  // the map of the objects' 84x84 boxes in the resample pass
   static constexpr int kLtabAt = 4 * kChunk + kMapBitsOut / 32;  // words into `tor`: behind that pass's records and map
   static constexpr int kResampleWords = kLtabAt + 4 * kLtabEntries;
-  static constexpr int kTorWords = sftd::kLdsWordsF > sftd::kLdsWords ? sftd::kLdsWordsF : sftd::kLdsWords;
+  static constexpr int kTorWords = sftd::kLdsWordsF;
   static_assert(kTorWords >= kResampleWords, "the resample pass's records fit");
   static_assert(kLtabAt % 4 == 0, "the period of the tap tables is 16-byte aligned");
-  __device__ __forceinline__ sftd::Ctx tor_ctx() const { return sftd::Ctx{tor, fb, SF_IMG_W, SF_IMG_H, lane, sftd::kMaxQuads, sftd::kAccAtF}; }
   __device__ __forceinline__ sftd::CtxF tor_ctx_fast() const { return sftd::CtxF{tor, fb, SF_IMG_W, SF_IMG_H, lane}; }
-  // one call of sf_tor_dev.h: the fast arrangement unless a quad of the call reaches over a border or is oddly shaped
+  // every stroke of the frame goes through sf_tor_dev.h's fast arrangement: objects over the surface's left / right border
+  // and curve pieces with three edges on a side included
   __device__ __forceinline__ void raster_any(const sft::Quad& q, bool valid, int obj0, int kind, int grey) const {
-#ifdef SF_NO_GENERAL /* timing experiment: what the kernel is without the general arrangement in it (wrong frames at the borders) */
-    sftd::raster_fast(tor_ctx_fast(), q, valid && !sftd::needs_general(q, SF_IMG_W * 256), obj0, kind, grey);
-#else
-    if (__ballot(valid && sftd::needs_general(q, SF_IMG_W * 256)) || !sftd::raster_fast(tor_ctx_fast(), q, valid, obj0, kind, grey))
-      raster_general(tor_ctx(), q, valid, obj0, kind, grey);
-#endif
-  }
-  // (a real call: the general arrangement is the rare path -- a missile leaving the view -- and its registers are its own)
-  __device__ __attribute__((noinline)) static void raster_general(const sftd::Ctx C, const sft::Quad q, bool valid, int obj0, int kind, int grey) {
-    sftd::raster(C, q, valid, obj0, kind, grey);
+    sftd::raster_fast(tor_ctx_fast(), q, valid, obj0, kind, grey);
   }
   __device__ __forceinline__ void draw_strokes(const sft::Quad& mine, bool valid, int obj0, int kind) const {
 #define SF_DS_STAMP(k) do { if (SF_RENDER_STOP == 41 + (k)) return; } while (0)

@@ -60,6 +60,18 @@ SFT_HD double floor_div(double a, double b) {
   else if (r >= b) q += 1.0;
   return q;
 }
+// 1 / d where a few ulp do not matter (every use below states its margin): on the device v_rcp_f64 and two Newton steps instead
+// of the IEEE division's expansion
+SFT_HD double rcp(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / d;
+#endif
+}
 SFT_HD double trunc_div(double a, double b) { return a >= 0.0 ? floor_div(a, b) : -floor_div(-a, b); }  // C's integer division
 
 // ---- coverage -> pixel ---------------------------------------------------------------------------------------------------
@@ -263,7 +275,7 @@ SFT_HD void quad_interval(const QuadScan& q, int s, int* L, int* R) {
 // 1 / 7680 pixel, for every column: 0 left of the edge, 7680 right of it, cairo's trapezoids where it passes.
 struct RowEdge {
   int ix1, fx1, ix2, fx2;  // the edge at the row's top and bottom (after the half-sub-row step back), left end first
-  double X1, U, DX;        // the multi-column case: top x as a numerator over U = 30 dy, and the run (x2 - x1) * U
+  double X1, U, DX, rDX;   // the multi-column case: top x as a numerator over U = 30 dy, the run (x2 - x1) * U and 1 / run
   int single;              // ix1 == ix2
 };
 SFT_HD RowEdge row_edge(int x1, int y1, int x2, int y2, int s0) {
@@ -299,6 +311,7 @@ SFT_HD RowEdge row_edge(int x1, int y1, int x2, int y2, int s0) {
   r.U = U;
   r.X1 = q1 * U + r1;
   r.DX = (q2 - q1) * U + (r2 - r1);
+  r.rDX = r.single ? 0.0 : rcp(r.DX);
   return r;
 }
 // The same WITHOUT a division, from the edge's A + B s (edge_ab) -- what the lanes use.  x(s) is a rational with denominator
@@ -307,12 +320,12 @@ SFT_HD RowEdge row_edge(int x1, int y1, int x2, int y2, int s0) {
 // (dx, dy: the edge's run in fixed point, dy > 0 after orienting it downwards; x1: its upper end's x; vertical edges: dx == 0.)
 SFT_HD RowEdge row_edge_ab(const EdgeAB& e, int dx, int dy, int x1, int s0) {
   RowEdge r;
-  const double U = 30.0 * (double)dy, hU = 0.5 / U;
+  const double U = 30.0 * (double)dy, hU = 0.5 * rcp(U);  // (the half steps below: margins of 1 / (2 U) against 1e-10)
   double q1, r1, q2, r2;
   if (dx == 0) {
     q1 = q2 = (double)x1; r1 = r2 = 0.0;
   } else {
-    const double off = 0.5 + 0.25 / (2.0 * U);  // what edge_ab folded into A
+    const double off = 0.5 + 0.25 * hU;  // what edge_ab folded into A
     const double xa = fma(e.B, (double)s0, e.A) - off, xb = fma(e.B, (double)(s0 + kGridY), e.A) - off;
     q1 = floor(xa + hU); r1 = rint((xa - q1) * U);
     q2 = floor(xb + hU); r2 = rint((xb - q2) * U);
@@ -335,13 +348,14 @@ SFT_HD RowEdge row_edge_ab(const EdgeAB& e, int dx, int dy, int x1, int s0) {
   r.U = U;
   r.X1 = q1 * U + r1;
   r.DX = (q2 - q1) * U + (r2 - r1);
+  r.rDX = r.single ? 0.0 : rcp(r.DX);
   return r;
 }
 // whole sub-rows the edge needs to reach column boundary 256 c (multi-column case), cairo's quotient stepping = exact floors
 // (the quotient is 0 .. 15 and its numerator and denominator are whole: off a whole number by 1 / DX at least)
 SFT_HD int row_edge_y(const RowEdge& e, int c) {
   const double t = ((double)c * 256.0 * e.U - e.X1) * 15.0;
-  return (int)floor(t / e.DX + 0.5 / e.DX);
+  return (int)floor((t + 0.5) * e.rDX);
 }
 SFT_HD int row_edge_area(const RowEdge& e, int c) {
   if (c < e.ix1) return 0;

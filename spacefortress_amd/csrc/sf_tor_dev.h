@@ -433,15 +433,24 @@ __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool
 //   * a row taken whole is handed to one lane per (row, quad) for its two trapezoid edges; rows in which two quads of an object
 //     overlap while taken whole (rare: the overlap of two lines is shorter than a pixel) go to one lane with the general code;
 //   * spans are added with straight-line code for the one- and two-pixel cases.
-constexpr int kRecWordsF = 32;  // slots L1 L2 R1 R2 (16), s0, s1, slot -> edge (2 bits each) | counts, object (4), gy[4], x[4], y[4]
+constexpr int kRecWordsF = 48;
+// A quad's record:
+//    0 .. 15   the slots L1 L2 R1 R2: an edge as two doubles (A - 1/2, B): cell(s) = round(A' + B s)   (cell_fast)
+//   16 17      the quad's sub-rows [s0, s1)
+//   18         the slots' edge numbers (2 bits each, slots 0 .. 5) | left edges << 12 | right edges << 14 | kRecBorder | kRecThird
+//   19         the rows slots L3 | R3 << 16 span whole (as 46, 47)
+//   20 .. 31   gy[4], x[4], y[4]: the corners
+//   32 .. 39   the slots L3 R3: a third edge on one side (the curve pieces of an explosion; else a copy of L1 / R1)
+//   40 .. 45   a slot's piece along the surface's border (cairo-polygon.c: _add_clipped_edge): in the sub-rows [b0, b1) the edge is
+//              the vertical x = 0 / x = the surface's width: b0 | b1 << 12 | right border << 24; 0 = none
+//   46 47      the pixel rows a slot's edge spans whole, [lo, hi) as lo | hi << 8: L1 | L2 << 16, R1 | R2 << 16
+constexpr unsigned kRecBorder = 1u << 16, kRecThird = 1u << 17;
 constexpr int kHdrWordsF = 4;   // per quad, for the sub-rows' lanes: see raster_fast
 constexpr int kObjWordsF = 12;  // as kObjWords, + the rows that hold a vertex: 96 bits
-constexpr int kTasksF = 64;     // (row, quad) pairs taken whole
-constexpr int kMapWordsF = 192; // the sub-rows' enumeration: a bit per start of a quad's run (6 144 sub-rows: more, and the general
-                                // arrangement takes the call)
+constexpr int kTasksF = 64;     // (row, quad) pairs taken whole, per round
+constexpr int kMapWordsF = 64;  // the sub-rows' enumeration: a bit per start of a quad's run, 2 048 sub-rows per round
 constexpr int kAccAtF = kMaxQuads * (kRecWordsF + kHdrWordsF) + kMaxObjs * kObjWordsF + kTasksF + 8 + kMapWordsF;
 constexpr int kLdsWordsF = kAccAtF + kAccPixels / 2;
-static_assert(kAccAtF >= kMaxQuads * kRecWords + kMaxObjs * kObjWords, "one accumulator behind both arrangements' records");
 
 struct CtxF {
   uint32_t* lds;
@@ -450,7 +459,7 @@ struct CtxF {
   __device__ __forceinline__ uint32_t* rec(int q) const { return lds + q * kRecWordsF; }
   __device__ __forceinline__ uint32_t* hdr(int q) const { return lds + kMaxQuads * kRecWordsF + q * kHdrWordsF; }
   __device__ __forceinline__ uint32_t* obj(int o) const { return lds + kMaxQuads * (kRecWordsF + kHdrWordsF) + o * kObjWordsF; }
-  __device__ __forceinline__ uint32_t* tasks() const { return obj(kMaxObjs); }  // [kTasksF], the count, (3 free)
+  __device__ __forceinline__ uint32_t* tasks() const { return obj(kMaxObjs); }  // [kTasksF], the count, "more rows than fit", (2 free)
   __device__ __forceinline__ uint8_t* qtab() const { return reinterpret_cast<uint8_t*>(tasks() + kTasksF + 4); }  // [16]: the r-th run's quad
   __device__ __forceinline__ uint32_t* map() const { return tasks() + kTasksF + 8; }
   __device__ __forceinline__ uint32_t* acc() const { return lds + kAccAtF; }
@@ -466,27 +475,29 @@ __device__ __forceinline__ int cell_fast(const uint32_t* slot, double sd) {  // 
   const double2 ab = *reinterpret_cast<const double2*>(slot);
   return __double2loint(fma(ab.y, sd, ab.x) + kMagic52);
 }
-// 1 / d to a few ulp: v_rcp_f64 and two Newton steps (the A + B s form tolerates 1e-11: sf_tor.h)
-__device__ __forceinline__ double rcp_fast(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = fma(fma(-d, r, 1.0), r, r);
-  r = fma(fma(-d, r, 1.0), r, r);
-  return r;
+__device__ __forceinline__ int slot_at(int slot) { return slot < 4 ? 4 * slot : 16 + 4 * slot; }  // (slots 4, 5 at words 32, 36)
+// a slot's cell where its border piece stands in for it
+__device__ __forceinline__ int border_cell(int c, unsigned bw, int s, int xmax) {
+  const int b0 = (int)(bw & 4095u), b1 = (int)((bw >> 12) & 4095u);
+  return (s >= b0 && s < b1) ? ((bw >> 24) ? xmax : 0) : c;
 }
-
-// does this quad need the general arrangement: it reaches over the left / right border, or has three edges on one side
-__device__ __forceinline__ bool needs_general(const sft::Quad& q, int xmax) {
-  const int lo = min(min(q.x[0], q.x[1]), min(q.x[2], q.x[3])), hi = max(max(q.x[0], q.x[1]), max(q.x[2], q.x[3]));
-  if (lo < 0 || hi > xmax) return true;
-  // edges that go down lie on one side, edges that go up on the other: three on a side is the odd shape
-  int down = 0, up = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int d = q.y[(k + 1) & 3] - q.y[k];
-    down += d > 0;
-    up += d < 0;
+// the quad's span [L, R) in sub-row s (sd = (double)s); `on`: this lane asks (the rare parts sit behind a ballot)
+__device__ __forceinline__ void span_fast(const uint32_t* rc, int s, double sd, bool on, int xmax, int* L, int* R) {
+  int l1 = cell_fast(rc, sd), l2 = cell_fast(rc + 4, sd), r1 = cell_fast(rc + 8, sd), r2 = cell_fast(rc + 12, sd);
+  const bool ext = on && (rc[18] & (kRecBorder | kRecThird));
+  if (__ballot(ext)) {
+    if (ext) {
+      int l3 = cell_fast(rc + 32, sd), r3 = cell_fast(rc + 36, sd);
+      const uint4 b = *reinterpret_cast<const uint4*>(rc + 40);
+      const uint2 b3 = *reinterpret_cast<const uint2*>(rc + 44);
+      l1 = border_cell(l1, b.x, s, xmax); l2 = border_cell(l2, b.y, s, xmax);
+      r1 = border_cell(r1, b.z, s, xmax); r2 = border_cell(r2, b.w, s, xmax);
+      l3 = border_cell(l3, b3.x, s, xmax); r3 = border_cell(r3, b3.y, s, xmax);
+      l1 = max(l1, l3); r1 = min(r1, r3);
+    }
   }
-  return down > 2 || up > 2;
+  *L = max(l1, l2);
+  *R = min(r1, r2);
 }
 
 __device__ __forceinline__ void add_span_fast(uint32_t* acc, int arow, int bx0, int bw, int L, int R, int sign) {
@@ -503,37 +514,53 @@ __device__ __forceinline__ void add_span_fast(uint32_t* acc, int arow, int bx0, 
   for (int px = p0 + 1; px < p1; px++) acc_add(acc, arow + px - bx0, sign * 512);
 }
 
-// the two edges of a quad's record through a row taken whole, as cairo's trapezoid edges (slots ls, rs)
-__device__ __forceinline__ sft::RowEdge rec_row_edge(const uint32_t* rc, int slot, int s0) {
+// a slot's edge through the row that starts at sub-row s0, taken whole, as cairo's trapezoid edge
+__device__ __forceinline__ sft::RowEdge rec_row_edge(const uint32_t* rc, int slot, int s0, int xmax) {
+  const unsigned bw = rc[40 + slot];
+  if (s0 >= (int)(bw & 4095u) && s0 < (int)((bw >> 12) & 4095u)) {  // along the border: a vertical
+    const int bx = (bw >> 24) ? xmax : 0;
+    return sft::row_edge_ab(sft::EdgeAB{0.0, 0.0}, 0, 256, bx, s0);
+  }
   const int e = (int)((rc[18] >> (2 * slot)) & 3u), j = (e + 1) & 3;
   int x1 = (int)rc[24 + e], y1 = (int)rc[28 + e], x2 = (int)rc[24 + j], y2 = (int)rc[28 + j];
   if (y2 < y1) { int t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
-  const double2 ab = *reinterpret_cast<const double2*>(rc + 4 * slot);
+  const double2 ab = *reinterpret_cast<const double2*>(rc + slot_at(slot));
   return sft::row_edge_ab(sft::EdgeAB{ab.x + 0.5, ab.y}, x2 - x1, y2 - y1, x1, s0);
 }
+// the slots (left, right) whose edges span pixel row `row` whole, or -1
+__device__ __forceinline__ void row_slots(const uint32_t* rc, int row, int* ls, int* rs) {
+  const uint2 rw = *reinterpret_cast<const uint2*>(rc + 46);
+  const unsigned r3 = rc[19];
+  auto in = [&](unsigned h) { return row >= (int)(h & 255u) && row < (int)((h >> 8) & 255u); };
+  *ls = in(rw.x) ? 0 : (in(rw.x >> 16) ? 1 : (in(r3) ? 4 : -1));
+  *rs = in(rw.y) ? 2 : (in(rw.y >> 16) ? 3 : (in(r3 >> 16) ? 5 : -1));
+}
 
-// false: too many sub-rows for the enumeration's bit map -- nothing drawn, the caller takes the general arrangement
-__device__ __forceinline__ bool raster_fast(const CtxF& C, const sft::Quad& mine, bool valid, int obj0, int kind, int grey) {
-  if (SFTD_STOP == 0) return true;
-  const int lane = C.lane;
+// `mine`: this lane's quad (valid lanes); obj0: the first lane of its object (lanes of an object are consecutive)
+__device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine, bool valid, int obj0, int kind, int grey) {
+  if (SFTD_STOP == 0) return;
+  const int lane = C.lane, xmax = C.W * 256;
   uint32_t* const acc = C.acc();
   const unsigned long long vmask = __ballot(valid);
-  if (!vmask) return true;
+  if (!vmask) return;
   const int qi = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vmask, 0u));
-  const int nquads = (int)__popcll(vmask);
   const bool leader = valid && lane == obj0;
   const unsigned long long lmask = __ballot(leader);
   const int oi = (int)__popcll(lmask & ((2ull << obj0) - 1ull)) - 1;
   const int nobj = (int)__popcll(lmask);
+  // (this quad's place in its object: number, and whether it is the last)
+  const unsigned long long from_obj0 = ~((1ull << obj0) - 1ull);
+  const unsigned long long later_leaders = lmask & ~((2ull << obj0) - 1ull);
+  const unsigned long long obj_lanes = vmask & from_obj0 & (later_leaders ? ((later_leaders & (~later_leaders + 1ull)) - 1ull) : ~0ull);
+  const int kq = (int)__popcll(obj_lanes & ((1ull << lane) - 1ull)), nq_mine = (int)__popcll(obj_lanes);
   // ---- records
   if (leader) {
     uint32_t* o = C.obj(oi);
     o[0] = 0x7fffffffu; o[1] = 0x7fffffffu; o[2] = 0x80000000u; o[3] = 0x80000000u;  // min x, min s, max x, max s
-    o[4] = (uint32_t)qi | ((uint32_t)(kind & 255) << 16) | ((uint32_t)grey << 24);
+    o[4] = (uint32_t)qi | ((uint32_t)nq_mine << 8) | ((uint32_t)(kind & 255) << 16) | ((uint32_t)grey << 24);
     o[5] = 0u; o[6] = 0u; o[7] = (uint32_t)(kind >> 8);
     o[8] = 0u; o[9] = 0u; o[10] = 0u; o[11] = 0u;
   }
-  if (lane == 0) C.tasks()[kTasksF] = 0u;
 #pragma unroll
   for (int i = 0; i < kMapWordsF; i += 64) C.map()[i + lane] = 0u;
   C.sync();
@@ -542,64 +569,126 @@ __device__ __forceinline__ bool raster_fast(const CtxF& C, const sft::Quad& mine
     uint32_t* r = C.rec(qi);
     int gy[4], lo = 1 << 30, hi = -(1 << 30), minx = 1 << 30, maxx = -(1 << 30);
     unsigned vr0 = 0u, vr1 = 0u, vr2 = 0u;
+    // the row that holds sub-row boundary g strictly inside (a vertex on a row's boundary is no event for either row)
+    auto event_row = [&](int g) {
+      const int vrow = (g * 34953) >> 19;  // g / 15 for 0 <= g < 2^16
+      if (g > 0 && vrow < 96 && g != vrow * sft::kGridY) {
+        vr0 |= vrow < 32 ? 1u << vrow : 0u;
+        vr1 |= (vrow >= 32 && vrow < 64) ? 1u << (vrow - 32) : 0u;
+        vr2 |= vrow >= 64 ? 1u << (vrow - 64) : 0u;
+      }
+    };
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       gy[k] = sft::to_grid_y(mine.y[k]);
       lo = min(lo, gy[k]); hi = max(hi, gy[k]);
       minx = min(minx, mine.x[k]); maxx = max(maxx, mine.x[k]);
-      // the row that holds this vertex strictly inside (a vertex on a row's boundary is no event for either row)
-      const int vrow = (gy[k] * 34953) >> 19;  // gy / 15 for 0 <= gy < 2^16
-      if (gy[k] > 0 && vrow < 96 && gy[k] != vrow * sft::kGridY) {
-        vr0 |= vrow < 32 ? 1u << vrow : 0u;
-        vr1 |= (vrow >= 32 && vrow < 64) ? 1u << (vrow - 32) : 0u;
-        vr2 |= vrow >= 64 ? 1u << (vrow - 64) : 0u;
-      }
+      event_row(gy[k]);
     }
     *reinterpret_cast<int4*>(r + 20) = int4{gy[0], gy[1], gy[2], gy[3]};
     *reinterpret_cast<int4*>(r + 24) = int4{mine.x[0], mine.x[1], mine.x[2], mine.x[3]};
     *reinterpret_cast<int4*>(r + 28) = int4{mine.y[0], mine.y[1], mine.y[2], mine.y[3]};
+    *reinterpret_cast<uint4*>(r + 40) = uint4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<uint4*>(r + 44) = uint4{0u, 0u, 0u, 0u};
+    r[19] = 0u;
     // which side an edge is on: with the corners in order, the edges that go down are all on one side (the right one when the
     // doubled area (x2 - x0)(y3 - y1) - (x3 - x1)(y2 - y0) is positive: y points down)
     const int area2 = (mine.x[2] - mine.x[0]) * (mine.y[3] - mine.y[1]) - (mine.x[3] - mine.x[1]) * (mine.y[2] - mine.y[0]);
     // a parallelogram's opposite edges share their slope: two reciprocals instead of four
     const bool para = mine.x[1] - mine.x[0] == mine.x[2] - mine.x[3] && mine.y[1] - mine.y[0] == mine.y[2] - mine.y[3];
-    double Kc[4];
+    double Kc[4], Qc[4];  // K = dx / (30 dy) of the line (the same whichever way the edge is read); Q = 1 / (8 * 30 |dy|)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int j = (k + 1) & 3;
       const int dx = mine.x[j] - mine.x[k], dy = mine.y[j] - mine.y[k];
-      // K = dx / (30 dy) of the line (the same whichever way the edge is read)
-      if (k >= 2 && para) Kc[k] = Kc[k - 2];
-      else Kc[k] = dy != 0 ? (double)dx * rcp_fast(30.0 * (double)dy) : 0.0;
+      if (k >= 2 && para) { Kc[k] = Kc[k - 2]; Qc[k] = Qc[k - 2]; }
+      else {
+        const double rd = dy != 0 ? sft::rcp(30.0 * (double)dy) : 0.0;
+        Kc[k] = (double)dx * rd;
+        Qc[k] = 0.125 * fabs(rd);
+      }
     }
+    const bool chain = (kind & 255) == kKindSingle || (kind & 255) == kKindRing;
     int nl = 0, nr = 0;
-    unsigned slot_edges = 0u;
+    unsigned flags = 0u;
+    uint16_t* const rows_lo = reinterpret_cast<uint16_t*>(r + 46);  // [4]: slots 0 .. 3
+    uint16_t* const rows_hi = reinterpret_cast<uint16_t*>(r + 19);  // [2]: slots 4, 5
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int j = (k + 1) & 3;
       const int dy = mine.y[j] - mine.y[k];
       if (dy == 0 || area2 == 0) continue;
       const bool right = (dy > 0) == (area2 > 0);
-      const int slot = right ? 2 + nr : nl;
+      const int n = right ? nr : nl;
+      const int slot = right ? (n == 0 ? 2 : (n == 1 ? 3 : 5)) : (n == 0 ? 0 : (n == 1 ? 1 : 4));
       if (right) nr++; else nl++;
-      const int xt = dy > 0 ? mine.x[k] : mine.x[j], yt = dy > 0 ? mine.y[k] : mine.y[j];  // the upper end
-      const double ady30 = 30.0 * (double)(dy > 0 ? dy : -dy);
+      const bool down = dy > 0;
+      const int x1 = down ? mine.x[k] : mine.x[j], y1 = down ? mine.y[k] : mine.y[j];  // the upper end
+      const int x2 = down ? mine.x[j] : mine.x[k], y2 = down ? mine.y[j] : mine.y[k];
+      const int g1 = down ? gy[k] : gy[j], g2 = down ? gy[j] : gy[k];
       // cell(s) = round(A + B s): A = x + (256 - 30 y) K + a quarter of the least distance to a rounding boundary (sf_tor.h: edge_ab)
-      const double A = (double)xt + (256.0 - 30.0 * (double)yt) * Kc[k] + 0.25 * rcp_fast(2.0 * ady30);
-      if (slot < 4) *reinterpret_cast<double2*>(r + 4 * slot) = double2{A, 512.0 * Kc[k]};
-      slot_edges |= (unsigned)k << (2 * (slot & 3));
+      const double A = (double)x1 + (256.0 - 30.0 * (double)y1) * Kc[k] + Qc[k];
+      *reinterpret_cast<double2*>(r + slot_at(slot)) = double2{A, 512.0 * Kc[k]};
+      flags |= (unsigned)k << (2 * slot);
+      // the pixel rows the edge spans whole
+      const int r_lo = g1 <= 0 ? 0 : ((g1 + 14) * 34953) >> 19, r_hi = g2 <= 0 ? 0 : min((g2 * 34953) >> 19, 255);
+      const uint16_t rows = (uint16_t)(r_lo | (max(r_hi, r_lo) << 8));
+      if (slot < 4) rows_lo[slot] = rows; else rows_hi[slot - 4] = rows;
     }
-    if (nl == 1) { *reinterpret_cast<double2*>(r + 4) = *reinterpret_cast<const double2*>(r); slot_edges |= (slot_edges & 3u) << 2; }
-    if (nr == 1) { *reinterpret_cast<double2*>(r + 12) = *reinterpret_cast<const double2*>(r + 8); slot_edges |= ((slot_edges >> 4) & 3u) << 6; }
-    if (nl == 0 || nr == 0) hi = lo;  // (a degenerate quad spans nothing)
+    // where an edge leaves the surface sideways the polygon runs along the border (sf_tor.h: quad_scan) -- rare: a loop over
+    // the slots, one copy of the code.  _cairo_fixed_mul_div_floor's C division as a float64 one: numerator below 2^31,
+    // denominator below 2^16 -- a quotient that is no whole number is 2^-16 or more off one.
+    if (minx < 0 || maxx > xmax || minx >= xmax || maxx <= 0) {
+      auto muldiv = [](int p, int q, int d) { return (int)trunc((double)p * (double)q / (double)d); };
+#pragma unroll 1
+      for (int slot = 0; slot < 6; slot++) {
+        const int n = slot == 0 ? 0 : (slot == 1 ? 1 : (slot == 4 ? 2 : (slot == 2 ? 0 : (slot == 3 ? 1 : 2))));
+        if (n >= ((slot == 0 || slot == 1 || slot == 4) ? nl : nr)) continue;
+        const int k = (int)((flags >> (2 * slot)) & 3u), j = (k + 1) & 3;
+        const bool down = (int)r[28 + j] > (int)r[28 + k];
+        const int x1 = (int)r[24 + (down ? k : j)], y1 = (int)r[28 + (down ? k : j)], g1 = (int)r[20 + (down ? k : j)];  // the upper end
+        const int x2 = (int)r[24 + (down ? j : k)], y2 = (int)r[28 + (down ? j : k)], g2 = (int)r[20 + (down ? j : k)];
+        const int pl = min(x1, x2), pr = max(x1, x2);
+        if (!(pr <= 0 || pl >= xmax || pl < 0 || pr > xmax)) continue;
+        int b0 = 0, b1 = 0, bx = 0;
+        const bool down_right = x1 <= x2;
+        if (pr <= 0 || pl >= xmax) { bx = pr <= 0 ? 0 : 1; b0 = g1; b1 = g2; }
+        else {
+          const int xb = pl < 0 ? 0 : xmax;
+          bx = pl < 0 ? 0 : 1;
+          // _cairo_edge_compute_intersection_y_for_x, then x_for_y of that y: one more step if it is still outside
+          int y = xb == x1 ? y1 : (xb == x2 ? y2 : y1 + muldiv(xb - x1, y2 - y1, x2 - x1));
+          const int xy = y == y1 ? x1 : (y == y2 ? x2 : x1 + muldiv(y - y1, x2 - x1, y2 - y1));
+          if (bx == 0 ? xy < 0 : xy > xmax) y += (down_right == (bx == 0)) ? 1 : -1;
+          y = y < y1 ? y1 : (y > y2 ? y2 : y);
+          const int gc = sft::to_grid_y(y);
+          // (outside above the crossing: left border with x growing downwards, right border with x shrinking downwards)
+          if (down_right == (bx == 0)) { b0 = g1; b1 = gc; } else { b0 = gc; b1 = g2; }
+        }
+        if (b1 > b0) {
+          // (the end of the piece inside the edge is one more vertex of the polygon -- unless the edge is a face between two
+          //  pieces of a flattened curve: no edge of the polygon, nothing is clipped)
+          if (!(chain && ((k == 1 && kq < nq_mine - 1) || (k == 3 && kq > 0)))) { event_row(b0); event_row(b1); }
+          r[40 + slot] = (uint32_t)min(max(b0, 0), 4095) | ((uint32_t)min(max(b1, 0), 4095) << 12) | ((uint32_t)bx << 24);
+          flags |= kRecBorder;
+        }
+      }
+    }
+    // a side with one edge holds it twice (max / min of a value with itself) -- the copies span no rows --, the third slots hold
+    // copies unless a side has three edges; a degenerate quad (no edge at all on a side) spans nothing
+    if (nl == 1) { *reinterpret_cast<double2*>(r + 4) = *reinterpret_cast<const double2*>(r); r[41] = r[40]; }
+    if (nr == 1) { *reinterpret_cast<double2*>(r + 12) = *reinterpret_cast<const double2*>(r + 8); r[43] = r[42]; }
+    if (nl < 3) { *reinterpret_cast<double2*>(r + 32) = *reinterpret_cast<const double2*>(r); r[44] = r[40]; }
+    if (nr < 3) { *reinterpret_cast<double2*>(r + 36) = *reinterpret_cast<const double2*>(r + 8); r[45] = r[42]; }
+    if (nl == 3 || nr == 3) flags |= kRecThird;
+    if (nl == 0 || nr == 0) hi = lo;
     my_lo = lo; my_hi = hi;
-    *reinterpret_cast<int4*>(r + 16) = int4{lo, hi, (int)(slot_edges | ((unsigned)nl << 8) | ((unsigned)nr << 10)), oi};
+    r[16] = (uint32_t)lo; r[17] = (uint32_t)hi; r[18] = flags | ((unsigned)nl << 12) | ((unsigned)nr << 14);
     int* o = reinterpret_cast<int*>(C.obj(oi));
     __hip_atomic_fetch_min(o + 0, minx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_min(o + 1, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_max(o + 2, maxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_max(o + 3, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(C.obj(oi) + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (vr0) __hip_atomic_fetch_or(C.obj(oi) + 8, vr0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (vr1) __hip_atomic_fetch_or(C.obj(oi) + 9, vr1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (vr2) __hip_atomic_fetch_or(C.obj(oi) + 10, vr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -625,11 +714,9 @@ __device__ __forceinline__ bool raster_fast(const CtxF& C, const sft::Quad& mine
   const int tot_rows = __builtin_amdgcn_readlane(rbase, kMaxObjs - 1), tot_pix = __builtin_amdgcn_readlane(abase, kMaxObjs - 1);
   if (lane < nobj) {
     uint32_t* o = C.obj(lane);
-    const uint32_t nq = o[5];
     o[0] = (uint32_t)bx0 | ((uint32_t)by0 << 8) | ((uint32_t)bw << 16) | ((uint32_t)bh << 24);
     o[1] = o[7] << 16;            // (a circle's first half)
     o[3] = (uint32_t)(abase - bw * bh);
-    o[4] |= nq << 8;
     o[5] = (uint32_t)(rbase - bh);
     o[6] = 0u;
   }
@@ -639,21 +726,18 @@ __device__ __forceinline__ bool raster_fast(const CtxF& C, const sft::Quad& mine
     s_lo = max(my_lo, 0);
     cnt = max(min(my_hi, C.H * sft::kGridY) - s_lo, 0);
   }
-  // (the scan runs over the owners' lanes: any lanes of the wave)
   int incl = cnt;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int a = __shfl_up(incl, d);
     if (lane >= d) incl += a;
   }
-  const int tot_sub = __builtin_amdgcn_readlane(incl, 63);
-  if (tot_sub > 32 * kMapWordsF) return false;
+  const int tot_sub = __builtin_amdgcn_readlane(incl, 63), start = incl - cnt;
   C.sync();
   if (valid) {
     const uint32_t* ob = C.obj(oi);
     const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u);
-    const int q0 = (int)(ob[4] & 255u), nq = (int)((ob[4] >> 8) & 255u), okind = (int)((ob[4] >> 16) & 255u), m0 = (int)(ob[1] >> 16);
-    const int start = incl - cnt, k = qi - q0;
+    const int q0 = qi - kq, okind = kind & 255, m0 = kind >> 8, nq = nq_mine, k = kq;
     // the earlier quads this one may overlap (at most two, and whether all three can meet): by kind
     int p1 = 255, p2 = 255, triple = 0;
     if (okind == kKindLines3) { p1 = k >= 1 ? q0 : 255; p2 = k == 2 ? q0 + 1 : 255; triple = k == 2; }
@@ -661,254 +745,285 @@ __device__ __forceinline__ bool raster_fast(const CtxF& C, const sft::Quad& mine
     else if (okind == kKindRing) { p1 = k == m0 ? q0 + m0 - 1 : (k == nq - 1 ? q0 : 255); }
     *reinterpret_cast<int4*>(C.hdr(qi)) =
         int4{start | (s_lo << 16), (int)ob[3] - oby0 * obw, obx0 | (obw << 8) | (oby0 << 16) | (oi << 24), p1 | (p2 << 8) | (triple << 16)};
-    if (cnt > 0 && start > 0) __hip_atomic_fetch_or(C.map() + ((start - 1) >> 5), 1u << ((start - 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  // (which quad a run belongs to: the r-th run with sub-rows is the r-th such quad: a small table)
-  {
-    const unsigned long long nz = __ballot(valid && cnt > 0);
-    const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nz >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nz, 0u));
-    if (valid && cnt > 0) C.qtab()[rk] = (uint8_t)qi;
-  }
+  // (which quad a run belongs to: the r-th run with sub-rows is the r-th such quad)
+  const unsigned long long runs = __ballot(valid && cnt > 0);
+  if (valid && cnt > 0)
+    C.qtab()[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(runs >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)runs, 0u))] = (uint8_t)qi;
   C.sync();
-  if (SFTD_STOP == 1) return true;
+  if (SFTD_STOP == 1) return;
   auto find_obj = [&](int t, int which) {
     int o = 0;
     for (int j = 1; j < nobj; j++) o += t >= (int)C.obj(j)[which] ? 1 : 0;
     return o;
   };
-  // ---- rows: which are taken whole; their (row, quad) pairs go on the task list
-  for (int base = 0; base < tot_rows; base += 64) {
-    const int t = base + lane;
-    const bool have = t < tot_rows;
-    const int o = have ? find_obj(t, 5) : 0;
-    const uint32_t* ob = C.obj(o);
-    const int oby0 = (int)((ob[0] >> 8) & 255u), q0 = (int)(ob[4] & 255u), nq = (int)((ob[4] >> 8) & 255u), okind = (int)((ob[4] >> 16) & 255u);
-    const int r = t - (int)ob[5], row = oby0 + r, s0 = row * sft::kGridY;
-    const unsigned vbits = row < 32 ? ob[8] : (row < 64 ? ob[9] : ob[10]);
-    bool full = have && !((vbits >> (row & 31)) & 1u);
-    int nsp = 0;
-    unsigned sp0 = 0u, sp1 = 0u, sp2 = 0u, sp3 = 0u;  // k | left slot << 8 | right slot << 10
-    if (__ballot(full)) {
-      for (int k = 0; __ballot(full && k < nq); k++) {
-        if (!(full && k < nq)) continue;
-        const uint32_t* rc = C.rec(q0 + k);
-        const int4 hd = *reinterpret_cast<const int4*>(rc + 16);
-        if (!(hd.x <= s0 && hd.y >= s0 + sft::kGridY)) continue;
-        const int4 gy = *reinterpret_cast<const int4*>(rc + 20);
-        const unsigned se = (unsigned)hd.z;
-        int ls = -1, rs = -1;
-#pragma unroll
-        for (int sl = 0; sl < 4; sl++) {
-          const int e = (int)((se >> (2 * sl)) & 3u);
-          const int ga = e == 0 ? gy.x : (e == 1 ? gy.y : (e == 2 ? gy.z : gy.w)), gb = e == 0 ? gy.y : (e == 1 ? gy.z : (e == 2 ? gy.w : gy.x));
-          const bool spans = min(ga, gb) <= s0 && max(ga, gb) >= s0 + sft::kGridY;
-          if (spans) { if (sl < 2) ls = sl; else rs = sl; }
-        }
-        if (ls < 0 || rs < 0) continue;
-        if (nsp == 4) { full = false; continue; }
-        const unsigned ent = (unsigned)k | ((unsigned)ls << 8) | ((unsigned)rs << 10);
-        sp0 = nsp == 0 ? ent : sp0; sp1 = nsp == 1 ? ent : sp1; sp2 = nsp == 2 ? ent : sp2; sp3 = nsp == 3 ? ent : sp3;
-        nsp++;
-      }
-    }
-    bool complex_row = false;
-    if (__ballot(full && nsp >= 2)) {
-      if (full && nsp >= 2) {
-        const unsigned sp[4] = {sp0, sp1, sp2, sp3};
-        const double sd0 = (double)s0, sd1 = (double)(s0 + sft::kGridY), sdm = (double)(s0 - 1);
-        int top[8], bot[8], tie[8], nw[8], rk[8];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-#pragma unroll
-          for (int side = 0; side < 2; side++) {
-            const int i = 2 * a + side;
-            top[i] = bot[i] = tie[i] = rk[i] = 0;
-            nw[i] = -1;
-            if (a < nsp) {
-              const int k = (int)(sp[a] & 255u), sl = (int)((sp[a] >> (side ? 10 : 8)) & 3u);
-              const uint32_t* rc = C.rec(q0 + k);
-              const int e = (int)((rc[18] >> (2 * sl)) & 3u);
-              top[i] = cell_fast(rc + 4 * sl, sd0);
-              bot[i] = cell_fast(rc + 4 * sl, sd1);
-              const int ga = (int)rc[20 + e], gb = (int)rc[20 + ((e + 1) & 3)];
-              const int start = max(min(ga, gb), 0);
-              const int rank = 8 * k + (e == 0 ? 0 : (e == 1 ? 1 : (e == 2 ? 3 : 2)));
-              nw[i] = start == s0 ? 1 : 0;
-              tie[i] = nw[i] ? rank : cell_fast(rc + 4 * sl, sdm);
-              rk[i] = rank;
-              // (a face between two pieces of a flattened curve is no edge of the polygon: out of the order test)
-              if ((okind == kKindSingle || okind == kKindRing) && ((e == 1 && k < nq - 1) || (e == 3 && k > 0))) nw[i] = -1;
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-          for (int j = i + 1; j < 8; j++) {
-            const bool both = nw[i] >= 0 && nw[j] >= 0;
-            bool i_first;
-            if (top[i] != top[j]) i_first = top[i] < top[j];
-            else if (nw[i] != nw[j]) i_first = nw[i] < nw[j];
-            else if (tie[i] != tie[j]) i_first = tie[i] < tie[j];
-            else i_first = rk[i] < rk[j];
-            const bool ok = i_first ? bot[i] <= bot[j] : bot[j] <= bot[i];
-            full = full && (!both || ok);
-          }
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int b = a + 1; b < 4; b++)
-            if (b < nsp) complex_row |= top[2 * b] <= top[2 * a + 1] && top[2 * a] <= top[2 * b + 1];
-      }
-    }
-    if (full) {
-      const int n_tasks = complex_row ? 1 : nsp;
-      unsigned at = 0u;
-      if (n_tasks) at = __hip_atomic_fetch_add(C.tasks() + kTasksF, (unsigned)n_tasks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      // (a list that is full -- never with this game's objects -- leaves the row to the sub-rows: nothing is lost, cairo's
-      //  whole-row arithmetic is not reproduced there)
-      if (at + (unsigned)n_tasks <= (unsigned)kTasksF) {
-        __hip_atomic_fetch_or(const_cast<uint32_t*>(ob) + 6, 1u << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const unsigned head = (unsigned)o | ((unsigned)r << 8);
-        const unsigned sp[4] = {sp0, sp1, sp2, sp3};
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-          if (a < n_tasks)
-            C.tasks()[at + a] = head | (complex_row ? 0x80000000u : ((sp[a] & 255u) << 16) | (((sp[a] >> 8) & 15u) << 24));
-      }
-    }
-  }
-  C.sync();
-  // ---- the rows taken whole: a lane per (row, quad): the area between the quad's two edges (cell_list_render_edge)
-  {
-    const unsigned n_tasks = min(C.tasks()[kTasksF], (unsigned)kTasksF);  // (a row that did not fit has added to the count only)
-    const unsigned tk = (unsigned)lane < n_tasks ? C.tasks()[lane] : 0u;
-    const bool on = (unsigned)lane < n_tasks;
-    const uint32_t* ob = C.obj((int)(tk & 255u));
-    const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u);
-    const int q0 = (int)(ob[4] & 255u), nq = (int)((ob[4] >> 8) & 255u), okind = (int)((ob[4] >> 16) & 255u), m0 = (int)(ob[1] >> 16);
-    const int r = (int)((tk >> 8) & 255u), s0 = (oby0 + r) * sft::kGridY, arow = (int)ob[3] + r * obw;
-    if (__ballot(on && !(tk >> 31))) {
-      if (on && !(tk >> 31)) {
-        const uint32_t* rc = C.rec(q0 + (int)((tk >> 16) & 255u));
-        const sft::RowEdge EL = rec_row_edge(rc, (int)((tk >> 24) & 3u), s0), ER = rec_row_edge(rc, (int)((tk >> 26) & 3u), s0);
-        const int c0 = max(EL.ix1, obx0), c1 = min(ER.ix2, obx0 + obw - 1);
-        for (int c = c0; c <= c1; c++) {
-          const int v = sft::row_edge_area(EL, c) - sft::row_edge_area(ER, c);
-          if (v) acc_add(acc, arow + c - obx0, v);
-        }
-      }
-    }
-    if (__ballot(on && (tk >> 31))) {  // a row with overlapping quads: every source, the general way
-      if (on && (tk >> 31)) {
-        const unsigned multi = multi_sources(okind);
-        int a_quad[4], a_ls[4], a_rs[4], a_lt[4], a_lb[4], a_rt[4], a_rb[4], nact = 0;
-        const double sd0 = (double)s0, sd1 = (double)(s0 + sft::kGridY);
-        for (int k = 0; k < nq && nact < 4; k++) {
+  // ---- rows: which are taken whole (can_do_full_row and the buckets: no vertex strictly inside the row, no two edges that change
+  // places); their (row, quad) pairs go on the task list, the list is worked off by a lane per pair.  A list that is full (never
+  // with this game's objects) leaves its rows for another round.
+  for (bool more = true; more;) {
+    if (lane == 0) { C.tasks()[kTasksF] = 0u; C.tasks()[kTasksF + 1] = 0u; }
+    C.sync();
+    for (int base = 0; base < tot_rows; base += 64) {
+      const int t = base + lane;
+      const bool have = t < tot_rows;
+      const int o = have ? find_obj(t, 5) : 0;
+      const uint32_t* ob = C.obj(o);
+      const int oby0 = (int)((ob[0] >> 8) & 255u), q0 = (int)(ob[4] & 255u), nq = (int)((ob[4] >> 8) & 255u), okind = (int)((ob[4] >> 16) & 255u);
+      const int r = t - (int)ob[5], row = oby0 + r, s0 = row * sft::kGridY;
+      const unsigned vbits = row < 32 ? ob[8] : (row < 64 ? ob[9] : ob[10]);
+      // (rows 32 and up of an object -- none of this game's is that tall -- go by sub-rows; a row of an earlier round is done)
+      bool full = have && r < 32 && !((vbits >> (row & 31)) & 1u) && !((ob[6] >> (r & 31)) & 1u);
+      int nsp = 0;
+      unsigned sp0 = 0u, sp1 = 0u, sp2 = 0u, sp3 = 0u;  // the quads through the row: k | left slot << 8 | right slot << 11
+      if (__ballot(full)) {
+        for (int k = 0; __ballot(full && k < nq); k++) {
+          if (!(full && k < nq)) continue;
           const uint32_t* rc = C.rec(q0 + k);
-          if (!((int)rc[16] <= s0 && (int)rc[17] >= s0 + sft::kGridY)) continue;
-          int ls = -1, rs = -1;
-          for (int sl = 0; sl < 4; sl++) {
-            const int e = (int)((rc[18] >> (2 * sl)) & 3u);
-            const int ga = (int)rc[20 + e], gb = (int)rc[20 + ((e + 1) & 3)];
-            if (min(ga, gb) <= s0 && max(ga, gb) >= s0 + sft::kGridY) { if (sl < 2) ls = sl; else rs = sl; }
-          }
+          const int2 rg = *reinterpret_cast<const int2*>(rc + 16);
+          if (!(rg.x <= s0 && rg.y >= s0 + sft::kGridY)) continue;
+          int ls, rs;
+          row_slots(rc, row, &ls, &rs);
           if (ls < 0 || rs < 0) continue;
-          a_quad[nact] = k; a_ls[nact] = ls; a_rs[nact] = rs;
-          a_lt[nact] = cell_fast(rc + 4 * ls, sd0); a_lb[nact] = cell_fast(rc + 4 * ls, sd1);
-          a_rt[nact] = cell_fast(rc + 4 * rs, sd0); a_rb[nact] = cell_fast(rc + 4 * rs, sd1);
-          nact++;
+          if (nsp == 4) { full = false; continue; }
+          const unsigned ent = (unsigned)k | ((unsigned)ls << 8) | ((unsigned)rs << 11);
+          sp0 = nsp == 0 ? ent : sp0; sp1 = nsp == 1 ? ent : sp1; sp2 = nsp == 2 ? ent : sp2; sp3 = nsp == 3 ? ent : sp3;
+          nsp++;
         }
-        for (int si = 0; si < nact + 4; si++) {
-          unsigned members = 0u;
-          int sign = 1;
-          if (si >= nact) {
-            members = (multi >> (4 * (si - nact))) & 15u;
-            if (!members) continue;
-            sign = (__popc(members) & 1) ? 1 : -1;
-          }
-          int lq = -1, rq = -1, lt = 0, lb = 0, rt = 0, rb = 0, ls = 0, rs = 0, cn = 0;
-          for (int a = 0; a < nact; a++) {
-            if (si < nact) { if (a != si) continue; }
-            else {
-              const int sl = slot_of(okind, a_quad[a], nq, m0);
-              if (sl < 0 || !((members >> sl) & 1u)) continue;
+      }
+      // The edges through the row must keep their order, and quads that overlap make the row a "complex" one.
+      // An edge's place in cairo's list at the row's top: by cell; equal cells keep the order of one sub-row earlier; an edge that
+      // starts with this row comes behind the ones already there, edges that start together in the polygon's edge order: one
+      // 64-bit key.  The cells at the next row's top must not decrease in that order -- the two edges of one quad included.
+      bool complex_row = false;
+      if (__ballot(full && nsp >= 1)) {
+        // (how many quads a row of this round has at most: nearly always one or two; three or four: an explosion's circle)
+        const int lvl = __ballot(full && nsp > 2) ? 4 : (__ballot(full && nsp > 1) ? 2 : 1);
+        if (full && nsp >= 1) {
+          const unsigned sp[4] = {sp0, sp1, sp2, sp3};
+          const double sd0 = (double)s0, sd1 = (double)(s0 + sft::kGridY), sdm = (double)(s0 - 1);
+          unsigned long long key[8];
+          int bot[8];
+          unsigned in_order = 0u;
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+              const int i = 2 * a + side;
+              key[i] = 0ull; bot[i] = 0;
+              if (a < lvl && a < nsp) {
+                const int k = (int)(sp[a] & 255u), sl = (int)((sp[a] >> (side ? 11 : 8)) & 7u);
+                const uint32_t* rc = C.rec(q0 + k);
+                const int e = (int)((rc[18] >> (2 * sl)) & 3u);
+                const unsigned bwd = rc[40 + sl];
+                const int b0 = (int)(bwd & 4095u), b1 = (int)((bwd >> 12) & 4095u);
+                const bool out = s0 >= b0 && s0 < b1;
+                const int g0 = max(min((int)rc[20 + e], (int)rc[20 + ((e + 1) & 3)]), 0);
+                // the piece of the edge that is in the list: along the border, or the edge proper (from its top / the border piece's end)
+                const int begin = out ? b0 : ((b1 > b0 && b1 <= s0 && b1 > g0) ? b1 : g0);
+                const int bx = (bwd >> 24) ? xmax : 0;
+                const int top = out ? bx : cell_fast(rc + slot_at(sl), sd0);
+                bot[i] = out ? bx : cell_fast(rc + slot_at(sl), sd1);
+                const int rank = 8 * k + (e == 0 ? 0 : (e == 1 ? 1 : (e == 2 ? 3 : 2))) + (out ? 4 : 0);
+                const bool is_new = begin == s0;
+                const int tie = is_new ? rank : (out ? bx : cell_fast(rc + slot_at(sl), sdm)) + 65536;
+                key[i] = ((unsigned long long)(unsigned)(top + 65536) << 26) | ((unsigned long long)is_new << 25) |
+                         ((unsigned long long)(unsigned)tie << 7) | (unsigned long long)rank;
+                // (a face between two pieces of a flattened curve is no edge of the polygon: out of the order test)
+                if (!((okind == kKindSingle || okind == kKindRing) && ((e == 1 && k < nq - 1) || (e == 3 && k > 0)))) in_order |= 1u << i;
+              }
             }
-            cn++;
-            if (lq < 0 || a_lt[a] > lt || (a_lt[a] == lt && a_lb[a] > lb)) { lq = a_quad[a]; lt = a_lt[a]; lb = a_lb[a]; ls = a_ls[a]; }
-            if (rq < 0 || a_rt[a] < rt || (a_rt[a] == rt && a_rb[a] < rb)) { rq = a_quad[a]; rt = a_rt[a]; rb = a_rb[a]; rs = a_rs[a]; }
           }
-          if (cn != (si < nact ? 1 : __popc(members)) || lt > rt) continue;
-          const sft::RowEdge EL = rec_row_edge(C.rec(q0 + lq), ls, s0), ER = rec_row_edge(C.rec(q0 + rq), rs, s0);
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = i + 1; j < 8; j++) {
+              if (j >= 2 * lvl) continue;
+              const bool both = ((in_order >> i) & (in_order >> j) & 1u) != 0u;
+              const bool ok = key[i] < key[j] ? bot[i] <= bot[j] : bot[j] <= bot[i];
+              full = full && (!both || ok);
+            }
+          // overlapping quads (their spans at the row's top touch or cross): inclusion-exclusion terms needed
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = a + 1; b < 4; b++) {
+              if (b >= lvl) continue;
+              if (b < nsp) complex_row |= (key[2 * b] >> 26) <= (key[2 * a + 1] >> 26) && (key[2 * a] >> 26) <= (key[2 * b + 1] >> 26);
+            }
+        }
+      }
+      if (full) {
+        const int n_tasks = complex_row ? 1 : nsp;
+        unsigned at = 0u;
+        if (n_tasks) at = __hip_atomic_fetch_add(C.tasks() + kTasksF, (unsigned)n_tasks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (at + (unsigned)n_tasks <= (unsigned)kTasksF) {
+          __hip_atomic_fetch_or(const_cast<uint32_t*>(ob) + 6, 1u << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const unsigned head = (unsigned)o | ((unsigned)r << 8);
+          const unsigned sp[4] = {sp0, sp1, sp2, sp3};
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+            if (a < n_tasks)
+              C.tasks()[at + a] = head | (complex_row ? 0x80000000u : ((sp[a] & 255u) << 16) | (((sp[a] >> 8) & 63u) << 24));
+        } else {
+          C.tasks()[kTasksF + 1] = 1u;  // another round
+        }
+      }
+    }
+    C.sync();
+    // ---- the rows taken whole: a lane per (row, quad): the area between the quad's two edges (cell_list_render_edge)
+    {
+      const unsigned n_tasks = min(C.tasks()[kTasksF], (unsigned)kTasksF);  // (a row that did not fit has added to the count only)
+      more = C.tasks()[kTasksF + 1] != 0u;
+      const unsigned tk = (unsigned)lane < n_tasks ? C.tasks()[lane] : 0u;
+      const bool on = (unsigned)lane < n_tasks;
+      const uint32_t* ob = C.obj((int)(tk & 255u));
+      const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u);
+      const int q0 = (int)(ob[4] & 255u), nq = (int)((ob[4] >> 8) & 255u), okind = (int)((ob[4] >> 16) & 255u), m0 = (int)(ob[1] >> 16);
+      const int r = (int)((tk >> 8) & 255u), row = oby0 + r, s0 = row * sft::kGridY, arow = (int)ob[3] + r * obw;
+      if (__ballot(on && !(tk >> 31))) {
+        if (on && !(tk >> 31)) {
+          const uint32_t* rc = C.rec(q0 + (int)((tk >> 16) & 255u));
+          const sft::RowEdge EL = rec_row_edge(rc, (int)((tk >> 24) & 7u), s0, xmax), ER = rec_row_edge(rc, (int)((tk >> 27) & 7u), s0, xmax);
           const int c0 = max(EL.ix1, obx0), c1 = min(ER.ix2, obx0 + obw - 1);
           for (int c = c0; c <= c1; c++) {
             const int v = sft::row_edge_area(EL, c) - sft::row_edge_area(ER, c);
-            if (v) acc_add(acc, arow + c - obx0, sign * v);
+            if (v) acc_add(acc, arow + c - obx0, v);
           }
         }
       }
-    }
-  }
-  C.sync();
-  if (SFTD_STOP == 2) return true;
-  // ---- sub-rows of the other rows: a lane per (quad, sub-row of the quad).  The lane adds its quad's span; what the quad shares
-  // with the EARLIER quads it may overlap is taken off again by the same lane: -(pairs) +(the triple): the union of the object's
-  // quads by inclusion-exclusion.  Which quad a lane's sub-row belongs to: the bit map of the runs' starts (a v_mbcnt pair).
-  {
-    const uint8_t* qtab = C.qtab();
-    int kb = 0;
-    for (int base = 0; base < tot_sub; base += 64) {
-      const int t = base + lane;
-      const uint2 mw = *reinterpret_cast<const uint2*>(C.map() + (base >> 5));
-      const int rk = kb + (int)__builtin_amdgcn_mbcnt_hi(mw.y, __builtin_amdgcn_mbcnt_lo(mw.x, 0u));
-      kb += __popc(mw.x) + __popc(mw.y);
-      const bool have = t < tot_sub;
-      const int q = have ? (int)qtab[rk] : 0;
-      const int4 hd = *reinterpret_cast<const int4*>(C.hdr(q));
-      const uint32_t* rc = C.rec(q);
-      const int s = (int)((unsigned)hd.x >> 16) + t - (int)(hd.x & 0xffff);
-      const int obx0 = hd.z & 255, obw = (hd.z >> 8) & 255, oby0 = (hd.z >> 16) & 255, o = (int)((unsigned)hd.z >> 24);
-      const int row = (s * 34953) >> 19;
-      const bool live = have && !((C.obj(o)[6] >> (row - oby0)) & 1u);
-      const int arow = hd.y + row * obw;
-      const double sd = (double)s;
-      int L = 0, R = 0;
-      if (live) {
-        L = max(cell_fast(rc, sd), cell_fast(rc + 4, sd));
-        R = min(cell_fast(rc + 8, sd), cell_fast(rc + 12, sd));
-        add_span_fast(acc, arow, obx0, obw, L, R, 1);
-      }
-      const int p1 = hd.w & 255, p2 = (hd.w >> 8) & 255;
-      const bool want = live && R > L && p1 != 255;
-      if (__ballot(want)) {
-        int L1 = 1, R1 = 0, L2 = 1, R2 = 0;
-        if (want) {
-          const uint32_t* r1 = C.rec(p1);
-          const int2 rg = *reinterpret_cast<const int2*>(r1 + 16);
-          if (s >= rg.x && s < rg.y) {
-            L1 = max(max(cell_fast(r1, sd), cell_fast(r1 + 4, sd)), L);
-            R1 = min(min(cell_fast(r1 + 8, sd), cell_fast(r1 + 12, sd)), R);
-            add_span_fast(acc, arow, obx0, obw, L1, R1, -1);
+      if (__ballot(on && (tk >> 31))) {  // a row with overlapping quads: every source of the object (sf_tor.h), one by one
+        if (on && (tk >> 31)) {
+          const unsigned multi = multi_sources(okind);
+          // the quads through the row (at most four: the rows' pass has seen to it), their slots and their cells at the row's top / the next row's
+          unsigned aq = 0u;  // per quad a byte: k | ls << 4 ... (k < 16, slots < 8: k | ls << 4 in one byte, rs apart)
+          unsigned ars = 0u;
+          int nact = 0;
+          for (int k = 0; k < nq && nact < 4; k++) {
+            const uint32_t* rc = C.rec(q0 + k);
+            if (!((int)rc[16] <= s0 && (int)rc[17] >= s0 + sft::kGridY)) continue;
+            int ls, rs;
+            row_slots(rc, row, &ls, &rs);
+            if (ls < 0 || rs < 0) continue;
+            aq |= ((unsigned)k | ((unsigned)ls << 4)) << (8 * nact);
+            ars |= (unsigned)rs << (8 * nact);
+            nact++;
           }
-        }
-        const bool want2 = want && p2 != 255;
-        if (__ballot(want2)) {
-          if (want2) {
-            const uint32_t* r2 = C.rec(p2);
-            const int2 rg = *reinterpret_cast<const int2*>(r2 + 16);
-            if (s >= rg.x && s < rg.y) {
-              L2 = max(max(cell_fast(r2, sd), cell_fast(r2 + 4, sd)), L);
-              R2 = min(min(cell_fast(r2 + 8, sd), cell_fast(r2 + 12, sd)), R);
-              add_span_fast(acc, arow, obx0, obw, L2, R2, -1);
-              if ((hd.w >> 16) & 1) add_span_fast(acc, arow, obx0, obw, max(L1, L2), min(R1, R2), 1);
+          const double sd0 = (double)s0, sd1 = (double)(s0 + sft::kGridY);
+          auto cells = [&](int k, int sl, int* t, int* b) {
+            const uint32_t* rc = C.rec(q0 + k);
+            const unsigned bwd = rc[40 + sl];
+            if (s0 >= (int)(bwd & 4095u) && s0 < (int)((bwd >> 12) & 4095u)) { *t = *b = (bwd >> 24) ? xmax : 0; return; }
+            *t = cell_fast(rc + slot_at(sl), sd0);
+            *b = cell_fast(rc + slot_at(sl), sd1);
+          };
+          for (int si = 0; si < nact + 4; si++) {
+            unsigned members = 0u;
+            int sign = 1;
+            if (si >= nact) {
+              members = (multi >> (4 * (si - nact))) & 15u;
+              if (!members) continue;
+              sign = (__popc(members) & 1) ? 1 : -1;
+            }
+            int lq = -1, rq = -1, lt = 0, lb = 0, rt = 0, rb = 0, ls = 0, rs = 0, cn = 0;
+            for (int a = 0; a < nact; a++) {
+              const int k = (int)((aq >> (8 * a)) & 15u), als = (int)((aq >> (8 * a + 4)) & 15u), ars_a = (int)((ars >> (8 * a)) & 15u);
+              if (si < nact) { if (a != si) continue; }
+              else {
+                const int sl = slot_of(okind, k, nq, m0);
+                if (sl < 0 || !((members >> sl) & 1u)) continue;
+              }
+              cn++;
+              int a_lt, a_lb, a_rt, a_rb;
+              cells(k, als, &a_lt, &a_lb);
+              cells(k, ars_a, &a_rt, &a_rb);
+              if (lq < 0 || a_lt > lt || (a_lt == lt && a_lb > lb)) { lq = k; lt = a_lt; lb = a_lb; ls = als; }
+              if (rq < 0 || a_rt < rt || (a_rt == rt && a_rb < rb)) { rq = k; rt = a_rt; rb = a_rb; rs = ars_a; }
+            }
+            if (cn != (si < nact ? 1 : __popc(members)) || lt > rt) continue;
+            const sft::RowEdge EL = rec_row_edge(C.rec(q0 + lq), ls, s0, xmax), ER = rec_row_edge(C.rec(q0 + rq), rs, s0, xmax);
+            const int c0 = max(EL.ix1, obx0), c1 = min(ER.ix2, obx0 + obw - 1);
+            for (int c = c0; c <= c1; c++) {
+              const int v = sft::row_edge_area(EL, c) - sft::row_edge_area(ER, c);
+              if (v) acc_add(acc, arow + c - obx0, sign * v);
             }
           }
         }
       }
     }
+    C.sync();
   }
-  C.sync();
-  if (SFTD_STOP == 3) return true;
+  if (SFTD_STOP == 2) return;
+  // ---- sub-rows of the other rows: a lane per (quad, sub-row of the quad).  The lane adds its quad's span; what the quad shares
+  // with the EARLIER quads it may overlap is taken off again by the same lane: -(pairs) +(the triple): the union of the object's
+  // quads by inclusion-exclusion.  Which quad a lane's sub-row belongs to: a bit map of the runs' starts (a v_mbcnt pair and a
+  // small table), kMapWordsF words of it per round.
+  {
+    const uint8_t* qtab = C.qtab();
+    constexpr int kRound = 32 * kMapWordsF;
+    for (int p0 = 0; p0 < tot_sub; p0 += kRound) {
+      if (p0 > 0) {
+#pragma unroll
+        for (int i = 0; i < kMapWordsF; i += 64) C.map()[i + lane] = 0u;
+        C.sync();
+      }
+      // (a run's start t > 0 is marked by the bit of t - 1: lane t's count of the bits below it is the run's number)
+      const bool marks = valid && cnt > 0 && start > 0;
+      if (marks && start - 1 >= p0 && start - 1 < p0 + kRound)
+        __hip_atomic_fetch_or(C.map() + ((start - 1 - p0) >> 5), 1u << ((start - 1 - p0) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int kb = (int)__popcll(__ballot(marks && start - 1 < p0));
+      C.sync();
+      const int end = min(tot_sub, p0 + kRound);
+      for (int base = p0; base < end; base += 64) {
+        const int t = base + lane;
+        const uint2 mw = *reinterpret_cast<const uint2*>(C.map() + ((base - p0) >> 5));
+        const int rk = kb + (int)__builtin_amdgcn_mbcnt_hi(mw.y, __builtin_amdgcn_mbcnt_lo(mw.x, 0u));
+        kb += __popc(mw.x) + __popc(mw.y);
+        const bool have = t < tot_sub;
+        const int q = have ? (int)qtab[rk] : 0;
+        const int4 hd = *reinterpret_cast<const int4*>(C.hdr(q));
+        const uint32_t* rc = C.rec(q);
+        const int s = (int)((unsigned)hd.x >> 16) + t - (int)(hd.x & 0xffff);
+        const int obx0 = hd.z & 255, obw = (hd.z >> 8) & 255, oby0 = (hd.z >> 16) & 255, o = (int)((unsigned)hd.z >> 24);
+        const int row = (s * 34953) >> 19;
+        const bool live = have && (row - oby0 >= 32 || !((C.obj(o)[6] >> (row - oby0)) & 1u));
+        const int arow = hd.y + row * obw;
+        const double sd = (double)s;
+        int L, R;
+        span_fast(rc, s, sd, live, xmax, &L, &R);
+        if (live) add_span_fast(acc, arow, obx0, obw, L, R, 1);
+        const int p1 = hd.w & 255, p2 = (hd.w >> 8) & 255;
+        const bool want = live && R > L && p1 != 255;
+        if (__ballot(want)) {
+          int L1 = 1, R1 = 0, L2 = 1, R2 = 0;
+          const uint32_t* r1 = C.rec(want ? p1 : q);
+          const int2 rg1 = *reinterpret_cast<const int2*>(r1 + 16);
+          const bool in1 = want && s >= rg1.x && s < rg1.y;
+          if (__ballot(in1)) {
+            span_fast(r1, s, sd, in1, xmax, &L1, &R1);
+            L1 = max(L1, L); R1 = min(R1, R);
+            if (in1) add_span_fast(acc, arow, obx0, obw, L1, R1, -1);
+            else { L1 = 1; R1 = 0; }
+          }
+          const bool want2 = want && p2 != 255;
+          if (__ballot(want2)) {
+            const uint32_t* r2 = C.rec(want2 ? p2 : q);
+            const int2 rg2 = *reinterpret_cast<const int2*>(r2 + 16);
+            const bool in2 = want2 && s >= rg2.x && s < rg2.y;
+            if (__ballot(in2)) {
+              span_fast(r2, s, sd, in2, xmax, &L2, &R2);
+              L2 = max(L2, L); R2 = min(R2, R);
+              if (in2) {
+                add_span_fast(acc, arow, obx0, obw, L2, R2, -1);
+                if ((hd.w >> 16) & 1) add_span_fast(acc, arow, obx0, obw, max(L1, L2), min(R1, R2), 1);
+              }
+            }
+          }
+        }
+      }
+      C.sync();
+    }
+  }
+  if (SFTD_STOP == 3) return;
   // ---- pixels: object after object (the reference composites its strokes in order; boxes of different objects may overlap)
   for (int o = 0; o < nobj; o++) {
     const uint32_t* ob = C.obj(o);
@@ -928,7 +1043,6 @@ __device__ __forceinline__ bool raster_fast(const CtxF& C, const sft::Quad& mine
   }
   for (int i = lane; i < (tot_pix + 1) / 2; i += 64) acc[i] = 0u;
   C.sync();
-  return true;
 }
 
 }  // namespace sftd
