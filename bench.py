@@ -139,6 +139,32 @@ def committed_profile(gametype, envs, obs_type):
     w = rep.get("workload", {})
     if (w.get("gametype"), w.get("envs_per_gpu"), w.get("obs_type")) != (gametype, envs, obs_type):
         return {}
+    # the profile belongs to ONE build of the library (sf_build_id = the hash of its sources, stored by
+    # tools/profile_version.sh): replayed under any other build it is marked stale
+    try:
+        from spacefortress_amd import _lib
+        rep["loaded_build_id"] = _lib.lib().sf_build_id().decode()
+    except Exception:
+        rep["loaded_build_id"] = None
+    rep["stale"] = not (rep.get("sf_build_id") and rep.get("sf_build_id") == rep["loaded_build_id"])
+    return rep
+
+
+def committed_image_profile(envs):
+    """The render kernel's rocprofv3 --kernel-trace mean at the image config (profiles/image_kernel_latest.json, written by
+    tools/profile_version.sh from the same run as profiles/rNN_render_kernel_stats_*.csv), with the same stale rule."""
+    try:
+        rep = json.load(open(os.path.join(ROOT, "profiles", "image_kernel_latest.json")))
+    except Exception:
+        return {}
+    if rep.get("envs") != envs:
+        return {}
+    try:
+        from spacefortress_amd import _lib
+        rep["loaded_build_id"] = _lib.lib().sf_build_id().decode()
+    except Exception:
+        rep["loaded_build_id"] = None
+    rep["stale"] = not (rep.get("sf_build_id") and rep.get("sf_build_id") == rep["loaded_build_id"])
     return rep
 
 
@@ -456,6 +482,7 @@ def main():
 
     blocks, own_blocks, periods, with_ev = timed_blocks(graph, launch_ring, repeats)
     tpos[0] += K * repeats
+    env.check_state()  # after the timed blocks (every rank its own shard)
     med, order = pick(blocks, with_ev)
     elapsed = blocks[med]
     ev_blocks = sorted(blocks[r] for r in range(repeats) if with_ev[r])
@@ -498,6 +525,7 @@ def main():
         steady_total_ms += s0.elapsed_time(s1)
         n_steady += chunk
     steady_ms = steady_total_ms / n_steady
+    env.check_state()  # (raises on the sticky device error word: nothing below is reported for a batch that overflowed)
 
     # ---- the only collective of the path, outside the timed blocks and timed on its own: 64 bytes over RCCL
     sync()
@@ -598,17 +626,25 @@ def main():
         ims = e0.elapsed_time(e1) / isteps
         floor_us = (ni * (84 * 84 + 1200)) / 6.3e12 * 1e6  # 7 056 B written + about 1.2 KB of state read per env at 6.3 TB/s
         i_ach = IMAGE_ALGO_BYTES * ni / (ims * 1e-3) / 1e9
-        image_obs = {"value": ni / ims * 1e3, "unit": "env-steps/s", "envs": ni, "steps": isteps, "us_per_step": ims * 1e3,
+        iprof = committed_image_profile(ni)
+        ienv.check_state()
+        image_obs = {"state_ok": True,
+                     "kernel": "sf_render_kernel<true>", "kernel_ms_rocprof": iprof.get("kernel_ms_rocprof"),
+                     "kernel_ms_rocprof_median": iprof.get("kernel_ms_rocprof_median"),
+                     "kernel_ms_rocprof_stale": iprof.get("stale") if iprof else None,
+                     "kernel_ms_rocprof_source": ("rocprofv3 --kernel-trace mean of build %s (profiles/%s), replayed"
+                                                  % (iprof.get("sf_build_id"), iprof.get("stats_file"))) if iprof else None,
+                     "value": ni / ims * 1e3, "unit": "env-steps/s", "envs": ni, "steps": isteps, "us_per_step": ims * 1e3,
                      "frame_bytes_per_step": ni * 84 * 84, "frames_GBps": ni * 84 * 84 / ims / 1e6,
                      "output_floor_us": floor_us, "frac_of_output_floor": floor_us / (ims * 1e3),
                      "roofline": {"bound": "hbm", "achieved": i_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": i_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": IMAGE_ALGO_BYTES,
                                   "note": "SURVEY 8(d)'s 7 448 B per env-step over the whole step (sf_step + sf_render_stack); "
-                                          "the render kernel is issue-bound, not memory-bound (DESIGN.md 5)"},
+                                          "the render kernel restates cairo's scan converter exactly and is latency- / issue-bound, not memory-bound (DESIGN.md 5)"},
                      "note": "BASELINE configs[4]: youturn image obs, 84x84 grey raster + 4-frame stack (device ring "
                              "[N,4,84,84], one new frame per env and step, finished envs' older slots zeroed by the same launch), "
                              "sf_step + sf_render_stack per step; one wave per env rasterises the 90x92 frame in LDS (INTER_AREA to 84x84); HIP "
-                             "events; pixel model pinned to the numpy restatement, not to cairo/cv2 (DESIGN.md 5)"}
+                             "events; every frame equals the reference's own cairo 1.16 renderer bit for bit (tests/golden/frames, DESIGN.md 5)"}
         ienv.close()
     configs = None
     if solo and not args.no_configs:
@@ -707,11 +743,16 @@ def main():
             nb = ctypes.c_size_t()
             _lib.check(_lib.lib().sf_calibration_copy(env._h, which, ctypes.byref(nb)))
 
+    env.check_state()
+    state_ok = True  # (check_state raises otherwise)
     if rank == 0:
         total_steps = float(n) * K * world
         value = total_steps / elapsed
         algo = ALGO_BYTES[args.gametype] * n
-        achieved = algo / (region_ms * 1e-3) / 1e9
+        # `achieved` / `frac`: the algorithmic bytes of one launch over ms_per_step of the blocks that give `value` (the same
+        # clock as `value`); the HIP-event launch period of the event-carrying blocks stands beside it as a labelled extra
+        achieved = algo / (elapsed / K) / 1e9
+        achieved_event = algo / (region_ms * 1e-3) / 1e9
         prof = committed_profile(args.gametype, n, args.obs_type)
         out = {
             "metric": METRIC,
@@ -754,18 +795,27 @@ def main():
                                       "collective" % (world, n * world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "frac_source": "algorithmic_bytes_per_launch / ms_per_step (the blocks that give `value`)",
+                         "achieved_event_period": achieved_event, "frac_event_period": achieved_event / HBM_PEAK_GBS,
+                         "event_period_note": "the same bytes over launch_period_ms: HIP events around the launches of the "
+                                              "event-carrying blocks (end of the first launch to end of the last)",
                          "frac_note": "of the 8 TB/s HBM spec peak; the 77 MB state of this workload is Infinity-Cache "
                                       "resident (256 MB), so the bytes mostly move between L2 and the Infinity Cache",
                          "measured_copy_ceiling_GBps": copy_gbs,
                          "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                          "traffic": prof.get("traffic_bytes_per_launch"),
+                         "stale": prof.get("stale") if prof else None,
+                         "profile_build_id": prof.get("sf_build_id") if prof else None,
+                         "loaded_build_id": prof.get("loaded_build_id") if prof else None,
+                         "stale_note": "traffic and kernel_ms_rocprof are replayed from the committed rocprofv3 runs of the "
+                                       "build named in profile_build_id; stale = the loaded library is another build",
                          "traffic_source": ("replayed from the committed rocprofv3 --pmc passes of kernel version %s "
                                             "(profiles/%s), not measured by this run" % (prof.get("version"), prof.get("pmc_file")))
                                            if prof else None,
                          "kernel": "sf_step_kernel", "launch_period_ms": region_ms,
                          "launch_period_steady_ms": steady_ms, "frac_steady": algo / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "steady_note": "%d back-to-back launches (%.1f s of the Python loop) outside the timed blocks; `achieved` / "
-                                        "`frac` use the timed region's period, which for a block of a few launches includes its "
+                                        "`frac` use the timed blocks' ms_per_step, which for a block of a few launches includes its "
                                         "start on an idle GPU" % (n_steady, steady_total_ms * 1e-3),
                          "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
                          "kernel_ms_rocprof_median": prof.get("kernel_ms_rocprof_median"),
@@ -774,6 +824,10 @@ def main():
                          "kernel_ms_event_pair_mean": kern_ms, "kernel_ms_event_pair_median": kern_ms_med,
                          "algorithmic_bytes_per_launch": algo, "launches_timed": K},
             "cpu_baseline": base,
+            "state_ok": state_ok,
+            "state_ok_note": "env.check_state() (sf_check_state: the sticky device-side words -- a split launch's hand-over that timed "
+                             "out, a per-episode counter or key timer that left its packed width) after the timed blocks, after the steady "
+                             "region and at the end: it raises on any error, so a line that prints has passed all three",
             "ranks": ranks,
             "rccl_world": rccl_world,
             "rollout_fused": fused,

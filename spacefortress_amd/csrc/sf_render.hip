@@ -1010,7 +1010,8 @@ static_assert(((SF_BAR_BOX_Y1 - SF_BAR_BOX_Y0) * SF_HUD_BAR_ROW + 15) / 16 * 16 
 
 template <bool RESIZE>
 #ifndef SF_RENDER_WPE
-#define SF_RENDER_WPE 4 /* waves per SIMD the register budget is held to (128 VGPRs); LDS -- 9.9 KB per frame -- allows 16 workgroups per CU = 4 per SIMD */
+#define SF_RENDER_WPE 3 /* waves per SIMD the register budget is held to (168 VGPRs, some thirty spilled: measured 184 against 202 us
+                            at two waves); LDS -- 14 KB per frame -- allows 11 workgroups per CU */
 #endif
 __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];

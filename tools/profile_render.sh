@@ -4,6 +4,7 @@
 #   rNN_render_probe_vNN.txt          tools/image_probe.py 16384 300 image, unprofiled (step+render and render alone, HIP events)
 #   rNN_render_kernel_stats_vNN.csv   rocprofv3 --kernel-trace --stats of the same command
 #   rNN_pmc_render_vNN.txt            SQ instruction mix, wait / active cycles (tools/pmc_render.sh)
+#   image_kernel_latest.json          what bench.py replays as image_obs.kernel_ms_rocprof (with the library's sf_build_id)
 set -e
 RND=$1; VER=$2
 R=$GRAFT_REPO_ROOT
@@ -15,9 +16,25 @@ echo "probe done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/tools/image_probe.py 16384 300 image > /dev/null 2>&1
 ST=$(find $OUT/kt -name "*kernel_stats.csv" | head -1)
 cp $ST $OUT/${RND}_render_kernel_stats_${VER}.csv
+TR=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
+cd $R
+python3 - "$TR" "$OUT" "$RND" "$VER" <<'PY'
+import csv, json, os, sys
+tr, out, rnd, ver = sys.argv[1:5]
+sys.path.insert(0, os.getcwd())
+from spacefortress_amd import _lib
+d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr))
+           if "sf_render_kernel<true>" in r["Kernel_Name"])
+rep = {"version": "%s_%s" % (rnd, ver), "sf_build_id": _lib.lib().sf_build_id().decode(), "envs": 16384,
+       "kernel": "sf_render_kernel<true>", "calls": len(d), "kernel_ms_rocprof": sum(d) / len(d) * 1e-6,
+       "kernel_ms_rocprof_median": d[len(d) // 2] * 1e-6, "stats_file": "%s_render_kernel_stats_%s.csv" % (rnd, ver),
+       "note": "rocprofv3 --kernel-trace of tools/image_probe.py 16384 300 image (youturn, random actions, 400 steps in): per-dispatch "
+               "End - Start of sf_render_kernel<true>; what bench.py replays as image_obs.kernel_ms_rocprof"}
+json.dump(rep, open(os.path.join(out, "image_kernel_latest.json"), "w"), indent=1)
+print(json.dumps(rep))
+PY
 rm -rf $OUT/kt
 echo "kernel trace done"
-cd $R
 bash tools/pmc_render.sh spacefortress_amd/libsfmi.so gpurun_out/profiles_render_${RND}_${VER}/${RND}_pmc_render_${VER}.txt > /dev/null 2>&1
 echo "pmc done"
 cat $OUT/${RND}_render_probe_${VER}.txt

@@ -51,14 +51,17 @@ json.dump(rep, open(os.path.join(out, "%s_kernel_trace_%s_step65536.json" % (rnd
 main = [k for k in rep if k.endswith("grid 131072") and ", false, 1, false, 1256>" in k] or \
        [k for k in rep if k.endswith("grid 65536") and ", false, 1, false, 256>" in k]
 t = json.load(open(os.path.join(out, "%s_pmc_traffic_%s.json" % (rnd, ver))))
-latest = {"version": "%s_%s" % (rnd, ver), "workload": t["workload"], "kernel": "sf_step_kernel",
+sys.path.insert(0, os.getcwd())
+from spacefortress_amd import _lib
+latest = {"version": "%s_%s" % (rnd, ver), "sf_build_id": _lib.lib().sf_build_id().decode(),
+          "workload": t["workload"], "kernel": "sf_step_kernel",
           "traffic_bytes_per_launch": t["traffic_bytes_per_launch"], "read_bytes_per_launch": t["read_bytes_per_launch"],
           "write_bytes_per_launch": t["write_bytes_per_launch"], "pmc_file": "%s_pmc_traffic_%s.json" % (rnd, ver),
           "kernel_ms_rocprof": rep[main[0]]["mean_ns"] * 1e-6 if main else None,
           "kernel_ms_rocprof_median": rep[main[0]]["median_ns"] * 1e-6 if main else None,
           "trace_file": "%s_kernel_trace_%s_step65536.json" % (rnd, ver),
-          "note": "what bench.py replays as roofline.traffic / roofline.kernel_ms_rocprof; rewritten by tools/profile_version.sh "
-                  "with every profiled kernel version"}
+          "note": "what bench.py replays as roofline.traffic / roofline.kernel_ms_rocprof (marked stale when the loaded library's "
+                  "sf_build_id is not this one); rewritten by tools/profile_version.sh with every profiled kernel version"}
 json.dump(latest, open(os.path.join(out, "step_kernel_latest.json"), "w"), indent=1)
 print(json.dumps(latest))
 PY
