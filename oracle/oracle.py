@@ -61,7 +61,10 @@ def build(force=False):
     ):
         subprocess.check_call(["make", "-C", HERE, "liboracle"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/python/spacefortress/src"):
-        subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+        # the reference engine; and, where the image has cairo (the build container: /opt/conda), its real renderer, its real
+        # CPython extension and the cairo probe -- what the fixtures under tests/golden/{frames,getters} were recorded from
+        subprocess.check_call(["make", "-C", HERE, "ref", "refdraw", "refpy", "cairoprobe"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
 
 
 def oracle_lib():

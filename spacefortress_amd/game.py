@@ -114,12 +114,15 @@ class Game:
 
     @property
     def pb_pixels(self):
-        """The surface as the reference exposes it: RGB24 rows of 4 bytes per pixel (B, G, R, x)."""
+        """The surface as the reference exposes it: rows of 4 bytes per pixel (B, G, R, x); the grey value three times and
+        255 -- what cairo's ARGB32 surface holds there behind an opaque paint (tests/golden/getters: `frames`)."""
         f = getattr(self, "_frame", None)
         if f is None:
             self.draw()
             f = self._frame
-        return np.repeat(f[:, :, None], 4, axis=2).tobytes()
+        px = np.repeat(f[:, :, None], 4, axis=2)
+        px[:, :, 3] = 255
+        return px.tobytes()
 
     def config(self, key):
         p = self._preset
@@ -242,14 +245,17 @@ class Game:
         """The tick's mEvents (SRC/game.cpp:124-127 and its addEvent call sites) from the recorded key calls
         and the state before / after, in stepOneTick's phase order (:473-485)."""
         ev = []
-        new_missile = (int(a["missile_mask"]) | self._gone_missiles(b, a)) & ~int(b["missile_mask"])
+        # fireMissile (SRC/game.cpp:175-191) makes a missile -- and the event -- when the ship is alive and one of the twenty
+        # slots is free; the slots the lanes keep are not the reference's (a hit and a shot in one tick may leave the same
+        # mask), so the conditions are evaluated as written there, on the state before the tick
+        new_missile = bool(int(b["flags"]) & 1) and bin(int(b["missile_mask"])).count("1") < 20
         fire_was = bool(int(b["flags"]) & 4)
         for pressed, sym in self._calls:                                     # processKeyState :218-272
             ev.append(("press-" if pressed else "release-") + _KEY_NAME[sym])
             if sym == FIRE_KEY:
                 if pressed and not fire_was and new_missile:
                     ev.append("missile-fired")                               # :186
-                    new_missile = 0
+                    new_missile = bin(int(b["missile_mask"])).count("1") + 1 < 20
                 fire_was = pressed
         sb, sa = b["stats"], a["stats"]
         if not (int(b["flags"]) & 1) and (int(a["flags"]) & 1 or sa[3] > sb[3]):
@@ -275,10 +281,6 @@ class Game:
     @staticmethod
     def _missiles_gone_count(b, a):
         return bin(int(b["missile_mask"]) & ~int(a["missile_mask"])).count("1")
-
-    @staticmethod
-    def _gone_missiles(b, a):
-        return 0  # a missile created and removed inside one tick cannot be seen in the masks
 
     @staticmethod
     def _shell_fired_and_gone(b, a):

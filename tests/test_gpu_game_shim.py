@@ -1,6 +1,7 @@
-"""The `Game`-shaped single-lane view (spacefortress.core.Game) against the REAL reference engine: the
-recorded runs of tests/golden (state, raw engine reward of every tick) and the dumpState() strings recorded
-from oracle/_ref (tests/golden/telemetry/dumps.npz), character for character."""
+"""The `Game`-shaped single-lane view (spacefortress.core.Game) against the REAL reference: what every attribute of the
+reference's own CPython extension returned tick by tick (tests/golden/getters, recorded from `_spacefortress` built from
+SRC/pymodule.cpp: make_getters_golden.py), the recorded runs of tests/golden (state, raw engine reward of every tick) and the
+dumpState() strings recorded from oracle/_ref (tests/golden/telemetry/dumps.npz), character for character."""
 import json
 import os
 
@@ -67,6 +68,61 @@ def test_game_shim_replays_the_reference(name):
         g.max_points
     with pytest.raises(ValueError):
         g.step_one_tick(33)
+    g.close()
+
+
+GETTER_RUNS = ["autoturn_destroy", "youturn_deaths", "youturn_rapid_fire", "youturn_allkeys", "autoturn_allkeys",
+               "autoturn_small_hex", "youturn_hunter", "testyouturn_random", "testautoturn_random"]
+
+
+@pytest.mark.parametrize("name", GETTER_RUNS)
+def test_game_shim_equals_the_real_extensions_getters(name):
+    """Every attribute of SRC/pymodule.cpp:372-411 but the three undefined ones, after every tick, as the reference's own
+    extension module returned it for the same key calls (ENV:213-231): floats to the bit, tuples element by element --
+    `shells` is the reference's walk over the MISSILES (:131-134), `stats` the 15-tuple (:78-96), `timers` (:98-105),
+    `events`, `collisions`, the four duration vectors, `pb_pixels` after draw() outside the score's text rows."""
+    import spacefortress.core as sf
+    z = np.load(os.path.join(GOLDEN, "getters", name + ".npz"))
+    keys = np.load(os.path.join(GOLDEN, name + ".npz"))["keys"]
+    meta = json.loads(str(z["meta"]))
+    youturn = meta["gametype"] in ("youturn", "test-youturn")
+    kw = dict(meta["kwargs"], viewport=tuple(meta["kwargs"]["viewport"]))
+    g = sf.Game(meta["gametype"], seed=meta["seed"], **kw)
+    assert set(meta["undefined"]) == {"vulnerability_time", "vulnerability_timer", "max_points"} and len(meta["getters"]) == 37
+    vectors = ("thrust_durations", "shot_durations", "shot_intervals_invul", "shot_intervals_vul")
+    scalars = [k for k in meta["getters"] if k in z.files and z[k].ndim == 1 and k not in ("events", "collisions") + vectors]
+    assert len(scalars) == 23, scalars
+    mi, frames = 0, dict(zip(z["frame_ticks"].tolist(), z["frames"]))
+    for t in range(len(keys)):
+        drive(g, int(keys[t]), youturn)
+        assert g.step_one_tick(34) == int(z["eng_reward"][t]), t
+        for k in scalars:
+            got, want = getattr(g, k), z[k][t]
+            assert type(got) is (bool if z[k].dtype == np.uint8 else float if z[k].dtype == np.float64 else int), (k, type(got))
+            if k in ("aim", "vdir", "ndist"):
+                # Game::calculateExtra's bearings (SRC/game.cpp:304-322): the lanes' own degrees arithmetic (sf_deg_dd.h) against
+                # glibc's atan2 * 180 / pi -- 1e-9 where north_star allows 1e-5; every whole-degree decision they feed is exact
+                assert abs(got - want) < 1e-9, (t, k, got, want)
+            else:
+                assert got == want, (t, k, got, want)
+        assert g.stats == tuple(int(v) for v in z["stats_i"][t]) + tuple(float(v) for v in z["stats_d"][t]), t
+        assert g.timers == tuple(int(v) for v in z["timers"][t]), t
+        n = int(z["n_missiles"][t])
+        want = tuple(tuple(float(v) for v in row) for row in z["missiles"][mi:mi + n])
+        assert g.missiles == want and g.shells == tuple(tuple(float(v) for v in row) for row in z["shells"][mi:mi + n]), t
+        assert len(g.shells) == int(z["n_shells"][t])
+        mi += n
+        assert g.events == tuple(e for e in str(z["events"][t]).split(",") if e), (t, g.events, z["events"][t])
+        assert g.collisions == tuple(e for e in str(z["collisions"][t]).split(",") if e), (t, g.collisions, z["collisions"][t])
+        for k in ("thrust_durations", "shot_durations", "shot_intervals_invul", "shot_intervals_vul"):
+            assert len(getattr(g, k)) == int(z[k + "_len"][t]), (t, k)
+        assert g.is_game_over() == bool(z["game_over"][t])
+        if t in frames:
+            g.draw()
+            got = np.frombuffer(g.pb_pixels, np.uint8).reshape(92, 90, 4)
+            assert np.array_equal(got[9:], frames[t].reshape(92, 90, 4)[9:]), t  # (rows 0 .. 8: the score's toy-font text)
+    for k in ("thrust_durations", "shot_durations", "shot_intervals_invul", "shot_intervals_vul"):
+        assert len(z[k + "_games"]) == 1 and getattr(g, k) == tuple(int(v) for v in z[k]), k
     g.close()
 
 
