@@ -1,7 +1,8 @@
 """SSF_Env -- the single-environment gym.Env surface of the reference (ENV:43-269), as a
 batch-of-one view over the HIP engine.  Same constructor arguments, `action_space`,
 `observation_space`, `reset()`, `step(a) -> (obs, int reward, bool done, bool info)`,
-`tickdur`, `max_ticks`, `actions_taken`.  Like the reference it does NOT auto-reset.
+`tickdur`, `max_ticks`, `actions_taken`, `g` (the env's Game, ENV:164), `np_random` (ENV:159-161).  Like the reference it
+does NOT auto-reset.
 """
 import numpy as np
 
@@ -57,17 +58,38 @@ class SSF_Env(_Base):
             from .spaces import Box
             self.observation_space = Box(0, 255, (self.h, self.w, 3), np.uint8)
         self.actions_taken = {i: 0 for i in range(self.action_space.n)}  # ENV:91
+        self._g = None
+        self.np_random = None
         # ENV:93: __init__ ends with reset(), i.e. the first Game -- sf_create already made it
 
-    def seed(self, seed=None):  # ENV:159-161: seeds an RNG the game never reads
+    @property
+    def g(self):
+        """The env's Game (ENV:164 `self.g = sf.Game(...)`): a `spacefortress.core.Game`-shaped view over this env's own lane
+        (game.py: Game._over) -- `env.g.points`, `.missiles`, `.timers`, `.stats`, `.events`, `.dump()`, `.draw()` /
+        `.pb_pixels`.  Made on first use; from then on step() reports the tick's key calls to it (events, duration vectors)."""
+        if self._g is None:
+            from .game import Game
+            self._g = Game._over(self._vec, self.gametype, self.action_set, self.w, self.h)
+        return self._g
+
+    def seed(self, seed=None):
+        """ENV:159-161: `self.np_random, seed = seeding.np_random(seed)` -- an RNG the game never reads (the ship's spawn comes
+        from the C library's rand(), SRC/game.cpp:137-148).  np_random is a numpy RandomState seeded with `seed`."""
+        self.np_random = np.random.RandomState(None if seed is None else int(seed) & 0xFFFFFFFF)
         return [seed]
 
     def reset(self):
+        if self._g is not None:
+            self._g._new_game()
         return self._vec.reset(numpy=True)[0]
 
     def step(self, action):
         self.actions_taken[action] += 1  # KeyError for an unknown action, like ENV:211
-        obs, r, d, i = self._vec.step(np.array([action]))
+        if self._g is not None:
+            obs, r, d, i = self._g._env_tick(action, lambda: self._vec.step(np.array([action])))
+            self._g._obs = obs[0] if self.obs_type == "features" else None
+        else:
+            obs, r, d, i = self._vec.step(np.array([action]))
         self.last_action = action
         return obs[0], int(r[0]), bool(d[0]), bool(i[0])
 

@@ -54,6 +54,67 @@ class Game:
         p = _lib.Preset()
         _lib.check(_lib.lib().sf_preset_get(config.encode(), C.byref(p)))
         self._preset = p
+        self._owns = True
+
+    @classmethod
+    def _over(cls, vec, config, action_set, width, height):
+        """The Game of an SSF_Env (`env.g`, ENV:164): a view over the env's own batch of one -- the same lane the env steps,
+        no second engine.  Reading is what the reference offers on it (`env.g.points`, `.missiles`, `.timers`, `.stats`,
+        `dump()`, `draw()` / `pb_pixels`); the env's step() tells the view the key calls of the tick (_env_tick), so
+        `events` and the duration vectors follow the env's game."""
+        import ctypes as C
+        import torch
+        from . import _lib
+
+        g = cls.__new__(cls)
+        g._torch, g._C, g._lib = torch, C, _lib
+        g._vec = vec
+        keys = (C.c_uint8 * 16)()
+        n = _lib.lib().sf_action_table(config.encode(), int(action_set), keys)
+        g._action_of = {int(keys[i]): i for i in range(n)}
+        g._keys_of = [int(keys[i]) for i in range(n)]
+        g._n_keys = 4 if config in ("youturn", "test-youturn") else 2
+        g._config = config
+        g._keys = 0
+        g._calls = []
+        g._events = ()
+        g.thrust_durations, g.shot_durations = (), ()
+        g.shot_intervals_invul, g.shot_intervals_vul = (), ()
+        g._obs = None
+        g._sd = None
+        g.pb_width, g.pb_height = width, height
+        p = _lib.Preset()
+        _lib.check(_lib.lib().sf_preset_get(config.encode(), C.byref(p)))
+        g._preset = p
+        g._owns = False
+        return g
+
+    def _env_tick(self, action, step):
+        """One SSF_Env.step through the view: the key calls ENV:213-229 makes for `action` (fire, thrust, then left, right
+        in the game types that turn), the tick itself (`step()`: the env's own call into the batch), the tick's events."""
+        keys = self._keys_of[action]
+        self._calls = [(bool(keys & 1), FIRE_KEY), (bool(keys & 2), THRUST_KEY)]
+        if self._n_keys == 4:
+            self._calls += [(bool(keys & 4), LEFT_KEY), (bool(keys & 8), RIGHT_KEY)]
+        self._keys = keys
+        self._sd = None
+        before = self._state()
+        self._telemetry_vectors(before)
+        out = step()
+        self._sd = None
+        after = self._state()
+        self._events = tuple(self._derive_events(before, after))
+        self._calls = []
+        return out
+
+    def _new_game(self):
+        """SSF_Env.reset(): `self.g = sf.Game(...)` -- the vectors and events of a fresh Game."""
+        self._keys, self._calls, self._events = 0, [], ()
+        self.thrust_durations, self.shot_durations = (), ()
+        self.shot_intervals_invul, self.shot_intervals_vul = (), ()
+        self._obs, self._sd = None, None
+        if hasattr(self, "_frame"):
+            del self._frame
 
     # ------------------------------------------------------------------ methods (SRC/pymodule.cpp:361-370)
     def press_key(self, sym):
@@ -71,6 +132,9 @@ class Game:
         self._keys = (self._keys | _KEY_BIT[sym]) if pressed else (self._keys & ~_KEY_BIT[sym])
 
     def step_one_tick(self, ms):
+        if not self._owns:
+            raise RuntimeError("this Game is an SSF_Env's (env.g): the env steps it (env.step); a Game of its own is "
+                               "spacefortress.core.Game(...)")
         if ms != self._vec.tickdur:
             raise ValueError("the device engine ticks in %d ms steps (ENV:61)" % self._vec.tickdur)
         before = self._state()
@@ -137,7 +201,8 @@ class Game:
         return table[key]
 
     def close(self):
-        self._vec.close()
+        if self._owns:
+            self._vec.close()
 
     # ------------------------------------------------------------------ state
     def _state(self):
@@ -181,7 +246,8 @@ class Game:
 
     def _extra(self, i):
         if self._obs is None:
-            raise AttributeError("vdir / aim / ndist are defined after the first tick (mExtra is uninitialised before)")
+            raise AttributeError("vdir / aim / ndist are defined after the first tick (mExtra is uninitialised before); on an "
+                                 "SSF_Env's Game they are read from the env's 'features' observation")
         return float(self._obs[i])
 
     aim = property(lambda s: s._extra(6))    # feature order ENV:134-157

@@ -126,6 +126,47 @@ def test_game_shim_equals_the_real_extensions_getters(name):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["youturn_rapid_fire", "autoturn_destroy"])
+def test_an_envs_own_game_follows_the_envs_steps(name):
+    """`env.g` (ENV:164): rl/envs.py:10-16-style code makes the env with gym.make, wraps it, and scripts reach through to
+    `env.g.points`, `.missiles`, `.events`...  The recorded run's ACTIONS go through SSF_Env.step; after every step the
+    env's Game shows what the reference's extension showed for the same tick (tests/golden/getters)."""
+    import spacefortress.gym as sfg
+    z = np.load(os.path.join(GOLDEN, "getters", name + ".npz"))
+    gz = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+
+    # rl/envs.py:10-16: gym.make(env_id) -> env.seed(seed + rank) -> wrapper; the symbolic observation is an explicit kwarg
+    env = sfg.make_env("SpaceFortress-%s-image-v0" % meta["gametype"].replace("-", ""), 3, 1, obs_type="features",
+                       action_set=meta["action_set"])()
+    assert env.np_random is not None and 0 <= env.np_random.randint(10) < 10  # ENV:159-161
+    g = env.g
+    assert g is env.g and g.points == 0.0 and g.tick == 0 and g.missiles == ()
+    mi = 0
+    for t, a in enumerate(gz["actions"]):
+        obs, r, done, info = env.step(int(a))
+        assert r == int(gz["reward"][t]) and done == bool(gz["done"][t]) and info == bool(gz["info"][t]), t
+        assert (g.tick, g.time, g.vulnerability) == (int(z["tick"][t]), int(z["time"][t]), int(z["vulnerability"][t])), t
+        assert (g.ship_x, g.ship_y, g.points, g.raw_points) == tuple(float(z[k][t]) for k in ("ship_x", "ship_y", "points", "raw_points")), t
+        n = int(z["n_missiles"][t])
+        assert g.missiles == tuple(tuple(float(v) for v in row) for row in z["missiles"][mi:mi + n]) and len(g.shells) == n, t
+        mi += n
+        assert g.stats == tuple(int(v) for v in z["stats_i"][t]) + tuple(float(v) for v in z["stats_d"][t]), t
+        assert g.timers == tuple(int(v) for v in z["timers"][t]), t
+        assert g.events == tuple(e for e in str(z["events"][t]).split(",") if e), (t, g.events)
+        assert abs(g.aim - z["aim"][t]) < 1e-9 and abs(g.vdir - z["vdir"][t]) < 1e-9 and abs(g.ndist - z["ndist"][t]) < 1e-9
+        assert len(obs) == (19 if meta["gametype"] == "youturn" else 17) and obs[11] == g.vulnerability  # ENV:134-157
+    for k in ("thrust_durations", "shot_durations", "shot_intervals_invul", "shot_intervals_vul"):
+        assert getattr(g, k) == tuple(int(v) for v in z[k]), k
+    g.draw()
+    assert len(g.pb_pixels) == 92 * 90 * 4
+    with pytest.raises(RuntimeError):
+        g.step_one_tick(34)  # the env steps its Game
+    env.reset()  # ENV:164: a new Game
+    assert env.g.tick == 0 and env.g.events == () and env.g.shot_durations == ()
+    env.close()
+
+
 def test_game_shim_errors():
     import spacefortress.core as sf
     with pytest.raises(RuntimeError):

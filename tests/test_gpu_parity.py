@@ -578,13 +578,40 @@ def test_bearings_a_whisker_off_the_axes(sfa, oracle_mod, gametype):
     env.close()
 
 
+def _atan2_correctly_rounded(y, x):
+    """atan2(y, x) of two doubles, correctly rounded, by 70-digit arithmetic: the libm value t0 plus
+    atan((y cos t0 - x sin t0) / (x cos t0 + y sin t0)), sin and cos of t0 by their series."""
+    import math
+    from decimal import Decimal, getcontext
+    getcontext().prec = 70
+    t0 = math.atan2(y, x)
+    T = Decimal(t0)
+    s, c, term, k = Decimal(0), Decimal(0), Decimal(1), 0
+    while abs(term) > Decimal(10) ** -68:
+        if k % 2 == 0:
+            c += term if k % 4 == 0 else -term
+        else:
+            s += term if k % 4 == 1 else -term
+        k += 1
+        term = term * T / k
+    Y, X = Decimal(y), Decimal(x)
+    t = (Y * c - X * s) / (X * c + Y * s)
+    theta = T + t - t ** 3 / 3  # (|t| < 1e-15: the next term is below 1e-75)
+    cands = [t0, math.nextafter(t0, math.inf), math.nextafter(t0, -math.inf)]
+    return min(cands, key=lambda v: abs(Decimal(v) - theta))
+
+
 @pytest.mark.parametrize("gametype", ["autoturn", "youturn"])
 def test_bearings_on_exact_degree_rays(sfa, oracle_mod, gametype):
     """Ships on (and an ulp or two off) the rays of integer degrees from the fortress -- where an autoturn ship that
-    thrusts at the fortress flies.  ceil() of the bearing follows the last bit of atan2 there; the device forms it
-    correctly rounded (sf_atan2, RAZOR), glibc mis-rounds about 0.08 % of such arguments itself (tools/atan2_razor),
-    so a handful of differences in a few thousand are the reference's; the plain device libm differs in a large
-    fraction of them."""
+    thrusts at the fortress flies.  ceil() of the bearing follows the last bit of atan2 there.  The device forms atan2
+    correctly rounded (sf_atan2, RAZOR); the reference calls glibc 2.35's, whose dbl-64 atan2 returns its last stage's
+    value without the multi-precision check older versions had, and is off by one ulp on about 0.08 % of such arguments
+    (tools/atan2_razor).  Reproducing THOSE roundings would take glibc's own tables (sysdeps/ieee754/dbl-64/uatan.tbl,
+    atnat2.h: not in this image, no network), so the statement tested is: wherever device and reference differ, the
+    argument is one that glibc itself does not round correctly -- arbitrated here with 70-digit arithmetic --, and
+    there are few of them; everywhere else the two are identical.  (The plain device libm differs in a large fraction.)"""
+    import math
     O = oracle_mod
     rng = np.random.default_rng(11)
     pts = []
@@ -607,6 +634,14 @@ def test_bearings_on_exact_degree_rays(sfa, oracle_mod, gametype):
     sd, sn = env.state_dict(), orc.snapshots()
     diff = (sd["fort_angle"].astype(np.float64) != sn["fort_angle"]) | (sd["ship_angle"].astype(np.float64) != sn["ship_angle"])
     assert diff.mean() <= 0.005, (int(diff.sum()), n, pts[diff][:5])
+    # every difference: glibc's atan2 of the lane's bearing argument (SRC/game.cpp:194-197, :317-319: fortress -> ship or
+    # ship -> fortress) is not the correctly rounded double
+    unexplained = []
+    for i in np.flatnonzero(diff):
+        dx, dy = float(sn["ship_x"][i]) - 355.0, float(sn["ship_y"][i]) - 315.0
+        if all(math.atan2(sy, sx) == _atan2_correctly_rounded(sy, sx) for sy, sx in ((dy, dx), (-dy, -dx))):
+            unexplained.append((float(sn["ship_x"][i]), float(sn["ship_y"][i])))
+    assert not unexplained, unexplained[:5]
     env.close()
 
 
