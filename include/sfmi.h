@@ -167,8 +167,10 @@ int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, 
  *      frames to obs_dev themselves (sf_obs_dim = 7056 / 8280 bytes per env); sf_rollout with
  *      obs_dev [n_steps][n_envs][frame] then issues its ticks as n_steps step launches, each followed
  *      by its frames (the fused launch keeps the state in registers), with obs_dev = NULL it stays fused;
- *      sf_rollout_sampled likewise.  Pixel-level anti-aliasing is this library's own model: see
- *      DESIGN.md "image observation". ---- */
+ *      sf_rollout_sampled likewise.  A batch with another geometry (sf_set_image_geometry) asks less of the buffers: 84x84
+ *      frames 4-byte aligned with env_stride a multiple of 4, raw frames any alignment.  The pixels are the reference's:
+ *      cairo 1.16's rasterisation of SRC/draw.cpp's paths, bit for bit outside the score's text rows (DESIGN.md "image
+ *      observation"; tests/golden/frames holds frames drawn by the reference's own renderer). ---- */
 int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, void* stream);
 
 /* ---- SSF_Env(scale, viewport, ls) (ENV:50-60 -> sf.Game(width = int(vw * scale), height = int(vh * scale), viewport, lw),

@@ -552,6 +552,11 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
       sf_set_error("sf_render_shift is built for the default image geometry; use sf_render_stack with this one");
       return SF_ERR_ARG;
     }
+    // (the general renderer writes an 84x84 frame in 32-bit words; the surface itself goes out with byte heads and tails)
+    if (mode == SF_OBS_IMAGE && ((((uintptr_t)frames_dev) | env_stride) & 3) != 0) {
+      sf_set_error("image frames of a non-default geometry must be 4-byte aligned and env_stride a multiple of 4");
+      return SF_ERR_ARG;
+    }
     SF_FLUSH_VIEW(b, stream);
     if (stack_done)  // `current_obs *= masks` for the finished envs, then the new frame into its slot
       HIP_TRY(sf_launch_stack_clear(frames_dev - (size_t)stack_slot * frame, (size_t)stack_n * frame, stack_done, b->n_envs, stream));

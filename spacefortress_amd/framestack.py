@@ -33,6 +33,7 @@ class FrameStack:
     def reset(self):
         """envs.reset() + update_current_obs(obs) on a zeroed stack (rl/train.py:43,60-61)."""
         e = self.env
+        e._touch()  # (a recording cannot go on across a reset: vecenv.py)
         _lib.check(e._L.sf_reset(e._h, None, e._stream()))
         self.ring.zero_()
         self.head = self.num_stack - 1
@@ -47,6 +48,7 @@ class FrameStack:
         at = {torch.uint8: 1, torch.int32: 4, torch.int64: 8}[actions.dtype]
         _lib.check(e._L.sf_step(e._h, C.c_void_p(actions.data_ptr()), at, None, C.c_void_p(self._rew.data_ptr()),
                                 C.c_void_p(self._done.data_ptr()), C.c_void_p(self._info.data_ptr()), e._stream()))
+        e._stepped(actions, self._rew, self._done, self._info)
         # the new frame into the next slot; finished envs get their other slots zeroed by the same launch
         # (current_obs *= masks, rl/train.py:92-93)
         self.head = (self.head + 1) % self.num_stack

@@ -60,6 +60,7 @@ class DeviceRollout:
     def reset(self):
         """obs = envs.reset(); rollouts.observations[0].copy_(obs) (rl/train.py:60-62)."""
         e = self.env
+        e._touch()  # (a recording cannot go on across a reset: vecenv.py)
         if self.num_stack > 1:  # update_current_obs on a zeroed stack (rl/train.py:43,60-62)
             _lib.check(e._L.sf_reset(e._h, None, e._stream()))
             self.observations[0].zero_()
@@ -113,6 +114,7 @@ class DeviceRollout:
                                                   P["mask"][step + 1], P["ep"], P["fin"], ap, at, P["act"][step], stream))
         else:
             self._step_record(ap, at, step, stream)
+        e._stepped(a, self._rew, self._done, self._info)  # (the engine's own int reward, whatever VecNormalize makes of it)
         if value_pred is not None:
             self.value_preds[step].copy_(value_pred)
         if action_log_prob is not None:
@@ -128,7 +130,13 @@ class DeviceRollout:
             # observations[step]: shift by a frame, zero the finished envs, new frame last
             _lib.check(self._L.sf_step_record(e._h, ap, at, None, P["r"], P["d"], P["i"], P["rew"][step],
                                               P["mask"][step + 1], P["ep"], P["fin"], P["act"][step], stream))
-            _lib.check(self._L.sf_render_shift(e._h, P["obs"][step], P["obs"][step + 1], self.num_stack, P["d"], stream))
+            if e.default_geometry:
+                _lib.check(self._L.sf_render_shift(e._h, P["obs"][step], P["obs"][step + 1], self.num_stack, P["d"], stream))
+            else:
+                # the general renderer (another surface geometry) draws into ONE slot: the shift is a copy here, then the new
+                # frame into the last slot with the finished envs' older slots zeroed by the same launch (sf_render_stack)
+                self.observations[step + 1][:, :-1].copy_(self.observations[step][:, 1:])
+                _lib.check(self._L.sf_render_stack(e._h, P["obs"][step + 1], self.num_stack, self.num_stack - 1, P["d"], stream))
             return
         # one launch: the step kernel's epilogue does the trainer's bookkeeping (sfmi.h: sf_step_record)
         _lib.check(self._L.sf_step_record(e._h, ap, at, P["obs"][step + 1], P["r"], P["d"], P["i"], P["rew"][step],

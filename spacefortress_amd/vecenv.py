@@ -65,6 +65,7 @@ class SFVecEnv:
         # what a replay file needs to make this batch again (spacefortress_amd/replay.py)
         self._create = {"action_set": int(action_set), "seed": int(seed) & 0xFFFFFFFF, "spawn_skip": int(spawn_skip),
                         "spawn_stride": int(spawn_stride), "auto_reset": bool(auto_reset)}
+        self.default_geometry = True
         self._fresh = True  # nothing has changed the state sf_create left: a recording may start here
         self._rec = None
         self.num_envs = int(num_envs)
@@ -181,6 +182,15 @@ class SFVecEnv:
         return obs, rew, done, info
 
     # ------------------------------------------------------------------ replay files (spacefortress_amd/replay.py)
+    def _stepped(self, actions, rew, done, info):
+        """THE hook behind every launch that steps the batch -- step_tensors / rollout / the *_sampled calls above, and the
+        wrappers that call the C ABI themselves (FrameStack.step, DeviceRollout.step, SFVecNormalize's fused step): the state is
+        no longer the one sf_create left, and a recording gets the actions with the engine's own (unnormalised) reward,
+        done and info of the step(s): [N] or [K, N] device tensors, not synchronised."""
+        self._fresh = False
+        if self._rec is not None:
+            self._rec.add(actions.to(torch.uint8), rew, done, info)
+
     def _touch(self):
         """The state is about to change otherwise than by a recorded step: a recording cannot go on."""
         self._fresh = False
@@ -330,6 +340,9 @@ class SFVecEnv:
         w, h = C.c_int32(), C.c_int32()
         _lib.check(self._L.sf_image_size(self._h, C.byref(w), C.byref(h)))
         self.image_w, self.image_h = int(w.value), int(h.value)
+        # (the default geometry's frame kernel also shifts a frame stack in the same launch -- sf_render_shift; the general
+        #  renderer draws into one slot: DeviceRollout asks)
+        self.default_geometry = (float(scale), (vx, vy, vw, vh), float(ls)) == (.2, (130., 80., 450., 460.), 3.)
         if self.obs_type == "image-raw":
             self.obs_shape = (self.image_h, self.image_w)
             self.obs_dim = self._L.sf_obs_dim(self._h)

@@ -77,6 +77,7 @@ class SFVecNormalize:
         p = lambda t: C.c_void_p(t.data_ptr())
         _lib.check(self._L.sf_step_normalize(v._h, self._h, p(actions), at, p(obs), p(rew), p(done), p(info), p(self._rew),
                                              0 if self.training else 1, self._stream()))
+        v._stepped(actions, rew, done, info)  # (rew: the engine's int reward; self._rew the normalised one)
         return obs, self._rew, done, info
 
     def step_async(self, actions):

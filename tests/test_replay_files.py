@@ -105,3 +105,50 @@ def test_record_save_load_replay(tmp_path):
     bad.actions[500, 17] = (bad.actions[500, 17] + 1) % 3
     with pytest.raises(ReplayMismatch):
         bad.run(chunk=256)
+
+
+@pytest.mark.gpu
+def test_the_trainers_wrappers_record_too(tmp_path):
+    """FrameStack.step, DeviceRollout.step and SFVecNormalize's fused step call the C ABI themselves; they report every launch to
+    the batch's one hook (SFVecEnv._stepped), so a recording made on the image / PPO paths holds the actions played and
+    verifies when replayed -- and a batch stepped only through a wrapper is no longer a new one."""
+    import torch
+
+    from spacefortress_amd import DeviceRollout, FrameStack, SFVecEnv, SFVecNormalize
+
+    N = 256
+    g = torch.Generator().manual_seed(5)
+    # a frame stack on an image batch
+    env = SFVecEnv(N, gametype="youturn", obs_type="image", spawn_stride=1, seed=3)
+    env.start_recording()
+    fs = FrameStack(env, 4)
+    acts = torch.randint(0, env.n_actions, (120, N), generator=g, dtype=torch.uint8).to(env.device)
+    for t in range(120):
+        fs.step(acts[t])
+    rp = env.save_replay(str(tmp_path / "stack.sfreplay"))
+    assert rp.actions.shape == (120, N) and np.array_equal(rp.actions, acts.cpu().numpy())
+    with pytest.raises(RuntimeError):
+        fs.reset()  # a reset ends a recording loudly, through the wrapper as well
+    env.close()
+    out = SFVecEnv.load_replay(str(tmp_path / "stack.sfreplay")).run(chunk=64)
+    assert np.array_equal(out["returns"], rp.returns) and out["digest"] == rp.digest
+    out["env"].close()
+    # the PPO path: a rollout buffer over a normalised features batch
+    env = SFVecEnv(N, gametype="autoturn", obs_type="features", spawn_stride=1, seed=9)
+    env.start_recording()
+    ro = DeviceRollout(SFVecNormalize(env), num_steps=16)
+    acts = torch.randint(0, env.n_actions, (48, N), generator=g, dtype=torch.int64).to(env.device)
+    for t in range(48):
+        ro.step(t % 16, acts[t])
+    rp = env.save_replay(str(tmp_path / "ppo.sfreplay"))
+    assert rp.actions.shape == (48, N) and np.array_equal(rp.actions, acts.cpu().numpy().astype(np.uint8))
+    env.close()
+    out = SFVecEnv.load_replay(str(tmp_path / "ppo.sfreplay")).run(chunk=16)
+    assert np.array_equal(out["returns"], rp.returns) and out["digest"] == rp.digest
+    out["env"].close()
+    # stepped through a wrapper only: not a new batch any more
+    env = SFVecEnv(N, gametype="youturn", obs_type="image")
+    FrameStack(env, 2).step(torch.zeros(N, dtype=torch.uint8, device=env.device))
+    with pytest.raises(RuntimeError):
+        env.start_recording()
+    env.close()
