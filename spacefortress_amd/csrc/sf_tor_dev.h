@@ -445,7 +445,7 @@ constexpr int kRecWordsF = 48;
 //              the vertical x = 0 / x = the surface's width: b0 | b1 << 12 | right border << 24; 0 = none
 //   46 47      the pixel rows a slot's edge spans whole, [lo, hi) as lo | hi << 8: L1 | L2 << 16, R1 | R2 << 16
 constexpr unsigned kRecBorder = 1u << 16, kRecThird = 1u << 17;
-constexpr int kHdrWordsF = 4;   // per quad, for the sub-rows' lanes: see raster_fast
+constexpr int kHdrWordsF = 8;   // per RUN of sub-rows (= per quad that has any), for the sub-rows' lanes; word 5: see raster_fast
 constexpr int kObjWordsF = 12;  // as kObjWords, + the rows that hold a vertex: 96 bits
 constexpr int kTasksF = 64;     // (row, quad) pairs taken whole, per round
 constexpr int kMapWordsF = 64;  // the sub-rows' enumeration: a bit per start of a quad's run, 2 048 sub-rows per round
@@ -460,7 +460,6 @@ struct CtxF {
   __device__ __forceinline__ uint32_t* hdr(int q) const { return lds + kMaxQuads * kRecWordsF + q * kHdrWordsF; }
   __device__ __forceinline__ uint32_t* obj(int o) const { return lds + kMaxQuads * (kRecWordsF + kHdrWordsF) + o * kObjWordsF; }
   __device__ __forceinline__ uint32_t* tasks() const { return obj(kMaxObjs); }  // [kTasksF], the count, "more rows than fit", (2 free)
-  __device__ __forceinline__ uint8_t* qtab() const { return reinterpret_cast<uint8_t*>(tasks() + kTasksF + 4); }  // [16]: the r-th run's quad
   __device__ __forceinline__ uint32_t* map() const { return tasks() + kTasksF + 8; }
   __device__ __forceinline__ uint32_t* acc() const { return lds + kAccAtF; }
   __device__ __forceinline__ void sync() const {
@@ -733,8 +732,14 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
     if (lane >= d) incl += a;
   }
   const int tot_sub = __builtin_amdgcn_readlane(incl, 63), start = incl - cnt;
+  if (valid) {  // the quad's extent in pixel columns, [lo, hi) clamped to a byte each: for the overlap test of the sub-rows' lanes
+    const int lo = min(min(mine.x[0], mine.x[1]), min(mine.x[2], mine.x[3])), hi = max(max(mine.x[0], mine.x[1]), max(mine.x[2], mine.x[3]));
+    C.hdr(qi)[5] = (uint32_t)(min(max(lo >> 8, 0), 255) | (min(max((hi + 255) >> 8, 0), 255) << 8));
+  }
   C.sync();
-  if (valid) {
+  // (which quad a run belongs to: the r-th run with sub-rows is the r-th such quad: its header sits at r)
+  const unsigned long long runs = __ballot(valid && cnt > 0);
+  if (valid && cnt > 0) {
     const uint32_t* ob = C.obj(oi);
     const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u);
     const int q0 = qi - kq, okind = kind & 255, m0 = kind >> 8, nq = nq_mine, k = kq;
@@ -743,18 +748,22 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
     if (okind == kKindLines3) { p1 = k >= 1 ? q0 : 255; p2 = k == 2 ? q0 + 1 : 255; triple = k == 2; }
     else if (okind == kKindShell) { p1 = k >= 1 ? q0 + k - 1 : 255; p2 = k == 3 ? q0 : 255; }
     else if (okind == kKindRing) { p1 = k == m0 ? q0 + m0 - 1 : (k == nq - 1 ? q0 : 255); }
-    *reinterpret_cast<int4*>(C.hdr(qi)) =
-        int4{start | (s_lo << 16), (int)ob[3] - oby0 * obw, obx0 | (obw << 8) | (oby0 << 16) | (oi << 24), p1 | (p2 << 8) | (triple << 16)};
+    // (the partners' pixel columns: word 5 of the header slot with the partner's NUMBER, written before the barrier above)
+    const int px1 = p1 != 255 ? (int)C.hdr(p1)[5] : 0, px2 = p2 != 255 ? (int)C.hdr(p2)[5] : 0;
+    const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(runs >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)runs, 0u));
+    uint32_t* h = C.hdr(rk);
+    *reinterpret_cast<int4*>(h) =
+        int4{start | (s_lo << 16), (int)ob[3] - oby0 * obw, obx0 | (obw << 8) | (oby0 << 16) | (oi << 24), p1 | (p2 << 8) | (triple << 16) | (qi << 24)};
+    h[4] = (uint32_t)(px1 & 0xffff) | ((uint32_t)(px2 & 0xffff) << 16);
   }
-  // (which quad a run belongs to: the r-th run with sub-rows is the r-th such quad)
-  const unsigned long long runs = __ballot(valid && cnt > 0);
-  if (valid && cnt > 0)
-    C.qtab()[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(runs >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)runs, 0u))] = (uint8_t)qi;
   C.sync();
   if (SFTD_STOP == 1) return;
-  auto find_obj = [&](int t, int which) {
+  // (row t of the enumeration belongs to the last object whose rows start at or before it: the starts come out of lanes
+  //  0 .. nobj - 1's registers -- scalar reads, no round trips to LDS)
+  const int row_start = rbase - bh;
+  auto find_obj = [&](int t, int) {
     int o = 0;
-    for (int j = 1; j < nobj; j++) o += t >= (int)C.obj(j)[which] ? 1 : 0;
+    for (int j = 1; j < nobj; j++) o += t >= __builtin_amdgcn_readlane(row_start, j) ? 1 : 0;
     return o;
   };
   // ---- rows: which are taken whole (can_do_full_row and the buckets: no vertex strictly inside the row, no two edges that change
@@ -958,7 +967,6 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
   // quads by inclusion-exclusion.  Which quad a lane's sub-row belongs to: a bit map of the runs' starts (a v_mbcnt pair and a
   // small table), kMapWordsF words of it per round.
   {
-    const uint8_t* qtab = C.qtab();
     constexpr int kRound = 32 * kMapWordsF;
     for (int p0 = 0; p0 < tot_sub; p0 += kRound) {
       if (p0 > 0) {
@@ -979,8 +987,10 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
         const int rk = kb + (int)__builtin_amdgcn_mbcnt_hi(mw.y, __builtin_amdgcn_mbcnt_lo(mw.x, 0u));
         kb += __popc(mw.x) + __popc(mw.y);
         const bool have = t < tot_sub;
-        const int q = have ? (int)qtab[rk] : 0;
-        const int4 hd = *reinterpret_cast<const int4*>(C.hdr(q));
+        const uint32_t* hp = C.hdr(have ? rk : 0);
+        const int4 hd = *reinterpret_cast<const int4*>(hp);
+        const unsigned pxr = hp[4];
+        const int q = (int)((unsigned)hd.w >> 24);
         const uint32_t* rc = C.rec(q);
         const int s = (int)((unsigned)hd.x >> 16) + t - (int)(hd.x & 0xffff);
         const int obx0 = hd.z & 255, obw = (hd.z >> 8) & 255, oby0 = (hd.z >> 16) & 255, o = (int)((unsigned)hd.z >> 24);
@@ -992,19 +1002,23 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
         span_fast(rc, s, sd, live, xmax, &L, &R);
         if (live) add_span_fast(acc, arow, obx0, obw, L, R, 1);
         const int p1 = hd.w & 255, p2 = (hd.w >> 8) & 255;
-        const bool want = live && R > L && p1 != 255;
+        // (a partner whose pixel columns the span does not reach shares nothing with it: most of a quad's sub-rows)
+        const bool near1 = R > (int)((pxr & 255u) << 8) && L < (int)(((pxr >> 8) & 255u) << 8);
+        const bool near2 = R > (int)(((pxr >> 16) & 255u) << 8) && L < (int)((pxr >> 24) << 8);
+        const bool want = live && R > L && ((p1 != 255 && near1) || (p2 != 255 && near2));
         if (__ballot(want)) {
           int L1 = 1, R1 = 0, L2 = 1, R2 = 0;
-          const uint32_t* r1 = C.rec(want ? p1 : q);
+          const bool want1 = want && p1 != 255 && near1;
+          const uint32_t* r1 = C.rec(want1 ? p1 : q);
           const int2 rg1 = *reinterpret_cast<const int2*>(r1 + 16);
-          const bool in1 = want && s >= rg1.x && s < rg1.y;
+          const bool in1 = want1 && s >= rg1.x && s < rg1.y;
           if (__ballot(in1)) {
             span_fast(r1, s, sd, in1, xmax, &L1, &R1);
             L1 = max(L1, L); R1 = min(R1, R);
             if (in1) add_span_fast(acc, arow, obx0, obw, L1, R1, -1);
             else { L1 = 1; R1 = 0; }
           }
-          const bool want2 = want && p2 != 255;
+          const bool want2 = want && p2 != 255 && near2;
           if (__ballot(want2)) {
             const uint32_t* r2 = C.rec(want2 ? p2 : q);
             const int2 rg2 = *reinterpret_cast<const int2*>(r2 + 16);
