@@ -178,7 +178,8 @@ int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, voi
  *      viewport (130, 80, 450, 460), line width 3: every registered gym id and the trainer use it -- has the fast frame
  *      kernel (92x90 surface, caches, draw records); any other geometry switches the batch to the general renderer (one
  *      workgroup per env, every stroke in place): surface width, height in [84, 251] with width * height <= 49 152, i.e.
- *      cv2's INTER_AREA shrink to 84x84 stays below threefold.  SF_OBS_IMAGE_RAW frames are then uint8 [h][w]
+ *      cv2's INTER_AREA shrink to 84x84 stays below threefold, and at most 0.75 pixels per user unit either way (beyond
+ *      that cairo cuts the explosion's circle into more Bezier segments than the renderer's form of it has).  SF_OBS_IMAGE_RAW frames are then uint8 [h][w]
  *      (sf_image_size; sf_obs_dim follows), sf_render_shift is not available, sf_render_stack clears a finished env's
  *      slots with a launch of its own.  May be called any time between frames; synchronous.  SF_ERR_ARG for a geometry
  *      outside those bounds (the batch keeps the one it had). ---- */

@@ -492,6 +492,13 @@ extern "C" int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, dou
                  w, h, scale, vp_w, vp_h, SF_OUT, 3 * SF_OUT - 1);
     return SF_ERR_ARG;
   }
+  // cairo cuts an arc into Bezier segments by the tolerance over its DEVICE radius (cairo-arc.c: _arc_segments_needed): the
+  // explosion's radius-7 circle is one segment per half up to 5.4 device pixels, and that is the form the renderer draws
+  if (!((double)w / vp_w <= 0.75) || !((double)h / vp_h <= 0.75)) {
+    sf_set_error("sf_set_image_geometry: %d x %d pixels for a %g x %g viewport: more than 0.75 pixels per unit is a close-up "
+                 "this renderer does not draw (the explosion's circle takes more Bezier segments there)", w, h, vp_w, vp_h);
+    return SF_ERR_ARG;
+  }
   std::vector<uint8_t> bg(((size_t)w * h + 15) & ~(size_t)15, 0);  // (whole 16-byte pieces: the kernel copies it that way)
   int rc = sf_image_background_geom(w, h, vp_x, vp_y, vp_w, vp_h, line_width, bg.data());
   if (rc != SF_OK) return rc;

@@ -182,14 +182,37 @@ __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool
     __hip_atomic_fetch_add(C.obj(oi) + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // the object's quads
   }
   C.sync();
-  // ---- the objects' boxes, in one lane each (lane o < nobj), then prefix sums over the objects
+  // ---- the objects' boxes, in one lane each (lane o < nobj).  The accumulators hold kAccPixels pixels and a row's mode is a bit
+  // of one word: objects that are larger (another geometry's close-up: a ship of forty rows, an arc sixty pixels out) are taken in
+  // WINDOWS of pixel rows, each through all the passes below -- a row's mode, its whole-row areas and its sub-rows depend on nothing
+  // outside the row, so the windows add up to the same picture.
+  int fx0 = 0, fw = 0, fs0 = 0, fs1 = 0, m0_mine = 0;
+  if (lane < nobj) {
+    uint32_t* o = C.obj(lane);
+    const int* oi_ = reinterpret_cast<const int*>(o);
+    const int x0 = max(oi_[0] >> 8, 0), x1 = min((oi_[2] + 255) >> 8, C.W);
+    const int s0 = max(oi_[1], 0), s1 = min(oi_[3], C.H * sft::kGridY);
+    if (x1 > x0 && s1 > s0) { fx0 = x0; fw = x1 - x0; fs0 = s0; fs1 = s1; }
+    m0_mine = (int)o[7];
+    o[4] |= o[5] << 8;  // (the object's quads, counted above)
+  }
+  int wsum = fw, ylo = fs1 > fs0 ? fs0 / sft::kGridY : (1 << 20), yhi = fs1 > fs0 ? (fs1 - 1) / sft::kGridY + 1 : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    wsum += __shfl_xor(wsum, d);
+    ylo = min(ylo, __shfl_xor(ylo, d));
+    yhi = max(yhi, __shfl_xor(yhi, d));
+  }
+  // (a call whose objects are wider in all than the accumulators hold pixels cannot be drawn in windows of whole rows: the
+  //  callers' chunks -- five wireframes, twelve arcs, one circle on a surface of at most 251 pixels -- stay far below)
+  if (wsum > kAccPixels) return;
+  const int hwin = max(1, min(32, kAccPixels / max(wsum, 1)));
+  for (int w0 = ylo; w0 < yhi; w0 += hwin) {
   int bx0 = 0, by0 = 0, bw = 0, bh = 0, S0 = 0, nsub = 0;
   if (lane < nobj) {
-    const int* o = reinterpret_cast<const int*>(C.obj(lane));
-    const int x0 = max(o[0] >> 8, 0), x1 = min((o[2] + 255) >> 8, C.W);
-    const int s0 = max(o[1], 0), s1 = min(o[3], C.H * sft::kGridY);
-    if (x1 > x0 && s1 > s0) {
-      bx0 = x0; bw = x1 - x0;
+    const int s0 = max(fs0, w0 * sft::kGridY), s1 = min(fs1, (w0 + hwin) * sft::kGridY);
+    if (fw > 0 && s1 > s0) {
+      bx0 = fx0; bw = fw;
       by0 = s0 / sft::kGridY; bh = (s1 - 1) / sft::kGridY + 1 - by0;
       S0 = s0; nsub = s1 - s0;
     }
@@ -204,12 +227,10 @@ __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool
   const int tot_pix = __builtin_amdgcn_readlane(abase, kMaxObjs - 1);
   if (lane < nobj) {
     uint32_t* o = C.obj(lane);
-    const uint32_t nq = o[5];
     o[0] = (uint32_t)bx0 | ((uint32_t)by0 << 8) | ((uint32_t)bw << 16) | ((uint32_t)bh << 24);
-    o[1] = (uint32_t)S0 | (o[7] << 16);    // (+ a circle's first half in the upper bits)
+    o[1] = (uint32_t)S0 | ((uint32_t)m0_mine << 16);    // (+ a circle's first half in the upper bits)
     o[2] = (uint32_t)nsub;
     o[3] = (uint32_t)(abase - bw * bh);         // where the object's accumulator starts (pixels)
-    o[4] |= nq << 8;
     o[5] = (uint32_t)(rbase - bh);             // where its rows start in the enumeration of rows
     o[6] = 0u;                                  // its rows' modes (bit r: row by0 + r is taken whole)
     o[7] = (uint32_t)(sbase - nsub);           // where its sub-rows start
@@ -420,6 +441,7 @@ __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool
   }
   for (int i = lane; i < (tot_pix + 1) / 2; i += 64) acc[i] = 0u;
   C.sync();
+  }  // (the next window of rows)
 }
 
 

@@ -91,3 +91,17 @@ def test_live_reference_renderer_if_built(oracle_mod):
             if t % 5 == 0:
                 s = g.snapshot()
                 assert np.array_equal(R.render_raw(s, hx[:12], hx[12:], text=False)[9:], g.draw()[9:]), (gt, t)
+
+
+def test_model_equals_reference_frames_in_a_close_up():
+    """zoom.npz (make_zoom_golden.py): scale 0.75 on a 250 x 260 viewport around the fortress -- every pixel."""
+    from oracle import render_np as R
+    z = np.load(os.path.join(GOLDEN, "frames", "zoom.npz"))
+    g = z["geometry"]
+    hx = z["hex_points"]
+    R.set_geometry(g[0], tuple(g[1:5]), g[5])
+    try:
+        for i, (s, f) in enumerate(zip(z["snaps"], z["frames"])):
+            assert np.array_equal(R.render_raw(s, hx[:12], hx[12:], text=False), f), i
+    finally:
+        R.set_geometry(.2, (130, 80, 450, 460), 3)

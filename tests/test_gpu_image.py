@@ -94,6 +94,23 @@ def test_frames_equal_the_references_renderer_in_other_geometries(sfa):
         env.close()
 
 
+def test_frames_equal_the_references_renderer_in_a_close_up(sfa):
+    """SSF_Env(scale=0.75, viewport=(230, 185, 250, 260)): a 187 x 195 surface around the fortress (zoom.npz, drawn by the
+    reference's renderer), the largest scale sf_set_image_geometry takes -- a wireframe's box is larger than one pass of the
+    rasteriser's accumulators (windows of rows), the dead ship's arcs reach 47 pixels out, the big hexagon lies outside the
+    view, no text rows: every pixel."""
+    z = np.load(os.path.join(GOLDEN, "frames", "zoom.npz"))
+    sc, vx, vy, vw, vh, ls = z["geometry"]
+    snaps = z["snaps"]
+    env = sfa.SFVecEnv(len(snaps), gametype="youturn", obs_type="image-raw", image_geometry=(sc, (vx, vy, vw, vh), ls))
+    _load_snaps(env, snaps)
+    got = env.render("image-raw").cpu().numpy()
+    assert got.shape == z["frames"].shape == (len(snaps), 195, 187)
+    for i in range(len(snaps)):
+        frames_close(got[i], z["frames"][i], ("zoom", i))
+    env.close()
+
+
 @pytest.mark.parametrize("name,stride", [
     ("autoturn_destroy", 7), ("youturn_hunter", 61), ("youturn_deaths", 13), ("youturn_rapid_fire", 11),
     ("youturn_random_short", 9),
@@ -734,6 +751,8 @@ def test_frames_in_another_geometry_vs_model(sfa, oracle_mod, scale, viewport, l
     e1.close()
     with pytest.raises(ValueError):
         sfa.SSF_Env("youturn", scale=.1, obs_type="image")  # a 45 x 46 surface: nothing to shrink to 84 x 84
+    with pytest.raises(ValueError):  # more than 0.75 pixels per unit: cairo's circle takes more Bezier segments than the renderer's
+        sfa.SSF_Env("youturn", scale=1.0, viewport=(255, 215, 200, 200), obs_type="image")
     e2 = sfa.SSF_Env("youturn", scale=.1, obs_type="features")  # ... but fine where no frame is drawn
     with pytest.raises(ValueError):
         e2.render("rgb_array")
