@@ -240,7 +240,8 @@ int sf_check_actions(sf_batch* b, void* stream);
  * presses: 65 535; vlner: 4 095; a key timer: +-32 767 ticks without an edge; time: 2^24 ms).  Every time a field of
  * some env leaves its range (the tick on which it wraps) is counted on the device; this reads the count (synchronises
  * `stream`) and returns SF_ERR_STATE while it is not zero -- the values sf_get_field returns for those envs have wrapped,
- * and stay wrapped: the count is STICKY until sf_reset starts new games everywhere.  Auto-resetting batches start every
+ * and stay wrapped: the count is STICKY until sf_reset starts new games everywhere or sf_set_field rewrites a packed field
+ * (every env's: a restored checkpoint rewrites them all).  Auto-resetting batches start every
  * field over at each episode end and cannot get there.  sf_set_field refuses (SF_ERR_ARG) values that do not fit a
  * field, and a `stats` row 3 (ship deaths) that is not the sum of rows 0-2. */
 int sf_check_state(sf_batch* b, void* stream);
@@ -266,7 +267,9 @@ int sf_set_field(sf_batch* b, int field_id, const void* host, size_t bytes);
  *      at every episode end; this copies them out (synchronises `stream`) and optionally clears.
  *      out[0]=episodes, [1]=sum of returns, [2]=sum of squared returns, [3]=fortress kills seen by
  *      the wrapper (sum of info), [4]=ship deaths, [5]=shots, [6]=min return, [7]=max return
- *      ([6],[7] are INT64_MAX / INT64_MIN while no episode has ended). ---- */
+ *      ([6],[7] are INT64_MAX / INT64_MIN while no episode has ended).  Returns SF_ERR_STATE (out[] filled all the same)
+ *      if a split step launch ever gave up on a hand-over (sf_check_state's internal-error case): whoever reads the
+ *      statistics learns of it without a second call. ---- */
 #define SF_EPISODE_STATS_LEN 8
 #define SF_SPAWN_MARGIN 65536 /* default spawn table: entries past the last lane's start (sf_create_params.spawn_table_len) */
 int sf_episode_stats(sf_batch* b, int64_t* out, int clear, void* stream);

@@ -106,11 +106,18 @@ def scan_wide_store_hazard(text):
     return found
 
 
-def device_disassembly(lib=None):
-    """The gfx950 code objects inside a built libsfmi.so (one per .hip source), disassembled: one string."""
+def offload_arch(flags=None):
+    """The one GPU target of the build, from its own flags (--offload-arch=...)."""
+    archs = [f.split("=", 1)[1] for f in (flags or FLAGS) if f.startswith("--offload-arch=")]
+    return archs[-1] if archs else "gfx950"
+
+
+def device_disassembly(lib=None, arch=None):
+    """The device code objects inside a built libsfmi.so (one per .hip source), disassembled: one string."""
     import tempfile
 
     lib = lib or LIB
+    arch = arch or offload_arch()
     llvm = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
     out = []
     with tempfile.TemporaryDirectory() as td:
@@ -128,9 +135,9 @@ def device_disassembly(lib=None):
             part, co = os.path.join(td, "b%d.bin" % n), os.path.join(td, "b%d.co" % n)
             open(part, "wb").write(blob[a:b])
             subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o",
-                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part, "--output=" + co],
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--" + arch, "--input=" + part, "--output=" + co],
                                   stderr=subprocess.DEVNULL)
-            out.append(subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], text=True))
+            out.append(subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=" + arch, co], text=True))
     return "\n".join(out)
 
 
@@ -156,11 +163,19 @@ def build(force=False, verbose=False, extra_flags=()):
 
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
             list(ex.map(one, zip(SOURCES, objs)))
-        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "--hip-link"] + objs + ["-o", LIB]
+        arch = offload_arch(cflags)
+        cmd = [hipcc, "--offload-arch=" + arch, "-fPIC", "-shared", "--hip-link"] + objs + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    bare = scan_wide_store_hazard(device_disassembly(LIB))
+    # the store-hazard scan needs llvm-objcopy, clang-offload-bundler and llvm-objdump: a library that could not be scanned is
+    # removed like one that failed the scan -- never a .so without its .id (every later import would rebuild and fail again)
+    try:
+        bare = scan_wide_store_hazard(device_disassembly(LIB, arch))
+    except (FileNotFoundError, subprocess.CalledProcessError) as e:
+        os.remove(LIB)
+        raise RuntimeError("libsfmi.so was built but its device code could not be scanned for the wide-store hazard (%s); "
+                           "ROCM_LLVM_BIN names the directory of llvm-objcopy / clang-offload-bundler / llvm-objdump" % (e,))
     if bare:  # (see scan_wide_store_hazard: such a library plays wrong games in batches beyond 65 536 envs)
         os.remove(LIB)
         raise RuntimeError("libsfmi.so: %d wide buffer stores without their wait state, e.g. %s" % (len(bare), bare[0]))

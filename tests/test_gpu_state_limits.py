@@ -96,6 +96,10 @@ def test_a_key_timer_that_outgrows_int16_is_flagged(sfa):
     env.step_tensors(noop)
     with pytest.raises(OverflowError):
         env.check_state()
+    # rewriting the packed field (every env's) repairs what had wrapped: the sticky count starts over (a restored checkpoint
+    # -- load_state_dict -- rewrites all of them)
+    env.set_field("fire_timer", np.full(64, -5, np.int32))
+    env.check_state()
     env.close()
 
 
