@@ -351,7 +351,7 @@ struct Frame {
   // (drawWireFrame, SRC/draw.cpp:82-100), i.e. the union of its lines' rectangles through cairo's scan conversion.  Lane s holds
   // line s of the frame's draw order as a fixed-point quad (`mine`, `valid`); `obj0` = the first lane of the line's object, `kind`
   // the object's (sf_tor_dev.h).  sftd::raster takes up to sixteen lines of whole objects at a time.
-  static constexpr int kChunk = 16;
+  static constexpr int kChunk = sftd::kMaxQuadsF;
   static_assert(SF_IMG_H * sft::kGridY < 4096 && SF_IMG_W * 256 + 65536 < (1 << 18) && SF_IMG_H <= 96, "sf_tor_dev.h's fast arrangement: packed sub-rows, cells, rows");
   static constexpr int kMapBitsOut = 1024;  // the map of the objects' 84x84 boxes in the resample pass
   static constexpr int kLtabAt = 4 * kChunk + kMapBitsOut / 32;  // words into `tor`: behind that pass's records and map
@@ -463,7 +463,7 @@ struct Frame {
   }
 };
 static_assert(Frame<true>::kResampleWords <= sftd::kMaxQuads * sftd::kRecWords + sftd::kMaxObjs * sftd::kObjWords &&
-              Frame<true>::kResampleWords <= sftd::kMaxQuads * sftd::kRecWordsF + sftd::kMaxObjs * sftd::kObjWordsF,
+              Frame<true>::kResampleWords <= sftd::kMaxQuadsF * sftd::kRecWordsF + sftd::kMaxObjs * sftd::kObjWordsF,
               "the resample pass's records, map and tap period stay clear of sf_tor_dev.h's accumulators (which must stay zero)");
 
 // ---- the objects' lines as cairo has them: path points through the matrices of drawGameStateScaled + drawWireFrame

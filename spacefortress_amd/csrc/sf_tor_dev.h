@@ -455,6 +455,11 @@ __device__ __forceinline__ void raster(const Ctx& C, const sft::Quad& mine, bool
 //   * a row taken whole is handed to one lane per (row, quad) for its two trapezoid edges; rows in which two quads of an object
 //     overlap while taken whole (rare: the overlap of two lines is shorter than a pixel) go to one lane with the general code;
 //   * spans are added with straight-line code for the one- and two-pixel cases.
+#ifndef SFTD_FAST_QUADS
+#define SFTD_FAST_QUADS 16 /* quads per call of the fast arrangement (A/B: 32 -- fewer calls in crowded frames, 4.4 KB more LDS) */
+#endif
+constexpr int kMaxQuadsF = SFTD_FAST_QUADS;
+constexpr int kAccPixelsF = SFTD_FAST_QUADS > 16 ? 1024 : kAccPixels;  // (ten wireframes' boxes instead of five)
 constexpr int kRecWordsF = 48;
 // A quad's record:
 //    0 .. 15   the slots L1 L2 R1 R2: an edge as two doubles (A - 1/2, B): cell(s) = round(A' + B s)   (cell_fast)
@@ -471,16 +476,16 @@ constexpr int kHdrWordsF = 8;   // per RUN of sub-rows (= per quad that has any)
 constexpr int kObjWordsF = 12;  // as kObjWords, + the rows that hold a vertex: 96 bits
 constexpr int kTasksF = 64;     // (row, quad) pairs taken whole, per round
 constexpr int kMapWordsF = 64;  // the sub-rows' enumeration: a bit per start of a quad's run, 2 048 sub-rows per round
-constexpr int kAccAtF = kMaxQuads * (kRecWordsF + kHdrWordsF) + kMaxObjs * kObjWordsF + kTasksF + 8 + kMapWordsF;
-constexpr int kLdsWordsF = kAccAtF + kAccPixels / 2;
+constexpr int kAccAtF = kMaxQuadsF * (kRecWordsF + kHdrWordsF) + kMaxObjs * kObjWordsF + kTasksF + 8 + kMapWordsF;
+constexpr int kLdsWordsF = kAccAtF + kAccPixelsF / 2;
 
 struct CtxF {
   uint32_t* lds;
   uint8_t* fb;
   int W, H, lane;
   __device__ __forceinline__ uint32_t* rec(int q) const { return lds + q * kRecWordsF; }
-  __device__ __forceinline__ uint32_t* hdr(int q) const { return lds + kMaxQuads * kRecWordsF + q * kHdrWordsF; }
-  __device__ __forceinline__ uint32_t* obj(int o) const { return lds + kMaxQuads * (kRecWordsF + kHdrWordsF) + o * kObjWordsF; }
+  __device__ __forceinline__ uint32_t* hdr(int q) const { return lds + kMaxQuadsF * kRecWordsF + q * kHdrWordsF; }
+  __device__ __forceinline__ uint32_t* obj(int o) const { return lds + kMaxQuadsF * (kRecWordsF + kHdrWordsF) + o * kObjWordsF; }
   __device__ __forceinline__ uint32_t* tasks() const { return obj(kMaxObjs); }  // [kTasksF], the count, "more rows than fit", (2 free)
   __device__ __forceinline__ uint32_t* map() const { return tasks() + kTasksF + 8; }
   __device__ __forceinline__ uint32_t* acc() const { return lds + kAccAtF; }
