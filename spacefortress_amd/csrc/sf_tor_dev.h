@@ -563,7 +563,14 @@ __device__ __forceinline__ void row_slots(const uint32_t* rc, int row, int* ls, 
 }
 
 // `mine`: this lane's quad (valid lanes); obj0: the first lane of its object (lanes of an object are consecutive)
+#ifndef SFTD_FAST_CALL
+#define SFTD_FAST_CALL 0 /* A/B: 1 = raster_fast as ONE function the frame kernel calls from its twelve places instead of twelve copies */
+#endif
+#if SFTD_FAST_CALL
+__device__ __attribute__((noinline)) void raster_fast(const CtxF C, const sft::Quad mine, bool valid, int obj0, int kind, int grey) {
+#else
 __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine, bool valid, int obj0, int kind, int grey) {
+#endif
   if (SFTD_STOP == 0) return;
   const int lane = C.lane, xmax = C.W * 256;
   uint32_t* const acc = C.acc();
