@@ -262,6 +262,11 @@ int sf_field_info(int field_id, sf_field_desc* out);
 int sf_field_id(const char* name); /* < 0 if unknown */
 int sf_get_field(sf_batch* b, int field_id, void* host, size_t bytes);
 int sf_set_field(sf_batch* b, int field_id, const void* host, size_t bytes);
+/* The same read into DEVICE memory ([count][n_envs] of the field's element type), ordered on `stream`, no synchronise and no
+ * PCIe copy: for on-device bookkeeping between two steps (the batch-level counterpart of the reference's per-Game getters,
+ * SRC/pymodule.cpp:24-48,78-105; spacefortress_amd/durations.py keeps SRC/game.hh:98-101's four vectors with it).  Every
+ * field but missile_x / missile_y / missile_angle (SF_ERR_FIELD: their per-slot view is made on the host's demand). */
+int sf_get_field_dev(sf_batch* b, int field_id, void* dev, size_t bytes, void* stream);
 
 /* ---- episode statistics (host side of rl/train.py:81,84-88,161-164): accumulated on the device
  *      at every episode end; this copies them out (synchronises `stream`) and optionally clears.

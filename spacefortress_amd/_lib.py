@@ -81,6 +81,7 @@ SYMBOLS = {
     "sf_field_id": (C.c_int, [C.c_char_p]),
     "sf_get_field": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "sf_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "sf_get_field_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sf_episode_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sf_calibration_copy": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "sf_draw_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),

@@ -1069,3 +1069,28 @@ extern "C" int sf_get_field(sf_batch* b, int f, void* host, size_t bytes) {
 extern "C" int sf_set_field(sf_batch* b, int f, const void* host, size_t bytes) {
   return field_copy(b, f, const_cast<void*>(host), bytes, false);
 }
+
+// One state field of every env into DEVICE memory, [count][n_envs] in the field's element type like sf_get_field's host
+// layout, ordered on `stream` behind the steps issued there and without a synchronise or a PCIe copy: what on-device
+// bookkeeping reads between two steps (spacefortress_amd/durations.py).  Not for the missile fields (their per-slot view is a
+// host-side convenience made on demand: sf_get_field).
+extern "C" int sf_get_field_dev(sf_batch* b, int f, void* dev, size_t bytes, void* stream) {
+  if (!b || !dev || f < 0 || f >= SF_F_COUNT) {
+    sf_set_error("sf_get_field_dev: bad argument (field %d)", f);
+    return b && dev ? SF_ERR_FIELD : SF_ERR_ARG;
+  }
+  const sfl::FieldMeta& m = sfl::kFields[f];
+  const size_t total = (size_t)b->n_envs * m.elem_size * m.count;
+  if (bytes != total) {
+    sf_set_error("field %s: expected %zu bytes, got %zu", m.name, total, bytes);
+    return SF_ERR_FIELD;
+  }
+  if (m.kind == SF_FK_MPOOL) {
+    sf_set_error("sf_get_field_dev: %s is a per-slot view of the tiles' missile pools: read it with sf_get_field", m.name);
+    return SF_ERR_FIELD;
+  }
+  DeviceGuard guard(b->device);
+  SF_FLUSH_VIEW(b, (hipStream_t)stream);
+  HIP_TRY(sf_launch_field_copy(b->d_state, b->n_envs, f, (unsigned char*)dev, 1, (hipStream_t)stream));
+  return SF_OK;
+}

@@ -66,6 +66,7 @@ class SFVecEnv:
         self._create = {"action_set": int(action_set), "seed": int(seed) & 0xFFFFFFFF, "spawn_skip": int(spawn_skip),
                         "spawn_stride": int(spawn_stride), "auto_reset": bool(auto_reset)}
         self.default_geometry = True
+        self._durations = None
         self._fresh = True  # nothing has changed the state sf_create left: a recording may start here
         self._rec = None
         self.num_envs = int(num_envs)
@@ -125,6 +126,8 @@ class SFVecEnv:
         """env.reset() in every lane (ENV:163-178): new games; returns obs [N, obs_dim]."""
         obs = self._alloc()[0]
         self._touch()
+        if self._durations is not None:
+            self._durations.reset()  # new Games: empty vectors
         _lib.check(self._L.sf_reset(self._h, C.c_void_p(obs.data_ptr()), self._stream()))
         return obs.cpu().numpy() if numpy else obs
 
@@ -141,8 +144,12 @@ class SFVecEnv:
         else:
             bufs = out if out is not None else self._alloc()
             ptrs = tuple(C.c_void_p(t.data_ptr()) for t in bufs)
+        if self._durations is not None:
+            self._durations.before(actions)
         _lib.check(self._L.sf_step(self._h, C.c_void_p(actions.data_ptr()), at, ptrs[0], ptrs[1], ptrs[2], ptrs[3],
                                    self._stream()))
+        if self._durations is not None:
+            self._durations.after(bufs[2])
         self._fresh = False
         if self._rec is not None:
             self._rec.add(actions.to(torch.uint8), bufs[1], bufs[2], bufs[3])
@@ -372,6 +379,15 @@ class SFVecEnv:
         _lib.check(self._L.sf_draw_records(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes, int(bool(from_state))))
         return out
 
+    def enable_durations(self, capacity=512):
+        """The reference's four telemetry vectors (SRC/game.hh:98-101; getters SRC/pymodule.cpp:143-181) for every env of the
+        batch: `thrust_durations`, `shot_durations`, `shot_intervals_invul`, `shot_intervals_vul`, kept on the device by
+        `step_tensors` / `step` from here on (durations.py).  Returns the log: `log.get(name)` -> (values [N, capacity],
+        counts [N]).  Off by default: four small gathers and a handful of elementwise kernels per step."""
+        from .durations import DurationLog
+        self._durations = DurationLog(self, capacity)
+        return self._durations
+
     def enable_events(self, on=True):
         """Per-tick event bitmasks (sfmi.h SF_EV_*; `_lib.EVENT_NAMES`): after every step `self.events` holds
         uint32 [N] for that tick.  Off by default: it is one more 4-byte store per env and step."""
@@ -420,6 +436,21 @@ class SFVecEnv:
         arr = np.empty((count, self.num_envs), dt)
         _lib.check(self._L.sf_get_field(self._h, f, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
         return arr[0] if count == 1 else arr
+
+    def get_field_tensor(self, name, out=None):
+        """One state field as a DEVICE tensor, [N] or [count, N], without synchronising (sfmi.h: sf_get_field_dev): ordered on
+        the current stream behind the steps issued there.  Every field but missile_x / missile_y / missile_angle."""
+        self.field_names()
+        if name not in self._fields:
+            raise KeyError(name)
+        f, dt, count = self._fields[name]
+        tdt = {np.dtype(np.int32): torch.int32, np.dtype(np.uint32): torch.int32, np.dtype(np.float64): torch.float64,
+               np.dtype(np.float32): torch.float32, np.dtype(np.int16): torch.int16, np.dtype(np.uint8): torch.uint8,
+               np.dtype(np.int8): torch.int8, np.dtype(np.uint64): torch.int64, np.dtype(np.int64): torch.int64}[np.dtype(dt)]
+        if out is None:
+            out = torch.empty((count, self.num_envs), dtype=tdt, device=self.device)
+        _lib.check(self._L.sf_get_field_dev(self._h, f, C.c_void_p(out.data_ptr()), out.numel() * out.element_size(), self._stream()))
+        return out[0] if count == 1 and out.dim() == 2 else out
 
     def set_field(self, name, value):
         self.field_names()
