@@ -19,10 +19,13 @@ HOW a stroke becomes grey levels is cairo's image backend (1.16.0 in this image)
 (stroker, 15-sub-row scan converter with its full-row shortcut, box converter, 8-bit lerp) and is pinned bit for bit to the
 real library (tests/test_cairo_model.py) and to frames of the reference's real draw.cpp (tests/golden/frames/, made by
 make_frames_golden.py through oracle/_ref/libsfrefdraw.so): this module builds the draw script of a frame and runs it through
-that model.  PINNED: every pixel outside the score text.  NOT pinned: the score text itself -- cairo's toy font API resolves
-"monospace bold" through whatever fontconfig finds on the box, so its pixels are not a property of the reference; it is
-modelled as seven-segment glyphs of the same metrics (layout pinned to rl/imgs/screens.png) and its rows (0..8) are masked
-in every comparison with reference frames.  cv2 is not in this image: INTER_AREA follows OpenCV's published algorithm
+that model.  The score text (drawScore, SRC/draw.cpp:147-173) is cairo's toy font: FreeType A8 glyph bitmaps blitted at
+whole-pixel origins and composited with pixman's OVER -- data plus a placement rule, taken from the image's real cairo and
+held to frames of the reference's own renderer (tests/golden/frames/make_score_golden.py -> score_glyphs.npz, scores.npz):
+`score_text_atlas`.  PINNED: every pixel, text included, on a box whose fontconfig resolves "monospace bold" to the font of
+this image (DejaVu Sans Mono Bold).  The seven-segment glyph model of earlier rounds (`score_text`) survives as the named
+fallback for a geometry / font without an atlas (`text="segments"`); it equals no reference pixels and is never compared
+with any.  cv2 is not in this image: INTER_AREA follows OpenCV's published algorithm
 (imgproc/resize.cpp, computeResizeAreaTab + resizeArea_).
 """
 import ctypes as _C
@@ -36,10 +39,12 @@ W, H, OUT = 90, 92, 84
 VP_X, VP_Y, VP_W, VP_H, SCALE, LINE_W = 130.0, 80.0, 450.0, 460.0, 0.2, 3.0
 SX, SY = W / VP_W, H / VP_H  # newPixelBuffer: scale_x = width / vp_width, scale_y = height / vp_height (SRC/draw.cpp:70-71)
 FORT = (355.0, 315.0)
-TEXT_ROWS = 9  # rows 0..8 of the default 92 x 90 surface hold the score text: masked against reference frames
+TEXT_ROWS = 9  # rows 0..8 of the default 92 x 90 surface hold the score text (compared like every other row since round 6)
 
 HERE = _os.path.dirname(_os.path.abspath(__file__))
 MODEL_SO = _os.path.join(HERE, "libsfcairomodel.so")
+GLYPHS_NPZ = _os.path.join(_os.path.dirname(HERE), "tests", "golden", "frames", "score_glyphs.npz")
+GLYPH_CHARS = "0123456789-"
 _model = None
 
 # the draw-script vocabulary of oracle/cairo_model.h
@@ -171,7 +176,7 @@ def s_objects(snap):
     return s
 
 
-# ---- the score text: our glyph model (not pinned, see the module docstring) ------------------------------------------------
+# ---- the score text: the seven-segment FALLBACK model (equals no reference pixels, see the module docstring) ------------------------------------------------
 def _dev(pts):
     pts = np.asarray(pts, np.float64)
     return np.stack([(pts[:, 0] - VP_X) * SX, (pts[:, 1] - VP_Y) * SY], 1)
@@ -254,13 +259,56 @@ def bar_frame(fb, vlner, kill):
     return run_script(s_begin()[:8] + s_bar(vlner, kill), fb.shape[1], fb.shape[0], onto=fb)
 
 
-def render_raw(snap, hex_big, hex_small, vuln_time=250, bg=None, text=True):
+_glyphs = {}
+
+
+def load_glyphs(k=0):
+    """Glyph atlas `k` of tests/golden/frames/score_glyphs.npz (0: the default geometry) as dict(alpha, layout, x0, geometry)."""
+    if k not in _glyphs:
+        z = np.load(GLYPHS_NPZ)
+        _glyphs[k] = dict(alpha=z["alpha_%d" % k], layout=z["layout_%d" % k], x0=z["x0_%d" % k], geometry=z["geometry_%d" % k])
+    return _glyphs[k]
+
+
+def glyphs_for_geometry():
+    """The atlas whose geometry is the module's current one (set_geometry), or None."""
+    z = np.load(GLYPHS_NPZ)
+    cur = np.array([SCALE, VP_X, VP_Y, VP_W, VP_H, LINE_W])
+    for key in z.files:
+        if key.startswith("geometry_") and np.array_equal(z[key], cur):
+            return load_glyphs(int(key[9:]))
+    return None
+
+
+def score_text_atlas(fb, points, A):
+    """drawScore (SRC/draw.cpp:161-173) from a glyph atlas: "%07d", box i at (x0[first][last] + i * advance, y0), grey .5 IN the
+    glyph's coverage OVER the frame (pixman: mul_un8(128, a) + mul_un8(d, 255 - a)).  Returns a new frame."""
+    out = np.array(fb, np.uint8).copy()
+    text = ("%07d" % int(points))[:7]
+    gw, gh, adv, y0 = (int(v) for v in A["layout"])
+    x0 = int(A["x0"][GLYPH_CHARS.index(text[0]), int(text[-1])])
+    for i, ch in enumerate(text):
+        a = A["alpha"][GLYPH_CHARS.index(ch)]
+        for r in range(gh):
+            for q in range(gw):
+                m, y, x = int(a[r, q]), y0 + r, x0 + i * adv + q
+                if m and 0 <= y < out.shape[0] and 0 <= x < out.shape[1]:
+                    out[y, x] = mul_un8(128, m) + mul_un8(int(out[y, x]), 255 - m)
+    return out
+
+
+def render_raw(snap, hex_big, hex_small, vuln_time=250, bg=None, text=True, glyphs=None):
     """One [H][W] uint8 frame from an oracle snapshot record (oracle.SNAPSHOT_DTYPE): drawGameStateScaled's calls in its
     order -- hexagons, objects, score, bar.  `bg` (the hexagons' frame) is accepted for the callers that keep one; the
-    hexagons are the first strokes on black either way."""
+    hexagons are the first strokes on black either way.  text: True = the glyph atlas (`glyphs`, else the one recorded for
+    the current geometry; an error if there is none), "segments" = the named seven-segment fallback, False = no text."""
     fb = run_script(s_begin() + s_hexagon(hex_big) + s_hexagon(hex_small) + s_objects(snap))
-    if text:
+    if text == "segments":
         score_text(fb, snap["points"])
+    elif text:
+        A = glyphs if glyphs is not None else glyphs_for_geometry()
+        assert A is not None, "no glyph atlas for this geometry: pass glyphs= or text='segments'"
+        fb = score_text_atlas(fb, snap["points"], A)
     vlner = int(snap["vlner"])
     kill = vlner > 10 and int(snap["fort_vuln_timer"]) < vuln_time
     return bar_frame(fb, vlner, kill)

@@ -1,7 +1,9 @@
 """The image observation's model (oracle/render_np.py over oracle/cairo_model.c) against frames drawn by the REFERENCE's
 real renderer -- SRC/draw.cpp + SRC/wireframe.cpp against cairo 1.16, through oracle/_ref/libsfrefdraw.so; fixtures made by
-tests/golden/frames/make_frames_golden.py.  Bar: BIT-EXACT on every pixel outside the score text's rows (font-dependent:
-see the generator's docstring).  No GPU; the HIP frames are held to the same fixtures in tests/test_gpu_image.py."""
+tests/golden/frames/make_frames_golden.py and make_score_golden.py.  Bar: BIT-EXACT on EVERY pixel, the score text's rows
+included (round 6: the text is a glyph atlas taken from the image's real cairo + FreeType and held to 2 520 frames of the
+reference's renderer: score_glyphs.npz, scores.npz).  No GPU; the HIP frames are held to the same fixtures in
+tests/test_gpu_image.py."""
 import json
 import os
 
@@ -26,13 +28,45 @@ def test_model_equals_reference_frames(name):
     hb, hs = z["hex_points"][:12], z["hex_points"][12:]
     frames, snaps = z["frames"], z["snaps"]
     assert frames.shape[1:] == (92, 90) and len(frames) == len(snaps) > 600
-    rows = meta["text_rows"]
     bad = []
     for i in range(len(frames)):
-        got = R.render_raw(snaps[i], hb, hs, text=False)
-        if not np.array_equal(got[rows:], frames[i][rows:]):
-            bad.append((str(z["labels"][i]), int(np.abs(got[rows:].astype(int) - frames[i][rows:].astype(int)).max())))
+        got = R.render_raw(snaps[i], hb, hs)  # all 92 rows: the text comes from the glyph atlas
+        if not np.array_equal(got, frames[i]):
+            bad.append((str(z["labels"][i]), int(np.abs(got.astype(int) - frames[i].astype(int)).max())))
     assert not bad, bad[:10]
+
+
+def test_score_text_equals_the_references_own_renderer():
+    """scores.npz: 2 200 scores (every first / last character pair, negative ones) on a quiet state -- rows 0..8 -- and 320 frames
+    with explosion rings, ships, missiles and shells UNDER the text -- whole frames: atlas + placement + pixman's OVER."""
+    from oracle import render_np as R
+    z, meta = _load("scores.npz")
+    hb, hs = z["hex_points"][:12], z["hex_points"][12:]
+    A = R.load_glyphs(0)
+    assert tuple(A["layout"]) == (4, 4, 4, 1) and (A["x0"] == 31).all() and meta["grey"] == 128
+    pts, rows = z["points"], z["rows"]
+    assert len(pts) >= 2000 and rows.shape[1:] == (9, 90)
+    assert {("%07d" % p)[0] + ("%07d" % p)[-1] for p in pts} >= {a + b for a in "0123456789-" for b in "0123456789"}
+    quiet = R.render_raw(z["base"], hb, hs, text=False)
+    for p, r in zip(pts, rows):
+        assert np.array_equal(R.score_text_atlas(quiet, int(p), A)[:9], r), int(p)
+    under = 0
+    for s, f in zip(z["snaps"], z["frames"]):
+        bare = R.render_raw(s, hb, hs, text=False)
+        under += int(((bare[1:5, 31:59] > 0) & (f[1:5, 31:59] != bare[1:5, 31:59])).sum())
+        assert np.array_equal(R.render_raw(s, hb, hs), f)
+    assert under > 2000  # glyph pixels composited over something that is not black
+
+
+def test_the_segment_fallback_is_not_the_references_text():
+    """The seven-segment model is a named fallback (a geometry / font without an atlas): it must never stand in for the atlas
+    silently -- on the default geometry the two differ by dozens of grey levels."""
+    from oracle import render_np as R
+    z, _ = _load("scores.npz")
+    hb, hs = z["hex_points"][:12], z["hex_points"][12:]
+    a = R.render_raw(z["base"], hb, hs).astype(int)
+    b = R.render_raw(z["base"], hb, hs, text="segments").astype(int)
+    assert np.abs(a - b)[:9].max() > 50 and np.array_equal(a[9:], b[9:])
 
 
 def test_fixtures_cover_what_the_renderer_can_draw():
@@ -63,10 +97,10 @@ def test_model_equals_reference_frames_in_other_geometries():
         try:
             frames = z["frames_%d" % gi]
             assert frames.shape[1:] == (R.H, R.W) == (int(vh * sc), int(vw * sc))
-            rows = int((112 - vy) * R.SY) + 1
+            A = R.load_glyphs(gi + 1)  # this geometry's glyphs, from the same cairo (make_score_golden.py)
+            assert np.array_equal(A["geometry"], [sc, vx, vy, vw, vh, ls])
             for i in range(len(snaps)):
-                got = R.render_raw(snaps[i], hb, hs, text=False)
-                assert np.array_equal(got[rows:], frames[i][rows:]), (gi, i)
+                assert np.array_equal(R.render_raw(snaps[i], hb, hs, glyphs=A), frames[i]), (gi, i)  # every row
         finally:
             R.set_geometry(*prev)
     assert (R.W, R.H, R.SX, R.SY) == (90, 92, .2, .2)
@@ -90,7 +124,7 @@ def test_live_reference_renderer_if_built(oracle_mod):
             g.step_one_tick(34)
             if t % 5 == 0:
                 s = g.snapshot()
-                assert np.array_equal(R.render_raw(s, hx[:12], hx[12:], text=False)[9:], g.draw()[9:]), (gt, t)
+                assert np.array_equal(R.render_raw(s, hx[:12], hx[12:]), g.draw()), (gt, t)
 
 
 def test_model_equals_reference_frames_in_a_close_up():
