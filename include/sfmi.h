@@ -169,8 +169,9 @@ int sf_rollout(sf_batch* b, const void* actions_dev, int act_type, int n_steps, 
  *      by its frames (the fused launch keeps the state in registers), with obs_dev = NULL it stays fused;
  *      sf_rollout_sampled likewise.  A batch with another geometry (sf_set_image_geometry) asks less of the buffers: 84x84
  *      frames 4-byte aligned with env_stride a multiple of 4, raw frames any alignment.  The pixels are the reference's:
- *      cairo 1.16's rasterisation of SRC/draw.cpp's paths, bit for bit outside the score's text rows (DESIGN.md "image
- *      observation"; tests/golden/frames holds frames drawn by the reference's own renderer). ---- */
+ *      cairo 1.16's rasterisation of SRC/draw.cpp's paths and -- in the default geometry, or with sf_set_score_glyphs -- its
+ *      score text, bit for bit on all rows (DESIGN.md "image observation"; tests/golden/frames holds frames drawn by the
+ *      reference's own renderer). ---- */
 int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, void* stream);
 
 /* ---- SSF_Env(scale, viewport, ls) (ENV:50-60 -> sf.Game(width = int(vw * scale), height = int(vh * scale), viewport, lw),
@@ -185,6 +186,32 @@ int sf_render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride, voi
  *      outside those bounds (the batch keeps the one it had). ---- */
 int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, double vp_y, double vp_w, double vp_h, double line_width);
 int sf_image_size(const sf_batch* b, int32_t* width, int32_t* height); /* of SF_OBS_IMAGE_RAW frames: 90 x 92 by default */
+int sf_image_geometry_is_default(const sf_batch* b); /* 1: the fast frame kernel draws this batch; 0: the general renderer */
+
+/* ---- The score text (drawScore / centeredText, SRC/draw.cpp:147-173: cairo's toy font API, "monospace" bold, 30 user
+ *      units).  On cairo's image backend the text is FreeType's 8-bit coverage bitmap of every glyph, blitted at a
+ *      whole-pixel origin and composited as grey .5 OVER the frame: data + a placement rule, not a rasteriser.  A batch
+ *      draws it from a glyph atlas:
+ *          alpha[c][gh][gw]   coverage of '0'..'9' (c = 0..9) and '-' (c = 10), one gw x gh box each (<= 24 x 24)
+ *          advance, y0        pixels between consecutive boxes; top row of the boxes
+ *          x0[first][last]    left column of the first box, by the string's first ('0'..'9', '-') and last character
+ *                             (centeredText centres on the ink width, which depends on them in some geometries)
+ *      Default geometry: the BUILT-IN atlas (sf_default_score_glyphs) = 6-pixel DejaVu Sans Mono Bold as this image's
+ *      cairo 1.16 + FreeType draw it, equal to the reference's own frames (tests/golden/frames/scores.npz).  Any other
+ *      geometry starts WITHOUT an atlas -- the seven-segment fallback, which equals no reference pixels -- until one is set
+ *      (tests/golden/frames/make_score_golden.py shows how an atlas is taken from a box's cairo).  sf_set_score_glyphs:
+ *      layout + alpha = that atlas for the batch's CURRENT geometry (for the default geometry its ink must stay inside
+ *      columns 31..58, rows 1..5); layout NULL = the seven-segment fallback, by name.  sf_set_image_geometry resets to the
+ *      geometry's default (built-in / none).  Synchronous; rebuilds the cached pictures. ---- */
+typedef struct sf_score_glyphs {
+  int32_t gw, gh, advance, y0;
+  int16_t x0[11][10];
+} sf_score_glyphs;
+int sf_set_score_glyphs(sf_batch* b, const sf_score_glyphs* layout, const uint8_t* alpha);
+/* the atlas the batch draws with now: *has_atlas = 0 -> the fallback (layout, alpha untouched); alpha_bytes >= 11 gw gh */
+int sf_get_score_glyphs(const sf_batch* b, int32_t* has_atlas, sf_score_glyphs* layout, uint8_t* alpha, size_t alpha_bytes);
+/* the built-in atlas of the default geometry (host only, no GPU needed): alpha uint8[11][4][4] */
+int sf_default_score_glyphs(sf_score_glyphs* layout, uint8_t* alpha, size_t alpha_bytes);
 
 /* One step of the trainer's frame stack in one launch (rl/train.py:51-56,92-97): the 84x84 frame of every env
  * goes to slot `slot` of stack_dev uint8 [n_envs][num_stack][84][84] (16-byte aligned), and an env whose
@@ -395,8 +422,8 @@ int sf_trig_deg(int deg, double* cos_sin);
 int sf_image_arc_alpha(double xc, double yc, double r, double a1, double a2, int w, int h, double vp_x, double vp_y, double vp_w,
                        double vp_h, double lw, uint8_t* alpha);
 /* the background plus the overlays the render kernel starts from when they are static: variant bit 0 =
- * the score text "0000000", bit 1 = the vulnerability bar at 0 (drawScore / drawVlner, SRC/draw.cpp:
- * 190-225); out is uint8[92][90] */
+ * the score text "0000000" (built-in glyph atlas), bit 1 = the vulnerability bar at 0 (drawScore / drawVlner,
+ * SRC/draw.cpp:161-173,207-225); out is uint8[92][90] */
 int sf_image_static(int variant, uint8_t* out);
 /* cv2.resize(..., INTER_AREA) taps for one axis, ssize -> dsize with dsize <= ssize < 3*dsize
  * (rl/envs.py:29: 90 -> 84 and 92 -> 84 in the default geometry): destination i reads source cells first[i] ..

@@ -59,6 +59,11 @@ class Preset(C.Structure):
     ]
 
 
+class ScoreGlyphs(C.Structure):
+    """sf_score_glyphs (include/sfmi.h): the layout of a score-text glyph atlas"""
+    _fields_ = [("gw", C.c_int32), ("gh", C.c_int32), ("advance", C.c_int32), ("y0", C.c_int32), ("x0", (C.c_int16 * 10) * 11)]
+
+
 # every symbol include/sfmi.h declares: (restype, argtypes)
 SYMBOLS = {
     "sf_create": (C.c_int, [C.POINTER(CreateParams), C.POINTER(C.c_void_p)]),
@@ -87,6 +92,10 @@ SYMBOLS = {
     "sf_draw_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "sf_set_image_geometry": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
     "sf_image_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sf_image_geometry_is_default": (C.c_int, [C.c_void_p]),
+    "sf_set_score_glyphs": (C.c_int, [C.c_void_p, C.POINTER(ScoreGlyphs), C.c_void_p]),
+    "sf_get_score_glyphs": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(ScoreGlyphs), C.c_void_p, C.c_size_t]),
+    "sf_default_score_glyphs": (C.c_int, [C.POINTER(ScoreGlyphs), C.c_void_p, C.c_size_t]),
     "sf_preset_get": (C.c_int, [C.c_char_p, C.POINTER(Preset)]),
     "sf_action_table": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p]),
     "sf_spawn_table": (C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),

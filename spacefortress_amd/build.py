@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfmi.so")
 SOURCES = ["sf_kernels.hip", "sf_render.hip", "sf_render_generic.hip", "sf_normalize.hip", "sf_rollout_ops.hip", "sf_capi.cpp", "sf_norm_capi.cpp", "sf_host.cpp", "sf_image.cpp", "sf_cairo_host.cpp"]
-HEADERS = ["sf_layout.h", "sf_drawrec.h", "sf_internal.h", "sf_raster.h", "sf_tor.h", "sf_tor_dev.h", "sf_cairo_host.h", "sf_deg_dd.h", os.path.join(ROOT, "include", "sfmi.h")]
+HEADERS = ["sf_layout.h", "sf_drawrec.h", "sf_internal.h", "sf_raster.h", "sf_tor.h", "sf_tor_dev.h", "sf_cairo_host.h", "sf_deg_dd.h", "sf_glyphs.h", os.path.join(ROOT, "include", "sfmi.h")]
 
 
 # -amdgpu-kernarg-preload-count: the first eight kernel parameters (as many as fit the 14 free user SGPRs) arrive in

@@ -55,6 +55,10 @@ struct sf_batch {
   uint8_t* d_gbg;            // g_w * g_h bytes: the hexagons
   uint32_t* d_gtabs;         // the INTER_AREA taps g_w -> 84, g_h -> 84
   bool render_ready;         // the render caches and pictures exist (or were declined: SFMI_NO_EXPLOSION_CACHE)
+  // the score text's glyph atlas of the CURRENT geometry (sf_glyphs.h; gw == 0: the seven-segment fallback), its device copy,
+  // and the atlas the default geometry's static backgrounds and cached pictures were made with
+  SfGlyphAtlas h_glyphs, baked_glyphs;
+  SfGlyphAtlas* d_glyphs;
 };
 
 namespace {
@@ -132,11 +136,37 @@ int ensure_render_resources(sf_batch* b, hipStream_t stream) {
     const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES, tail = 36 * SF_FP_BYTES + SF_XC_BYTES + SF_HUD_BYTES;
     HIP_TRY(hipMalloc((void**)&b->d_xcache, bytes + tail));
     HIP_TRY(hipMemsetAsync(b->d_xcache, 0, bytes + tail, stream));
-    HIP_TRY(sf_launch_hud_pictures(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes + 36 * SF_FP_BYTES + SF_XC_BYTES, stream));
+    HIP_TRY(sf_launch_hud_pictures(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes + 36 * SF_FP_BYTES + SF_XC_BYTES, b->d_glyphs, stream));
     HIP_TRY(sf_launch_fort_patches(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes, b->d_arcs, b->d_falpha, stream));
   }
   HIP_TRY(hipStreamSynchronize(stream));
   b->render_ready = true;
+  b->draw_current = false;
+  return SF_OK;
+}
+
+// What the default geometry's frame kernel keeps of the score text, (re)made from b->h_glyphs: the four static backgrounds
+// (variant bit 0 = the score 0000000 baked in) with their 84x84 images and -- where they exist already -- the explosion
+// cache, the score / bar pictures and the backgrounds with the fortress in them.  Synchronous.
+int bake_default_glyphs(sf_batch* b) {
+  std::vector<uint8_t> bg(4 * SF_BG_STRIDE, 0), bg84(4 * SF_OUT * SF_OUT);
+  for (int v = 0; v < 4; v++) {  // static background variants: sf_raster.h
+    int rc = sf_image_static_glyphs(v, &b->h_glyphs, bg.data() + v * SF_BG_STRIDE);
+    if (rc == SF_OK) rc = sf_resize_area_u8(bg.data() + v * SF_BG_STRIDE, SF_IMG_W, SF_IMG_H, bg84.data() + v * SF_OUT * SF_OUT, SF_OUT, SF_OUT);
+    if (rc != SF_OK) return rc;
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(b->d_bg84, bg84.data(), bg84.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_bg, bg.data(), bg.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_glyphs, &b->h_glyphs, sizeof(SfGlyphAtlas), hipMemcpyHostToDevice));
+  b->baked_glyphs = b->h_glyphs;
+  if (b->render_ready && b->d_xcache) {
+    const size_t bytes = (size_t)b->n_envs * SF_XC_BYTES, tail = 36 * SF_FP_BYTES + SF_XC_BYTES + SF_HUD_BYTES;
+    HIP_TRY(hipMemset(b->d_xcache, 0, bytes + tail));
+    HIP_TRY(sf_launch_hud_pictures(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes + 36 * SF_FP_BYTES + SF_XC_BYTES, b->d_glyphs, nullptr));
+    HIP_TRY(sf_launch_fort_patches(b->d_bg, b->d_bg84, b->d_tabs, b->d_xcache + bytes, b->d_arcs, b->d_falpha, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+  }
   b->draw_current = false;
   return SF_OK;
 }
@@ -249,11 +279,6 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
     // whatever obs_type the batch steps with (the reference's render(), ENV:190-193)
     static_assert(SF_IMG_W == SF_IMAGE_W && SF_IMG_H == SF_IMAGE_H && SF_OUT == SF_IMAGE_OUT, "sfmi.h vs sf_raster.h");
     static_assert(SF_IMG_W == (int)sfc::pb_width && SF_IMG_H == (int)sfc::pb_height, "ENV:57-58");
-    std::vector<uint8_t> bg(4 * SF_BG_STRIDE, 0), bg84(4 * SF_OUT * SF_OUT);
-    for (int v = 0; v < 4; v++) {  // static background variants: sf_raster.h
-      sf_image_static(v, bg.data() + v * SF_BG_STRIDE);
-      sf_resize_area_u8(bg.data() + v * SF_BG_STRIDE, SF_IMG_W, SF_IMG_H, bg84.data() + v * SF_OUT * SF_OUT, SF_OUT, SF_OUT);
-    }
     // device layout of the INTER_AREA tables: sf_raster.h
     std::vector<uint32_t> tabs(SF_TAB_WORDS, 0u);
     {
@@ -296,7 +321,6 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
     // (room for the backgrounds with the fortress in them, filled by the first frame: sf_launch_fort_patches)
     HIP_TRY_FREE(hipMalloc((void**)&b->d_bg84, (size_t)SF_BG_COUNT * SF_OUT * SF_OUT));
     HIP_TRY_FREE(hipMemset(b->d_bg84, 0, (size_t)SF_BG_COUNT * SF_OUT * SF_OUT));
-    HIP_TRY_FREE(hipMemcpy(b->d_bg84, bg84.data(), bg84.size(), hipMemcpyHostToDevice));
     HIP_TRY_FREE(hipMalloc((void**)&b->d_bg, (size_t)SF_BG_COUNT * SF_BG_STRIDE));
     HIP_TRY_FREE(hipMemset(b->d_bg, 0, (size_t)SF_BG_COUNT * SF_BG_STRIDE));
     {
@@ -314,8 +338,17 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
       HIP_TRY_FREE(hipMemcpy(b->d_falpha, fa.data(), fa.size(), hipMemcpyHostToDevice));
     }
     HIP_TRY_FREE(hipMalloc((void**)&b->d_tabs, tabs.size() * sizeof(uint32_t)));
-    HIP_TRY_FREE(hipMemcpy(b->d_bg, bg.data(), bg.size(), hipMemcpyHostToDevice));
     HIP_TRY_FREE(hipMemcpy(b->d_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // the score text: the built-in glyph atlas (sf_glyphs.h) and the four static backgrounds made with it
+    HIP_TRY_FREE(hipMalloc((void**)&b->d_glyphs, sizeof(SfGlyphAtlas)));
+    sf_glyphs_default(&b->h_glyphs);
+    {
+      const int rc = bake_default_glyphs(b);
+      if (rc != SF_OK) {
+        sf_destroy(b);
+        return rc;
+      }
+    }
   }
 
   SfKernelArgs& a = b->args;
@@ -423,6 +456,7 @@ extern "C" int sf_destroy(sf_batch* b) {
   if (b->d_draw) (void)hipFree(b->d_draw);
   if (b->d_gbg) (void)hipFree(b->d_gbg);
   if (b->d_gtabs) (void)hipFree(b->d_gtabs);
+  if (b->d_glyphs) (void)hipFree(b->d_glyphs);
   if (b->args.dbg) (void)hipFree(b->args.dbg);
   if (b->args.hint) (void)hipFree(b->args.hint);
   delete b;
@@ -470,6 +504,8 @@ extern "C" int sf_image_size(const sf_batch* b, int32_t* width, int32_t* height)
   return SF_OK;
 }
 
+extern "C" int sf_image_geometry_is_default(const sf_batch* b) { return b && b->g_w == 0 ? 1 : 0; }
+
 extern "C" int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, double vp_y, double vp_w, double vp_h, double line_width) {
   if (!b) {
     sf_set_error("sf_set_image_geometry: null batch");
@@ -483,7 +519,10 @@ extern "C" int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, dou
   DeviceGuard guard(b->device);
   HIP_TRY(hipDeviceSynchronize());
   if (vp_x == SF_VP_X && vp_y == SF_VP_Y && vp_w == 450.0 && vp_h == 460.0 && w == SF_IMG_W && h == SF_IMG_H && line_width == SF_LINE_W) {
-    b->g_w = b->g_h = 0;  // the default geometry: the fast frame kernel
+    b->g_w = b->g_h = 0;  // the default geometry: the fast frame kernel, the built-in glyph atlas
+    sf_glyphs_default(&b->h_glyphs);
+    if (memcmp(&b->h_glyphs, &b->baked_glyphs, sizeof(SfGlyphAtlas)) != 0) return bake_default_glyphs(b);
+    HIP_TRY(hipMemcpy(b->d_glyphs, &b->h_glyphs, sizeof(SfGlyphAtlas), hipMemcpyHostToDevice));
     return SF_OK;
   }
   if (w < SF_OUT || h < SF_OUT || w >= 3 * SF_OUT || h >= 3 * SF_OUT || (long)w * h > 49152) {
@@ -541,6 +580,48 @@ extern "C" int sf_set_image_geometry(sf_batch* b, double scale, double vp_x, dou
   b->g_vx = vp_x;
   b->g_vy = vp_y;
   b->g_lw = line_width;
+  // no glyph atlas is known for this geometry: the seven-segment fallback until sf_set_score_glyphs gives one
+  memset(&b->h_glyphs, 0, sizeof(SfGlyphAtlas));
+  HIP_TRY(hipMemcpy(b->d_glyphs, &b->h_glyphs, sizeof(SfGlyphAtlas), hipMemcpyHostToDevice));
+  return SF_OK;
+}
+
+extern "C" int sf_set_score_glyphs(sf_batch* b, const sf_score_glyphs* layout, const uint8_t* alpha) {
+  if (!b) {
+    sf_set_error("sf_set_score_glyphs: null batch");
+    return SF_ERR_ARG;
+  }
+  SfGlyphAtlas G;
+  const int box[4] = {SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1};
+  const int rc = sf_glyphs_pack(layout, alpha, b->g_w ? nullptr : box, &G);
+  if (rc != SF_OK) return rc;
+  DeviceGuard guard(b->device);
+  HIP_TRY(hipDeviceSynchronize());
+  b->h_glyphs = G;
+  if (!b->g_w) return bake_default_glyphs(b);
+  HIP_TRY(hipMemcpy(b->d_glyphs, &b->h_glyphs, sizeof(SfGlyphAtlas), hipMemcpyHostToDevice));
+  return SF_OK;
+}
+
+extern "C" int sf_get_score_glyphs(const sf_batch* b, int32_t* has_atlas, sf_score_glyphs* layout, uint8_t* alpha, size_t alpha_bytes) {
+  if (!b || !has_atlas) {
+    sf_set_error("sf_get_score_glyphs: null argument");
+    return SF_ERR_ARG;
+  }
+  const SfGlyphAtlas& G = b->h_glyphs;
+  *has_atlas = G.gw ? 1 : 0;
+  if (!G.gw) return SF_OK;
+  const size_t need = (size_t)SF_GLYPH_CHARS * G.gw * G.gh;
+  if (!layout || !alpha || alpha_bytes < need) {
+    sf_set_error("sf_get_score_glyphs: need layout and %zu bytes for alpha", need);
+    return SF_ERR_ARG;
+  }
+  layout->gw = G.gw;
+  layout->gh = G.gh;
+  layout->advance = G.advance;
+  layout->y0 = G.y0;
+  for (int i = 0; i < SF_GLYPH_CHARS * 10; i++) layout->x0[i / 10][i % 10] = G.x0[i];
+  memcpy(alpha, G.alpha, need);
   return SF_OK;
 }
 
@@ -568,7 +649,7 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
     if (stack_done)  // `current_obs *= masks` for the finished envs, then the new frame into its slot
       HIP_TRY(sf_launch_stack_clear(frames_dev - (size_t)stack_slot * frame, (size_t)stack_n * frame, stack_done, b->n_envs, stream));
     HIP_TRY(sf_launch_render_generic(b->d_state, b->n_envs, b->g_w, b->g_h, b->g_sx, b->g_sy, b->g_vx, b->g_vy, b->g_lw, b->d_consts + SF_LDS_TRIG, b->d_arcs, b->d_gbg,
-                                     b->d_gtabs, frames_dev, env_stride, mode == SF_OBS_IMAGE ? 1 : 0, stream));
+                                     b->d_gtabs, frames_dev, env_stride, mode == SF_OBS_IMAGE ? 1 : 0, b->d_glyphs, stream));
     return SF_OK;
   }
   if (env_stride == 0) env_stride = frame;
@@ -594,7 +675,7 @@ static int render(sf_batch* b, int mode, uint8_t* frames_dev, size_t env_stride,
   const unsigned char* fpatch = b->d_xcache ? b->d_xcache + (size_t)b->n_envs * SF_XC_BYTES : nullptr;
   HIP_TRY(sf_launch_render(b->d_state, b->d_draw, b->n_envs, b->d_bg, b->d_bg84, b->d_tabs, frames_dev, env_stride, b->d_xcache, fpatch,
                            mode == SF_OBS_IMAGE ? 1 : 0, stack_done, stack_slot, stack_n, stack_prev, b->args.hint,
-                           fpatch ? fpatch + 36 * SF_FP_BYTES + SF_XC_BYTES : nullptr, b->d_consts + SF_LDS_TRIG, b->d_arcs, b->d_falpha, stream));
+                           fpatch ? fpatch + 36 * SF_FP_BYTES + SF_XC_BYTES : nullptr, b->d_consts + SF_LDS_TRIG, b->d_arcs, b->d_falpha, b->d_glyphs, stream));
   return SF_OK;
 }
 

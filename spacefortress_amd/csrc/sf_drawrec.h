@@ -211,7 +211,9 @@ SFD_FN Header make_header(double sx, double sy, int ship_angle, bool ship_alive,
   const bool mt = sb.meets(widened(text_box())), mb = sb.meets(widened(bar_box()));
   const bool ex_text = !ship_alive && mt, ex_bar = !ship_alive && mb;
   const bool other_text = (ship_alive && mt) || (proj & 4u), other_bar = (ship_alive && mb) || (proj & 8u);
-  const bool near_text = ex_text || (proj & 1u), near_bar = ex_bar || (proj & 2u);
+  // (a live ship ON one of the boxes: not in play -- it dies outside the big hexagon -- but a caller's sf_set_field can put it there)
+  const bool near_text = ex_text || (proj & 1u) || (ship_alive && sb.meets(text_box()));
+  const bool near_bar = ex_bar || (proj & 2u) || (ship_alive && sb.meets(bar_box()));
   const int pnts = (int)points;
   const bool baked_text = pnts == 0 && !near_text, baked_bar = vlner == 0 && !near_bar;
   const unsigned variant = (baked_text ? 1u : 0u) | (baked_bar ? 2u : 0u);

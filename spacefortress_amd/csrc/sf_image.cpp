@@ -177,7 +177,60 @@ extern "C" int sf_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* ds
   return SF_OK;
 }
 
-extern "C" int sf_image_static(int variant, uint8_t* out) {
+// the built-in glyph atlas of the default geometry (sf_glyphs.h)
+void sf_glyphs_default(SfGlyphAtlas* G) {
+  memset(G, 0, sizeof(*G));
+  G->gw = sfg::kDefW;
+  G->gh = sfg::kDefH;
+  G->advance = sfg::kDefAdvance;
+  G->y0 = sfg::kDefY0;
+  for (int i = 0; i < SF_GLYPH_CHARS * 10; i++) G->x0[i] = sfg::kDefX0;
+  G->x_min = G->x_max = sfg::kDefX0;
+  memcpy(G->alpha, sfg::kDefAlpha, sizeof(sfg::kDefAlpha));
+}
+
+// caller's layout + dense alpha -> the kernels' atlas; layout null = no atlas (the seven-segment fallback).  `box`: the
+// pixel box the text must stay in (the default geometry's fast kernel keeps a fixed one), or null
+int sf_glyphs_pack(const sf_score_glyphs* layout, const uint8_t* alpha, const int* box, SfGlyphAtlas* G) {
+  memset(G, 0, sizeof(*G));
+  if (!layout) return SF_OK;
+  if (!alpha || layout->gw < 1 || layout->gw > SF_GLYPH_MAX_W || layout->gh < 1 || layout->gh > SF_GLYPH_MAX_H || layout->advance < 1 ||
+      layout->advance > 64) {
+    sf_set_error("score glyphs: need alpha and 1 <= gw <= %d, 1 <= gh <= %d, 1 <= advance <= 64", SF_GLYPH_MAX_W, SF_GLYPH_MAX_H);
+    return SF_ERR_ARG;
+  }
+  G->gw = layout->gw;
+  G->gh = layout->gh;
+  G->advance = layout->advance;
+  G->y0 = layout->y0;
+  int lo = 32767, hi = -32768;
+  for (int i = 0; i < SF_GLYPH_CHARS * 10; i++) {
+    const int v = layout->x0[i / 10][i % 10];
+    G->x0[i] = (int16_t)v;
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+  }
+  G->x_min = (int16_t)lo;
+  G->x_max = (int16_t)hi;
+  memcpy(G->alpha, alpha, (size_t)SF_GLYPH_CHARS * layout->gw * layout->gh);
+  if (box) {
+    // every inked pixel of every character in every cell, for every placement, inside [box[0], box[2]) x [box[1], box[3])
+    for (int c = 0; c < SF_GLYPH_CHARS; c++)
+      for (int r = 0; r < G->gh; r++)
+        for (int q = 0; q < G->gw; q++)
+          if (G->alpha[(c * G->gh + r) * G->gw + q]) {
+            const int y = G->y0 + r, xa = lo + q, xb = hi + 6 * G->advance + q;
+            if (y < box[1] || y >= box[3] || xa < box[0] || xb >= box[2]) {
+              sf_set_error("score glyphs: ink at row %d, columns %d..%d leaves the text box [%d, %d) x [%d, %d) of the default geometry",
+                           y, xa, xb, box[0], box[2], box[1], box[3]);
+              return SF_ERR_ARG;
+            }
+          }
+  }
+  return SF_OK;
+}
+
+int sf_image_static_glyphs(int variant, const SfGlyphAtlas* G, uint8_t* out) {
   // the static background plus what the kernel may take as given (sf_render.hip): bit 0 the score text
   // "0000000", bit 1 the vulnerability bar at 0 -- drawn with the kernel's own per-pixel arithmetic
   if (variant < 0 || variant > 3 || !out) {
@@ -188,13 +241,36 @@ extern "C" int sf_image_static(int variant, uint8_t* out) {
   if (rc != SF_OK) return rc;
   if (variant & 1) {
     const unsigned long long masks = sfr::score_masks(0);
+    const uint32_t chars = sfg::score_chars(0);
     for (int y = SF_TXT_BOX_Y0; y < SF_TXT_BOX_Y1; y++)
-      for (int x = SF_TXT_BOX_X0; x < SF_TXT_BOX_X1; x++)
-        out[y * SF_IMG_W + x] = (uint8_t)sfr::text_pixel(x, y, masks, out[y * SF_IMG_W + x]);
+      for (int x = SF_TXT_BOX_X0; x < SF_TXT_BOX_X1; x++) {
+        uint8_t* p = out + y * SF_IMG_W + x;
+        *p = (uint8_t)(G && G->gw ? sfg::text_pixel(G, chars, x, y, *p) : sfr::text_pixel(x, y, masks, *p));
+      }
   }
   if (variant & 2)
     for (int y = SF_BAR_BOX_Y0; y < SF_BAR_BOX_Y1; y++)
       for (int x = SF_BAR_BOX_X0; x < SF_BAR_BOX_X1; x++)
         out[y * SF_IMG_W + x] = (uint8_t)sfr::bar_pixel(x, y, 0, 168, out[y * SF_IMG_W + x]);
+  return SF_OK;
+}
+
+extern "C" int sf_image_static(int variant, uint8_t* out) {
+  SfGlyphAtlas G;
+  sf_glyphs_default(&G);
+  return sf_image_static_glyphs(variant, &G, out);
+}
+
+extern "C" int sf_default_score_glyphs(sf_score_glyphs* layout, uint8_t* alpha, size_t alpha_bytes) {
+  if (!layout || !alpha || alpha_bytes < sizeof(sfg::kDefAlpha)) {
+    sf_set_error("sf_default_score_glyphs: need layout and %zu bytes for alpha", sizeof(sfg::kDefAlpha));
+    return SF_ERR_ARG;
+  }
+  layout->gw = sfg::kDefW;
+  layout->gh = sfg::kDefH;
+  layout->advance = sfg::kDefAdvance;
+  layout->y0 = sfg::kDefY0;
+  for (int i = 0; i < SF_GLYPH_CHARS * 10; i++) layout->x0[i / 10][i % 10] = sfg::kDefX0;
+  memcpy(alpha, sfg::kDefAlpha, sizeof(sfg::kDefAlpha));
   return SF_OK;
 }

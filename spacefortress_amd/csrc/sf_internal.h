@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sf_glyphs.h"
 #include "sf_layout.h"
 #include "sfmi.h"
 
@@ -35,10 +36,11 @@ hipError_t sf_launch_render(const unsigned char* state, const unsigned char* dra
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
                             const uint8_t* stack_prev, const unsigned long long* hint, const unsigned char* hud,
-                            const double* trig, const double* arcs, const unsigned char* falpha, hipStream_t stream);
+                            const double* trig, const double* arcs, const unsigned char* falpha, const SfGlyphAtlas* glyphs,
+                            hipStream_t stream);
 // the score / bar pictures (SF_HUD_BYTES, sf_raster.h)
 hipError_t sf_launch_hud_pictures(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* hud,
-                                  hipStream_t stream);
+                                  const SfGlyphAtlas* glyphs, hipStream_t stream);
 // ... and the 36 x 4 backgrounds with the fortress in them, behind the four plain ones (SF_BG_COUNT, sf_raster.h)
 hipError_t sf_launch_fort_patches(uint32_t* bg, uint32_t* bg84, const uint32_t* tabs, unsigned char* fpatch, const double* arcs,
                                   const unsigned char* falpha, hipStream_t stream);
@@ -56,7 +58,7 @@ hipError_t sf_launch_normalize(const void* obs, void* obs_out, int obs_f64, cons
 // per row: first, count, 4 weights, 2 pad)
 hipError_t sf_launch_render_generic(const unsigned char* state, int n_envs, int W, int H, double sx, double sy, double vp_x, double vp_y,
                                     double line_w, const double* trig, const double* arcs, const uint8_t* bg, const uint32_t* tabs,
-                                    uint8_t* out, size_t out_stride, int resize, hipStream_t stream);
+                                    uint8_t* out, size_t out_stride, int resize, const SfGlyphAtlas* glyphs, hipStream_t stream);
 hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uint8_t* done, int n, hipStream_t stream);
 
 hipError_t sf_launch_normalize_after_step(const void* obs, void* obs_out, int obs_f64, const int32_t* rew, float* rew_out, int n,
@@ -71,3 +73,8 @@ int sf_step_with_norm_partials(sf_batch* b, const void* actions_dev, int act_typ
 // sf_host.cpp (no HIP calls: usable and tested without a GPU)
 void sf_host_fill_consts(const sf_preset& p, double* consts /* SF_CONST_DOUBLES */);
 void sf_set_error(const char* fmt, ...);
+// sf_image.cpp: the score text's glyph atlas (sf_glyphs.h) -- the built-in one, a caller's, and the static background with
+// the score 0000000 of a given atlas baked in
+void sf_glyphs_default(SfGlyphAtlas* G);
+int sf_glyphs_pack(const sf_score_glyphs* layout, const uint8_t* alpha, const int* box, SfGlyphAtlas* G);
+int sf_image_static_glyphs(int variant, const SfGlyphAtlas* G, uint8_t* out);

@@ -2,9 +2,9 @@
 // (static background, resize tables).  What is drawn, where, in which order and colour follows the
 // reference renderer (SRC/draw.cpp:227-270, SRC/wireframe.cpp:8-70, ENV:50-58,203-206,
 // rl/envs.py:28-30); HOW a stroke or a filled rectangle becomes pixel values is cairo's image backend,
-// restated in sf_tor.h and pinned to the reference's own frames (tests/golden/frames).  The one thing here
-// that is a MODEL is the score text: cairo's toy font API draws it with whatever font fontconfig resolves
-// on the box, so its pixels are not a property of the reference (see below).
+// restated in sf_tor.h and pinned to the reference's own frames (tests/golden/frames).  The score text is a glyph
+// atlas (sf_glyphs.h: FreeType's bitmaps as the image's cairo blits them, held to the reference's frames); the
+// seven-segment glyphs below are the named FALLBACK for a geometry / font without an atlas.
 #pragma once
 #include <math.h>
 
@@ -24,8 +24,8 @@
 #define SF_SCALE 0.2  /* ENV:50 */
 #define SF_LINE_W 3.0 /* ls = 3 user units (ENV:50), i.e. 0.6 device pixels */
 
-// Score text (drawScore, SRC/draw.cpp:190-203): "%07d", bold monospace 30 user units, centred on
-// (355, 97), grey .5.  No font rasteriser here: seven-segment glyphs in a cell of the same metrics,
+// Score text FALLBACK (drawScore, SRC/draw.cpp:161-173): "%07d", bold monospace 30 user units, centred on
+// (355, 97), grey .5 -- used only where no glyph atlas is set (sf_glyphs.h).  Seven-segment glyphs in a cell of the same metrics,
 // user units: advance 18, ink 16 x 22 starting 3 into the cell, stem 5 -- calibrated so that the ink box of
 // the seven characters is where the reference's own screenshot has it (rl/imgs/screens.png: 295..419 x
 // 85..107; tests/test_image_host.py::test_layout_matches_the_references_own_screenshot).  At .2 scale a
@@ -86,8 +86,10 @@ SF_HD float dev_y(float y) { return (y - (float)SF_VP_Y) * (float)SF_SCALE; }
 // variants of the static background with exactly this arithmetic.
 
 // pixel boxes [x0, x1) x [y0, y1) that contain them
-#define SF_TXT_BOX_X0 32
-#define SF_TXT_BOX_X1 58
+// (the built-in atlas's ink: columns 31..58, rows 1..4; the fallback's: 32..57, 1..5; an atlas given for the default
+//  geometry must keep its ink inside: sf_set_score_glyphs)
+#define SF_TXT_BOX_X0 31
+#define SF_TXT_BOX_X1 59
 #define SF_TXT_BOX_Y0 1
 #define SF_TXT_BOX_Y1 6
 #define SF_BAR_BOX_X0 25
@@ -101,7 +103,7 @@ SF_HD unsigned seg_mask(int glyph) {
   return k[glyph];
 }
 
-// "%07d" of the score (drawScore, SRC/draw.cpp:190-203) as 7 x 7 segment bits, cell 0 = leftmost character
+// "%07d" of the score (drawScore, SRC/draw.cpp:161-173) as 7 x 7 segment bits, cell 0 = leftmost character
 SF_HD unsigned long long score_masks(int pnts) {
   const bool neg = pnts < 0;
   unsigned mag = neg ? (unsigned)(-(long long)pnts) : (unsigned)pnts;

@@ -779,6 +779,7 @@ struct SfRenderArgs {
   const double* trig;        // cos, sin of deg2rad(k), k = 0 .. 359, as the reference's libm gives them (sf_trig_table)
   const double* arcs;        // 86 x 8: the explosion's arcs (sft::ArcK; sf_arc_table)
   const unsigned char* falpha;  // 36 x 256: the live fortress's coverage over its 16 x 16 box, heading 10 k (sf_image_fort_alpha)
+  const SfGlyphAtlas* glyphs;   // the score text's glyph atlas (sf_glyphs.h); null or gw == 0: the seven-segment fallback
 };
 
 // ---- Which env a workgroup draws.  The first frame of a dead ship's explosion costs about three ordinary frames (96
@@ -903,19 +904,31 @@ __device__ __forceinline__ void fort_in_place(const Frame<RESIZE>& F, const unsi
   F.resample(Box{kFpX0, kFpY0, kFpX1, kFpY1});
 }
 
-// ---- score (drawScore, SRC/draw.cpp:190-203): "%07d", grey .5, seven-segment digits; a lane per pixel of the box
+// ---- score (drawScore, SRC/draw.cpp:161-173): "%07d", grey .5 through the glyph atlas's coverage (sf_glyphs.h), a lane per
+// pixel of the box; without an atlas the seven-segment fallback (sf_raster.h)
 template <bool RESIZE>
-__device__ __forceinline__ void draw_score(const Frame<RESIZE>& F, int pnts) {
-  const unsigned long long masks = sfr::score_masks(pnts);
+__device__ __forceinline__ void draw_score(const Frame<RESIZE>& F, int pnts, const SfGlyphAtlas* G) {
   constexpr int w = SF_TXT_BOX_X1 - SF_TXT_BOX_X0, h = SF_TXT_BOX_Y1 - SF_TXT_BOX_Y0;
   static_assert(SF_TXT_BOX_X0 <= (SF_TXT_X0 + SF_TXT_PAD - SF_VP_X) * SF_SCALE &&
                 SF_TXT_BOX_X1 >= (SF_TXT_X0 + 6 * SF_TXT_ADV + SF_TXT_PAD + SF_TXT_W - SF_VP_X) * SF_SCALE &&
                 SF_TXT_BOX_Y0 <= (SF_TXT_TOP - SF_VP_Y) * SF_SCALE &&
-                SF_TXT_BOX_Y1 >= (SF_TXT_TOP + SF_TXT_H - SF_VP_Y) * SF_SCALE, "text box");
-  for (int i = F.lane; i < w * h; i += 64) {
-    const int ry = i / w, rx = i - ry * w;
-    uint8_t* p = F.fb + (SF_TXT_BOX_Y0 + ry) * SF_IMG_W + SF_TXT_BOX_X0 + rx;
-    *p = (uint8_t)sfr::text_pixel(SF_TXT_BOX_X0 + rx, SF_TXT_BOX_Y0 + ry, masks, *p);
+                SF_TXT_BOX_Y1 >= (SF_TXT_TOP + SF_TXT_H - SF_VP_Y) * SF_SCALE, "text box (fallback glyphs)");
+  static_assert(SF_TXT_BOX_X0 <= sfg::kDefX0 && SF_TXT_BOX_X1 >= sfg::kDefX0 + 6 * sfg::kDefAdvance + sfg::kDefW &&
+                SF_TXT_BOX_Y0 <= sfg::kDefY0 && SF_TXT_BOX_Y1 >= sfg::kDefY0 + sfg::kDefH, "text box (built-in atlas)");
+  if (G && G->gw) {  // (uniform)
+    const uint32_t chars = sfg::score_chars(pnts);
+    for (int i = F.lane; i < w * h; i += 64) {
+      const int ry = i / w, rx = i - ry * w;
+      uint8_t* p = F.fb + (SF_TXT_BOX_Y0 + ry) * SF_IMG_W + SF_TXT_BOX_X0 + rx;
+      *p = (uint8_t)sfg::text_pixel(G, chars, SF_TXT_BOX_X0 + rx, SF_TXT_BOX_Y0 + ry, *p);
+    }
+  } else {
+    const unsigned long long masks = sfr::score_masks(pnts);
+    for (int i = F.lane; i < w * h; i += 64) {
+      const int ry = i / w, rx = i - ry * w;
+      uint8_t* p = F.fb + (SF_TXT_BOX_Y0 + ry) * SF_IMG_W + SF_TXT_BOX_X0 + rx;
+      *p = (uint8_t)sfr::text_pixel(SF_TXT_BOX_X0 + rx, SF_TXT_BOX_Y0 + ry, masks, *p);
+    }
   }
   __builtin_amdgcn_wave_barrier();
   F.resample(Box{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1});
@@ -1360,7 +1373,7 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
       pic = xc_mine + kXcScore;
       draw = save = !((xst.flags & kBits) == kBits && xst.points == pnts);
     }
-    if (draw) draw_score(F, pnts);
+    if (draw) draw_score(F, pnts, a.glyphs);
     if (pic) hud_picture(F, pic, SF_HUD_SCORE_ROW, tbox, save, with_out, pre, hscore);
     if (save) {
       xst.flags |= kBits;
@@ -1466,7 +1479,7 @@ hipError_t sf_launch_fort_patches(uint32_t* bg, uint32_t* bg84, const uint32_t* 
 // one workgroup per picture: the score for blockIdx - SF_HUD_SCORE_HALF points, then the bar's states, drawn on the
 // bare background by the frames' own code and saved for hud_picture
 __global__ __launch_bounds__(64) void sf_hud_kernel(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs,
-                                                    unsigned char* hud) {
+                                                    unsigned char* hud, const SfGlyphAtlas* glyphs) {
   __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
   __shared__ __attribute__((aligned(16))) uint32_t obufw[kOutBytes / 4];
   __shared__ __attribute__((aligned(16))) uint32_t tabw[SF_TAB_WORDS];
@@ -1478,7 +1491,7 @@ __global__ __launch_bounds__(64) void sf_hud_kernel(const uint32_t* bg, const ui
   const Frame<true> F{reinterpret_cast<uint8_t*>(fbw), reinterpret_cast<uint8_t*>(obufw), tabw, nullptr, lane, nullptr, nullptr, uint4{0u, 0u, 0u, 0u}};
   if (pic < 2 * SF_HUD_SCORE_HALF) {
     const int pnts = pic - SF_HUD_SCORE_HALF;
-    draw_score(F, pnts);
+    draw_score(F, pnts, glyphs);
     __syncthreads();
     hud_picture(F, hud_score_picture(hud, pnts), SF_HUD_SCORE_ROW, Box{SF_TXT_BOX_X0, SF_TXT_BOX_Y0, SF_TXT_BOX_X1, SF_TXT_BOX_Y1}, true);
   } else {
@@ -1490,8 +1503,8 @@ __global__ __launch_bounds__(64) void sf_hud_kernel(const uint32_t* bg, const ui
 }
 
 hipError_t sf_launch_hud_pictures(const uint32_t* bg, const uint32_t* bg84, const uint32_t* tabs, unsigned char* hud,
-                                  hipStream_t stream) {
-  hipLaunchKernelGGL(sf_hud_kernel, dim3(2 * SF_HUD_SCORE_HALF + SF_HUD_BAR_STATES), dim3(64), 0, stream, bg, bg84, tabs, hud);
+                                  const SfGlyphAtlas* glyphs, hipStream_t stream) {
+  hipLaunchKernelGGL(sf_hud_kernel, dim3(2 * SF_HUD_SCORE_HALF + SF_HUD_BAR_STATES), dim3(64), 0, stream, bg, bg84, tabs, hud, glyphs);
   return hipGetLastError();
 }
 
@@ -1514,13 +1527,14 @@ hipError_t sf_launch_render(const unsigned char* state, const unsigned char* dra
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
                             const uint8_t* stack_prev, const unsigned long long* hint, const unsigned char* hud,
-                            const double* trig, const double* arcs, const unsigned char* falpha, hipStream_t stream) {
+                            const double* trig, const double* arcs, const unsigned char* falpha, const SfGlyphAtlas* glyphs,
+                            hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
   // the front of the grid: a sixteenth of the batch (ships die in about 1.3 % of the ticks of random play); batches
   // whose hint words no longer fit a short scan (> 32 per lane) are drawn in env order
   const int n_front = hint && n_envs <= 64 * 64 * 32 ? (n_envs / 16 > 64 ? n_envs / 16 : 64) : 0;
   SfRenderArgs a{state, draw, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n, stack_prev,
-                 n_front ? hint : nullptr, n_front, hud, trig, arcs, falpha};
+                 n_front ? hint : nullptr, n_front, hud, trig, arcs, falpha, glyphs};
   const unsigned grid = (unsigned)(n_envs + n_front);
   if (resize)
     hipLaunchKernelGGL(sf_render_kernel<true>, dim3(grid), dim3(64), 0, stream, a);

@@ -153,9 +153,23 @@ struct Ctx {
     }
     sftd::raster<8>(tc(), q, valid, 0, sftd::kKindRing | (m0 << 8), 191);
   }
-  // the score (drawScore, SRC/draw.cpp:161-173): "%07d", grey .5, seven-segment glyphs (sf_raster.h: the font is the box's, the
-  // glyphs are a model) -- a lane per pixel of the text's box composites the segments that touch it in the strokes' order
-  __device__ void score(int pnts) const {
+  // the score (drawScore, SRC/draw.cpp:161-173): "%07d", grey .5 through the coverage of this geometry's glyph atlas
+  // (sf_glyphs.h, sf_set_score_glyphs) -- a lane per pixel of the text's box --, or, without one, the seven-segment FALLBACK
+  // (sf_raster.h: equal to no reference pixels) -- a lane per pixel composites the segments that touch it in the strokes' order
+  __device__ void score(int pnts, const SfGlyphAtlas* G) const {
+    if (G && G->gw) {  // (uniform)
+      const uint32_t chars = sfg::score_chars(pnts);
+      const int bx0 = max((int)G->x_min, 0), bx1 = min((int)G->x_max + 6 * G->advance + G->gw, W);
+      const int by0 = max(G->y0, 0), by1 = min(G->y0 + G->gh, H);
+      const int bw = bx1 - bx0, n = bw > 0 && by1 > by0 ? bw * (by1 - by0) : 0;
+      for (int i = tid; i < n; i += 64) {
+        const int ry = i / bw, px = bx0 + (i - ry * bw), py = by0 + ry;
+        uint8_t* p = fb + py * W + px;
+        *p = (uint8_t)sfg::text_pixel(G, chars, px, py, *p);
+      }
+      order();
+      return;
+    }
     // (float64 here: the glyph model is ours, oracle/render_np.py evaluates it in float64, and this kernel has the time)
     const unsigned long long masks = sfr::score_masks(pnts);
     auto dx = [&](double x) { return (x - vx) * sx; };
@@ -229,6 +243,7 @@ struct SfGenericArgs {
   uint8_t* out;
   size_t out_stride;
   int resize;
+  const SfGlyphAtlas* glyphs;  // the score text's glyph atlas for THIS geometry (sf_glyphs.h); null or gw == 0: the fallback
 };
 
 __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericArgs a) {
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericAr
         C.wireframe(3, (int)ang, p.x, p.y);
       }
     }
-  C.score(pnts);
+  C.score(pnts, a.glyphs);
   // vulnerability bar (drawVlner, :205-225,268)
   {
     const bool kill = vlner > 10 && tb.w < sfc::vuln_time;
@@ -360,9 +375,9 @@ __global__ __launch_bounds__(kThreads) void sf_render_generic_kernel(SfGenericAr
 
 hipError_t sf_launch_render_generic(const unsigned char* state, int n_envs, int W, int H, double sx, double sy, double vp_x, double vp_y,
                                     double line_w, const double* trig, const double* arcs, const uint8_t* bg, const uint32_t* tabs,
-                                    uint8_t* out, size_t out_stride, int resize, hipStream_t stream) {
+                                    uint8_t* out, size_t out_stride, int resize, const SfGlyphAtlas* glyphs, hipStream_t stream) {
   if (n_envs <= 0) return hipSuccess;
-  SfGenericArgs a{state, n_envs, W, H, sx, sy, vp_x, vp_y, line_w, trig, arcs, bg, tabs, out, out_stride, resize};
+  SfGenericArgs a{state, n_envs, W, H, sx, sy, vp_x, vp_y, line_w, trig, arcs, bg, tabs, out, out_stride, resize, glyphs};
   const size_t lds = ((size_t)W * H + 15) & ~(size_t)15;
   hipLaunchKernelGGL(sf_render_generic_kernel, dim3((unsigned)n_envs), dim3(kThreads), lds, stream, a);
   return hipGetLastError();

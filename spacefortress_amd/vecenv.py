@@ -349,12 +349,41 @@ class SFVecEnv:
         self.image_w, self.image_h = int(w.value), int(h.value)
         # (the default geometry's frame kernel also shifts a frame stack in the same launch -- sf_render_shift; the general
         #  renderer draws into one slot: DeviceRollout asks)
-        self.default_geometry = (float(scale), (vx, vy, vw, vh), float(ls)) == (.2, (130., 80., 450., 460.), 3.)
+        self.default_geometry = bool(self._L.sf_image_geometry_is_default(self._h))  # the library's word, not a second predicate
         if self.obs_type == "image-raw":
             self.obs_shape = (self.image_h, self.image_w)
             self.obs_dim = self._L.sf_obs_dim(self._h)
             self.observation_space = Box(0, 255, self.obs_shape, np.uint8)
             self._bufs = self._buf_ptrs = None
+
+    def set_score_glyphs(self, alpha=None, layout=None, x0=None):
+        """The glyph atlas the score text is drawn from in the batch's CURRENT geometry (sfmi.h: sf_set_score_glyphs; how one is
+        taken from a box's cairo: tests/golden/frames/make_score_golden.py).  alpha uint8 [11, gh, gw] ('0'..'9', '-'), layout
+        (gw, gh, advance, y0), x0 int [11, 10] (or one int).  alpha=None: the seven-segment fallback, by name.  The default
+        geometry starts with the built-in atlas (= the reference's frames on this image), any other geometry with none."""
+        if alpha is None:
+            _lib.check(self._L.sf_set_score_glyphs(self._h, None, None))
+            return
+        a = np.ascontiguousarray(alpha, np.uint8)
+        gw, gh, adv, y0 = (int(v) for v in layout)
+        if a.shape != (11, gh, gw):
+            raise ValueError("alpha must be uint8 [11, gh, gw] = [11, %d, %d]" % (gh, gw))
+        g = _lib.ScoreGlyphs(gw, gh, adv, y0)
+        xs = np.broadcast_to(np.asarray(x0, np.int16), (11, 10))
+        for i in range(11):
+            for j in range(10):
+                g.x0[i][j] = int(xs[i, j])
+        _lib.check(self._L.sf_set_score_glyphs(self._h, C.byref(g), a.ctypes.data_as(C.c_void_p)))
+
+    def score_glyphs(self):
+        """The atlas in use: dict(alpha, layout, x0), or None while the seven-segment fallback draws the text."""
+        has, g = C.c_int32(), _lib.ScoreGlyphs()
+        a = np.zeros(11 * 24 * 24, np.uint8)
+        _lib.check(self._L.sf_get_score_glyphs(self._h, C.byref(has), C.byref(g), a.ctypes.data_as(C.c_void_p), a.size))
+        if not has.value:
+            return None
+        return dict(alpha=a[:11 * g.gw * g.gh].reshape(11, g.gh, g.gw).copy(), layout=(g.gw, g.gh, g.advance, g.y0),
+                    x0=np.array([[g.x0[i][j] for j in range(10)] for i in range(11)], np.int16))
 
     def render(self, mode="image-raw", out=None):
         """Frames of the CURRENT state of every env, whatever obs_type the batch steps with (the

@@ -120,7 +120,7 @@ def test_game_shim_equals_the_real_extensions_getters(name):
         if t in frames:
             g.draw()
             got = np.frombuffer(g.pb_pixels, np.uint8).reshape(92, 90, 4)
-            assert np.array_equal(got[9:], frames[t].reshape(92, 90, 4)[9:]), t  # (rows 0 .. 8: the score's toy-font text)
+            assert np.array_equal(got, frames[t].reshape(92, 90, 4)), t  # (all rows: the score's text is the reference's since round 6)
     for k in ("thrust_durations", "shot_durations", "shot_intervals_invul", "shot_intervals_vul"):
         assert len(z[k + "_games"]) == 1 and getattr(g, k) == tuple(int(v) for v in z[k]), k
     g.close()

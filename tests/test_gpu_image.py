@@ -4,10 +4,10 @@ states they were drawn from, and (2) the model (oracle/render_np.py over oracle/
 fixtures and against the real cairo) on states recorded from the real reference engine (tests/golden/*.npz) and on oracle
 lock-step runs.
 
-Bar: BIT-EXACT.  Against the reference's frames on every pixel outside the score text's rows (the text is drawn by whatever
-font fontconfig finds on the reference's box: not a property of the reference; the kernel and the model share a glyph
-model for it); against the model on every pixel.  The 84x84 image is OpenCV's INTER_AREA of that surface (cv2 is not in
-this image: its published algorithm, restated twice)."""
+Bar: BIT-EXACT on EVERY pixel, against the reference's frames and against the model -- the score text's rows included since
+round 6: the text is drawn from a glyph atlas (sf_glyphs.h) taken from the image's cairo + FreeType and held to frames of the
+reference's renderer (tests/golden/frames/scores.npz, make_score_golden.py).  The 84x84 image is OpenCV's INTER_AREA of that
+surface (cv2 is not in this image: its published algorithm, restated twice)."""
 import json
 import os
 
@@ -57,11 +57,10 @@ def _load_snaps(env, snaps, gametype="youturn"):
 @pytest.mark.parametrize("name", ["poses.npz", "scenarios.npz"])
 def test_frames_equal_the_references_own_renderer(sfa, name):
     """Every fixture frame: the state the reference drew it from goes into a lane (set_field), the frame kernel draws it,
-    and every pixel outside the text rows equals what SRC/draw.cpp + cairo 1.16 drew."""
+    and every pixel of all 92 rows -- the score text too -- equals what SRC/draw.cpp + cairo 1.16 drew."""
     z = np.load(os.path.join(GOLDEN, "frames", name))
-    meta = json.loads(str(z["meta"]))
     frames, snaps, gt = z["frames"], z["snaps"], z["gametype"]
-    rows = meta["text_rows"]
+    rows = 0  # (rounds 1-5 masked meta["text_rows"] = 9 rows here)
     names = ["youturn", "autoturn", "test-youturn", "test-autoturn"]
     total = 0
     for g in sorted(set(int(x) for x in gt)):
@@ -78,19 +77,99 @@ def test_frames_equal_the_references_own_renderer(sfa, name):
     assert total == len(frames) > 600
 
 
+def test_score_text_equals_the_references_own_renderer(sfa):
+    """scores.npz: 2 200 scores drawn by the reference's renderer on a quiet state (rows 0..8) -- through the cached score
+    pictures (|points| < 512), the in-place path (beyond) -- and 320 whole frames with explosion rings, ships, missiles and
+    shells UNDER the text (the in-place path over objects, the explosion cache's score box).  Both frame sizes' code paths:
+    the raw surface is compared, the 84x84 image against cv2's arithmetic on the reference's frame."""
+    from oracle import render_np as R
+    z = np.load(os.path.join(GOLDEN, "frames", "scores.npz"))
+    pts, rows = z["points"], z["rows"]
+    n = len(pts)
+    base = np.repeat(z["base"].reshape(1), n)
+    base["points"] = pts
+    env = sfa.SFVecEnv(n, gametype="youturn", obs_type="image-raw")
+    assert env.score_glyphs()["layout"] == (4, 4, 4, 1)
+    _load_snaps(env, base)
+    got = env.render("image-raw").cpu().numpy()
+    bad = [int(pts[i]) for i in range(n) if not np.array_equal(got[i][:9], rows[i])]
+    assert not bad, (len(bad), bad[:10])
+    assert all(np.array_equal(got[i][9:], got[0][9:]) for i in range(0, n, 97))
+    small = env.render("image").cpu().numpy()[:, 0]
+    for i in range(0, n, 53):
+        ref = got[0].copy()
+        ref[:9] = rows[i]
+        assert np.array_equal(small[i], R.resize_area(ref)), int(pts[i])
+    env.close()
+    frames, snaps = z["frames"], z["snaps"]
+    env = sfa.SFVecEnv(len(snaps), gametype="youturn", obs_type="image-raw")
+    _load_snaps(env, snaps)
+    for rep in range(2):  # twice: the second frame of a dead ship comes out of the explosion cache, its score box with it
+        got = env.render("image-raw").cpu().numpy()
+        for i in range(len(snaps)):
+            frames_close(got[i], frames[i], ("under the text", rep, i))
+        small = env.render("image").cpu().numpy()[:, 0]
+        for i in range(0, len(snaps), 7):
+            frames_close(small[i], R.resize_area(frames[i]), ("under the text, 84x84", rep, i))
+    env.close()
+
+
+def test_score_glyphs_can_be_set_and_named_fallback(sfa, model):
+    """sf_set_score_glyphs on the default geometry: the seven-segment fallback by name (equal to the model's fallback, NOT to
+    the reference), an atlas of another 'font' (the built-in one moved a row down and thinned), and back to the built-in one
+    through set_image_geometry -- cached pictures, baked backgrounds and in-place text all follow."""
+    R, hb, hs, bg = model
+    z = np.load(os.path.join(GOLDEN, "frames", "scores.npz"))
+    pts = np.array([0, 7, 123, 511, 512, 99999, -3], np.int32)
+    base = np.repeat(z["base"].reshape(1), len(pts))
+    base["points"] = pts
+    env = sfa.SFVecEnv(len(pts), gametype="youturn", obs_type="image-raw")
+    _load_snaps(env, base)
+    builtin = env.score_glyphs()
+    f0 = env.render("image-raw").cpu().numpy()
+    for i, p in enumerate(pts):
+        frames_close(f0[i], R.render_raw(base[i], hb, hs), ("built-in", int(p)))
+    env.set_score_glyphs(None)
+    assert env.score_glyphs() is None
+    f1 = env.render("image-raw").cpu().numpy()
+    for i, p in enumerate(pts):
+        frames_close(f1[i], R.render_raw(base[i], hb, hs, text="segments"), ("fallback", int(p)))
+    assert np.abs(f1.astype(int) - f0.astype(int))[:, :9].max() > 50
+    other = dict(alpha=(builtin["alpha"] // 2).astype(np.uint8), layout=(4, 4, 4, 2), x0=np.full((11, 10), 31, np.int16))
+    env.set_score_glyphs(other["alpha"], other["layout"], other["x0"])
+    f2 = env.render("image-raw").cpu().numpy()
+    for i, p in enumerate(pts):
+        frames_close(f2[i], R.render_raw(base[i], hb, hs, glyphs=other), ("another atlas", int(p)))
+    with pytest.raises(ValueError):  # ink outside the default geometry's text box
+        env.set_score_glyphs(builtin["alpha"], (4, 4, 4, 3), 31)
+    env.set_image_geometry()  # the default geometry again: the built-in atlas
+    assert np.array_equal(env.score_glyphs()["alpha"], builtin["alpha"])
+    frames_close(env.render("image-raw").cpu().numpy(), f0, "built-in again")
+    env.close()
+
+
 def test_frames_equal_the_references_renderer_in_other_geometries(sfa):
-    """sf_render_generic.hip against the reference's frames in four other geometries (one with vw * scale not whole)."""
+    """sf_render_generic.hip against the reference's frames in four other geometries (one with vw * scale not whole) -- every
+    row: each geometry's glyph atlas (score_glyphs.npz, from the same cairo) goes in through sf_set_score_glyphs; without one
+    the text is the seven-segment fallback and only the rows below it are the reference's."""
+    from oracle import render_np as R
     z = np.load(os.path.join(GOLDEN, "frames", "geometries.npz"))
     snaps = z["snaps"]
     for gi, (sc, vx, vy, vw, vh, ls) in enumerate(z["geometries"]):
         env = sfa.SFVecEnv(len(snaps), gametype="youturn", obs_type="image-raw", image_geometry=(sc, (vx, vy, vw, vh), ls))
+        assert env.score_glyphs() is None and not env.default_geometry
         _load_snaps(env, snaps)
-        got = env.render("image-raw").cpu().numpy()
         want = z["frames_%d" % gi]
+        got = env.render("image-raw").cpu().numpy()
         assert got.shape == want.shape
         rows = int((112 - vy) * (want.shape[1] / vh)) + 1
         for i in range(len(snaps)):
-            frames_close(got[i][rows:], want[i][rows:], ("geometry", gi, i))
+            frames_close(got[i][rows:], want[i][rows:], ("geometry, fallback text", gi, i))
+        A = R.load_glyphs(gi + 1)
+        env.set_score_glyphs(A["alpha"], A["layout"], A["x0"])
+        got = env.render("image-raw").cpu().numpy()
+        for i in range(len(snaps)):
+            frames_close(got[i], want[i], ("geometry", gi, i))
         env.close()
 
 
@@ -563,14 +642,19 @@ def test_config5_at_its_size_against_the_model(sfa, oracle_mod, model):
 
 
 @pytest.mark.gpu
-def test_frames_reproduce_the_fingerprints_of_round_5s_exact_kernel(sfa):
-    """tests/golden/render_fingerprints_youturn_1024x640_hunter.txt holds a 63-bit weighted sum of every byte of every frame
-    (84x84 each step, the raw 90x92 every eighth) of 1 024 envs over 640 steps of the fortress-hunting policy -- ships
-    exploding, missiles, shells, the fortress destroyed, scores and every state of the bar --, made by tools/render_hash.py
-    under round 5's kernel once it equalled every frame of the reference's own renderer (tests/golden/frames).  Two
-    independent lane arrangements of the scan (sf_tor_dev.h: the general one of commit 0a3dd54 and the one the frame kernel
-    uses now) gave the same 640 lines.  Any later kernel has to reproduce every sum: a single changed byte in 655 360
-    frames shows.  (Rounds 2-4 kept such a file for their own pixel model, which was not cairo's.)"""
+@pytest.mark.parametrize("text,name", [("segments", "render_fingerprints_youturn_1024x640_hunter.txt"),
+                                       ("atlas", "render_fingerprints_r6_atlas_youturn_1024x640_hunter.txt")])
+def test_frames_reproduce_the_recorded_fingerprints(sfa, text, name):
+    """A fingerprint file holds a 63-bit weighted sum of every byte of every frame (84x84 each step, the raw 90x92 every
+    eighth) of 1 024 envs over 640 steps of the fortress-hunting policy -- ships exploding, missiles, shells, the fortress
+    destroyed, scores and every state of the bar --, made by tools/render_hash.py.  A single changed byte in 655 360 frames
+    shows.
+      "segments": round 5's file, made once its kernel equalled every frame of the reference's renderer outside the text
+      rows (two independent lane arrangements of the scan -- commit 0a3dd54's general one and the frame kernel's -- gave the
+      same 640 lines).  With the seven-segment fallback selected BY NAME today's kernel still has to give these sums: nothing
+      but the text changed in round 6.
+      "atlas": the same run with the built-in glyph atlas (the reference's text), recorded in round 6 under the build that
+      passed every fixture test of this file with all 92 rows compared; the guard for every later change of the kernel."""
     import sys
 
     from conftest import ROOT
@@ -578,8 +662,8 @@ def test_frames_reproduce_the_fingerprints_of_round_5s_exact_kernel(sfa):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from render_hash import fingerprints
 
-    want = open(os.path.join(GOLDEN, "render_fingerprints_youturn_1024x640_hunter.txt")).read().split("\n")[:-1]
-    got = fingerprints("youturn", 1024, 640, "hunter")
+    want = open(os.path.join(GOLDEN, name)).read().split("\n")[:-1]
+    got = fingerprints("youturn", 1024, 640, "hunter", text)
     assert len(got) == len(want) == 640
     bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
     assert not bad, "frames differ from the recorded ones at steps %s ..." % bad[:5]
@@ -721,6 +805,8 @@ def test_frames_in_another_geometry_vs_model(sfa, oracle_mod, scale, viewport, l
     acts = open_loop_actions("hunter", (T, N), env.n_actions, rng, phase=rng.integers(0, 96, N))
     prev = R.set_geometry(scale, viewport, ls)
     try:
+        A = R.glyphs_for_geometry()  # both geometries are among score_glyphs.npz's: the text is the reference's here too
+        env.set_score_glyphs(A["alpha"], A["layout"], A["x0"])
         bg = R.background(hb, hs)
         checked = 0
         for t in range(T):

@@ -162,7 +162,7 @@ def test_model_draws_what_the_state_says(oracle_mod):
     assert box.sum() > 255 * 4
     assert d[41:54, 38:54].sum() > 255 * 8          # fortress
     assert (f[89, 25:65] == 84).all()            # empty bar: .33 grey
-    assert d[1:6, 32:58].sum() > 128 * 20           # seven zeros
+    assert d[1:5, 31:59].sum() > 128 * 20           # seven zeros
     s["vlner"] = 4
     f4 = R.render_raw(s, hb, hs, bg=bg)
     assert (f4[89, 25:41] == 168).all() and (f4[89, 41:65] == 84).all()
@@ -188,11 +188,26 @@ def test_static_variants_match_model():
         assert L.sf_image_static(v, out.ctypes.data_as(C.c_void_p)) == 0
         want = bg.copy()
         if v & 1:
-            R.score_text(want, 0)
+            want = R.score_text_atlas(want, 0, R.load_glyphs(0))  # the reference's glyphs (score_glyphs.npz)
         if v & 2:
             want = R.bar_frame(want, 0, False)
         assert np.array_equal(out, want), v
     assert L.sf_image_static(4, bg.ctypes.data_as(C.c_void_p)) < 0
+
+
+def test_builtin_glyph_atlas_is_the_fixture():
+    """The atlas compiled into the library (sf_glyphs.h) = tests/golden/frames/score_glyphs.npz geometry 0, which
+    make_score_golden.py took from the image's cairo + FreeType and held to the reference renderer's frames."""
+    from oracle import render_np as R
+    from spacefortress_amd._lib import ScoreGlyphs
+    L = _lib()
+    g, a = ScoreGlyphs(), np.zeros((11, 4, 4), np.uint8)
+    assert L.sf_default_score_glyphs(C.byref(g), a.ctypes.data_as(C.c_void_p), a.size) == 0
+    A = R.load_glyphs(0)
+    assert (g.gw, g.gh, g.advance, g.y0) == tuple(int(v) for v in A["layout"])
+    assert np.array_equal(np.array([[g.x0[i][j] for j in range(10)] for i in range(11)]), A["x0"])
+    assert np.array_equal(a, A["alpha"])
+    assert L.sf_default_score_glyphs(C.byref(g), a.ctypes.data_as(C.c_void_p), 10) < 0
 
 
 def test_layout_matches_the_references_own_screenshot():

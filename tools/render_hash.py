@@ -8,10 +8,13 @@ import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-def fingerprints(gametype="youturn", N=4096, T=3000, policy="hunter"):
-    """One line per step, see the module docstring."""
+def fingerprints(gametype="youturn", N=4096, T=3000, policy="hunter", text="atlas"):
+    """One line per step, see the module docstring.  text: "atlas" = the built-in glyph atlas (the reference's text),
+    "segments" = the seven-segment fallback, by name (what every build before round 6 drew)."""
     from spacefortress_amd import SFVecEnv
     env = SFVecEnv(N, gametype=gametype, obs_type="image", spawn_stride=3)
+    if text == "segments":
+        env.set_score_glyphs(None)
     env.reset()
     g = torch.Generator(device="cpu").manual_seed(11)
     w84 = torch.randint(1, 1 << 31, (N, 84 * 84), generator=g, dtype=torch.int64).to(env.device)
@@ -44,6 +47,7 @@ if __name__ == "__main__":
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
     T = int(sys.argv[4]) if len(sys.argv) > 4 else 3000
     policy = sys.argv[5] if len(sys.argv) > 5 else "hunter"
-    lines = fingerprints(gametype, N, T, policy)
+    text = sys.argv[6] if len(sys.argv) > 6 else "atlas"
+    lines = fingerprints(gametype, N, T, policy, text)
     open(out, "w").write("\n".join(lines) + "\n")
     print("wrote %d step fingerprints of %d lanes (%s, %s) to %s" % (T, N, gametype, policy, out))
