@@ -77,6 +77,12 @@ typedef enum {
 #define SF_FLAG_NO_AUTO_RESET 4u    /* bare SSF_Env semantics: a finished lane keeps ticking until sf_reset
                                        (the default is the vec-env worker's reset-on-done, rl/train.py:80) */
 
+#define SF_FLAG_REF_RESET_OBS 8u    /* the observation of a NEW game (sf_reset, a finished lane's auto-reset) carries aim = vdir =
+                                       ndist = 0: what the reference's wrapper returns there on fresh memory -- Game::Game leaves
+                                       mExtra unwritten (SRC/game.cpp:78) and reset() reads it before the first tick (ENV:163-178).
+                                       Default: computeExtra(spawn state), a defined value.
+                                       Pinned by tests/golden/wrapper (the real ssf_env.py, executed). */
+
 /* element type of the action array handed to sf_step */
 #define SF_ACT_U8 1
 #define SF_ACT_I32 4

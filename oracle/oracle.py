@@ -82,6 +82,9 @@ def oracle_lib():
             getattr(L, f).argtypes = [C.c_void_p]
         L.sfo_env_action_keys.argtypes = [C.c_void_p, C.c_int]
         L.sfo_env_set_faithful_bugs.argtypes = [C.c_void_p, C.c_int]
+        L.sfo_env_set_ref_reset_obs.argtypes = [C.c_void_p, C.c_int]
+        L.sfo_vec_env_at.restype = C.c_void_p
+        L.sfo_vec_env_at.argtypes = [C.c_void_p, C.c_int]
         L.sfo_env_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.sfo_env_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sfo_env_features.argtypes = [C.c_void_p, C.c_void_p]
@@ -193,6 +196,10 @@ class OracleEnv(_GameApi):
     def set_faithful_bugs(self, on):
         self.L.sfo_env_set_faithful_bugs(self.h, int(on))
 
+    def set_ref_reset_obs(self, on):
+        """A new Game's aim / vdir / ndist read 0 until its first tick, as in the reference on fresh memory (next reset on)."""
+        self.L.sfo_env_set_ref_reset_obs(self.h, int(on))
+
     @property
     def prev_vlner(self):
         return self.L.sfo_env_prev_vlner(self.h)
@@ -294,6 +301,10 @@ class OracleVecEnv:
         info = np.empty(self.n, np.uint8)
         self.L.sfo_vec_step(self.h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done), _ptr(info))
         return obs, rew, done.astype(bool), info.astype(bool)
+
+    def set_ref_reset_obs(self, on):
+        for i in range(self.n):
+            self.L.sfo_env_set_ref_reset_obs(self.L.sfo_vec_env_at(self.h, i), int(on))
 
     def snapshots(self):
         s = np.zeros(self.n, SNAPSHOT_DTYPE)

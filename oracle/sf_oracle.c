@@ -642,6 +642,7 @@ static int env_init_from(sfo_env* e, const char* gametype, int action_set, int o
   }
   e->obs_type = obs_type;
   e->faithful_bugs = 1;
+  e->ref_reset_obs = 0;
   e->tickdur = (int)ceil(1. / 30 * 1000); /* ENV:61 */
   e->prev_vlner = 0;                      /* ENV:92 */
   e->pb_width = (int)(450 * .2);          /* ENV:57 */
@@ -750,6 +751,7 @@ void sfo_env_features(const sfo_env* e, double* f) { /* ENV:95-157 */
 
 void sfo_env_reset(sfo_env* e, double* obs) { /* ENV:163-178; prev_vlner is NOT cleared */
   sfo_game_init(&e->g, &e->cfg, &e->rng);
+  if (e->ref_reset_obs) e->g.vdir = e->g.aim = e->g.fdist = e->g.ndist = 0; /* fresh memory under mExtra, SRC/game.cpp:78 */
   if (obs) sfo_env_features(e, obs);
 }
 
@@ -895,6 +897,7 @@ int sfo_env_n_actions(const sfo_env* e) { return e->n_actions; }
 int sfo_env_action_keys(const sfo_env* e, int a) { return e->action_keys[a]; }
 int sfo_env_prev_vlner(const sfo_env* e) { return e->prev_vlner; }
 void sfo_env_set_faithful_bugs(sfo_env* e, int on) { e->faithful_bugs = on; }
+void sfo_env_set_ref_reset_obs(sfo_env* e, int on) { e->ref_reset_obs = on; }
 void sfo_env_snapshot(const sfo_env* e, sfo_snapshot* s) { sfo_game_snapshot(&e->g, s); }
 void sfo_vec_snapshot(sfo_vec_env* v, int i, sfo_snapshot* s) { sfo_game_snapshot(&v->envs[i].g, s); }
 int sfo_vec_prev_vlner(sfo_vec_env* v, int i) { return v->envs[i].prev_vlner; }

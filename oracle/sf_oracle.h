@@ -139,6 +139,8 @@ typedef struct {
   int tickdur;          /* ENV:61 -> 34 */
   int prev_vlner;       /* ENV:92, survives reset() */
   int pb_width, pb_height; /* ENV:57-58 -> 90, 92 (normalized-features divisor) */
+  int ref_reset_obs;    /* 1: a new Game's mExtra reads 0, 0, 0 until its first tick -- what the reference's reset() returns on
+                           fresh memory (SRC/game.cpp:78 leaves it unwritten; ENV:163-178); 0: computeExtra(spawn state) */
 } sfo_env;
 
 /* action_set follows ENV:67-89 (1 = reduced set, 0/-1 = all key combinations) */
@@ -201,6 +203,7 @@ int sfo_env_n_actions(const sfo_env* e);
 int sfo_env_action_keys(const sfo_env* e, int a);
 int sfo_env_prev_vlner(const sfo_env* e);
 void sfo_env_set_faithful_bugs(sfo_env* e, int on);
+void sfo_env_set_ref_reset_obs(sfo_env* e, int on); /* takes effect at the next reset */
 void sfo_env_snapshot(const sfo_env* e, sfo_snapshot* s);
 void sfo_vec_snapshot(sfo_vec_env* v, int i, sfo_snapshot* s);
 int sfo_vec_prev_vlner(sfo_vec_env* v, int i);

@@ -25,6 +25,7 @@ EVENT_NAMES = {0x1: "press-fire", 0x2: "press-thrust", 0x4: "press-left", 0x8: "
 FLAG_OBS_F64 = 1
 FLAG_REAL_SHELL_COUNT = 2
 FLAG_NO_AUTO_RESET = 4
+FLAG_REF_RESET_OBS = 8
 EPISODE_STATS_LEN = 8
 
 

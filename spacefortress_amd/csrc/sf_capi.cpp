@@ -399,6 +399,7 @@ extern "C" int sf_create(const sf_create_params* p, sf_batch** out) {
   a.obs_f64 = (p->flags & SF_FLAG_OBS_F64) ? 1 : 0;
   a.real_shell_count = (p->flags & SF_FLAG_REAL_SHELL_COUNT) ? 1 : 0;
   a.auto_reset = (p->flags & SF_FLAG_NO_AUTO_RESET) ? 0 : 1;
+  a.ref_reset_obs = (p->flags & SF_FLAG_REF_RESET_OBS) ? 1 : 0;
   a.obs_dim = p->obs_type == SF_OBS_MONITORS ? 10 : ((p->obs_type == SF_OBS_NONE || image) ? 0 : 15 + preset.n_keys);
   static_assert(sfc::pb_width == (double)(int)(450 * .2) && sfc::pb_height == (double)(int)(460 * .2), "ENV:57-58");
   static_assert(sfc::max_ticks == (double)(sfc::game_time / sfc::tick_ms), "ENV:165");

@@ -850,8 +850,10 @@ __global__ __launch_bounds__(SF_BLOCK) void sf_reset_kernel(SfKernelArgs a, int 
   L.mpool = 0;  // every env of the tile starts over: the tile's missile pool is empty
   store_lane(tb, o, L);
   if (obs != nullptr && i < (unsigned)a.n_envs && a.obs_type != 3) {
-    // the reference's extras are stale heap until the first tick; defined as computeExtra(spawn)
+    // the reference's extras are stale heap until the first tick; defined as computeExtra(spawn) -- or, by flag, as the zeros
+    // a fresh process's heap holds there (SF_FLAG_REF_RESET_OBS)
     Extras e = compute_extras(a, L, sf_atan2<true>(L.sy - sfc::fort_y, L.sx - sfc::fort_x), sf_atan2<false>(L.vy, L.vx));
+    if (a.ref_reset_obs) e = Extras{0.0, 0.0, 0.0};
     if (a.obs_f64)
       write_obs<double>(a, (double*)obs + (size_t)i * a.obs_dim, L, e);
     else
@@ -1836,7 +1838,8 @@ __global__ __launch_bounds__(BLKP > 1000 ? 2 * (BLKP - 1000) : BLKP) void sf_ste
     if ((i & ~63u) < (unsigned)n_envs_p)  // the padding waves behind the batch write nothing
       flush_features_f32<DIM>(stage + (tid & ~63u) * DIM, (float*)obs + (so + (i & ~63u)) * DIM, lane);
   } else if (obs != nullptr && a.obs_type != 3) {  // uniform across the grid
-    const Extras e = compute_extras(a, L, a_pos, a_vel);
+    Extras e = compute_extras(a, L, a_pos, a_vel);
+    if (a.ref_reset_obs && done && a.auto_reset) e = Extras{0.0, 0.0, 0.0};  // (a new game's observation as the reference returns it: sf_launch_step keeps such batches here)
     if (a.obs_f64) {
       double* stage = lds + kLdsStage;
       write_obs<double>(a, stage + tid * a.obs_dim, L, e);
@@ -2206,7 +2209,7 @@ hipError_t sf_launch_step(const SfKernelArgs& a, bool autoturn, bool shaped, con
   const int vec_ok = ((uintptr_t)obs & 15u) == 0 && (!fused || ((size_t)a.n_envs * a.obs_dim * elem) % 16 == 0);
   // the default observation has its own instantiations (OBSK = 1): see write_features_f32
   const bool fast_obs = obs != nullptr && a.obs_type == 0 && !a.obs_f64 && vec_ok && a.n_envs % 64 == 0 &&
-                        a.obs_dim == (autoturn ? 17 : 19);
+                        a.obs_dim == (autoturn ? 17 : 19) && !a.ref_reset_obs;
   const bool xtra = act_type == SF_ACT_SAMPLED || a.act_out != nullptr || !a.auto_reset;
   // a split launch (sf_step_kernel: a missile wave per tile) where a tile's wave is alone on its SIMD otherwise
   // (SF_SPLIT 2, for tests: every batch it can serve)

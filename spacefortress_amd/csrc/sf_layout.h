@@ -309,6 +309,9 @@ struct SfKernelArgs {
   // kernel; else null.  draw_pics: the batch's render pictures exist (the records' decisions depend on it)
   unsigned char* draw;
   int draw_pics;
+  // SF_FLAG_REF_RESET_OBS: the observation of a NEW game (sf_reset, the auto-reset of a finished lane) carries aim = vdir =
+  // ndist = 0, what the reference's wrapper returns on fresh memory (Game::Game leaves mExtra unwritten, SRC/game.cpp:78)
+  int ref_reset_obs;
 };
 
 // words of SfKernelArgs::acc behind the SF_EPISODE_STATS_LEN (8) episode statistics

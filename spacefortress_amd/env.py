@@ -20,7 +20,7 @@ class SSF_Env(_Base):
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 30}  # ENV:45-48
 
     def __init__(self, gametype="youturn", scale=.2, viewport=(130, 80, 450, 460), ls=3, action_set=1,
-                 obs_type="image", device=None, seed=1):
+                 obs_type="image", device=None, seed=1, ref_reset_obs=False):
         assert obs_type in ("image", "features", "normalized-features", "monitors")  # ENV:51
         # scale / viewport / ls only shape the picture (ENV:56-60 -> sf.Game(width, height, viewport, lw)).  The default
         # geometry has the fast frame kernel (90x92 surface, 0.6-pixel strokes compiled in); any other one is drawn by the
@@ -40,7 +40,7 @@ class SSF_Env(_Base):
         # 'image' here is the bare [92, 90] grey frame (ENV:171); the 84x84 shrink is the trainer's wrapper
         self._vec = SFVecEnv(1, gametype=gametype, obs_type="image-raw" if obs_type == "image" else obs_type,
                              action_set=action_set, device=device,
-                             seed=seed, obs_dtype=__import__("torch").float64, auto_reset=False)
+                             seed=seed, obs_dtype=__import__("torch").float64, auto_reset=False, ref_reset_obs=ref_reset_obs)
         self._drawable = True
         if not self._default_geometry:
             try:
@@ -59,7 +59,7 @@ class SSF_Env(_Base):
             self.observation_space = Box(0, 255, (self.h, self.w, 3), np.uint8)
         self.actions_taken = {i: 0 for i in range(self.action_space.n)}  # ENV:91
         self._g = None
-        self.np_random = None
+        self.seed()  # ENV:53: __init__ seeds np_random (an RNG the game never reads)
         # ENV:93: __init__ ends with reset(), i.e. the first Game -- sf_create already made it
 
     @property

@@ -35,7 +35,7 @@ _UNSIGNED_FIELDS = {"spawn_cursor", "missile_mask", "shell_mask", "flags"}
 class SFVecEnv:
     def __init__(self, num_envs, gametype="youturn", obs_type="features", action_set=1, device=None,
                  seed=1, spawn_skip=0, spawn_stride=0, obs_dtype=torch.float32, faithful_bugs=True,
-                 auto_reset=True, spawn_table_len=0, reuse_buffers=False, image_geometry=None):
+                 auto_reset=True, spawn_table_len=0, reuse_buffers=False, image_geometry=None, ref_reset_obs=False):
         if obs_type not in _lib.OBS_TYPES:
             raise AssertionError("obs_type %r" % (obs_type,))  # ENV:51
         self._L = _lib.lib()
@@ -56,6 +56,8 @@ class SFVecEnv:
             flags |= _lib.FLAG_REAL_SHELL_COUNT
         if not auto_reset:
             flags |= _lib.FLAG_NO_AUTO_RESET
+        if ref_reset_obs:  # a new game's observation as the reference's wrapper returns it: aim = vdir = ndist = 0 (sfmi.h)
+            flags |= _lib.FLAG_REF_RESET_OBS
         p = _lib.CreateParams(gametype.encode(), int(num_envs), dev_index, int(action_set),
                               _lib.OBS_TYPES[obs_type], flags, int(seed) & 0xFFFFFFFF, int(spawn_skip),
                               int(spawn_stride), int(spawn_table_len))
