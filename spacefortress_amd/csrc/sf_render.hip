@@ -369,10 +369,16 @@ struct Frame {
 #define SF_DS_STAMP(k) do { if (SF_RENDER_STOP == 41 + (k)) return; } while (0)
     const Box myb = quad_box(mine);
     const bool mineok = valid && !myb.empty();
-    // an object whose box is empty in one of its lines may still touch the surface with another: keep whole objects
-    unsigned long long live = __ballot(valid);
+    // an object whose box is empty in one of its lines may still touch the surface with another: keep whole objects -- but an
+    // object NONE of whose lines touches the surface (a missile between the view's border and the game area's, a third of
+    // its life) draws nothing and is left out: no record, no sub-rows, and a frame with nothing else makes no call at all
     const unsigned long long drawn = __ballot(mineok);
     const int nq = kind == sftd::kKindShell ? 4 : 3;  // (per lane: the object's)
+#ifndef SF_CULL_OFFSCREEN
+#define SF_CULL_OFFSCREEN 1
+#endif
+    const bool obj_seen = !SF_CULL_OFFSCREEN || ((drawn >> obj0) & ((1ull << nq) - 1ull)) != 0ull;
+    unsigned long long live = __ballot(valid && obj_seen);
     SF_DS_STAMP(0);
     while (live) {
       // this chunk: the first objects whose lines fit sixteen records
@@ -1296,8 +1302,12 @@ __global__ __launch_bounds__(64, SF_RENDER_WPE) void sf_render_kernel(SfRenderAr
   const Frame<RESIZE> F{fb, frame_out, tabw, nullptr, lane, torw, torw + Frame<RESIZE>::kLtabAt, lt_e};
   if (SF_RENDER_STOP == 1) return;
 
-  // (sf_tor_dev.h's accumulators start out zero and every call leaves them so)
-  for (int i = lane; i < Frame<RESIZE>::kTorWords; i += 64) torw[i] = 0u;
+  // (sf_tor_dev.h's accumulators start out zero and every call leaves them so; what lies below them -- records, headers,
+  //  objects, task list, map -- is written by every call before it is read: twenty rounds of stores a frame that bought nothing)
+#ifndef SF_TOR_ZERO_ALL
+#define SF_TOR_ZERO_ALL 0
+#endif
+  for (int i = (SF_TOR_ZERO_ALL ? 0 : sftd::kAccAtF) + lane; i < Frame<RESIZE>::kTorWords; i += 64) torw[i] = 0u;
   __builtin_amdgcn_wave_barrier();
   // ---- what is restored from round trip 2's registers: the dead ship's explosion if its cache entry is this one
   // (the entry is keyed by where the ship died: the float64 position the picture is a function of)

@@ -496,6 +496,33 @@ struct CtxF {
   }
 };
 
+// inclusive prefix sum across the wave: six DPP adds (row_shr 1, 2, 4, 8; row_bcast 15 into rows 1 and 3, 31 into rows 2 and 3) --
+// no trips through LDS (__shfl_up is a ds_bpermute a step: six dependent LDS round trips for one scan)
+#ifndef SFTD_DPP_SCANS
+#define SFTD_DPP_SCANS 1
+#endif
+__device__ __forceinline__ int wave_incl_sum(int v) {
+#if SFTD_DPP_SCANS
+#define SFTD_SCAN_STEP(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, (ctrl), (rmask), 0xf, false)
+  SFTD_SCAN_STEP(0x111, 0xf);
+  SFTD_SCAN_STEP(0x112, 0xf);
+  SFTD_SCAN_STEP(0x114, 0xf);
+  SFTD_SCAN_STEP(0x118, 0xf);
+  SFTD_SCAN_STEP(0x142, 0xa);
+  SFTD_SCAN_STEP(0x143, 0xc);
+#undef SFTD_SCAN_STEP
+  return v;
+#else
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int a = __shfl_up(v, d);
+    if (lane >= d) v += a;
+  }
+  return v;
+#endif
+}
+
 constexpr double kMagic52 = 6755399441055744.0;  // 1.5 * 2^52: adding it leaves round-to-nearest(x) in the low word
 __device__ __forceinline__ int cell_fast(const uint32_t* slot, double sd) {  // slot = (A - 1/2, B) as two doubles; sd = (double)s
   const double2 ab = *reinterpret_cast<const double2*>(slot);
@@ -738,12 +765,8 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
       by0 = (s0 * 34953) >> 19; bh = (((s1 - 1) * 34953) >> 19) + 1 - by0;
     }
   }
-  int abase = bw * bh, rbase = bh;
-#pragma unroll
-  for (int d = 1; d < kMaxObjs; d <<= 1) {
-    const int a = __shfl_up(abase, d), r = __shfl_up(rbase, d);
-    if (lane >= d) { abase += a; rbase += r; }
-  }
+  // (lanes nobj .. 63 carry zeros: the whole-wave scans give lanes 0 .. kMaxObjs - 1 what a sixteen-lane one would)
+  const int abase = wave_incl_sum(bw * bh), rbase = wave_incl_sum(bh);
   const int tot_rows = __builtin_amdgcn_readlane(rbase, kMaxObjs - 1), tot_pix = __builtin_amdgcn_readlane(abase, kMaxObjs - 1);
   if (lane < nobj) {
     uint32_t* o = C.obj(lane);
@@ -759,12 +782,7 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
     s_lo = max(my_lo, 0);
     cnt = max(min(my_hi, C.H * sft::kGridY) - s_lo, 0);
   }
-  int incl = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int a = __shfl_up(incl, d);
-    if (lane >= d) incl += a;
-  }
+  const int incl = wave_incl_sum(cnt);
   const int tot_sub = __builtin_amdgcn_readlane(incl, 63), start = incl - cnt;
   if (valid) {  // the quad's extent in pixel columns, [lo, hi) clamped to a byte each: for the overlap test of the sub-rows' lanes
     const int lo = min(min(mine.x[0], mine.x[1]), min(mine.x[2], mine.x[3])), hi = max(max(mine.x[0], mine.x[1]), max(mine.x[2], mine.x[3]));
