@@ -472,11 +472,12 @@ constexpr int kRecWordsF = 48;
 //              the vertical x = 0 / x = the surface's width: b0 | b1 << 12 | right border << 24; 0 = none
 //   46 47      the pixel rows a slot's edge spans whole, [lo, hi) as lo | hi << 8: L1 | L2 << 16, R1 | R2 << 16
 constexpr unsigned kRecBorder = 1u << 16, kRecThird = 1u << 17;
-constexpr int kHdrWordsF = 8;   // per RUN of sub-rows (= per quad that has any), for the sub-rows' lanes; word 5: see raster_fast
+constexpr int kHdrWordsF = 8;   // per RUN of sub-rows (up to two per quad: above and below its rows taken whole), for the sub-rows' lanes; word 5: see raster_fast
 constexpr int kObjWordsF = 12;  // as kObjWords, + the rows that hold a vertex: 96 bits
 constexpr int kTasksF = 64;     // (row, quad) pairs taken whole, per round
 constexpr int kMapWordsF = 64;  // the sub-rows' enumeration: a bit per start of a quad's run, 2 048 sub-rows per round
-constexpr int kAccAtF = kMaxQuadsF * (kRecWordsF + kHdrWordsF) + kMaxObjs * kObjWordsF + kTasksF + 8 + kMapWordsF;
+static_assert(kMapWordsF <= kTasksF + 8, "the sub-rows' map lies over the rows' task list (one is dead when the other is written)");
+constexpr int kAccAtF = kMaxQuadsF * (kRecWordsF + 2 * kHdrWordsF) + kMaxObjs * kObjWordsF + kTasksF + 8;
 constexpr int kLdsWordsF = kAccAtF + kAccPixelsF / 2;
 
 struct CtxF {
@@ -485,9 +486,9 @@ struct CtxF {
   int W, H, lane;
   __device__ __forceinline__ uint32_t* rec(int q) const { return lds + q * kRecWordsF; }
   __device__ __forceinline__ uint32_t* hdr(int q) const { return lds + kMaxQuadsF * kRecWordsF + q * kHdrWordsF; }
-  __device__ __forceinline__ uint32_t* obj(int o) const { return lds + kMaxQuadsF * (kRecWordsF + kHdrWordsF) + o * kObjWordsF; }
+  __device__ __forceinline__ uint32_t* obj(int o) const { return lds + kMaxQuadsF * (kRecWordsF + 2 * kHdrWordsF) + o * kObjWordsF; }
   __device__ __forceinline__ uint32_t* tasks() const { return obj(kMaxObjs); }  // [kTasksF], the count, "more rows than fit", (2 free)
-  __device__ __forceinline__ uint32_t* map() const { return tasks() + kTasksF + 8; }
+  __device__ __forceinline__ uint32_t* map() const { return tasks(); }  // (the rows' pass is over when the sub-rows' map is made)
   __device__ __forceinline__ uint32_t* acc() const { return lds + kAccAtF; }
   __device__ __forceinline__ void sync() const {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -621,8 +622,6 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
     o[5] = 0u; o[6] = 0u; o[7] = (uint32_t)(kind >> 8);
     o[8] = 0u; o[9] = 0u; o[10] = 0u; o[11] = 0u;
   }
-#pragma unroll
-  for (int i = 0; i < kMapWordsF; i += 64) C.map()[i + lane] = 0u;
   C.sync();
   int my_lo = 0, my_hi = 0;
   if (valid) {
@@ -775,38 +774,6 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
     o[3] = (uint32_t)(abase - bw * bh);
     o[5] = (uint32_t)(rbase - bh);
     o[6] = 0u;
-  }
-  // ... and the quads' runs of sub-rows (their owners' lanes): counts, scan, the headers the sub-rows' lanes read
-  int cnt = 0, s_lo = 0;
-  if (valid) {
-    s_lo = max(my_lo, 0);
-    cnt = max(min(my_hi, C.H * sft::kGridY) - s_lo, 0);
-  }
-  const int incl = wave_incl_sum(cnt);
-  const int tot_sub = __builtin_amdgcn_readlane(incl, 63), start = incl - cnt;
-  if (valid) {  // the quad's extent in pixel columns, [lo, hi) clamped to a byte each: for the overlap test of the sub-rows' lanes
-    const int lo = min(min(mine.x[0], mine.x[1]), min(mine.x[2], mine.x[3])), hi = max(max(mine.x[0], mine.x[1]), max(mine.x[2], mine.x[3]));
-    C.hdr(qi)[5] = (uint32_t)(min(max(lo >> 8, 0), 255) | (min(max((hi + 255) >> 8, 0), 255) << 8));
-  }
-  C.sync();
-  // (which quad a run belongs to: the r-th run with sub-rows is the r-th such quad: its header sits at r)
-  const unsigned long long runs = __ballot(valid && cnt > 0);
-  if (valid && cnt > 0) {
-    const uint32_t* ob = C.obj(oi);
-    const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u);
-    const int q0 = qi - kq, okind = kind & 255, m0 = kind >> 8, nq = nq_mine, k = kq;
-    // the earlier quads this one may overlap (at most two, and whether all three can meet): by kind
-    int p1 = 255, p2 = 255, triple = 0;
-    if (okind == kKindLines3) { p1 = k >= 1 ? q0 : 255; p2 = k == 2 ? q0 + 1 : 255; triple = k == 2; }
-    else if (okind == kKindShell) { p1 = k >= 1 ? q0 + k - 1 : 255; p2 = k == 3 ? q0 : 255; }
-    else if (okind == kKindRing) { p1 = k == m0 ? q0 + m0 - 1 : (k == nq - 1 ? q0 : 255); }
-    // (the partners' pixel columns: word 5 of the header slot with the partner's NUMBER, written before the barrier above)
-    const int px1 = p1 != 255 ? (int)C.hdr(p1)[5] : 0, px2 = p2 != 255 ? (int)C.hdr(p2)[5] : 0;
-    const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(runs >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)runs, 0u));
-    uint32_t* h = C.hdr(rk);
-    *reinterpret_cast<int4*>(h) =
-        int4{start | (s_lo << 16), (int)ob[3] - oby0 * obw, obx0 | (obw << 8) | (oby0 << 16) | (oi << 24), p1 | (p2 << 8) | (triple << 16) | (qi << 24)};
-    h[4] = (uint32_t)(px1 & 0xffff) | ((uint32_t)(px2 & 0xffff) << 16);
   }
   C.sync();
   if (SFTD_STOP == 1) return;
@@ -1014,6 +981,76 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
     C.sync();
   }
   if (SFTD_STOP == 2) return;
+  // ---- the quads' runs of sub-rows (their owners' lanes), NOW that the rows taken whole are known: a quad's sub-rows in such rows
+  // have nothing to add, and for a stroke they are the middle of it -- the rows between the two at its ends that hold its corners,
+  // a quarter to a half of its sub-rows.  Where a quad's whole rows are one block (always, for a stroke; anything else keeps one run
+  // and the per-sub-row test below) its run is cut in two, [s_lo, the block) and [behind the block, s_hi): counts, scans, the
+  // headers the sub-rows' lanes read -- first all the upper parts, then all the lower ones.
+#ifndef SFTD_SPLIT_RUNS
+#define SFTD_SPLIT_RUNS 1
+#endif
+  int cnt = 0, s_lo = 0, cnt_b = 0, s_b = 0;
+  if (valid) {
+    s_lo = max(my_lo, 0);
+    const int s_hi = min(my_hi, C.H * sft::kGridY);
+    cnt = max(s_hi - s_lo, 0);
+    if (SFTD_SPLIT_RUNS && cnt > 0) {
+      const uint32_t* ob = C.obj(oi);
+      const int oby0 = (int)((ob[0] >> 8) & 255u);
+      const int r0 = ((s_lo * 34953) >> 19) - oby0, r1 = (((s_hi - 1) * 34953) >> 19) - oby0;  // the quad's rows within its object
+      if (r0 >= 0 && r1 < 32) {
+        const unsigned m = (ob[6] >> r0) & ((2u << (r1 - r0)) - 1u);  // its rows that are taken whole
+        if (m) {
+          const int fw = __builtin_ctz(m), lw = 31 - __builtin_clz(m);
+          if (m == (((2u << (lw - fw)) - 1u) << fw)) {
+            const int a_end = (oby0 + r0 + fw) * sft::kGridY;
+            s_b = (oby0 + r0 + lw + 1) * sft::kGridY;
+            cnt = max(a_end - s_lo, 0);
+            cnt_b = max(s_hi - s_b, 0);
+          }
+        }
+      }
+    }
+  }
+  const int incl = wave_incl_sum(cnt), incl_b = wave_incl_sum(cnt_b);
+  const int tot_a = __builtin_amdgcn_readlane(incl, 63), tot_sub = tot_a + __builtin_amdgcn_readlane(incl_b, 63);
+  const int start = incl - cnt, start_b = tot_a + incl_b - cnt_b;
+  if (valid) {  // the quad's extent in pixel columns, [lo, hi) clamped to a byte each: for the overlap test of the sub-rows' lanes
+    const int lo = min(min(mine.x[0], mine.x[1]), min(mine.x[2], mine.x[3])), hi = max(max(mine.x[0], mine.x[1]), max(mine.x[2], mine.x[3]));
+    C.hdr(qi)[5] = (uint32_t)(min(max(lo >> 8, 0), 255) | (min(max((hi + 255) >> 8, 0), 255) << 8));
+  }
+#pragma unroll
+  for (int i = 0; i < kMapWordsF; i += 64) C.map()[i + lane] = 0u;  // (the task list's words: the rows are done with them)
+  C.sync();
+  // (which quad a run belongs to: the r-th run is the r-th (quad, part) that has sub-rows: its header sits at r)
+  const unsigned long long runs = __ballot(valid && cnt > 0), runs_b = __ballot(valid && cnt_b > 0);
+  if (valid && (cnt > 0 || cnt_b > 0)) {
+    const uint32_t* ob = C.obj(oi);
+    const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u);
+    const int q0 = qi - kq, okind = kind & 255, m0 = kind >> 8, nq = nq_mine, k = kq;
+    // the earlier quads this one may overlap (at most two, and whether all three can meet): by kind
+    int p1 = 255, p2 = 255, triple = 0;
+    if (okind == kKindLines3) { p1 = k >= 1 ? q0 : 255; p2 = k == 2 ? q0 + 1 : 255; triple = k == 2; }
+    else if (okind == kKindShell) { p1 = k >= 1 ? q0 + k - 1 : 255; p2 = k == 3 ? q0 : 255; }
+    else if (okind == kKindRing) { p1 = k == m0 ? q0 + m0 - 1 : (k == nq - 1 ? q0 : 255); }
+    // (the partners' pixel columns: word 5 of the header slot with the partner's NUMBER, written before the barrier above)
+    const int px1 = p1 != 255 ? (int)C.hdr(p1)[5] : 0, px2 = p2 != 255 ? (int)C.hdr(p2)[5] : 0;
+    const int4 common{0, (int)ob[3] - oby0 * obw, obx0 | (obw << 8) | (oby0 << 16) | (oi << 24), p1 | (p2 << 8) | (triple << 16) | (qi << 24)};
+    const uint32_t pxw = (uint32_t)(px1 & 0xffff) | ((uint32_t)(px2 & 0xffff) << 16);
+    if (cnt > 0) {
+      const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(runs >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)runs, 0u));
+      uint32_t* h = C.hdr(rk);
+      *reinterpret_cast<int4*>(h) = int4{start | (s_lo << 16), common.y, common.z, common.w};
+      h[4] = pxw;
+    }
+    if (cnt_b > 0) {
+      const int rk = (int)__popcll(runs) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(runs_b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)runs_b, 0u));
+      uint32_t* h = C.hdr(rk);
+      *reinterpret_cast<int4*>(h) = int4{start_b | (s_b << 16), common.y, common.z, common.w};
+      h[4] = pxw;
+    }
+  }
+  C.sync();
   // ---- sub-rows of the other rows: a lane per (quad, sub-row of the quad).  The lane adds its quad's span; what the quad shares
   // with the EARLIER quads it may overlap is taken off again by the same lane: -(pairs) +(the triple): the union of the object's
   // quads by inclusion-exclusion.  Which quad a lane's sub-row belongs to: a bit map of the runs' starts (a v_mbcnt pair and a
@@ -1027,10 +1064,12 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
         C.sync();
       }
       // (a run's start t > 0 is marked by the bit of t - 1: lane t's count of the bits below it is the run's number)
-      const bool marks = valid && cnt > 0 && start > 0;
+      const bool marks = valid && cnt > 0 && start > 0, marks_b = valid && cnt_b > 0 && start_b > 0;
       if (marks && start - 1 >= p0 && start - 1 < p0 + kRound)
         __hip_atomic_fetch_or(C.map() + ((start - 1 - p0) >> 5), 1u << ((start - 1 - p0) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      int kb = (int)__popcll(__ballot(marks && start - 1 < p0));
+      if (marks_b && start_b - 1 >= p0 && start_b - 1 < p0 + kRound)
+        __hip_atomic_fetch_or(C.map() + ((start_b - 1 - p0) >> 5), 1u << ((start_b - 1 - p0) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int kb = (int)__popcll(__ballot(marks && start - 1 < p0)) + (int)__popcll(__ballot(marks_b && start_b - 1 < p0));
       C.sync();
       const int end = min(tot_sub, p0 + kRound);
       for (int base = p0; base < end; base += 64) {
