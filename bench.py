@@ -242,6 +242,18 @@ def device_identity(torch, local_rank):
             "uuid": str(getattr(p, "uuid", "")) or None}
 
 
+def whole_job_value(ranks, elapsed_s):
+    """`value` of an N-rank line: the units all ranks processed in a timed block (each rank's own report, `env_steps`) over the
+    block's time (barrier-to-barrier, MAX over ranks).  Leaves every rank's share at that clock in its entry (`value_share`):
+    the line's value is their sum, and the ranks' lane ranges must tile [0, N n) -- one batch cut into contiguous shards."""
+    for r in ranks:
+        r["value_share"] = r["env_steps"] / elapsed_s
+    lanes = sorted(tuple(r["lanes"]) for r in ranks)
+    if lanes[0][0] != 0 or any(a[1] != b[0] for a, b in zip(lanes, lanes[1:])):
+        raise SystemExit("bench.py: the ranks' lane ranges do not tile one batch: %r" % (lanes,))
+    return sum(r["value_share"] for r in ranks)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -345,12 +357,14 @@ def main():
         # (dry run: a stand-in device id per rank; SF_BENCH_TEST_SAME_DEVICE makes two ranks claim the same one)
         fake = 0 if os.environ.get("SF_BENCH_TEST_SAME_DEVICE") else rank
         ranks = gather_ranks({"rank": rank, "device_index": None, "pci_bus_id": "dry:%02x" % fake, "uuid": "dry-%d" % fake,
-                              "block_ms_median": 1.0 + rank, "lanes": [lane0, lane1]})
+                              "block_ms_median": 1.0 + rank, "lanes": [lane0, lane1], "env_steps": (lane1 - lane0) * args.steps})
+        whole_job_value(ranks, float(tt.item()) * 1e-3)  # (the real path's arithmetic on the stand-in clock: MAX over ranks)
         if len({(r["pci_bus_id"], r["uuid"]) for r in ranks}) != world or dist.get_world_size() != world:
             sys.stderr.write("bench.py: %d ranks but not %d distinct devices\n" % (world, world))
             sys.exit(4)
         if rank == 0:
-            print(json.dumps({"metric": METRIC, "dry_run": True, "value": None, "n_gpus": world, "steps": args.steps,
+            print(json.dumps({"metric": METRIC, "dry_run": True, "value": None, "dry_value": whole_job_value(ranks, float(tt.item()) * 1e-3),
+                              "n_gpus": world, "steps": args.steps,
                               "rccl_world": dist.get_world_size(),
                               "warmup": args.warmup, "repeats": repeats, "lanes_rank0": [lane0, lane1],
                               "max_over_ranks": float(tt.item()), "ranks": ranks, "cpu_baseline": base,
@@ -536,7 +550,7 @@ def main():
     stats_reduce_us = (time.perf_counter() - ts) * 1e6
 
     # ---- who ran: one all-gather of (rank, device, PCI bus id, this rank's own median block)
-    mine = dict(device_identity(torch, local_rank), rank=rank, lanes=[lane0, lane1],
+    mine = dict(device_identity(torch, local_rank), rank=rank, lanes=[lane0, lane1], env_steps=(lane1 - lane0) * K,
                 block_ms_median=sorted(own_blocks[r] for r in order)[len(order) // 2] * 1e3, launch_period_steady_ms=steady_ms)
     ranks = gather_ranks(mine)
     # an N-GPU line is evidence of N GPUs: every rank on a device of its own, or the job fails (two ranks on one device would
@@ -747,7 +761,10 @@ def main():
     state_ok = True  # (check_state raises otherwise)
     if rank == 0:
         total_steps = float(n) * K * world
-        value = total_steps / elapsed
+        # the whole job's throughput: the env-steps EVERY rank reports for a timed block (gathered above) over the block's
+        # time, MAX over ranks -- i.e. the sum of the ranks' shares at the job's clock (`ranks[*].value_share`)
+        value = whole_job_value(ranks, elapsed)
+        assert abs(value - total_steps / elapsed) <= 1e-9 * value, (value, total_steps / elapsed)
         algo = ALGO_BYTES[args.gametype] * n
         # `achieved` / `frac`: the algorithmic bytes of one launch over ms_per_step of the blocks that give `value` (the same
         # clock as `value`); the HIP-event launch period of the event-carrying blocks stands beside it as a labelled extra

@@ -273,11 +273,15 @@ int sf_check_actions(sf_batch* b, void* stream);
  * presses: 65 535; vlner: 4 095; a key timer: +-32 767 ticks without an edge; time: 2^24 ms).  Every time a field of
  * some env leaves its range (the tick on which it wraps) is counted on the device; this reads the count (synchronises
  * `stream`) and returns SF_ERR_STATE while it is not zero -- the values sf_get_field returns for those envs have wrapped,
- * and stay wrapped: the count is STICKY until sf_reset starts new games everywhere or sf_set_field rewrites a packed field
- * (every env's: a restored checkpoint rewrites them all).  Auto-resetting batches start every
- * field over at each episode end and cannot get there.  sf_set_field refuses (SF_ERR_ARG) values that do not fit a
- * field, and a `stats` row 3 (ship deaths) that is not the sum of rows 0-2. */
+ * and stay wrapped: the count is STICKY until sf_reset starts new games everywhere, or until a caller that has rewritten EVERY
+ * packed field of every env (a restored checkpoint: SFVecEnv.load_state_dict) says so with sf_clear_state_errors -- a
+ * sf_set_field of one field repairs that field and leaves the count alone (other fields, other envs may have wrapped).
+ * Auto-resetting batches start every field over at each episode end and cannot get there.  sf_set_field refuses
+ * (SF_ERR_ARG) values that do not fit a field, and a `stats` row 3 (ship deaths) that is not the sum of rows 0-2.
+ * The hand-over counter of split launches (an internal error, never seen) is reported the same way and by sf_episode_stats
+ * (which then still delivers the statistics and clears nothing); it is cleared by nothing: make a new batch. */
 int sf_check_state(sf_batch* b, void* stream);
+int sf_clear_state_errors(sf_batch* b);
 
 /* ---- state access: the 37 read-only attributes of `Game` (SRC/pymodule.cpp:372-411) in batched
  *      form, plus writes for checkpoint/restore and constructed test states.  `host` is HOST memory,

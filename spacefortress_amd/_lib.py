@@ -79,6 +79,7 @@ SYMBOLS = {
     "sf_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_check_actions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sf_check_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sf_clear_state_errors": (C.c_int, [C.c_void_p]),
     "sf_seed_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "sf_step_sampled": (C.c_int, [C.c_void_p] * 7),
     "sf_rollout_sampled": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),

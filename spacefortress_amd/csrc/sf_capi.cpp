@@ -1009,15 +1009,16 @@ extern "C" int sf_episode_stats(sf_batch* b, int64_t* out, int clear, void* stre
   unsigned long long all[SF_ACC_WORDS];
   HIP_TRY(hipMemcpyAsync(all, b->d_acc, sizeof(all), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  memcpy(out, all, SF_EPISODE_STATS_LEN * sizeof(int64_t));
+  memcpy(out, all, SF_EPISODE_STATS_LEN * sizeof(int64_t));  // (delivered either way)
+  if (all[SF_ACC_HANDOVER]) {  // ... but NOT cleared: the window's statistics stay where they are for whoever looks into this
+    sf_set_error("%llu times a wave of a split step launch gave up waiting for its tile's other wave: the state of this batch is "
+                 "not the reference's any more (an internal error: please report it with the batch size and the GPU).  `out` holds "
+                 "the statistics; nothing was cleared; the counter is sticky: make a new batch", all[SF_ACC_HANDOVER]);
+    return SF_ERR_STATE;
+  }
   if (clear)
     HIP_TRY(hipMemcpyAsync(b->d_acc, kAccInit, SF_EPISODE_STATS_LEN * sizeof(int64_t), hipMemcpyHostToDevice,
                            (hipStream_t)stream));
-  if (all[SF_ACC_HANDOVER]) {
-    sf_set_error("%llu times a wave of a split step launch gave up waiting for its tile's other wave: the state of this batch is "
-                 "not the reference's any more (an internal error: please report it with the batch size and the GPU)", all[SF_ACC_HANDOVER]);
-    return SF_ERR_STATE;
-  }
   return SF_OK;
 }
 
@@ -1120,10 +1121,19 @@ static int field_copy(sf_batch* b, int f, void* host, size_t bytes, bool to_host
   }
   HIP_TRY(hipDeviceSynchronize());
   if (to_host) HIP_TRY(hipMemcpy(host, b->d_scratch, total, hipMemcpyDeviceToHost));
-  // a packed per-episode field (a bit field or the statistics) rewritten for every env with values that fit: what had wrapped in
-  // it is repaired, and the sticky count of sf_check_state starts over (a caller that restores a checkpoint -- load_state_dict --
-  // rewrites all of them; one that repairs a single field vouches for the others)
-  if (!to_host && (m.kind == SF_FK_BITS || m.kind == SF_FK_STATS)) HIP_TRY(hipMemset(b->d_acc + SF_ACC_OVERFLOW, 0, sizeof(unsigned long long)));
+  // (a packed per-episode field rewritten with values that fit repairs THAT field; the sticky count of sf_check_state is not
+  //  touched here -- other fields, other envs may have wrapped: sf_clear_state_errors, for a caller that has rewritten them all)
+  return SF_OK;
+}
+
+extern "C" int sf_clear_state_errors(sf_batch* b) {
+  if (!b) {
+    sf_set_error("sf_clear_state_errors: null batch");
+    return SF_ERR_ARG;
+  }
+  DeviceGuard guard(b->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(b->d_acc + SF_ACC_OVERFLOW, 0, sizeof(unsigned long long)));
   return SF_OK;
 }
 

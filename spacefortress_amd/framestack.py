@@ -46,6 +46,7 @@ class FrameStack:
         episode."""
         e = self.env
         at = {torch.uint8: 1, torch.int32: 4, torch.int64: 8}[actions.dtype]
+        e._before_step(actions)
         _lib.check(e._L.sf_step(e._h, C.c_void_p(actions.data_ptr()), at, None, C.c_void_p(self._rew.data_ptr()),
                                 C.c_void_p(self._done.data_ptr()), C.c_void_p(self._info.data_ptr()), e._stream()))
         e._stepped(actions, self._rew, self._done, self._info)

@@ -104,6 +104,7 @@ class DeviceRollout:
         P = self._ptr
         stream = self._stream()
         ap, at = C.c_void_p(a.data_ptr()), a.element_size()
+        e._before_step(a)
         if self.norm is not None:
             z = self.norm
             if not (z.ob and z.ret_on):

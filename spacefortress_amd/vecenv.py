@@ -127,9 +127,7 @@ class SFVecEnv:
     def reset(self, numpy=False):
         """env.reset() in every lane (ENV:163-178): new games; returns obs [N, obs_dim]."""
         obs = self._alloc()[0]
-        self._touch()
-        if self._durations is not None:
-            self._durations.reset()  # new Games: empty vectors
+        self._touch()  # (new Games: a recording ends, the duration log's vectors start empty)
         _lib.check(self._L.sf_reset(self._h, C.c_void_p(obs.data_ptr()), self._stream()))
         return obs.cpu().numpy() if numpy else obs
 
@@ -146,15 +144,10 @@ class SFVecEnv:
         else:
             bufs = out if out is not None else self._alloc()
             ptrs = tuple(C.c_void_p(t.data_ptr()) for t in bufs)
-        if self._durations is not None:
-            self._durations.before(actions)
+        self._before_step(actions)
         _lib.check(self._L.sf_step(self._h, C.c_void_p(actions.data_ptr()), at, ptrs[0], ptrs[1], ptrs[2], ptrs[3],
                                    self._stream()))
-        if self._durations is not None:
-            self._durations.after(bufs[2])
-        self._fresh = False
-        if self._rec is not None:
-            self._rec.add(actions.to(torch.uint8), bufs[1], bufs[2], bufs[3])
+        self._stepped(actions, bufs[1], bufs[2], bufs[3])
         return bufs
 
     def rollout(self, actions, out=None, want_obs=True):
@@ -177,6 +170,7 @@ class SFVecEnv:
             rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
             done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
             info = torch.empty((K, n), dtype=torch.uint8, device=self.device)
+        self._no_duration_log("rollout()")
         ev = self._rollout_events_begin(K)
         try:
             _lib.check(self._L.sf_rollout(self._h, C.c_void_p(actions.data_ptr()), at, int(K),
@@ -191,18 +185,39 @@ class SFVecEnv:
         return obs, rew, done, info
 
     # ------------------------------------------------------------------ replay files (spacefortress_amd/replay.py)
+    def _before_step(self, actions):
+        """THE hook in FRONT of every single-step launch with given actions -- step_tensors and the wrappers that call the C
+        ABI themselves (FrameStack.step, DeviceRollout.step, SFVecNormalize's fused step): the duration log reads the flags,
+        timers and vulnerability the tick's key calls meet (durations.py) before the launch changes them."""
+        if self._durations is not None:
+            self._durations.before(actions)
+
+    def _no_duration_log(self, what):
+        """Launches that play several ticks, or actions nobody has seen yet (rollout, the *_sampled calls), give the duration
+        log nothing to read between the ticks: refused while one is enabled, rather than leaving its vectors stale."""
+        if self._durations is not None:
+            raise RuntimeError("%s while a duration log is enabled (enable_durations): the log follows single steps with "
+                               "given actions -- step / step_tensors and the wrappers built on them" % what)
+
     def _stepped(self, actions, rew, done, info):
         """THE hook behind every launch that steps the batch -- step_tensors / rollout / the *_sampled calls above, and the
         wrappers that call the C ABI themselves (FrameStack.step, DeviceRollout.step, SFVecNormalize's fused step): the state is
-        no longer the one sf_create left, and a recording gets the actions with the engine's own (unnormalised) reward,
-        done and info of the step(s): [N] or [K, N] device tensors, not synchronised."""
+        no longer the one sf_create left, the duration log appends what the tick pushed (and empties the vectors of an env
+        whose episode ended), and a recording gets the actions with the engine's own (unnormalised) reward, done and info of
+        the step(s): [N] or [K, N] device tensors, not synchronised."""
         self._fresh = False
+        if self._durations is not None:
+            self._durations.after(done)
         if self._rec is not None:
             self._rec.add(actions.to(torch.uint8), rew, done, info)
 
     def _touch(self):
-        """The state is about to change otherwise than by a recorded step: a recording cannot go on."""
+        """The state is about to change otherwise than by a recorded step: a recording cannot go on, and the duration log starts
+        over (its vectors belong to the Games the batch held: reset() makes new ones, set_field / load_state_dict put the batch
+        somewhere the log has not followed)."""
         self._fresh = False
+        if self._durations is not None:
+            self._durations.reset()
         if self._rec is not None:
             self._rec = None
             raise RuntimeError("reset() / set_field() during a recording: a replay file is the game from a NEW batch on; "
@@ -272,6 +287,7 @@ class SFVecEnv:
                     or actions_out.numel() != self.num_envs:
                 raise ValueError("actions_out must be a contiguous uint8 tensor of %d elements on %s" % (self.num_envs, self.device))
             ao = C.c_void_p(actions_out.data_ptr())
+        self._no_duration_log("step_sampled()")
         _lib.check(self._L.sf_step_sampled(self._h, ao, ptrs[0], ptrs[1], ptrs[2], ptrs[3], self._stream()))
         self._fresh = False
         if self._rec is not None:
@@ -281,6 +297,7 @@ class SFVecEnv:
     def rollout_sampled(self, n_steps, want_obs=True, want_actions=True):
         """`rollout` on sampled actions: K ticks in one launch.  Returns (obs, reward, done, info, actions uint8 [K, N])."""
         K, n = int(n_steps), self.num_envs
+        self._no_duration_log("rollout_sampled()")
         obs = torch.empty((K, n) + self.obs_shape, dtype=self.obs_dtype, device=self.device) if want_obs else None
         rew = torch.empty((K, n), dtype=torch.int32, device=self.device)
         done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
@@ -499,3 +516,6 @@ class SFVecEnv:
     def load_state_dict(self, sd):
         for n in self.field_names():
             self.set_field(n, sd[n])
+        # every packed field of every env has just been rewritten with values that fit (set_field range-checks): whatever had
+        # wrapped is repaired, the sticky count of check_state() starts over (sfmi.h: sf_clear_state_errors)
+        _lib.check(self._L.sf_clear_state_errors(self._h))

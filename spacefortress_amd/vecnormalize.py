@@ -75,6 +75,7 @@ class SFVecNormalize:
             raise TypeError("actions dtype must be uint8, int32 or int64 (got %s)" % (actions.dtype,))
         obs, rew, done, info = v._alloc()
         p = lambda t: C.c_void_p(t.data_ptr())
+        v._before_step(actions)
         _lib.check(self._L.sf_step_normalize(v._h, self._h, p(actions), at, p(obs), p(rew), p(done), p(info), p(self._rew),
                                              0 if self.training else 1, self._stream()))
         v._stepped(actions, rew, done, info)  # (rew: the engine's int reward; self._rew the normalised one)

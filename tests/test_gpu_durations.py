@@ -68,3 +68,51 @@ def test_vectors_restart_with_every_new_game_and_overflow_is_counted(sfa):
     assert int(log.dropped) > 0                      # five presses before the game ended, four slots
     assert log.get("shot_durations")[1].max() <= 1   # ... and the new Game's vectors started empty
     env.close()
+
+
+@pytest.mark.parametrize("wrapper", ["framestack", "rollout", "rollout_stack", "vecnormalize", "rollout_vecnormalize"])
+def test_the_trainers_wrappers_keep_the_log_too(sfa, wrapper):
+    """the wrappers that call the C ABI themselves (FrameStack.step, DeviceRollout.step, SFVecNormalize's fused
+    step) report to the same two hooks as step_tensors (SFVecEnv._before_step / _stepped): the log they leave equals the
+    reference's vectors, as for plain steps.  Fused and sampled launches are refused while a log is enabled; set_field and
+    load_state_dict start it over."""
+    name = "youturn_rapid_fire"
+    z = np.load(os.path.join(GOLDEN, "getters", name + ".npz"))
+    gz = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    N = 64
+    image = wrapper in ("framestack", "rollout_stack")
+    env = sfa.SFVecEnv(N, gametype=meta["gametype"], action_set=meta["action_set"], seed=meta["seed"], spawn_stride=0,
+                       spawn_skip=meta["spawn_skip"], obs_type="image" if image else "features")
+    log = env.enable_durations(capacity=512)
+    acts = torch.from_numpy(gz["actions"].astype(np.uint8)).to(env.device)
+    T = len(acts)
+    if wrapper == "framestack":
+        w = sfa.FrameStack(env, 4)
+        step = lambda t: w.step(acts[t].repeat(N).contiguous())
+    elif wrapper == "vecnormalize":
+        w = sfa.SFVecNormalize(env)
+        step = lambda t: w.step_tensors(acts[t].repeat(N).contiguous())
+    else:
+        inner = sfa.SFVecNormalize(env) if wrapper == "rollout_vecnormalize" else env
+        w = sfa.DeviceRollout(inner, num_steps=T, num_stack=4 if wrapper == "rollout_stack" else 1)
+        step = lambda t: w.step(t, acts[t].repeat(N).contiguous())
+    # (no reset: the recorded run starts from the Game sf_create made; the wrappers' buffers start as they are)
+    for t in range(T):
+        step(t)
+    assert int(log.dropped) == 0
+    for k in NAMES:
+        want = tuple(int(v) for v in z[k])
+        assert len(want) > 0 or k == "thrust_durations"
+        for i in (0, N - 1):
+            assert log.of(i, k) == want, (wrapper, k, i)
+    for call in (lambda: env.rollout(acts[:4, None].repeat(1, N).contiguous()), lambda: env.step_sampled(), lambda: env.rollout_sampled(3)):
+        with pytest.raises(RuntimeError):
+            call()
+    env.set_field("vlner", np.zeros(N, np.int32))
+    assert all(int(log.get(k)[1].sum()) == 0 for k in NAMES)
+    step(0) if wrapper in ("framestack", "vecnormalize") else env.step_tensors(acts[0].repeat(N).contiguous())
+    sd = env.state_dict()
+    env.load_state_dict(sd)
+    assert all(int(log.get(k)[1].sum()) == 0 for k in NAMES)
+    env.close()

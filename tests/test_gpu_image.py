@@ -930,3 +930,36 @@ def test_an_image_batch_plays_the_same_game_as_a_features_batch(sfa, gametype):
         assert np.array_equal(a[k], b[k]), k
     img.close()
     fea.close()
+
+
+@pytest.mark.gpu
+def test_shells_on_exact_degree_headings(sfa, model):
+    """the frame kernels re-derive a shell's drawn heading from its velocity, (int)(atan2(vy, vx) * 180 / pi), where the
+    reference truncates the heading it stored when the shell was fired (SRC/game.cpp:159-173, SRC/draw.cpp:248-252).  A heading
+    that is a whole number of degrees must not land an ulp below it: shells flying along the axes and the diagonals -- the only
+    whole-degree bearings a fortress at whole coordinates has to a ship at whole coordinates (a game's first tick) -- with the
+    velocities the step kernel gives them, 6 (d / |d|), in both frame kernels."""
+    R, hb, hs, bg = model
+    from oracle import oracle as O
+    dirs = [(1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1)]
+    base = np.load(os.path.join(GOLDEN, "frames", "scores.npz"))["base"]
+    snaps = np.repeat(base.reshape(1), len(dirs))
+    for i, (dx, dy) in enumerate(dirs):
+        ddx, ddy = 60.0 * dx, 60.0 * dy
+        nrm = np.sqrt(ddx * ddx + ddy * ddy)
+        snaps["shell_alive"][i][2] = 1
+        snaps["shell_x"][i][2], snaps["shell_y"][i][2] = 355.0 + ddx, 315.0 + ddy
+        snaps["shell_vx"][i][2], snaps["shell_vy"][i][2] = 6.0 * (ddx / nrm), 6.0 * (ddy / nrm)
+        snaps["shell_angle"][i][2] = 45.0 * i  # what the reference stored: rad2deg(atan2(dy, dx)), exact for these
+    for geom in (None, (.25, (100, 60, 500, 520), 2)):
+        env = sfa.SFVecEnv(len(dirs), gametype="youturn", obs_type="image-raw", image_geometry=geom)
+        _load_snaps(env, snaps)
+        got = env.render("image-raw").cpu().numpy()
+        prev = R.set_geometry(*geom) if geom else None
+        try:
+            for i in range(len(dirs)):
+                frames_close(got[i], R.render_raw(snaps[i], hb, hs, text=True if geom is None else "segments"), ("heading", 45 * i, geom))
+        finally:
+            if prev:
+                R.set_geometry(*prev)
+        env.close()

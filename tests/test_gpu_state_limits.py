@@ -96,10 +96,15 @@ def test_a_key_timer_that_outgrows_int16_is_flagged(sfa):
     env.step_tensors(noop)
     with pytest.raises(OverflowError):
         env.check_state()
-    # rewriting the packed field (every env's) repairs what had wrapped: the sticky count starts over (a restored checkpoint
-    # -- load_state_dict -- rewrites all of them)
+    # rewriting ONE packed field repairs that field, and the sticky count stays (other fields, other envs may have
+    # wrapped -- one unrelated repair must not erase the evidence); a restored checkpoint -- load_state_dict: every packed field
+    # of every env rewritten with values that fit -- starts it over (sf_clear_state_errors)
     env.set_field("fire_timer", np.full(64, -5, np.int32))
+    with pytest.raises(OverflowError):
+        env.check_state()
+    env.load_state_dict(env.state_dict())
     env.check_state()
+    assert (env.get_field("fire_timer") == -5).all()
     env.close()
 
 

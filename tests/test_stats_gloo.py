@@ -130,6 +130,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert [x["rank"] for x in j["ranks"]] == [0, 1]
     assert [x["lanes"] for x in j["ranks"]] == [[0, 65536], [65536, 131072]]
     assert [x["block_ms_median"] for x in j["ranks"]] == [1.0, 2.0]
+    assert abs(sum(x["value_share"] for x in j["ranks"]) - j["dry_value"]) <= 1e-9 * j["dry_value"] and j["dry_value"] == 2 * 65536 * 20 / 2e-3
     # the CPU baseline of an N > 1 job: timed by the launcher before the ranks start, carried by rank 0's line
     cb = j["cpu_baseline"]
     assert cb is not None and cb["cores"] == 2 and cb["value"] > 1e4 and cb["kind"] in ("reference", "port")
@@ -185,6 +186,13 @@ def test_world_of_eight_dry_run():
     assert [x["lanes"] for x in j["ranks"]] == [[65536 * k, 65536 * (k + 1)] for k in range(8)]
     assert len({(x["pci_bus_id"], x["uuid"]) for x in j["ranks"]}) == 8
     assert j["max_over_ranks"] == 8.0
+    # what a first real 8-GPU line will be judged on: `value` is the SUM of the ranks' shares -- every rank's own
+    # count of env-steps over the job's clock (MAX over ranks: 8 ms here) --, and the ranks' lanes tile one batch of N n lanes
+    assert [x["env_steps"] for x in j["ranks"]] == [65536 * 20] * 8
+    assert abs(sum(x["value_share"] for x in j["ranks"]) - j["dry_value"]) <= 1e-9 * j["dry_value"]
+    assert abs(j["dry_value"] - 8 * 65536 * 20 / 8e-3) <= 1e-6 * j["dry_value"]
+    edges = sorted(tuple(x["lanes"]) for x in j["ranks"])
+    assert edges[0][0] == 0 and edges[-1][1] == 8 * 65536 and all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
     es = j["episode_stats"]  # sums over ranks of (rank + 1, ...); min of -5 - rank, max of 7 + rank
     assert es["episodes"] == 36 and es["min_return"] == -12 and es["max_return"] == 14
     cb = j["cpu_baseline"]
