@@ -101,9 +101,9 @@ def test_the_trainers_wrappers_keep_the_log_too(sfa, wrapper):
     for t in range(T):
         step(t)
     assert int(log.dropped) == 0
+    assert sum(len(z[k]) for k in NAMES) > 20  # (the run does push: dozens of shots)
     for k in NAMES:
         want = tuple(int(v) for v in z[k])
-        assert len(want) > 0 or k == "thrust_durations"
         for i in (0, N - 1):
             assert log.of(i, k) == want, (wrapper, k, i)
     for call in (lambda: env.rollout(acts[:4, None].repeat(1, N).contiguous()), lambda: env.step_sampled(), lambda: env.rollout_sampled(3)):
