@@ -653,6 +653,11 @@ def main():
                      "output_floor_us": floor_us, "frac_of_output_floor": floor_us / (ims * 1e3),
                      "roofline": {"bound": "hbm", "achieved": i_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": i_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": IMAGE_ALGO_BYTES,
+                                  "algorithmic_bytes_per_launch": IMAGE_ALGO_BYTES * ni,
+                                  "traffic": iprof.get("traffic_bytes_per_launch"),
+                                  "traffic_source": ("HBM-side bytes per launch of sf_render_kernel<true> from the committed --pmc passes of build %s "
+                                                     "(profiles/image_kernel_latest.json: FETCH_SIZE x 2 + WRITE_SIZE), replayed%s"
+                                                     % (iprof.get("sf_build_id"), " -- STALE: another build is loaded" if iprof.get("stale") else "")) if iprof.get("traffic_bytes_per_launch") else None,
                                   "note": "SURVEY 8(d)'s 7 448 B per env-step over the whole step (sf_step + sf_render_stack); "
                                           "the render kernel restates cairo's scan converter exactly and is latency- / issue-bound, not memory-bound (DESIGN.md 5)"},
                      "note": "BASELINE configs[4]: youturn image obs, 84x84 grey raster + 4-frame stack (device ring "

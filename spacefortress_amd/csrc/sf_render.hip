@@ -23,8 +23,9 @@
 // frames whose ship just died (the expensive ones) are started first (pick_env).
 //
 // Pixel values: PINNED to the reference's own renderer (SRC/draw.cpp against cairo 1.16): tests/golden/frames holds frames it
-// drew, oracle/cairo_model.c restates cairo's rasteriser bit for bit, and tests/test_gpu_image.py holds this kernel to both.
-// Not pinned: the score text (a font-dependent glyph model, sf_raster.h) and cv2's INTER_AREA (OpenCV's published algorithm).
+// drew, oracle/cairo_model.c restates cairo's rasteriser bit for bit, and tests/test_gpu_image.py holds this kernel to both --
+// all 92 rows: the score text is the reference's too, from a glyph atlas (sf_glyphs.h: FreeType's bitmaps as cairo blits them).
+// Not pinned: cv2's INTER_AREA (absent from the image: OpenCV's published algorithm).
 #include <hip/hip_runtime.h>
 
 #include "sf_drawrec.h"

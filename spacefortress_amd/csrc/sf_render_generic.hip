@@ -170,7 +170,7 @@ struct Ctx {
       order();
       return;
     }
-    // (float64 here: the glyph model is ours, oracle/render_np.py evaluates it in float64, and this kernel has the time)
+    // (the fallback: float64 here -- the segment model is ours, oracle/render_np.py evaluates it in float64, and this kernel has the time)
     const unsigned long long masks = sfr::score_masks(pnts);
     auto dx = [&](double x) { return (x - vx) * sx; };
     auto dy = [&](double y) { return (y - vy) * sy; };
