@@ -52,6 +52,9 @@
 #ifndef SF_RENDER_STOP
 #define SF_RENDER_STOP 0
 #endif
+#ifndef SF_PREPASS_MAX_ENVS
+#define SF_PREPASS_MAX_ENVS 6144 /* batches up to here get the explosion pre-pass (sf_explosion_kernel): measured break-even near 8 192 */
+#endif
 
 namespace {
 
@@ -505,28 +508,47 @@ __device__ __forceinline__ sft::Quad line_quad(const Seg4& g, double px, double 
 // degrees, each its own cairo_stroke -- one quad between the faces at its two ends (sf_tor.h: arc_quad_fixed) --, then the
 // radius-7 circle, one stroke of sixteen pieces.  `arcs` = the batch's table of the 84 + 2 arcs' constants (sft::ArcK, made
 // by the host's libm like cairo makes them).  Ring by ring: twelve arcs at once, each its own object.
+// call `ring` (0 .. 6: a ring's twelve arcs, each an object of its own; 7: the circle, one object of sixteen pieces) as the lanes'
+// quads for the rasteriser
+struct RingCall {
+  sft::Quad q;
+  bool valid;
+  int obj0, kind, grey;
+};
+__device__ __forceinline__ RingCall explosion_call(int ring, int lane, const double* arcs, double cx, double cy) {
+  const sft::Affine v = default_view();
+  RingCall c;
+  c.q = sft::Quad{};
+  if (ring < 7) {
+    c.valid = lane < 12;
+    if (c.valid) {
+      const double* kp = arcs + 8 * (12 * ring + lane);
+      const sft::ArcK k{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
+      c.q = sft::arc_quad_fixed(sft::arc_knots(v, cx, cy, k), SF_SCALE, SF_SCALE, (double)(float)SF_LINE_W / 2);
+    }
+    c.obj0 = lane;
+    c.kind = sftd::kKindSingle;
+    c.grey = 15 + 8 * ring < 60 ? 191 : 128;  // .75 / .5
+  } else {
+    c.valid = lane < 16;
+    if (c.valid) {
+      const double* kp = arcs + 8 * (84 + (lane >> 3));
+      const sft::ArcK k{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
+      c.q = sft::ring_piece_quad(sft::arc_knots(v, cx, cy, k), lane & 7, SF_SCALE, SF_SCALE, (double)(float)SF_LINE_W / 2);
+    }
+    c.obj0 = 0;
+    c.kind = sftd::kKindRing | (8 << 8);
+    c.grey = 191;
+  }
+  return c;
+}
 template <bool RESIZE>
 __device__ __forceinline__ void draw_explosion(const Frame<RESIZE>& F, const double* arcs, double cx, double cy) {
   const int lane = F.lane;
-  const sft::Affine v = default_view();
 #pragma unroll 1
-  for (int ring = 0; ring < 7; ring++) {
-    sft::Quad q = {};
-    if (lane < 12) {
-      const double* kp = arcs + 8 * (12 * ring + lane);
-      const sft::ArcK k{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
-      q = sft::arc_quad_fixed(sft::arc_knots(v, cx, cy, k), SF_SCALE, SF_SCALE, (double)(float)SF_LINE_W / 2);
-    }
-    F.raster_any(q, lane < 12, lane, sftd::kKindSingle, 15 + 8 * ring < 60 ? 191 : 128);  // .75 / .5
-  }
-  {
-    sft::Quad q = {};
-    if (lane < 16) {
-      const double* kp = arcs + 8 * (84 + (lane >> 3));
-      const sft::ArcK k{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
-      q = sft::ring_piece_quad(sft::arc_knots(v, cx, cy, k), lane & 7, SF_SCALE, SF_SCALE, (double)(float)SF_LINE_W / 2);
-    }
-    F.raster_any(q, lane < 16, 0, sftd::kKindRing | (8 << 8), 191);
+  for (int ring = 0; ring < 8; ring++) {
+    const RingCall c = explosion_call(ring, lane, arcs, cx, cy);
+    F.raster_any(c.q, c.valid, c.obj0, c.kind, c.grey);
   }
   F.resample(explosion_box((float)cx, (float)cy));
 }
@@ -1534,6 +1556,69 @@ hipError_t sf_launch_stack_clear(uint8_t* stack, size_t bytes_per_env, const uin
   return hipGetLastError();
 }
 
+// ---- The explosion PRE-PASS (small batches).  The first frame of a dead ship's explosion is eight calls of the rasteriser -- seven
+// rings of twelve arcs and the circle, 13 800 vector instructions -- and, drawn by the frame kernel, eight calls ONE AFTER THE OTHER
+// in one wave: 130 us, latency-bound even alone on its SIMD.  A batch of 16 384 envs hides that wave behind the other frames (it
+// starts first: pick_env); a batch that fits the chip in one round of waves does not: stepping took 137 us whatever the size
+// (profiles/r06_render_phases.md).  Here a workgroup of EIGHT waves takes an env whose ship died in the last tick (the step
+// kernel's hint words), every wave rasterises one of the eight calls into accumulators of its own, the waves composite in draw
+// order onto the bare background, and the workgroup leaves the env's explosion-cache entry exactly as ship_explosion(fill) would:
+// the frame kernel that follows finds the entry and copies.  What lies under an explosion's box (and within reach of it) is the
+// bare background in every variant the frame kernel starts from (sf_drawrec.h: ex_text / ex_bar / fort_pic), so the entry is the
+// same.  Not hinted, no cache, a box that does not fit an entry: nothing happens here and the frame kernel draws as before.
+constexpr int kPreWaves = 8;
+__global__ __launch_bounds__(64 * kPreWaves) void sf_explosion_kernel(SfRenderArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t fbw[kFbPadWords];
+  __shared__ __attribute__((aligned(16))) uint32_t torw[kPreWaves][Frame<true>::kTorWords];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int env = pick_env(a, (int)blockIdx.x, lane);  // the blockIdx-th hinted env (every wave works it out: the same value)
+  if (env < 0 || !a.xcache) return;  // (uniform over the workgroup, before any barrier)
+  const unsigned char* const rec = a.draw + (size_t)(env >> 6) * SF_DR_TILE_BYTES + (size_t)(env & 63) * SF_DR_LANE_STRIDE;
+  const unsigned fl = *reinterpret_cast<const unsigned*>(rec + SF_DR_PIECE_STRIDE + 4 * (SF_DRW_FLAGS - 4));
+  if (fl & SF_DRF_SHIP_ALIVE) return;
+  const d2_t shipd = *reinterpret_cast<const d2_t*>(rec + (unsigned)((SF_DR_PIECE_OBJ0 + SF_DR_OBJ_SHIP) * SF_DR_PIECE_STRIDE));
+  const double x = shipd.x, y = shipd.y;
+  unsigned char* const xc = a.xcache + (size_t)env * SF_XC_BYTES;
+  {
+    const double kx = *reinterpret_cast<const double*>(xc + kXcKey), ky = *reinterpret_cast<const double*>(xc + kXcKey + 8);
+    const unsigned xfl = *reinterpret_cast<const unsigned*>(xc + kXcFlags);
+    if (kx == x && ky == y && (xfl & 3u) == 3u) return;  // the entry is this explosion's already
+  }
+  const Box b = explosion_box((float)x, (float)y), o = out_box(b);
+  const bool fits = b.x1 - b.x0 <= kXcRow && b.y1 - b.y0 <= kXcFbRows && o.x1 - o.x0 <= kXcRow && o.y1 - o.y0 <= kXcOutRows &&
+                    b.x1 - b.x0 >= 16 && o.x1 - o.x0 >= 16;
+  if (!fits) return;
+  // the bare background (variant 0) into the shared surface; every wave's accumulators start out zero
+  for (int i = threadIdx.x; i < kFbPadWords; i += 64 * kPreWaves) fbw[i] = i < kFbWords ? a.bg[i] : 0u;
+  for (int i = sftd::kAccAtF + lane; i < Frame<true>::kTorWords; i += 64) torw[wave][i] = 0u;
+  __syncthreads();
+  uint8_t* const fb = reinterpret_cast<uint8_t*>(fbw);
+  const sftd::CtxF C{torw[wave], fb, SF_IMG_W, SF_IMG_H, lane};
+  sftd::RasterCarry carry;
+  {
+    const RingCall c = explosion_call(wave, lane, a.arcs, x, y);
+    sftd::raster_fast<1>(C, c.q, c.valid, c.obj0, c.kind, c.grey, &carry);
+  }
+  for (int r = 0; r < kPreWaves; r++) {  // the reference's order: ring by ring, the circle last
+    if (wave == r) sftd::raster_fast_pixels(C, carry.nobj, carry.tot_pix);
+    __syncthreads();
+  }
+  // the entry, as ship_explosion(fill) leaves it: the box of the surface, the box of the 84x84 image that reads it, key, flags
+  for (int i = threadIdx.x; i < kXcFbRows * kXcRow; i += 64 * kPreWaves) {
+    const int r = i / kXcRow, c = i - r * kXcRow;
+    if (r < b.y1 - b.y0 && c < b.x1 - b.x0) xc[kXcFb + i] = fb[(b.y0 + r) * SF_IMG_W + b.x0 + c];
+  }
+  if (wave == 0) {
+    const Frame<true> F{fb, nullptr, a.tabs, nullptr, lane, torw[0], nullptr, uint4{0u, 0u, 0u, 0u}};
+    F.resample_into(b, xc + kXcOut, kXcRow, o.x0, o.y0);
+  }
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<double*>(xc + kXcKey) = x;
+    *reinterpret_cast<double*>(xc + kXcKey + 8) = y;
+    *reinterpret_cast<unsigned*>(xc + kXcFlags) = 3u;
+  }
+}
+
 hipError_t sf_launch_render(const unsigned char* state, const unsigned char* draw, int n_envs, const uint32_t* bg, const uint32_t* bg84,
                             const uint32_t* tabs, uint8_t* out, size_t out_stride, unsigned char* xcache,
                             const unsigned char* fpatch, int resize, const uint8_t* stack_done, int stack_slot, int stack_n,
@@ -1546,6 +1631,11 @@ hipError_t sf_launch_render(const unsigned char* state, const unsigned char* dra
   const int n_front = hint && n_envs <= 64 * 64 * 32 ? (n_envs / 16 > 64 ? n_envs / 16 : 64) : 0;
   SfRenderArgs a{state, draw, n_envs, bg, bg84, tabs, out, out_stride, xcache, fpatch, stack_done, stack_slot, stack_n, stack_prev,
                  n_front ? hint : nullptr, n_front, hud, trig, arcs, falpha, glyphs};
+  // the explosion pre-pass where a fresh explosion would be the launch's pole: batches that fit the chip in about two rounds of
+  // waves (see sf_explosion_kernel); SFMI_EXPLOSION_PREPASS=0 / =1 in the environment: never / always (diagnostics, A/B)
+  static const int prepass_env = [] { const char* e = getenv("SFMI_EXPLOSION_PREPASS"); return e ? atoi(e) : -1; }();
+  if (n_front && xcache && (prepass_env > 0 || (prepass_env < 0 && n_envs <= SF_PREPASS_MAX_ENVS)))
+    hipLaunchKernelGGL(sf_explosion_kernel, dim3((unsigned)n_front), dim3(64 * kPreWaves), 0, stream, a);
   const unsigned grid = (unsigned)(n_envs + n_front);
   if (resize)
     hipLaunchKernelGGL(sf_render_kernel<true>, dim3(grid), dim3(64), 0, stream, a);

@@ -594,11 +594,22 @@ __device__ __forceinline__ void row_slots(const uint32_t* rc, int row, int* ls, 
 #ifndef SFTD_FAST_CALL
 #define SFTD_FAST_CALL 0 /* A/B: 1 = raster_fast as ONE function the frame kernel calls from its twelve places instead of twelve copies */
 #endif
+// what the pixels' pass needs of a call whose earlier passes ran apart from it (raster_fast<1>, then raster_fast_pixels: the frame
+// kernel's explosion pre-pass has eight waves rasterise a ring each into accumulators of their own and composite in draw order)
+struct RasterCarry {
+  int nobj, tot_pix;
+};
+__device__ __forceinline__ void raster_fast_pixels(const CtxF& C, int nobj, int tot_pix);
 #if SFTD_FAST_CALL
 __device__ __attribute__((noinline)) void raster_fast(const CtxF C, const sft::Quad mine, bool valid, int obj0, int kind, int grey) {
+  constexpr int PHASE = 0;
+  RasterCarry* const carry = nullptr;
 #else
-__device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine, bool valid, int obj0, int kind, int grey) {
+template <int PHASE = 0>  // 0: the whole call; 1: everything but the pixels' pass (*carry says what is left)
+__device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine, bool valid, int obj0, int kind, int grey,
+                                            RasterCarry* carry = nullptr) {
 #endif
+  if (PHASE == 1) *carry = RasterCarry{0, 0};
   if (SFTD_STOP == 0) return;
   const int lane = C.lane, xmax = C.W * 256;
   uint32_t* const acc = C.acc();
@@ -1129,7 +1140,18 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
     }
   }
   if (SFTD_STOP == 3) return;
-  // ---- pixels: object after object (the reference composites its strokes in order; boxes of different objects may overlap)
+  if (PHASE == 1) {
+    *carry = RasterCarry{nobj, tot_pix};
+    return;
+  }
+  raster_fast_pixels(C, nobj, tot_pix);
+}
+
+// ---- pixels: object after object (the reference composites its strokes in order; boxes of different objects may overlap);
+// then the accumulators are zero again for the next call
+__device__ __forceinline__ void raster_fast_pixels(const CtxF& C, int nobj, int tot_pix) {
+  const int lane = C.lane;
+  uint32_t* const acc = C.acc();
   for (int o = 0; o < nobj; o++) {
     const uint32_t* ob = C.obj(o);
     const int obx0 = (int)(ob[0] & 255u), oby0 = (int)((ob[0] >> 8) & 255u), obw = (int)((ob[0] >> 16) & 255u), obh = (int)(ob[0] >> 24);
