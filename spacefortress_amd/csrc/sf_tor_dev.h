@@ -837,56 +837,7 @@ __device__ __forceinline__ void raster_fast(const CtxF& C, const sft::Quad& mine
       if (__ballot(full && nsp >= 1)) {
         // (how many quads a row of this round has at most: nearly always one or two; three or four: an explosion's circle)
         const int lvl = __ballot(full && nsp > 2) ? 4 : (__ballot(full && nsp > 1) ? 2 : 1);
-        // The SHORT way, for nearly every row: where the cells at the row's top are all different the key IS the cell -- what breaks
-        // ties (who is new, the cell one sub-row earlier, the polygon's edge order) decides nothing --, so two cells an edge (the row's
-        // top, the next row's) and 32-bit compares do.  Not for a row with two equal top cells, an edge running along the surface's
-        // border, or an object whose quads share faces (a flattened curve): those take the long way below, as every row did.
-#ifndef SFTD_ROW_SHORTCUT
-#define SFTD_ROW_SHORTCUT 1
-#endif
-        bool long_way = full && nsp >= 1;
-        if (SFTD_ROW_SHORTCUT && full && nsp >= 1) {
-          const unsigned sp[4] = {sp0, sp1, sp2, sp3};
-          const double sd0 = (double)s0, sd1 = (double)(s0 + sft::kGridY);
-          int top[8], bot[8];
-          unsigned border = 0u;
-#pragma unroll
-          for (int a = 0; a < 4; a++) {
-#pragma unroll
-            for (int side = 0; side < 2; side++) {
-              const int i = 2 * a + side;
-              top[i] = 0; bot[i] = 0;
-              if (a < lvl && a < nsp) {
-                const uint32_t* rc = C.rec(q0 + (int)(sp[a] & 255u));
-                const uint32_t* sl = rc + slot_at((int)((sp[a] >> (side ? 11 : 8)) & 7u));
-                if (side == 0) border |= rc[18] & kRecBorder;
-                top[i] = cell_fast(sl, sd0);
-                bot[i] = cell_fast(sl, sd1);
-              }
-            }
-          }
-          bool ties = false, ordered = true, cplx = false;
-#pragma unroll
-          for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = i + 1; j < 8; j++) {
-              if (j >= 2 * lvl) continue;
-              const bool both = (j >> 1) < nsp;  // (i < j: both edges exist)
-              ties = ties || (both && top[i] == top[j]);
-              ordered = ordered && (!both || (top[i] < top[j] ? bot[i] <= bot[j] : bot[j] <= bot[i]));
-            }
-#pragma unroll
-          for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = a + 1; b < 4; b++) {
-              if (b >= lvl) continue;
-              if (b < nsp) cplx |= top[2 * b] <= top[2 * a + 1] && top[2 * a] <= top[2 * b + 1];
-            }
-          long_way = ties || border != 0u || !(okind == kKindLines3 || okind == kKindShell);
-          if (!long_way) { full = ordered; complex_row = cplx; }
-        }
-        if (__ballot(long_way))
-        if (long_way) {
+        if (full && nsp >= 1) {
           const unsigned sp[4] = {sp0, sp1, sp2, sp3};
           const double sd0 = (double)s0, sd1 = (double)(s0 + sft::kGridY), sdm = (double)(s0 - 1);
           unsigned long long key[8];
