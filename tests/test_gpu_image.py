@@ -654,7 +654,10 @@ def test_frames_reproduce_the_recorded_fingerprints(sfa, text, name):
       same 640 lines).  With the seven-segment fallback selected BY NAME today's kernel still has to give these sums: nothing
       but the text changed in round 6.
       "atlas": the same run with the built-in glyph atlas (the reference's text), recorded in round 6 under the build that
-      passed every fixture test of this file with all 92 rows compared; the guard for every later change of the kernel."""
+      passed every fixture test of this file with all 92 rows compared; the guard for every later change of the kernel.
+    Both files were recorded BEFORE the explosion pre-pass existed (sf_explosion_kernel: batches up to 6 144 envs -- this run's 1 024
+    -- have a freshly dead ship's explosion drawn by eight waves into its cache entry ahead of the frame kernel): that today's sums
+    equal them is the test that the pre-pass fills an entry exactly as drawing in place did, over the 7 000 deaths of the run."""
     import sys
 
     from conftest import ROOT
