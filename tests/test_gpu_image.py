@@ -966,3 +966,28 @@ def test_shells_on_exact_degree_headings(sfa, model):
             if prev:
                 R.set_geometry(*prev)
         env.close()
+
+
+@pytest.mark.gpu
+def test_explosion_prepass_equals_drawing_in_place():
+    """sf_explosion_kernel (batches up to 6 144 envs: a freshly dead ship's explosion drawn by eight waves into its cache entry
+    ahead of the frame kernel) against the frame kernel drawing it itself: the same run -- 512 envs, 400 random steps, some two
+    thousand deaths -- with SFMI_EXPLOSION_PREPASS=1 and =0 (read once per process: two child processes), every frame's
+    fingerprint equal (tools/render_hash.py: a changed byte anywhere changes a line)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, SFMI_EXPLOSION_PREPASS=flag)
+        r = subprocess.run([sys.executable, "-c",
+                            "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); from render_hash import fingerprints; "
+                            "print('\\n'.join(fingerprints('youturn', 512, 400, 'random')))" % (ROOT, os.path.join(ROOT, "tools"))],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l and l[0].isdigit()])
+    assert len(outs[0]) == len(outs[1]) == 400
+    bad = [i for i, (a, b) in enumerate(zip(*outs)) if a != b]
+    assert not bad, "frames with and without the pre-pass differ at steps %s ..." % bad[:5]
